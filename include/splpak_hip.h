@@ -1,0 +1,174 @@
+/*
+ * splpak_hip.h -- C ABI of the MI355X (gfx950) implementation of SPLPAK's
+ * least-squares cubic-spline fit / evaluate hot path.
+ *
+ * This is the drop-in boundary: a Fortran `splpak_module` (splpak_amd/fortran/
+ * splpak_module.F90) binds these symbols with ISO_C_BINDING and keeps the
+ * reference's public surface (`splpak_type%initialize/evaluate/destroy`,
+ * `splpak_wp`).  Citations are into the reference, /root/reference/src/splpak.F90.
+ *
+ * Conventions
+ *   - status return (`int32_t`) is the reference's `ierror`:
+ *       0, 101..107 for the fit (:674-686), 0, 101..104 for evaluation (:1155-1161).
+ *     Infrastructure failures (no GPU, HIP error, out of memory) are NEGATIVE
+ *     (SPLPAK_E_*) and `splpak_last_error_message` explains them.  Nothing is
+ *     printed by the library: the Fortran layer prints the reference's messages
+ *     (cfaerr, :399-407) so stdout ordering matches.
+ *   - `xdata` is the reference's column-major `xdata(l1xdat, ndata)` (:537-550),
+ *     i.e. point i is the `ndim` doubles at `xdata + i*l1xdat`.
+ *   - `coef` is ordered with the leftmost node index fastest (:657-673).
+ *   - pointers are HOST pointers in the one-shot entry points and DEVICE pointers
+ *     (same GPU as the plan) in the `_dev` / plan entry points.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with SPLPAK_E_NODEVICE.
+ */
+#ifndef SPLPAK_HIP_H
+#define SPLPAK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPLPAK_E_NODEVICE   (-1)  /* no HIP device / HIP runtime failure        */
+#define SPLPAK_E_NOMEM      (-2)  /* device allocation failed                   */
+#define SPLPAK_E_BADARG     (-3)  /* null pointer / inconsistent plan argument  */
+#define SPLPAK_E_UNSUPPORTED (-4) /* ndim > 4 (the reference documents 1..4, :1099) */
+#define SPLPAK_E_COMM       (-5)  /* the all-reduce callback reported failure   */
+
+#define SPLPAK_MAXDIM 4
+
+/* ---------------------------------------------------------------------------
+ * One-shot host entry points -- what `splpak_module` binds.
+ * ------------------------------------------------------------------------- */
+
+/* Replaces splcw (:512-513) and, with wdata == NULL, splcc (:421-422; the
+ * reference passes the sentinel wdata=[-1], :440).  A non-NULL wdata whose first
+ * element is negative is treated like NULL (:581-588, :796).
+ * `nwrk` is only used for the reference's 106 check (:772-781); the GPU path does
+ * not use the caller's `work` array, except that when `hist_out` != NULL and
+ * xtrap != 0 it receives the sparse-area histogram the reference leaves in
+ * work(1:ncol) (:879-907).  `info` (optional, 8 doubles) receives diagnostics:
+ *   [0] data rows used, [1] constraint rows, [2] refinement steps taken,
+ *   [3] |last correction|_inf / |coef|_inf, [4] min Cholesky pivot,
+ *   [5] seconds in assembly, [6] seconds in factorisation, [7] seconds in solve+refine */
+int32_t splpak_fit_f64(int32_t ndim, const double *xdata, int32_t l1xdat,
+                       const double *ydata, const double *wdata, int64_t ndata,
+                       const double *xmin, const double *xmax, const int32_t *nodes,
+                       double xtrap, double *coef, int64_t ncf, int64_t nwrk,
+                       double *hist_out, double *info);
+
+/* real32 twin (reference built with -DREAL32, :33-34).  Storage is f32, the
+ * arithmetic is f64 (converted on the device), so it is at least as accurate as
+ * the REAL32 reference. */
+int32_t splpak_fit_f32(int32_t ndim, const float *xdata, int32_t l1xdat,
+                       const float *ydata, const float *wdata, int64_t ndata,
+                       const float *xmin, const float *xmax, const int32_t *nodes,
+                       float xtrap, float *coef, int64_t ncf, int64_t nwrk,
+                       float *hist_out, double *info);
+
+/* Replaces a loop of splde (:1089) calls; nderiv == NULL gives splfe (:1258).
+ * Query i is the `ndim` doubles at xq + i*ldxq.  Error semantics per query are
+ * the reference's: 101/102/103 return without computing (out is set to 0),
+ * 104 (nderiv outside 0..2) is reported but the values are still computed with
+ * nderiv clamped to 0..2 (the reference computes on, :1190-1194). */
+int32_t splpak_eval_f64(int32_t ndim, int64_t nq, const double *xq, int32_t ldxq,
+                        const int32_t *nderiv, const double *coef,
+                        const double *xmin, const double *xmax, const int32_t *nodes,
+                        double *out);
+int32_t splpak_eval_f32(int32_t ndim, int64_t nq, const float *xq, int32_t ldxq,
+                        const int32_t *nderiv, const float *coef,
+                        const float *xmin, const float *xmax, const int32_t *nodes,
+                        float *out);
+
+/* ---------------------------------------------------------------------------
+ * Resident-data (device pointer) API: plans, used by bench.py, by batched
+ * callers and by the multi-GPU fit.  All work is enqueued on `stream`
+ * (a hipStream_t passed as void*, NULL = the default stream).
+ * ------------------------------------------------------------------------- */
+
+typedef struct splpak_plan splpak_plan;
+
+/* Sum-all-reduce hook for the sharded fit.  Called by
+ * splpak_plan_fit_dev with a device pointer into the plan's communication buffer;
+ * must sum `count` doubles in place across all ranks ON `stream` (or synchronise
+ * itself) and return 0.  With torch.distributed/RCCL this is
+ * `all_reduce(tensor_view)`.  NULL => single rank. */
+typedef int32_t (*splpak_allreduce_fn)(void *dev_buf, int64_t count, void *stream, void *user);
+
+/* Validates exactly like splcw (:716-781; 105/106 are checked at fit time) and
+ * allocates every device buffer the fit of a grid needs (band factor, stencil
+ * normal equations, sort scratch for up to `max_ndata` points per call).
+ * `comm_buf_dev`/`comm_len`: optional caller-owned device buffer (doubles) the
+ * all-reduced quantities live in -- pass a torch tensor's data_ptr so the
+ * callback can all-reduce views of it; NULL lets the plan allocate it.
+ * `splpak_plan_comm_len` tells the required length. */
+int64_t splpak_plan_comm_len(int32_t ndim, const int32_t *nodes);
+int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmin,
+                           const double *xmax, double xtrap, int64_t max_ndata,
+                           void *comm_buf_dev, int64_t comm_len, splpak_plan **plan);
+void    splpak_plan_destroy(splpak_plan *plan);
+void    splpak_plan_set_allreduce(splpak_plan *plan, splpak_allreduce_fn fn, void *user,
+                                  int32_t rank, int32_t world);
+/* tuning / test knobs: max refinement steps (default 4), relative correction
+ * tolerance (default 1e-13) */
+void    splpak_plan_set_refine(splpak_plan *plan, int32_t max_steps, double tol);
+
+/* The fit on resident data.  xdata_dev/ydata_dev/wdata_dev (wdata_dev may be
+ * NULL) hold THIS rank's `ndata` points; coef_dev receives ncol coefficients
+ * (identical on every rank).  Synchronises `stream` before returning (the error
+ * flag and the refinement's convergence test are read back).  info as above. */
+int32_t splpak_plan_fit_dev(splpak_plan *plan, const double *xdata_dev, int32_t l1xdat,
+                            const double *ydata_dev, const double *wdata_dev,
+                            int64_t ndata, double *coef_dev, void *stream, double *info);
+/* device pointer to the (all-reduced) sparse-area histogram of the last fit */
+const double *splpak_plan_hist_dev(const splpak_plan *plan);
+
+/* Per-kernel accounting of the last splpak_plan_fit_dev call, measured with HIP
+ * events on the stream the kernels ran on (bench.py's roofline object):
+ *   out[0] = number of trailing-update (SYRK, f64 MFMA) launches
+ *   out[1] = total milliseconds in them
+ *   out[2] = total floating-point operations they performed (algorithmic, 2*m*n*k/..)
+ *   out[3] = milliseconds in the whole factorisation
+ * Timing is only collected when enabled (costs an event pair per launch). */
+void    splpak_plan_enable_kernel_timing(splpak_plan *plan, int32_t on);
+void    splpak_plan_kernel_timing(const splpak_plan *plan, double *out4);
+
+/* Batched evaluation on resident data (asynchronous on `stream`; no validation
+ * beyond the reference's 101..104, which is done on the host from the small
+ * arguments). */
+int32_t splpak_eval_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int32_t ldxq,
+                            const int32_t *nderiv /* host, may be NULL */,
+                            const double *coef_dev, const double *xmin, const double *xmax,
+                            const int32_t *nodes, double *out_dev, void *stream);
+
+/* Device-side synthetic inputs of SURVEY 8d (Park-Miller stream, seed 42):
+ * points first_point .. first_point+ndata-1; any of the outputs may be NULL.
+ * xdata_dev is written with leading dimension ndim.  Queries continue the stream
+ * after `ndata_before` data points. */
+int32_t splpak_synth_points_f64(int32_t ndim, int64_t first_point, int64_t ndata,
+                                double *xdata_dev, double *ydata_dev, double *wdata_dev,
+                                void *stream);
+int32_t splpak_synth_queries_f64(int32_t ndim, int64_t ndata_before, int64_t first_query,
+                                 int64_t nq, double *xq_dev, void *stream);
+
+/* Diagnostics: solve A x = b for a symmetric positive definite band matrix with
+ * the library's blocked band Cholesky (no refinement).  `a_lower` is the dense
+ * column-major n x n matrix on the HOST, of which only the lower triangle within
+ * `halfbw` of the diagonal is read.  Returns 0, or 107 if a pivot is not
+ * positive.  Exists so the factorisation kernels (f64 MFMA trailing update, panel
+ * solve, band sweeps) can be tested in isolation against LAPACK. */
+int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double *a_lower,
+                                        const double *b, double *x);
+
+/* Human-readable text for the last negative status on this thread. */
+int32_t splpak_last_error_message(char *buf, int32_t buflen);
+
+/* Library / device identification: writes e.g. "gfx950:sramecc+:xnack-" */
+int32_t splpak_device_name(char *buf, int32_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLPAK_HIP_H */

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- generate golden vectors from the REAL reference.
+
+Runs the unmodified reference (oracle/_ref/libsplpak_ref.so, built by
+``make -C oracle ref`` from /root/reference/src/splpak.F90) over the case matrix
+in tests/cases.py and writes its OUTPUTS to tests/golden/<case>.npz:
+
+    coef     the fitted coefficients (src/splpak.F90:657-673)
+    ierror   the fit's error flag
+    hist     work(1:ncol) after the fit = the sparse-area histogram (:879-907), xtrap != 0 only
+    patterns the nderiv patterns evaluated           (n_pat, ndim)
+    values   reference `evaluate` at tests.cases.make_queries(spec)   (n_pat, NQ)
+
+Inputs are NOT stored: they are regenerated from the seeded generator
+(splpak_amd/synth.py).  Usage:
+
+    python oracle/gen_golden.py            # all fast cases
+    python oracle/gen_golden.py --slow     # also the ~1 h 64x64 case
+    python oracle/gen_golden.py NAME...    # selected cases
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.binding import Reference  # noqa: E402
+from tests.cases import CASES, make_inputs, make_queries, nderiv_patterns  # noqa: E402
+
+
+def run_case(R, name, spec, outdir):
+    inp = make_inputs(spec)
+    nd = inp["ndim"]
+    t0 = time.time()
+    coef, ierr, work = R.fit(nd, inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"],
+                             inp["xmax"], inp["nodes"], inp["xtrap"])
+    t_fit = time.time() - t0
+    ncol = int(np.prod(inp["nodes"]))
+    q = make_queries(spec)
+    pats = np.array(nderiv_patterns(nd), dtype=np.int32)
+    vals = np.zeros((len(pats), q.shape[0]))
+    for i, p in enumerate(pats):
+        vals[i], _ = R.evaluate(nd, q, p, coef, inp["xmin"], inp["xmax"], inp["nodes"])
+    # splfe (no nderiv) must equal the all-zero pattern; checked here, not stored
+    v0, _ = R.evaluate(nd, q, None, coef, inp["xmin"], inp["xmax"], inp["nodes"])
+    assert np.array_equal(v0, vals[0])
+    hist = work[:ncol].copy() if inp["xtrap"] != 0.0 else np.zeros(0)
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), coef=coef[:ncol],
+                        ierror=np.int32(ierr), hist=hist, patterns=pats, values=vals,
+                        fit_seconds=np.float64(t_fit))
+    print(f"{name:16s} ncol={ncol:5d} m={spec['m']:6d} ierror={ierr} fit={t_fit:8.2f}s "
+          f"|coef|max={np.abs(coef[:ncol]).max():.3e}", flush=True)
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("-")]
+    slow = "--slow" in sys.argv
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    R = Reference()
+    for name, spec in CASES.items():
+        if args and name not in args:
+            continue
+        if spec.get("slow") and not (slow or name in args):
+            continue
+        run_case(R, name, spec, outdir)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,287 @@
+"""ctypes plumbing over the C ABI in ``include/splpak_hip.h``.
+
+This is NOT a second implementation: every function forwards to
+``libsplpak_hip.so`` (hand-written HIP for gfx950).  It exists so that the
+pytest parity suite and ``bench.py`` can drive the same entry points the Fortran
+``splpak_module`` binds.  Loading fails loudly when the library is missing, and
+every compute entry point fails with ``SPLPAK_E_NODEVICE`` when there is no GPU;
+there is no CPU fallback on the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsplpak_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+
+# every symbol include/splpak_hip.h declares
+SYMBOLS = [
+    "splpak_fit_f64", "splpak_fit_f32", "splpak_eval_f64", "splpak_eval_f32",
+    "splpak_plan_comm_len", "splpak_plan_create", "splpak_plan_destroy",
+    "splpak_plan_set_allreduce", "splpak_plan_set_refine", "splpak_plan_fit_dev",
+    "splpak_plan_hist_dev", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing",
+    "splpak_eval_dev_f64", "splpak_synth_points_f64", "splpak_synth_queries_f64",
+    "splpak_debug_spd_band_solve_f64", "splpak_last_error_message", "splpak_device_name",
+]
+
+E_NODEVICE, E_NOMEM, E_BADARG, E_UNSUPPORTED, E_COMM = -1, -2, -3, -4, -5
+
+_lib = None
+
+
+class SplpakError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SplpakError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); the splpak HIP path has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.splpak_fit_f64.restype = i32
+    L.splpak_fit_f64.argtypes = [i32, _dp, i32, _dp, _dp, i64, _dp, _dp, _ip, dbl, _dp, i64, i64, _dp, _dp]
+    L.splpak_fit_f32.restype = i32
+    L.splpak_fit_f32.argtypes = [i32, _fp, i32, _fp, _fp, i64, _fp, _fp, _ip, C.c_float, _fp, i64, i64, _fp, _dp]
+    L.splpak_eval_f64.restype = i32
+    L.splpak_eval_f64.argtypes = [i32, i64, _dp, i32, _ip, _dp, _dp, _dp, _ip, _dp]
+    L.splpak_eval_f32.restype = i32
+    L.splpak_eval_f32.argtypes = [i32, i64, _fp, i32, _ip, _fp, _fp, _fp, _ip, _fp]
+    L.splpak_plan_comm_len.restype = i64
+    L.splpak_plan_comm_len.argtypes = [i32, _ip]
+    L.splpak_plan_create.restype = i32
+    L.splpak_plan_create.argtypes = [i32, _ip, _dp, _dp, dbl, i64, vp, i64, C.POINTER(vp)]
+    L.splpak_plan_destroy.restype = None
+    L.splpak_plan_destroy.argtypes = [vp]
+    L.splpak_plan_set_allreduce.restype = None
+    L.splpak_plan_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i32, i32]
+    L.splpak_plan_set_refine.restype = None
+    L.splpak_plan_set_refine.argtypes = [vp, i32, dbl]
+    L.splpak_plan_fit_dev.restype = i32
+    L.splpak_plan_fit_dev.argtypes = [vp, vp, i32, vp, vp, i64, vp, vp, _dp]
+    L.splpak_plan_hist_dev.restype = vp
+    L.splpak_plan_hist_dev.argtypes = [vp]
+    L.splpak_plan_enable_kernel_timing.restype = None
+    L.splpak_plan_enable_kernel_timing.argtypes = [vp, i32]
+    L.splpak_plan_kernel_timing.restype = None
+    L.splpak_plan_kernel_timing.argtypes = [vp, _dp]
+    L.splpak_eval_dev_f64.restype = i32
+    L.splpak_eval_dev_f64.argtypes = [i32, i64, vp, i32, _ip, vp, _dp, _dp, _ip, vp, vp]
+    L.splpak_synth_points_f64.restype = i32
+    L.splpak_synth_points_f64.argtypes = [i32, i64, i64, vp, vp, vp, vp]
+    L.splpak_synth_queries_f64.restype = i32
+    L.splpak_synth_queries_f64.argtypes = [i32, i64, i64, i64, vp, vp]
+    L.splpak_debug_spd_band_solve_f64.restype = i32
+    L.splpak_debug_spd_band_solve_f64.argtypes = [i32, i32, _dp, _dp, _dp]
+    L.splpak_last_error_message.restype = i32
+    L.splpak_last_error_message.argtypes = [C.c_char_p, i32]
+    L.splpak_device_name.restype = i32
+    L.splpak_device_name.argtypes = [C.c_char_p, i32]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib().splpak_last_error_message(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def _check(rc: int) -> int:
+    """Negative = infrastructure failure -> raise; >= 0 is the reference's ierror."""
+    if rc < 0:
+        raise SplpakError(f"splpak HIP library error {rc}: {last_error()}")
+    return rc
+
+
+def device_name() -> str:
+    buf = C.create_string_buffer(256)
+    _check(lib().splpak_device_name(buf, 256))
+    return buf.value.decode()
+
+
+def _p(a, ty):
+    return None if a is None else a.ctypes.data_as(ty)
+
+
+def _grid(ndim, xmin, xmax, nodes, dt=np.float64):
+    xmin = np.ascontiguousarray(np.atleast_1d(xmin), dtype=dt)
+    xmax = np.ascontiguousarray(np.atleast_1d(xmax), dtype=dt)
+    nodes = np.ascontiguousarray(np.atleast_1d(nodes), dtype=np.int32)
+    return xmin, xmax, nodes
+
+
+# ---------------------------------------------------------------------------
+# host-pointer entry points (what splpak_module binds)
+# ---------------------------------------------------------------------------
+
+def fit(ndim, xdata, ydata, wdata, xmin, xmax, nodes, xtrap, ncf=None, nwrk=-1, ndata=None,
+        l1xdat=None, want_hist=False, real32=False):
+    """splcw (wdata given) / splcc (wdata None).  -> (coef, ierror, hist|None, info)."""
+    dt = np.float32 if real32 else np.float64
+    rp = _fp if real32 else _dp
+    xdata = np.ascontiguousarray(xdata, dtype=dt)
+    if xdata.ndim == 1:
+        xdata = xdata.reshape(-1, 1)
+    ydata = np.ascontiguousarray(ydata, dtype=dt)
+    if wdata is not None:
+        wdata = np.ascontiguousarray(wdata, dtype=dt)
+    xmin, xmax, nodes = _grid(ndim, xmin, xmax, nodes, dt)
+    if ndata is None:
+        ndata = xdata.shape[0]
+    if l1xdat is None:
+        l1xdat = xdata.shape[1]
+    ncol = int(np.prod(np.maximum(nodes[:max(ndim, 1)].astype(np.int64), 1)))
+    if ncf is None:
+        ncf = ncol
+    coef = np.zeros(max(ncf, 1), dtype=dt)
+    hist = np.zeros(max(ncol, 1), dtype=dt) if want_hist else None
+    info = np.zeros(8)
+    fn = lib().splpak_fit_f32 if real32 else lib().splpak_fit_f64
+    xt = C.c_float(xtrap) if real32 else C.c_double(xtrap)
+    rc = _check(fn(ndim, _p(xdata, rp), l1xdat, _p(ydata, rp), _p(wdata, rp), ndata, _p(xmin, rp),
+                   _p(xmax, rp), _p(nodes, _ip), xt, _p(coef, rp), ncf, nwrk, _p(hist, rp),
+                   _p(info, _dp)))
+    return coef, rc, hist, info
+
+
+def evaluate(ndim, xq, nderiv, coef, xmin, xmax, nodes, real32=False):
+    """Batched splde (nderiv given) / splfe (nderiv None).  -> (values, ierror)."""
+    dt = np.float32 if real32 else np.float64
+    rp = _fp if real32 else _dp
+    xq = np.ascontiguousarray(xq, dtype=dt)
+    if xq.ndim == 1:
+        xq = xq.reshape(-1, 1)
+    nq, ldx = xq.shape
+    coef = np.ascontiguousarray(coef, dtype=dt)
+    xmin, xmax, nodes = _grid(ndim, xmin, xmax, nodes, dt)
+    nd = None if nderiv is None else np.ascontiguousarray(nderiv, dtype=np.int32)
+    out = np.zeros(nq, dtype=dt)
+    fn = lib().splpak_eval_f32 if real32 else lib().splpak_eval_f64
+    rc = _check(fn(ndim, nq, _p(xq, rp), ldx, _p(nd, _ip), _p(coef, rp), _p(xmin, rp), _p(xmax, rp),
+                   _p(nodes, _ip), _p(out, rp)))
+    return out, rc
+
+
+# ---------------------------------------------------------------------------
+# resident-data API (torch tensors own the device memory)
+# ---------------------------------------------------------------------------
+
+class Plan:
+    """A fit plan for one node grid on the current torch CUDA(HIP) device."""
+
+    def __init__(self, ndim, nodes, xmin, xmax, xtrap, max_ndata, comm=None):
+        self._L = lib()
+        self.ndim = ndim
+        self.xmin, self.xmax, self.nodes = _grid(ndim, xmin, xmax, nodes)
+        self.ncol = int(np.prod(self.nodes.astype(np.int64)))
+        self.comm_len = int(self._L.splpak_plan_comm_len(ndim, _p(self.nodes, _ip)))
+        self.comm = comm          # optional torch tensor (float64, device) of >= comm_len elements
+        self._cb = None
+        h = C.c_void_p()
+        comm_ptr = None if comm is None else C.c_void_p(comm.data_ptr())
+        comm_n = 0 if comm is None else comm.numel()
+        rc = self._L.splpak_plan_create(ndim, _p(self.nodes, _ip), _p(self.xmin, _dp),
+                                        _p(self.xmax, _dp), float(xtrap), int(max_ndata), comm_ptr,
+                                        comm_n, C.byref(h))
+        if rc != 0:
+            if rc < 0:
+                _check(rc)
+            raise SplpakError(f"plan rejected with ierror {rc}")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.splpak_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_refine(self, max_steps, tol):
+        self._L.splpak_plan_set_refine(self._h, int(max_steps), float(tol))
+
+    def set_allreduce(self, fn, rank, world):
+        """fn(offset_elems, count) must sum-all-reduce self.comm[offset:offset+count] in place."""
+        base = self.comm.data_ptr()
+
+        def _cb(ptr, count, stream, user):
+            try:
+                fn((int(ptr) - base) // 8, int(count))
+                return 0
+            except Exception as exc:  # pragma: no cover - surfaced as SPLPAK_E_COMM
+                print("all-reduce callback failed:", exc, flush=True)
+                return 1
+
+        self._cb = ALLREDUCE_FN(_cb)
+        self._L.splpak_plan_set_allreduce(self._h, self._cb, None, int(rank), int(world))
+
+    def enable_kernel_timing(self, on=True):
+        self._L.splpak_plan_enable_kernel_timing(self._h, 1 if on else 0)
+
+    def kernel_timing(self):
+        out = np.zeros(4)
+        self._L.splpak_plan_kernel_timing(self._h, _p(out, _dp))
+        return dict(syrk_launches=out[0], syrk_ms=out[1], syrk_flop=out[2], factor_ms=out[3])
+
+    def fit(self, xdata, ydata, wdata, coef, stream=0):
+        """All arguments are torch float64 device tensors; xdata is (ndata, l1xdat) row-major
+        (= the reference's column-major xdata(l1xdat, ndata)).  Returns (ierror, info)."""
+        info = np.zeros(8)
+        ndata, l1 = xdata.shape
+        rc = self._L.splpak_plan_fit_dev(self._h, xdata.data_ptr(), int(l1), ydata.data_ptr(),
+                                         None if wdata is None else wdata.data_ptr(), int(ndata),
+                                         coef.data_ptr(), C.c_void_p(stream), _p(info, _dp))
+        return _check(rc), info
+
+    def hist_ptr(self):
+        return self._L.splpak_plan_hist_dev(self._h)
+
+
+def evaluate_dev(ndim, xq, nderiv, coef, xmin, xmax, nodes, out, stream=0):
+    """Batched evaluation on torch device tensors (asynchronous on `stream`)."""
+    xmin, xmax, nodes = _grid(ndim, xmin, xmax, nodes)
+    nd = None if nderiv is None else np.ascontiguousarray(nderiv, dtype=np.int32)
+    nq, ldx = xq.shape
+    return _check(lib().splpak_eval_dev_f64(ndim, int(nq), xq.data_ptr(), int(ldx), _p(nd, _ip),
+                                            coef.data_ptr(), _p(xmin, _dp), _p(xmax, _dp),
+                                            _p(nodes, _ip), out.data_ptr(), C.c_void_p(stream)))
+
+
+def synth_points_dev(ndim, first_point, ndata, xdata, ydata, wdata, stream=0):
+    return _check(lib().splpak_synth_points_f64(ndim, int(first_point), int(ndata),
+                                                None if xdata is None else xdata.data_ptr(),
+                                                None if ydata is None else ydata.data_ptr(),
+                                                None if wdata is None else wdata.data_ptr(),
+                                                C.c_void_p(stream)))
+
+
+def synth_queries_dev(ndim, ndata_before, first_query, nq, xq, stream=0):
+    return _check(lib().splpak_synth_queries_f64(ndim, int(ndata_before), int(first_query), int(nq),
+                                                 xq.data_ptr(), C.c_void_p(stream)))
+
+
+def debug_spd_band_solve(a_lower, halfbw, b):
+    """Solve with the library's band Cholesky (diagnostics).  a_lower: (n, n) array, lower part used."""
+    a = np.asfortranarray(a_lower, dtype=np.float64)
+    n = a.shape[0]
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(n)
+    rc = _check(lib().splpak_debug_spd_band_solve_f64(n, int(halfbw), _p(a, _dp), _p(b, _dp), _p(x, _dp)))
+    return x, rc

@@ -1,0 +1,152 @@
+// 1-D natural-spline basis functions and the per-point 4-wide window table.
+//
+// What the reference computes one (point, basis tuple) at a time in bascmp
+// (src/splpak.F90:206-389) is restructured here as a separable table: for every
+// dimension the (at most) four 1-D factors that can be non-zero at x are
+// evaluated once, and the 4^ndim tensor products are formed by the caller.
+// Closed forms follow SURVEY.md appendix A (derived from :231-381); the strict
+// inequalities are kept exactly as in the reference so values at nodes agree in
+// sign and zero-ness.
+#pragma once
+#include "common.hpp"
+
+namespace splpak {
+
+// kind 1: left-linear (ib <= 1), 2: chapeau, 3: right-linear (ib >= nodes-2)  (:231-240)
+__host__ __device__ inline int basis_kind(int ib, int nod)
+{
+    return ib <= 1 ? 1 : (ib >= nod - 2 ? 3 : 2);
+}
+
+// value (deriv 0), d/dx (1) or d2/dx2 (2) of the 1-D basis function centred at xb.
+// s = 1/dx.
+__host__ __device__ inline double basis_1d(int kind, int deriv, double x, double xb, double s)
+{
+#pragma clang fp contract(off)
+    double b = 0.0;
+    if (kind == 2) {
+        if (deriv == 0) {                       // :253-270
+            const double z = fabs(s * (x - xb)) - 2.0;
+            if (z < 0.0) {
+                b = -0.25 * (z * z * z);
+                const double z1 = z + 1.0;
+                if (z1 < 0.0) b += z1 * z1 * z1;
+            }
+        } else if (deriv == 1) {                // :272-286
+            const double u = x - xb;
+            const double f = (u < 0.0) ? -s : s;
+            const double z = f * u - 2.0;
+            if (z < 0.0) {
+                b = -0.75 * (z * z);
+                const double z1 = z + 1.0;
+                if (z1 < 0.0) b += 3.0 * (z1 * z1);
+                b *= f;
+            }
+        } else {                                // :288-300
+            const double z = s * fabs(x - xb) - 2.0;
+            if (z < 0.0) {
+                b = -1.5 * z;
+                const double z1 = z + 1.0;
+                if (z1 < 0.0) b += 6.0 * z1;
+                b *= s * s;
+            }
+        }
+        return b;
+    }
+    // end functions: zero for z <= 0, cubic on (0,2), straight line 3z-3 beyond
+    // (natural boundary + linear extrapolation, :358-379).  kind 1 mirrors kind 3.
+    const double f = (kind == 1) ? -s : s;
+    if (deriv == 0) {                           // :345-379
+        const double z = (kind == 1) ? s * (xb - x) + 2.0 : s * (x - xb) + 2.0;
+        if (z > 0.0) {
+            if (z < 2.0) {
+                b = 0.5 * (z * z * z);
+                const double z1 = z - 1.0;
+                if (z1 > 0.0) b -= z1 * z1 * z1;
+            } else {
+                b = 3.0 * z - 3.0;
+            }
+        }
+    } else if (deriv == 1) {                    // :302-322
+        const double z = f * (x - xb) + 2.0;
+        if (z > 0.0) {
+            if (z < 2.0) {
+                b = 1.5 * (z * z);
+                const double z1 = z - 1.0;
+                if (z1 > 0.0) b -= 3.0 * (z1 * z1);
+                b *= f;
+            } else {
+                b = 3.0 * f;
+            }
+        }
+    } else {                                    // :324-340
+        const double z = f * (x - xb) + 2.0;
+        const double z1 = z - 1.0;
+        if (fabs(z1) < 1.0) {
+            b = 3.0 * z;
+            if (z1 > 0.0) b -= 6.0 * z1;
+            b *= f * f;
+        }
+    }
+    return b;
+}
+
+// Window rule of the fit (:821-827) and of the evaluation (:1201-1209):
+//   it = trunc(dxin*(x-xmin)); ibmn = min(max(it-1,0),nod-2); ibmx = max(min(it+2,nod-1),1).
+// The reference visits [ibmn, ibmx] (2..4 nodes).  Here every point gets a fixed
+// 4-wide window [ws, ws+3] that contains it; entries outside [ibmn, ibmx] are set
+// to exactly 0, which is what the reference's row holds there.
+__host__ __device__ inline int window_start(const Grid &g, int d, double x, int &lo, int &hi)
+{
+#pragma clang fp contract(off)
+    const int nod = g.nodes[d];
+    const double t = g.dxin[d] * (x - g.xmin[d]);
+    // saturating truncation toward zero (keeps far-outside points defined)
+    int it = (t >= 2.0e9) ? 2000000000 : (t <= -2.0e9 ? -2000000000 : (int)t);
+    int a = it - 1;
+    if (a < 0) a = 0;
+    lo = a < nod - 2 ? a : nod - 2;
+    int h = it + 2;
+    if (h > nod - 1) h = nod - 1;
+    hi = h > 1 ? h : 1;
+    return a < nod - 4 ? a : nod - 4;
+}
+
+__host__ __device__ inline int window_table(const Grid &g, int d, double x, int deriv, double b[4])
+{
+#pragma clang fp contract(off)
+    int lo, hi;
+    const int ws = window_start(g, d, x, lo, hi);
+    const int nod = g.nodes[d];
+    const double s = g.dxin[d];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ib = ws + k;
+        double v = 0.0;
+        if (ib >= lo && ib <= hi) {
+            const double xb = g.xmin[d] + (double)ib * g.dx[d];   // :246
+            v = basis_1d(basis_kind(ib, nod), deriv, x, xb, s);
+        }
+        b[k] = v;
+    }
+    return ws;
+}
+
+// nearest-node address of the sparse-area histogram (:894-902), including the
+// reference's quirk: an out-of-range coordinate only skips ITS dimension in the
+// Horner address; the point is still counted (:899).
+__host__ __device__ inline int nearest_node_address(const Grid &g, const double *x)
+{
+#pragma clang fp contract(off)
+    int iin = 0;
+    for (int dc = 0; dc < g.ndim; ++dc) {
+        const int d = g.ndim - 1 - dc;
+        const double t = g.dxin[d] * (x[d] - g.xmin[d]) + 0.5;
+        const int inidim = (t >= 2.0e9) ? 2000000000 : (t <= -2.0e9 ? -2000000000 : (int)t);
+        if (inidim < 0 || inidim > g.nodes[d] - 1) continue;
+        iin = g.nodes[d] * iin + inidim;
+    }
+    return iin;
+}
+
+}  // namespace splpak

@@ -1,0 +1,85 @@
+// Host-side launchers of the HIP kernels (implemented in the .hip files).
+#pragma once
+#include "common.hpp"
+#include <vector>
+
+namespace splpak {
+
+// ---- eval.hip
+hipError_t launch_eval(const Grid &g, long long nq, const double *xq, int ldxq, const int *nderiv,
+                       const double *coef, double *out, hipStream_t st);
+hipError_t launch_eval_f32(const Grid &g, long long nq, const float *xq, int ldxq, const int *nderiv,
+                           const float *coef, float *out, hipStream_t st);
+
+// ---- synth.hip
+hipError_t launch_synth_points(int ndim, long long first, long long n, double *x, double *y,
+                               double *w, hipStream_t st);
+hipError_t launch_synth_queries(int ndim, long long skip_draws, long long nq, double *xq,
+                                hipStream_t st);
+
+// ---- assemble.hip
+// scalars (device doubles) written by the assembly kernels
+enum { SC_TOTLWT = 0, SC_NROWS_DATA = 1, SC_NROWS_CONS = 2, SC_COUNT = 8 };
+
+struct SortScratch {
+    int *key;        // [max_ndata] cell key per point (ncell = zero-weight sentinel)
+    int *count;      // [ncell + 2]
+    int *offset;     // [ncell + 2] exclusive scan of count
+    int *cursor;     // [ncell + 1]
+    double *xs;      // [ndim][cap] sorted coordinates, SoA
+    double *ys;      // [cap]
+    double *ws;      // [cap]
+    long long cap;   // max_ndata
+};
+
+// keys + per-cell counts + (xtrap != 0) nearest-node histogram + scalars
+hipError_t launch_keys(const Grid &g, long long m, const double *x, int ldx, const double *w,
+                       const SortScratch &s, double *hist, double *scal, hipStream_t st);
+hipError_t launch_scan_scatter(const Grid &g, long long m, const double *x, int ldx,
+                               const double *y, const double *w, const SortScratch &s,
+                               hipStream_t st);
+// per-cell Gram blocks -> half-stencil normal equations nst[ncol][hstencil], rhs[ncol]
+hipError_t launch_gram(const Grid &g, const SortScratch &s, double *nst, double *rhs,
+                       hipStream_t st);
+// data part of the refinement residual: rho += A^T W (W y - W A x)
+hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rho,
+                           hipStream_t st);
+// derivative-constraint rows of the data-sparse nodes (:921-1046).
+//   nst != NULL : add c c^T of every constraint row to the normal equations and
+//                 count the rows into scal[SC_NROWS_CONS]
+//   xvec != NULL: rho -= c (c . x) for every constraint row (residual mode)
+hipError_t launch_constraints(const Grid &g, const double *hist, const double *scal, double xtrap,
+                              double *nst, const double *xvec, double *rho, double *scal_out,
+                              hipStream_t st);
+
+// ---- bandchol.hip
+constexpr int NBLK = 256;     // block size of the band factorisation
+struct Band {
+    double *ab;       // dense-view base: A(i,j) = ab[i + j*lda], j <= i <= j + halfbw
+    double *dinv;     // [nblk][NBLK*NBLK] inverses of the diagonal blocks of L (column-major)
+    long long lda;    // column stride of the dense view (ld - 1)
+    int n;            // logical order
+    int npad;         // padded to a multiple of NBLK (identity on the padding)
+    int nblk;         // npad / NBLK
+    int bw;           // block half-bandwidth: ceil(halfbw / NBLK)
+    size_t bytes;     // allocation size of ab
+};
+size_t band_bytes(int n, int halfbw, Band *desc);
+// zero the band, put 1 on the padded diagonal, scatter the half-stencil into it
+hipError_t launch_expand(const Grid &g, const double *nst, const Band &b, hipStream_t st);
+
+struct CholStats {            // optional per-kernel accounting (HIP events)
+    bool enabled = false;
+    double syrk_launches = 0, syrk_ms = 0, syrk_flop = 0, factor_ms = 0;
+};
+// in-place L L^T; *info_dev (device int) is set to 1 + column of the first
+// non-positive pivot (0 = success); min pivot is tracked in minpiv_dev
+hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipStream_t st,
+                         CholStats *stats);
+// x <- (L L^T)^{-1} x; x and tmp of length npad (padding entries of x must be 0)
+hipError_t band_solve(const Band &b, double *x, double *tmp, hipStream_t st);
+
+// small vector helpers (vecops in bandchol.hip)
+hipError_t launch_axpy_absmax(int n, double *x, const double *dx, double *absmax2, hipStream_t st);
+
+}  // namespace splpak

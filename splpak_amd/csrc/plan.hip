@@ -1,0 +1,641 @@
+// Fit driver and the C ABI (include/splpak_hip.h).
+//
+// The fit that the reference performs as "one dense row at a time through a dense
+// Householder solver" (splcw :512-1060 -> suprls :1375-1695) is done here as
+//   1. bin the points by 4-wide node window (counting sort),       assemble.hip
+//   2. per-window Gram blocks -> banded normal equations N, r,      assemble.hip
+//   3. derivative-constraint rows of data-sparse nodes -> N,        assemble.hip
+//   4. blocked band Cholesky on the f64 matrix cores,               bandchol.hip
+//   5. solve + iterative refinement with the residual recomputed FROM THE ROWS,
+//      rho = A^T W (W y - W A x) - C^T C x, which brings the normal-equation
+//      solution back to the accuracy of an orthogonal factorisation
+//      (1e-13..2e-12 max-norm vs the reference).
+// Multi-GPU: every rank runs 1-2 on its shard of the points; the
+// histogram, then (N, r), then each refinement residual are sum-all-reduced
+// through the caller's hook (RCCL via torch.distributed); 3 is applied by rank 0
+// before the reduction so all ranks hold bit-identical normal equations; 4-5 are
+// replicated.
+#include "kernels.hpp"
+#include "../../include/splpak_hip.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace splpak {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string &msg) { g_err = msg; }
+
+bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    (void)hipGetLastError();
+    return false;
+}
+
+// reference-order validation shared by fit and evaluation (:716-750, :1166-1210).
+// returns 0 or 101/102/103
+static int build_grid(int ndim, const int *nodes, const double *xmin, const double *xmax, Grid &g,
+                      long long *ncol_out)
+{
+    std::memset(&g, 0, sizeof(g));
+    if (ndim < 1) return 101;
+    if (ndim > MAXD) return SPLPAK_E_UNSUPPORTED;
+    g.ndim = ndim;
+    long long ncol = 1, ncell = 1, cs = 1, ls = 1;
+    int nb = 1, h = 1, hb = 0;
+    for (int d = 0; d < ndim; ++d) {
+        const int nod = nodes[d];
+        if (nod < 4) return 102;
+        const double xrng = xmax[d] - xmin[d];
+        if (xrng == 0.0) return 103;
+        g.nodes[d] = nod;
+        g.xmin[d] = xmin[d];
+        g.dx[d] = xrng / (double)(nod - 1);        // :747
+        g.dxin[d] = 1.0 / g.dx[d];                 // :748
+        g.colstride[d] = (int)cs;
+        g.cells[d] = nod - 3;
+        g.cellstride[d] = (int)ls;
+        hb += 3 * (int)cs;
+        cs *= nod;
+        ls *= (nod - 3);
+        ncol *= nod;
+        ncell *= (nod - 3);
+        nb *= 4;
+        h *= 7;
+        if (ncol > (1LL << 30)) { if (ncol_out) *ncol_out = ncol; return SPLPAK_E_UNSUPPORTED; }
+    }
+    for (int d = ndim; d < MAXD; ++d) { g.nodes[d] = 4; g.dx[d] = g.dxin[d] = 1.0; g.cells[d] = 1; }
+    g.ncol = (int)ncol;
+    g.ncell = (int)ncell;
+    g.nb = nb;
+    g.hstencil = (h + 1) / 2;
+    g.halfbw = hb;
+    if (ncol_out) *ncol_out = ncol;
+    return 0;
+}
+
+}  // namespace splpak
+
+using namespace splpak;
+
+struct splpak_plan {
+    Grid g{};
+    double xtrap = 0;
+    long long max_ndata = 0;
+    SortScratch s{};
+    Band band{};
+    double *comm = nullptr;
+    bool own_comm = false;
+    long long comm_len = 0;
+    // views into comm
+    double *nst = nullptr, *rhs = nullptr, *scalG = nullptr, *hist = nullptr, *scalH = nullptr,
+           *rho = nullptr;
+    long long lenG = 0, lenH = 0, lenR = 0;
+    double *xvec = nullptr, *tmp = nullptr, *small = nullptr;   // small: [absmax(2) | minpiv(1) | pad]
+    int *info = nullptr;
+    splpak_allreduce_fn ar = nullptr;
+    void *ar_user = nullptr;
+    int rank = 0, world = 1;
+    int max_refine = 4;
+    double tol = 1e-13;
+    CholStats stats;
+    std::vector<void *> owned;
+};
+
+static long long comm_len_of(const Grid &g)
+{
+    const long long npad = ((g.ncol + NBLK - 1) / NBLK) * (long long)NBLK;
+    return (long long)g.ncol * g.hstencil + g.ncol + SC_COUNT   // G: nst, rhs, scalG
+           + (long long)g.ncol + SC_COUNT                        // H: hist, scalH
+           + npad;                                               // R: rho
+}
+
+template <typename T>
+static bool dev_alloc(splpak_plan *p, T **ptr, size_t count)
+{
+    void *q = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "hipMalloc of %.3f GB failed: %s", (double)(count * sizeof(T)) / 1e9,
+                 hipGetErrorString(e));
+        set_error(buf);
+        (void)hipGetLastError();
+        return false;
+    }
+    p->owned.push_back(q);
+    *ptr = static_cast<T *>(q);
+    return true;
+}
+
+static int device_ready()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no usable HIP device: the splpak HIP path has no CPU fallback");
+        (void)hipGetLastError();
+        return SPLPAK_E_NODEVICE;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int64_t splpak_plan_comm_len(int32_t ndim, const int32_t *nodes)
+{
+    double xmin[MAXD] = {0, 0, 0, 0}, xmax[MAXD] = {1, 1, 1, 1};
+    Grid g;
+    if (!nodes || build_grid(ndim, nodes, xmin, xmax, g, nullptr) != 0) return -1;
+    return comm_len_of(g);
+}
+
+int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmin,
+                           const double *xmax, double xtrap, int64_t max_ndata,
+                           void *comm_buf_dev, int64_t comm_len, splpak_plan **plan)
+{
+    if (!plan || !nodes || !xmin || !xmax) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    *plan = nullptr;
+    Grid g;
+    long long ncol = 0;
+    const int v = build_grid(ndim, nodes, xmin, xmax, g, &ncol);
+    if (v != 0) {
+        if (v == SPLPAK_E_UNSUPPORTED) set_error("ndim > 4 or more than 2^30 nodes is not supported");
+        return v;
+    }
+    if (max_ndata < 1) return 105;
+    if (int r = device_ready()) return r;
+
+    splpak_plan *p = new splpak_plan();
+    p->g = g;
+    p->xtrap = xtrap;
+    p->max_ndata = max_ndata;
+    bool ok = true;
+    // sort scratch
+    p->s.cap = max_ndata;
+    ok = ok && dev_alloc(p, &p->s.key, (size_t)max_ndata);
+    ok = ok && dev_alloc(p, &p->s.count, (size_t)g.ncell + 2);
+    ok = ok && dev_alloc(p, &p->s.offset, (size_t)g.ncell + 2);
+    ok = ok && dev_alloc(p, &p->s.cursor, (size_t)g.ncell + 2);
+    ok = ok && dev_alloc(p, &p->s.xs, (size_t)max_ndata * g.ndim);
+    ok = ok && dev_alloc(p, &p->s.ys, (size_t)max_ndata);
+    ok = ok && dev_alloc(p, &p->s.ws, (size_t)max_ndata);
+    // band
+    band_bytes(g.ncol, g.halfbw, &p->band);
+    ok = ok && dev_alloc(p, &p->band.ab, p->band.bytes / sizeof(double));
+    ok = ok && dev_alloc(p, &p->band.dinv, (size_t)p->band.nblk * NBLK * NBLK);
+    // communication buffer
+    p->comm_len = comm_len_of(g);
+    if (comm_buf_dev) {
+        if (comm_len < p->comm_len) {
+            set_error("comm buffer too small");
+            splpak_plan_destroy(p);
+            return SPLPAK_E_BADARG;
+        }
+        p->comm = static_cast<double *>(comm_buf_dev);
+    } else {
+        ok = ok && dev_alloc(p, &p->comm, (size_t)p->comm_len);
+        p->own_comm = true;
+    }
+    ok = ok && dev_alloc(p, &p->xvec, (size_t)p->band.npad);
+    ok = ok && dev_alloc(p, &p->tmp, (size_t)p->band.npad);
+    ok = ok && dev_alloc(p, &p->small, 8);
+    ok = ok && dev_alloc(p, &p->info, 2);
+    if (!ok) {
+        splpak_plan_destroy(p);
+        return SPLPAK_E_NOMEM;
+    }
+    p->lenG = (long long)g.ncol * g.hstencil + g.ncol + SC_COUNT;
+    p->lenH = (long long)g.ncol + SC_COUNT;
+    p->lenR = p->band.npad;
+    p->nst = p->comm;
+    p->rhs = p->nst + (long long)g.ncol * g.hstencil;
+    p->scalG = p->rhs + g.ncol;
+    p->hist = p->scalG + SC_COUNT;
+    p->scalH = p->hist + g.ncol;
+    p->rho = p->scalH + SC_COUNT;
+    *plan = p;
+    return 0;
+}
+
+void splpak_plan_destroy(splpak_plan *p)
+{
+    if (!p) return;
+    for (void *q : p->owned) (void)hipFree(q);
+    delete p;
+}
+
+void splpak_plan_set_allreduce(splpak_plan *p, splpak_allreduce_fn fn, void *user, int32_t rank,
+                               int32_t world)
+{
+    if (!p) return;
+    p->ar = fn;
+    p->ar_user = user;
+    p->rank = rank;
+    p->world = world < 1 ? 1 : world;
+}
+
+void splpak_plan_set_refine(splpak_plan *p, int32_t max_steps, double tol)
+{
+    if (!p) return;
+    p->max_refine = max_steps < 0 ? 0 : max_steps;
+    p->tol = tol;
+}
+
+void splpak_plan_enable_kernel_timing(splpak_plan *p, int32_t on)
+{
+    if (p) p->stats.enabled = on != 0;
+}
+
+void splpak_plan_kernel_timing(const splpak_plan *p, double *out4)
+{
+    if (!p || !out4) return;
+    out4[0] = p->stats.syrk_launches;
+    out4[1] = p->stats.syrk_ms;
+    out4[2] = p->stats.syrk_flop;
+    out4[3] = p->stats.factor_ms;
+}
+
+const double *splpak_plan_hist_dev(const splpak_plan *p) { return p ? p->hist : nullptr; }
+
+static int do_allreduce(splpak_plan *p, double *buf, long long count, hipStream_t st)
+{
+    if (!p->ar || p->world <= 1) return 0;
+    const int r = p->ar(buf, count, (void *)st, p->ar_user);
+    if (r != 0) { set_error("all-reduce callback failed"); return SPLPAK_E_COMM; }
+    return 0;
+}
+
+int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, const double *y,
+                            const double *w, int64_t ndata, double *coef_dev, void *stream,
+                            double *info)
+{
+    if (!p || !x || !y || !coef_dev) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (ndata < 1 && p->world <= 1) return 105;                       // :759-764
+    if (ndata > p->max_ndata) { set_error("ndata exceeds the plan's max_ndata"); return SPLPAK_E_BADARG; }
+    if (l1xdat < p->g.ndim) { set_error("l1xdat < ndim"); return SPLPAK_E_BADARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const Grid &g = p->g;
+    const Band &b = p->band;
+    const bool smooth = p->xtrap != 0.0;                              // swght, :769
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+
+    // ---- assembly -------------------------------------------------------
+    SPLPAK_HIP_TRY(hipMemsetAsync(p->comm, 0, sizeof(double) * (size_t)(p->lenG + p->lenH), st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(launch_keys(g, ndata, x, l1xdat, w, p->s, smooth ? p->hist : nullptr, p->scalH, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(launch_scan_scatter(g, ndata, x, l1xdat, y, w, p->s, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(launch_gram(g, p->s, p->nst, p->rhs, st), SPLPAK_E_NODEVICE);
+    if (int r = do_allreduce(p, p->hist, p->lenH, st)) return r;
+    if (smooth && p->rank == 0)
+        SPLPAK_HIP_TRY(launch_constraints(g, p->hist, p->scalH, p->xtrap, p->nst, nullptr, nullptr, p->scalG, st), SPLPAK_E_NODEVICE);
+    if (int r = do_allreduce(p, p->nst, p->lenG, st)) return r;
+
+    double hs[2 * SC_COUNT];
+    SPLPAK_HIP_TRY(hipMemcpyAsync(hs, p->scalG, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+    // scalG and scalH are not adjacent (hist sits between): fetch scalH separately
+    SPLPAK_HIP_TRY(hipMemcpyAsync(hs + SC_COUNT, p->scalH, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+    const double rows_data = hs[SC_COUNT + SC_NROWS_DATA];
+    const double rows_cons = hs[SC_NROWS_CONS];
+    auto t1 = clk::now();
+    if (info) {
+        for (int i = 0; i < 8; ++i) info[i] = 0.0;
+        info[0] = rows_data;
+        info[1] = rows_cons;
+        info[5] = std::chrono::duration<double>(t1 - t0).count();
+    }
+    // suprls error 33 "array has too few rows" (:1650-1654) -> 107 (:1053-1058)
+    if (rows_data + rows_cons < (double)g.ncol) {
+        SPLPAK_HIP_TRY(hipMemsetAsync(coef_dev, 0, sizeof(double) * (size_t)g.ncol, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+        return 107;
+    }
+
+    // ---- factorisation --------------------------------------------------
+    const double inf = std::numeric_limits<double>::infinity();
+    SPLPAK_HIP_TRY(hipMemsetAsync(p->info, 0, 2 * sizeof(int), st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(hipMemcpyAsync(p->small + 2, &inf, sizeof(double), hipMemcpyHostToDevice, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(launch_expand(g, p->nst, b, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(band_cholesky(b, p->info, p->small + 2, st, &p->stats), SPLPAK_E_NODEVICE);
+    int hinfo = 0;
+    double minpiv = 0.0;
+    SPLPAK_HIP_TRY(hipMemcpyAsync(&hinfo, p->info, sizeof(int), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(hipMemcpyAsync(&minpiv, p->small + 2, sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+    auto t2 = clk::now();
+    if (info) {
+        info[4] = minpiv;
+        info[6] = std::chrono::duration<double>(t2 - t1).count();
+    }
+    if (hinfo != 0) {
+        // not positive definite: the reference's "system is singular" (suprls 34 -> 107)
+        SPLPAK_HIP_TRY(hipMemsetAsync(coef_dev, 0, sizeof(double) * (size_t)g.ncol, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+        return 107;
+    }
+
+    // ---- solve + refinement --------------------------------------------
+    SPLPAK_HIP_TRY(hipMemsetAsync(p->xvec, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(hipMemcpyAsync(p->xvec, p->rhs, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(band_solve(b, p->xvec, p->tmp, st), SPLPAK_E_NODEVICE);
+    int steps = 0;
+    double last_rel = 0.0, prev_rel = inf;
+    for (int it = 0; it < p->max_refine; ++it) {
+        SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rho, st), SPLPAK_E_NODEVICE);
+        if (smooth && p->rank == 0)
+            SPLPAK_HIP_TRY(launch_constraints(g, p->hist, p->scalH, p->xtrap, nullptr, p->xvec, p->rho, nullptr, st), SPLPAK_E_NODEVICE);
+        if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
+        SPLPAK_HIP_TRY(band_solve(b, p->rho, p->tmp, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_axpy_absmax(g.ncol, p->xvec, p->rho, p->small, st), SPLPAK_E_NODEVICE);
+        double am[2];
+        SPLPAK_HIP_TRY(hipMemcpyAsync(am, p->small, 2 * sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+        ++steps;
+        last_rel = (am[1] > 0.0) ? am[0] / am[1] : 0.0;
+        if (!(last_rel == last_rel)) break;                   // NaN
+        if (last_rel <= p->tol) break;
+        if (last_rel > 0.5 * prev_rel && it >= 1) break;      // stagnation at the rounding floor
+        prev_rel = last_rel;
+    }
+    SPLPAK_HIP_TRY(hipMemcpyAsync(coef_dev, p->xvec, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+    auto t3 = clk::now();
+    if (info) {
+        info[2] = steps;
+        info[3] = last_rel;
+        info[7] = std::chrono::duration<double>(t3 - t2).count();
+    }
+    if (!(last_rel == last_rel)) return 107;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// one-shot host entry points
+// ---------------------------------------------------------------------------
+
+static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const double *ydata,
+                        const double *wdata, int64_t ndata, const double *xmin, const double *xmax,
+                        const int32_t *nodes, double xtrap, double *coef, int64_t ncf, int64_t nwrk,
+                        double *hist_out, double *info)
+{
+    if (!nodes || !xmin || !xmax) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    Grid g;
+    long long ncol = 0;
+    const int v = build_grid(ndim, nodes, xmin, xmax, g, &ncol);       // 101, 102, 103
+    if (v != 0) return v;
+    if (ncol > ncf) return 104;                                        // :751-756
+    if (ndata < 1) return 105;                                         // :759-764
+    if (nwrk >= 0) {                                                   // :772-781
+        const long long nwrk1 = (xtrap != 0.0) ? ncol + 1 : 1;
+        if (nwrk - nwrk1 + 1 < 1) return 106;
+    }
+    if (!xdata || !ydata || !coef) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (wdata && wdata[0] < 0.0) wdata = nullptr;                      // :581-588, :796
+    if (int r = device_ready()) return r;
+
+    splpak_plan *p = nullptr;
+    int rc = splpak_plan_create(ndim, nodes, xmin, xmax, xtrap, ndata, nullptr, 0, &p);
+    if (rc != 0) return rc;
+    double *dx = nullptr, *dy = nullptr, *dw = nullptr, *dc = nullptr;
+    bool ok = dev_alloc(p, &dx, (size_t)ndata * l1xdat) && dev_alloc(p, &dy, (size_t)ndata) &&
+              dev_alloc(p, &dc, (size_t)ncol) && (!wdata || dev_alloc(p, &dw, (size_t)ndata));
+    if (!ok) { splpak_plan_destroy(p); return SPLPAK_E_NOMEM; }
+    hipError_t e = hipMemcpy(dx, xdata, sizeof(double) * (size_t)ndata * l1xdat, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dy, ydata, sizeof(double) * (size_t)ndata, hipMemcpyHostToDevice);
+    if (e == hipSuccess && wdata) e = hipMemcpy(dw, wdata, sizeof(double) * (size_t)ndata, hipMemcpyHostToDevice);
+    if (!hip_ok(e, "hipMemcpy H2D")) { splpak_plan_destroy(p); return SPLPAK_E_NODEVICE; }
+    rc = splpak_plan_fit_dev(p, dx, l1xdat, dy, dw, ndata, dc, nullptr, info);
+    if (rc == 0 || rc == 107) {
+        e = hipMemcpy(coef, dc, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && hist_out && xtrap != 0.0)
+            e = hipMemcpy(hist_out, p->hist, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost);
+        if (!hip_ok(e, "hipMemcpy D2H")) rc = SPLPAK_E_NODEVICE;
+    }
+    splpak_plan_destroy(p);
+    return rc;
+}
+
+int32_t splpak_fit_f64(int32_t ndim, const double *xdata, int32_t l1xdat, const double *ydata,
+                       const double *wdata, int64_t ndata, const double *xmin, const double *xmax,
+                       const int32_t *nodes, double xtrap, double *coef, int64_t ncf, int64_t nwrk,
+                       double *hist_out, double *info)
+{
+    return fit_host(ndim, xdata, l1xdat, ydata, wdata, ndata, xmin, xmax, nodes, xtrap, coef, ncf,
+                    nwrk, hist_out, info);
+}
+
+int32_t splpak_fit_f32(int32_t ndim, const float *xdata, int32_t l1xdat, const float *ydata,
+                       const float *wdata, int64_t ndata, const float *xmin, const float *xmax,
+                       const int32_t *nodes, float xtrap, float *coef, int64_t ncf, int64_t nwrk,
+                       float *hist_out, double *info)
+{
+    // REAL32 storage, f64 arithmetic: widen on the host (the arrays are small
+    // next to the factorisation), run the f64 path, narrow the results.
+    if (ndim < 1) return 101;
+    if (ndim > MAXD) return SPLPAK_E_UNSUPPORTED;
+    if (!nodes || !xmin || !xmax) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    double xmn[MAXD], xmx[MAXD];
+    long long ncol = 1;
+    for (int d = 0; d < ndim; ++d) { xmn[d] = xmin[d]; xmx[d] = xmax[d]; ncol *= nodes[d] > 0 ? nodes[d] : 1; }
+    const bool have = xdata && ydata && coef && ndata >= 1 && ncol <= ncf;
+    std::vector<double> X, Y, W, Cf, H;
+    if (have) {
+        X.assign(xdata, xdata + (size_t)ndata * l1xdat);
+        Y.assign(ydata, ydata + (size_t)ndata);
+        if (wdata && wdata[0] >= 0.0f) W.assign(wdata, wdata + (size_t)ndata);
+        Cf.resize((size_t)ncol);
+        if (hist_out) H.resize((size_t)ncol);
+    }
+    const int rc = fit_host(ndim, have ? X.data() : nullptr, l1xdat, have ? Y.data() : nullptr,
+                            W.empty() ? nullptr : W.data(), ndata, xmn, xmx, nodes, (double)xtrap,
+                            have ? Cf.data() : nullptr, ncf, nwrk, H.empty() ? nullptr : H.data(), info);
+    if (have && (rc == 0 || rc == 107)) {
+        for (long long i = 0; i < ncol; ++i) coef[i] = (float)Cf[(size_t)i];
+        if (hist_out && xtrap != 0.0f)
+            for (long long i = 0; i < ncol; ++i) hist_out[i] = (float)H[(size_t)i];
+    }
+    return rc;
+}
+
+// returns 0/101/102/103/104 exactly like splde's checks (:1166-1194)
+static int eval_validate(int32_t ndim, const int32_t *nderiv, const double *xmin, const double *xmax,
+                         const int32_t *nodes, Grid &g)
+{
+    int v = build_grid(ndim, nodes, xmin, xmax, g, nullptr);
+    if (v != 0) return v;
+    if (nderiv)
+        for (int d = 0; d < ndim; ++d)
+            if (nderiv[d] < 0 || nderiv[d] > 2) v = 104;
+    return v;
+}
+
+int32_t splpak_eval_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int32_t ldxq,
+                            const int32_t *nderiv, const double *coef_dev, const double *xmin,
+                            const double *xmax, const int32_t *nodes, double *out_dev, void *stream)
+{
+    if (!nodes || !xmin || !xmax) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    Grid g;
+    const int v = eval_validate(ndim, nderiv, xmin, xmax, nodes, g);
+    if (v != 0 && v != 104) {
+        if (v > 0 && out_dev && nq > 0) (void)hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)nq, (hipStream_t)stream);
+        return v;
+    }
+    if (nq <= 0) return v;
+    if (!xq_dev || !coef_dev || !out_dev) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (int r = device_ready()) return r;
+    SPLPAK_HIP_TRY(launch_eval(g, nq, xq_dev, ldxq, nderiv, coef_dev, out_dev, (hipStream_t)stream), SPLPAK_E_NODEVICE);
+    return v;
+}
+
+}  // extern "C"
+
+template <typename T>
+static int32_t eval_host(int32_t ndim, int64_t nq, const T *xq, int32_t ldxq, const int32_t *nderiv,
+                         const T *coef, const T *xmin_t, const T *xmax_t, const int32_t *nodes, T *out)
+{
+    if (!nodes || !xmin_t || !xmax_t) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (ndim < 1) return 101;
+    if (ndim > MAXD) return SPLPAK_E_UNSUPPORTED;
+    double xmin[MAXD], xmax[MAXD];
+    for (int d = 0; d < ndim; ++d) { xmin[d] = (double)xmin_t[d]; xmax[d] = (double)xmax_t[d]; }
+    Grid g;
+    const int v = eval_validate(ndim, nderiv, xmin, xmax, nodes, g);
+    if (v != 0 && v != 104) {
+        if (v > 0 && out) for (int64_t i = 0; i < nq; ++i) out[i] = (T)0;
+        return v;
+    }
+    if (nq <= 0) return v;
+    if (!xq || !coef || !out) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (int r = device_ready()) return r;
+    T *dq = nullptr, *dc = nullptr, *dout = nullptr;
+    splpak_plan holder;   // only used as an allocation owner
+    bool ok = dev_alloc(&holder, &dq, (size_t)nq * ldxq) && dev_alloc(&holder, &dc, (size_t)g.ncol) &&
+              dev_alloc(&holder, &dout, (size_t)nq);
+    int rc = v;
+    if (!ok) rc = SPLPAK_E_NOMEM;
+    if (ok) {
+        hipError_t e = hipMemcpy(dq, xq, sizeof(T) * (size_t)nq * ldxq, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dc, coef, sizeof(T) * (size_t)g.ncol, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            if constexpr (sizeof(T) == 8)
+                e = launch_eval(g, nq, (const double *)dq, ldxq, nderiv, (const double *)dc, (double *)dout, nullptr);
+            else
+                e = launch_eval_f32(g, nq, (const float *)dq, ldxq, nderiv, (const float *)dc, (float *)dout, nullptr);
+        }
+        if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(T) * (size_t)nq, hipMemcpyDeviceToHost);
+        if (!hip_ok(e, "evaluation")) rc = SPLPAK_E_NODEVICE;
+    }
+    for (void *q : holder.owned) (void)hipFree(q);
+    return rc;
+}
+
+extern "C" {
+
+int32_t splpak_eval_f64(int32_t ndim, int64_t nq, const double *xq, int32_t ldxq,
+                        const int32_t *nderiv, const double *coef, const double *xmin,
+                        const double *xmax, const int32_t *nodes, double *out)
+{
+    return eval_host<double>(ndim, nq, xq, ldxq, nderiv, coef, xmin, xmax, nodes, out);
+}
+
+int32_t splpak_eval_f32(int32_t ndim, int64_t nq, const float *xq, int32_t ldxq,
+                        const int32_t *nderiv, const float *coef, const float *xmin,
+                        const float *xmax, const int32_t *nodes, float *out)
+{
+    return eval_host<float>(ndim, nq, xq, ldxq, nderiv, coef, xmin, xmax, nodes, out);
+}
+
+int32_t splpak_synth_points_f64(int32_t ndim, int64_t first_point, int64_t ndata, double *xdata_dev,
+                                double *ydata_dev, double *wdata_dev, void *stream)
+{
+    if (ndim < 1 || ndim > MAXD) return SPLPAK_E_UNSUPPORTED;
+    if (int r = device_ready()) return r;
+    SPLPAK_HIP_TRY(launch_synth_points(ndim, first_point, ndata, xdata_dev, ydata_dev, wdata_dev, (hipStream_t)stream), SPLPAK_E_NODEVICE);
+    return 0;
+}
+
+int32_t splpak_synth_queries_f64(int32_t ndim, int64_t ndata_before, int64_t first_query, int64_t nq,
+                                 double *xq_dev, void *stream)
+{
+    if (ndim < 1 || ndim > MAXD) return SPLPAK_E_UNSUPPORTED;
+    if (int r = device_ready()) return r;
+    const long long skip = (long long)ndata_before * (ndim + 2) + (long long)first_query * ndim;
+    SPLPAK_HIP_TRY(launch_synth_queries(ndim, skip, nq, xq_dev, (hipStream_t)stream), SPLPAK_E_NODEVICE);
+    return 0;
+}
+
+int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double *a_lower,
+                                        const double *bvec, double *x)
+{
+    if (n < 1 || halfbw < 0 || !a_lower || !bvec || !x) { set_error("bad argument"); return SPLPAK_E_BADARG; }
+    if (int r = device_ready()) return r;
+    splpak_plan holder;
+    Band b;
+    band_bytes(n, halfbw, &b);
+    double *dsmall = nullptr, *dx = nullptr, *dtmp = nullptr;
+    int *dinfo = nullptr;
+    bool ok = dev_alloc(&holder, &b.ab, b.bytes / sizeof(double)) &&
+              dev_alloc(&holder, &b.dinv, (size_t)b.nblk * NBLK * NBLK) &&
+              dev_alloc(&holder, &dsmall, 8) && dev_alloc(&holder, &dx, (size_t)b.npad) &&
+              dev_alloc(&holder, &dtmp, (size_t)b.npad) && dev_alloc(&holder, &dinfo, 2);
+    int rc = 0;
+    if (!ok) rc = SPLPAK_E_NOMEM;
+    if (ok) {
+        std::vector<double> hb(b.bytes / sizeof(double), 0.0), hx((size_t)b.npad, 0.0);
+        for (int j = 0; j < n; ++j)
+            for (int i = j; i < n && i - j <= halfbw; ++i)
+                hb[(size_t)i + (size_t)j * b.lda] = a_lower[(size_t)i + (size_t)j * n];
+        for (int i = n; i < b.npad; ++i) hb[(size_t)i + (size_t)i * b.lda] = 1.0;
+        for (int i = 0; i < n; ++i) hx[(size_t)i] = bvec[i];
+        const double inf = std::numeric_limits<double>::infinity();
+        hipError_t e = hipMemcpy(b.ab, hb.data(), b.bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dx, hx.data(), sizeof(double) * (size_t)b.npad, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dsmall + 2, &inf, sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(dinfo, 0, 2 * sizeof(int));
+        if (e == hipSuccess) e = band_cholesky(b, dinfo, dsmall + 2, nullptr, nullptr);
+        if (e == hipSuccess) e = band_solve(b, dx, dtmp, nullptr);
+        int hinfo = 0;
+        if (e == hipSuccess) e = hipMemcpy(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hx.data(), dx, sizeof(double) * (size_t)b.npad, hipMemcpyDeviceToHost);
+        if (!hip_ok(e, "band solve")) rc = SPLPAK_E_NODEVICE;
+        else {
+            for (int i = 0; i < n; ++i) x[i] = hx[(size_t)i];
+            if (hinfo != 0) rc = 107;
+        }
+    }
+    for (void *q : holder.owned) (void)hipFree(q);
+    return rc;
+}
+
+int32_t splpak_last_error_message(char *buf, int32_t buflen)
+{
+    if (!buf || buflen <= 0) return (int32_t)g_err.size();
+    std::strncpy(buf, g_err.c_str(), (size_t)buflen - 1);
+    buf[buflen - 1] = '\0';
+    return (int32_t)g_err.size();
+}
+
+int32_t splpak_device_name(char *buf, int32_t buflen)
+{
+    if (int r = device_ready()) return r;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    SPLPAK_HIP_TRY(hipGetDevice(&dev), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(hipGetDeviceProperties(&prop, dev), SPLPAK_E_NODEVICE);
+    if (buf && buflen > 0) {
+        std::strncpy(buf, prop.gcnArchName, (size_t)buflen - 1);
+        buf[buflen - 1] = '\0';
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library loads, exports every symbol include/splpak_hip.h declares,
+and its host-side argument validation follows the reference's ierror order.
+No compute entry point is exercised here (there is no GPU in the CPU tier)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from splpak_amd import capi
+from tests.conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "splpak_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(splpak_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/splpak_hip.h but not exported"
+    assert sorted(capi.SYMBOLS) == declared
+
+
+def test_fit_validation_order_without_gpu():
+    """101..106 are decided on the host before any device work (:716-781)."""
+    x = np.linspace(0, 1, 20).reshape(-1, 1)
+    y = x[:, 0].copy()
+    f = lambda **k: capi.fit(k.get("ndim", 1), x, y, None, k.get("xmin", [0.0]), k.get("xmax", [1.0]),
+                             k.get("nodes", [10]), k.get("xtrap", 1.0), ncf=k.get("ncf"),
+                             nwrk=k.get("nwrk", -1), ndata=k.get("ndata"))[1]
+    assert f(ndim=0) == 101
+    assert f(nodes=[3]) == 102
+    assert f(xmax=[0.0]) == 103
+    assert f(ncf=9) == 104
+    assert f(ndata=0) == 105
+    assert f(nwrk=10) == 106
+    # first failing check wins
+    assert f(ndim=0, nodes=[3]) == 101
+    assert f(nodes=[3], ncf=1) == 102
+
+
+def test_eval_validation_without_gpu():
+    coef = np.ones(10)
+    e = lambda **k: capi.evaluate(k.get("ndim", 1), np.array([[0.3]]), k.get("nd"), coef,
+                                  k.get("xmin", [0.0]), k.get("xmax", [1.0]), k.get("nodes", [10]))
+    v, rc = e(ndim=0)
+    assert rc == 101 and v[0] == 0.0
+    assert e(nodes=[3])[1] == 102
+    assert e(xmax=[0.0])[1] == 103
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the compute path must fail loudly, not fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    x = np.linspace(0, 1, 20).reshape(-1, 1)
+    with pytest.raises(capi.SplpakError):
+        capi.fit(1, x, x[:, 0], None, [0.0], [1.0], [10], 1.0)
+    with pytest.raises(capi.SplpakError):
+        capi.evaluate(1, x, None, np.ones(10), [0.0], [1.0], [10])
+
+
+def test_comm_len_formula():
+    nodes = np.array([8, 8, 8], dtype=np.int32)
+    n = 512
+    npad = 512
+    assert capi.lib().splpak_plan_comm_len(3, capi._p(nodes, capi._ip)) == n * 172 + n + 8 + n + 8 + npad

@@ -1,0 +1,186 @@
+"""GPU: parity of the HIP path (through the C ABI) with the reference.
+
+Checked against (a) golden vectors generated from the unmodified reference
+(tests/golden/, oracle/gen_golden.py) and (b) the CPU oracle on fresh seeded
+inputs.  Tolerance: 1e-10 max-norm relative on coefficients (BASELINE.json
+north_star, real64); evaluation 1e-12 relative to the largest value.
+"""
+import numpy as np
+import pytest
+
+from splpak_amd import capi
+from tests.cases import CASES, make_inputs, make_queries, nderiv_patterns
+from tests.conftest import load_golden, relmax
+
+pytestmark = pytest.mark.gpu
+
+COEF_TOL = 1e-10
+EVAL_TOL = 1e-12
+
+ALL = list(CASES)
+
+
+def test_device_is_gfx950():
+    assert capi.device_name().startswith("gfx950")
+
+
+# ---------------------------------------------------------------------------
+# band Cholesky kernels in isolation (f64 MFMA trailing update, trsm, sweeps)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,halfbw", [(200, 199), (256, 40), (700, 699), (1000, 300), (1536, 257),
+                                      (2048, 700)])
+def test_band_cholesky_vs_lapack(n, halfbw):
+    rng = np.random.default_rng(n + halfbw)
+    i, j = np.indices((n, n))
+    mask = np.abs(i - j) <= halfbw
+    # asymmetric-looking random band made SPD by diagonal dominance
+    a = rng.standard_normal((n, n)) * mask
+    a = np.tril(a) + np.tril(a, -1).T
+    a[np.diag_indices(n)] = np.abs(a).sum(axis=1) + 1.0 + rng.random(n)
+    b = rng.standard_normal(n)
+    x, rc = capi.debug_spd_band_solve(a, halfbw, b)
+    assert rc == 0
+    xref = np.linalg.solve(a, b)
+    assert relmax(x, xref) < 1e-11
+    # not positive definite -> 107
+    a2 = a.copy()
+    a2[n // 2, n // 2] = -1.0
+    assert capi.debug_spd_band_solve(a2, halfbw, b)[1] == 107
+
+
+# ---------------------------------------------------------------------------
+# evaluation
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ALL)
+def test_eval_matches_reference_golden(name):
+    spec = CASES[name]
+    gold = load_golden(name)
+    inp = make_inputs(spec)
+    q = make_queries(spec)
+    for i, p in enumerate(nderiv_patterns(inp["ndim"])):
+        v, ierr = capi.evaluate(inp["ndim"], q, p, gold["coef"], inp["xmin"], inp["xmax"], inp["nodes"])
+        assert ierr == 0
+        scale = max(np.max(np.abs(gold["values"][i])), 1e-300)
+        assert np.max(np.abs(v - gold["values"][i])) / scale < EVAL_TOL, (name, p)
+    v0, ierr = capi.evaluate(inp["ndim"], q, None, gold["coef"], inp["xmin"], inp["xmax"], inp["nodes"])
+    assert ierr == 0
+    assert np.max(np.abs(v0 - gold["values"][0])) <= EVAL_TOL * max(np.max(np.abs(gold["values"][0])), 1e-300)
+
+
+def test_eval_ragged_and_strided():
+    gold = load_golden("3d8")
+    inp = make_inputs(CASES["3d8"])
+    q = make_queries(CASES["3d8"])
+    # leading dimension larger than ndim (xq(ldxq, nq))
+    qpad = np.zeros((q.shape[0], 5))
+    qpad[:, :3] = q
+    qpad[:, 3:] = 1e300
+    v, _ = capi.evaluate(3, qpad, None, gold["coef"], inp["xmin"], inp["xmax"], inp["nodes"])
+    assert np.max(np.abs(v - gold["values"][0])) <= EVAL_TOL * np.max(np.abs(gold["values"][0]))
+    # a single query and an empty batch
+    v1, _ = capi.evaluate(3, q[:1], None, gold["coef"], inp["xmin"], inp["xmax"], inp["nodes"])
+    assert abs(v1[0] - gold["values"][0][0]) <= EVAL_TOL * np.max(np.abs(gold["values"][0]))
+    v0, rc = capi.evaluate(3, np.zeros((0, 3)), None, gold["coef"], inp["xmin"], inp["xmax"], inp["nodes"])
+    assert rc == 0 and v0.size == 0
+    # nderiv out of range: 104, value still computed (clamped)
+    v, rc = capi.evaluate(3, q, [3, 0, 0], gold["coef"], inp["xmin"], inp["xmax"], inp["nodes"])
+    assert rc == 104 and np.all(np.isfinite(v))
+
+
+def test_eval_real32():
+    gold = load_golden("2d16")
+    inp = make_inputs(CASES["2d16"])
+    q = make_queries(CASES["2d16"]).astype(np.float32)
+    v, rc = capi.evaluate(2, q, None, gold["coef"].astype(np.float32), inp["xmin"], inp["xmax"],
+                          inp["nodes"], real32=True)
+    assert rc == 0 and v.dtype == np.float32
+    v64, _ = capi.evaluate(2, q.astype(np.float64), None, gold["coef"].astype(np.float32).astype(np.float64),
+                           inp["xmin"], inp["xmax"], inp["nodes"])
+    assert np.max(np.abs(v - v64)) <= 1e-6 * np.max(np.abs(v64))
+
+
+# ---------------------------------------------------------------------------
+# fit
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ALL)
+def test_fit_matches_reference_golden(name):
+    spec = CASES[name]
+    gold = load_golden(name)
+    inp = make_inputs(spec)
+    coef, ierr, hist, info = capi.fit(inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"],
+                                      inp["xmax"], inp["nodes"], inp["xtrap"], want_hist=True)
+    assert ierr == 0 == int(gold["ierror"])
+    err = relmax(coef, gold["coef"])
+    print(f"{name}: rel={err:.2e} refine_steps={info[2]:.0f} last_corr={info[3]:.1e} minpiv={info[4]:.2e} "
+          f"rows={info[0]:.0f}+{info[1]:.0f}")
+    assert err < COEF_TOL
+    if inp["xtrap"] != 0.0:
+        assert relmax(hist, gold["hist"]) < 1e-12
+
+
+def test_fit_fresh_inputs_vs_oracle(port):
+    rng = np.random.default_rng(11)
+    for nd, nodes, m in [(1, [9], 40), (2, [6, 11], 700), (3, [5, 4, 7], 900), (4, [4, 4, 5, 4], 1500)]:
+        x = rng.random((m, nd)) * 1.2 - 0.1
+        y = np.cos(x.sum(axis=1) * 2.0) + 0.05 * rng.standard_normal(m)
+        w = rng.random(m)
+        w[rng.random(m) < 0.1] = 0.0
+        for wd, xtrap in [(w, 1.0), (None, 0.3)]:
+            c0, e0, w0 = port.fit(nd, x, y, wd, [0.0] * nd, [1.0] * nd, nodes, xtrap)
+            c1, e1, h1, _ = capi.fit(nd, x, y, wd, [0.0] * nd, [1.0] * nd, nodes, xtrap, want_hist=True)
+            n = int(np.prod(nodes))
+            assert e0 == e1 == 0
+            assert relmax(c1[:n], c0[:n]) < COEF_TOL
+            assert relmax(h1[:n], w0[:n]) < 1e-12
+
+
+def test_fit_l1xdat_and_negative_first_weight(port):
+    """xdata(l1xdat, ndata) with l1xdat > ndim (:521-525); wdata(1) < 0 means unweighted (:581-588)."""
+    inp = make_inputs(CASES["2d8"])
+    m = inp["xdata"].shape[0]
+    xpad = np.full((m, 4), 1e300)
+    xpad[:, :2] = inp["xdata"]
+    c_ref = load_golden("2d8_cc")["coef"]
+    w = inp["wdata"].copy()
+    w[0] = -1.0
+    coef, ierr, _, _ = capi.fit(2, xpad, inp["ydata"], w, inp["xmin"], inp["xmax"], inp["nodes"], 1.0)
+    assert ierr == 0 and relmax(coef, c_ref) < COEF_TOL
+
+
+def test_fit_error_codes():
+    """107 conditions of the reference (:683-686)."""
+    x = np.linspace(0, 1, 50).reshape(-1, 1)
+    y = np.sin(x[:, 0])
+    assert capi.fit(1, x, y, np.zeros(50), [0.0], [1.0], [10], 1.0)[1] == 107   # all-zero weights
+    assert capi.fit(1, x, y, np.zeros(50), [0.0], [1.0], [10], 0.0)[1] == 107
+    x5 = np.linspace(0.1, 0.9, 5).reshape(-1, 1)
+    assert capi.fit(1, x5, np.sin(x5[:, 0]), None, [0.0], [1.0], [10], 0.0)[1] == 107  # too few rows
+    c, rc, _, _ = capi.fit(1, x5, np.sin(x5[:, 0]), None, [0.0], [1.0], [10], 1.0)       # constraints regularise
+    assert rc == 0 and np.all(np.isfinite(c))
+    # enough rows but rank deficient (all data in one corner, no smoothing): not positive definite
+    xc = np.random.default_rng(0).random((400, 2)) * 0.2
+    assert capi.fit(2, xc, xc.sum(axis=1), None, [0.0, 0.0], [1.0, 1.0], [8, 8], 0.0)[1] == 107
+
+
+def test_reference_known_answer_linear_on_gpu():
+    """test/splpak_test_linear.f90:65-89 through the HIP path: slope 2 within 1e-12."""
+    inp = make_inputs(CASES["ref_linear"])
+    coef, ierr, _, _ = capi.fit(1, inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"],
+                                inp["nodes"], inp["xtrap"])
+    assert ierr == 0
+    v, ie = capi.evaluate(1, np.array([[0.0], [1.0]]), [1], coef, inp["xmin"], inp["xmax"], inp["nodes"])
+    assert ie == 0 and np.all(np.abs(v - 2.0) <= 1e-12)
+    xs = (np.arange(100) / 100.0).reshape(-1, 1)
+    v, _ = capi.evaluate(1, xs, None, coef, inp["xmin"], inp["xmax"], inp["nodes"])
+    assert np.max(np.abs(v - 2.0 * xs[:, 0])) <= 1e-1
+
+
+def test_fit_real32_vs_reference32():
+    """REAL32 twin: f32 storage, f64 arithmetic; compare with the f64 golden at f32 tolerance."""
+    spec = CASES["2d8"]
+    gold = load_golden("2d8")
+    inp = make_inputs(spec)
+    coef, ierr, _, _ = capi.fit(2, inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"],
+                                inp["nodes"], inp["xtrap"], real32=True)
+    assert ierr == 0 and coef.dtype == np.float32
+    assert relmax(coef, gold["coef"]) < 2e-4   # inputs rounded to f32, cond(A) ~ 1e3..1e4
