@@ -60,7 +60,11 @@ def test_eval_matches_reference_golden(name):
     for i, p in enumerate(nderiv_patterns(inp["ndim"])):
         v, ierr = capi.evaluate(inp["ndim"], q, p, gold["coef"], inp["xmin"], inp["xmax"], inp["nodes"])
         assert ierr == 0
-        scale = max(np.max(np.abs(gold["values"][i])), 1e-300)
+        # scale: the size of the terms that are summed (|coef| * prod dxin^nderiv), so that
+        # derivatives that cancel to ~0 (e.g. f'' of a fitted straight line) are judged fairly
+        dxin = (np.array(spec["nodes"]) - 1) / (inp["xmax"] - inp["xmin"])
+        scale = max(np.max(np.abs(gold["values"][i])),
+                    np.max(np.abs(gold["coef"])) * float(np.prod(dxin ** np.array(p))))
         assert np.max(np.abs(v - gold["values"][i])) / scale < EVAL_TOL, (name, p)
     v0, ierr = capi.evaluate(inp["ndim"], q, None, gold["coef"], inp["xmin"], inp["xmax"], inp["nodes"])
     assert ierr == 0
