@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SPLPAK least-squares spline FIT (splcw) + EVALUATION (splfe)
+on MI355X, BASELINE.json config 3: 3-D, 1e7 scattered weighted points per GPU,
+64x64x64 nodes, real64.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete fit of this rank's points that are already resident in
+HBM: window binning, Gram assembly, (RCCL all-reduce of the normal equations when
+N > 1), derivative-constraint rows, band Cholesky on the f64 matrix cores,
+solve and iterative refinement, coefficients left in HBM.  For N > 1 the points
+are sharded (weak scaling: every rank holds --ndata points) and the histogram,
+the normal equations and each refinement residual are all-reduced over RCCL; the
+factorisation is replicated.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the dominant kernel (f64-MFMA trailing update of the band Cholesky):
+                algorithmic flop / HIP-event time measured inside the timed region
+  cpu_baseline  the reference itself (oracle/_ref, 1 core; it is single-threaded)
+                on a bounded sample -- the dense reference algorithm cannot run the
+                64^3 grid at all (550 GB workspace)
+  eval          batched evaluation throughput (one thread per query) + its HBM roofline
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix peak (AMD datasheet; = 256 CU * 4 SIMD * 32 flop/clk * 2.4 GHz)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ndim", type=int, default=3)
+    ap.add_argument("--nodes", type=int, default=64, help="nodes per dimension")
+    ap.add_argument("--ndata", type=int, default=10_000_000, help="points per GPU")
+    ap.add_argument("--neval", type=int, default=50_000_000, help="evaluation queries per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(ndim):
+    """Reference (oracle/_ref) or port on a bounded sample, 1 core."""
+    from oracle import binding
+    from splpak_amd.synth import synth_points, synth_queries
+    if binding.ref_available():
+        impl, kind = binding.Reference(), "reference"
+    else:
+        if not binding.port_available():
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "port"])
+        impl, kind = binding.Port(), "port"
+    nod, m = (12, 1500) if ndim == 3 else ((32, 8000) if ndim == 2 else (6, 3000))
+    nodes = [nod] * ndim
+    x, y, w = synth_points(ndim, m)
+    lo, hi = [0.0] * ndim, [1.0] * ndim
+    t0 = time.perf_counter()
+    coef, ierr, _ = impl.fit(ndim, x, y, w, lo, hi, nodes, 1.0)
+    t_fit = time.perf_counter() - t0
+    nq = 200_000
+    q = synth_queries(ndim, nq, m)
+    t0 = time.perf_counter()
+    impl.evaluate(ndim, q, None, coef, lo, hi, nodes)
+    t_ev = time.perf_counter() - t0
+    ncol = nod ** ndim
+    return {
+        "value": m / t_fit, "unit": "points/s", "cores": 1, "kind": kind,
+        "sample": (f"{ndim}-D splcw fit of {m} weighted points of the same stream on a "
+                   f"{'x'.join([str(nod)] * ndim)} node grid ({ncol} columns), xtrap=1, {t_fit:.1f} s; "
+                   f"the dense reference algorithm needs ncol*(ncol+1) reals of workspace (550 GB at 64^3) "
+                   f"and O(ncol^2) flop per row, so the full workload cannot run on it; its cost per "
+                   f"point grows ~(262144/{ncol})^2 = {(262144 / ncol) ** 2:.0f}x from this sample to 64^3"),
+        "ierror": int(ierr),
+        "evals_per_s": nq / t_ev,
+        "eval_sample": f"{nq} scalar splfe calls, {ndim}-D, same grid",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the splpak HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from splpak_amd import capi
+
+    nd, nod, m = args.ndim, args.nodes, args.ndata
+    nodes = [nod] * nd
+    lo, hi = [0.0] * nd, [1.0] * nd
+    ncol = nod ** nd
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- synthetic inputs, generated on the device, resident in HBM -----------
+    x = torch.empty((m, nd), dtype=torch.float64, device=dev)
+    y = torch.empty(m, dtype=torch.float64, device=dev)
+    w = torch.empty(m, dtype=torch.float64, device=dev)
+    capi.synth_points_dev(nd, rank * m, m, x, y, w, stream)
+    coef = torch.zeros(ncol, dtype=torch.float64, device=dev)
+
+    comm_len = int(capi.lib().splpak_plan_comm_len(nd, capi._p(np.array(nodes, dtype=np.int32), capi._ip)))
+    comm = torch.zeros(comm_len, dtype=torch.float64, device=dev)
+    plan = capi.Plan(nd, nodes, lo, hi, 1.0, m, comm=comm)
+    if world > 1:
+        def allreduce(off, count):
+            dist.all_reduce(comm[off:off + count])
+        plan.set_allreduce(allreduce, rank, world)
+    plan.enable_kernel_timing(not args.no_kernel_timing)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    info = None
+    for _ in range(args.warmup):
+        ierr, info = plan.fit(x, y, w, coef, stream)
+        assert ierr == 0, f"fit failed with ierror {ierr}"
+    barrier()
+    t0 = time.perf_counter()
+    kt_sum = dict(syrk_launches=0.0, syrk_ms=0.0, syrk_flop=0.0, factor_ms=0.0)
+    phase = np.zeros(3)
+    for _ in range(args.steps):
+        ierr, info = plan.fit(x, y, w, coef, stream)
+        kt = plan.kernel_timing()
+        for k in kt_sum:
+            kt_sum[k] += kt[k]
+        phase += info[5:8]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert ierr == 0, f"fit failed with ierror {ierr}"
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * m * args.steps / elapsed
+
+    # ---- evaluation throughput (splfe), queries sharded, no collectives ---------
+    nq = args.neval
+    xq = torch.empty((nq, nd), dtype=torch.float64, device=dev)
+    out = torch.empty(nq, dtype=torch.float64, device=dev)
+    capi.synth_queries_dev(nd, world * m, rank * nq, nq, xq, stream)
+    capi.evaluate_dev(nd, xq, None, coef, lo, hi, nodes, out, stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    barrier()
+    e0.record()
+    for _ in range(reps):
+        capi.evaluate_dev(nd, xq, None, coef, lo, hi, nodes, out, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ev_ms = e0.elapsed_time(e1) / reps
+    if world > 1:
+        t = torch.tensor([ev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ev_ms = float(t.item())
+    evals_per_s = world * nq / (ev_ms * 1e-3)
+    ev_bytes = 8.0 * (nd + 1) * nq
+
+    if rank == 0:
+        line = {
+            "metric": "fitted points/sec (splcw) + evals/sec (splfe), 3-D 1e7 pts 64^3 nodes",
+            "value": value,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"C3: {nd}-D splcw least-squares spline fit, {m} weighted scattered points per GPU "
+                             f"(Park-Miller stream, seed 42), {'x'.join(map(str, nodes))} nodes, xtrap=1, real64"),
+                "ncol": ncol, "points_per_gpu": m, "points_total": world * m,
+                "parallelism": "points sharded per GPU; RCCL all-reduce of histogram, normal equations and "
+                               "refinement residuals; band Cholesky replicated" if world > 1 else "single GPU",
+                "refine_steps": int(info[2]), "last_correction_rel": float(info[3]),
+                "data_rows": float(info[0]), "constraint_rows": float(info[1]),
+                "phase_seconds_per_step": {"assembly": phase[0] / args.steps, "factor": phase[1] / args.steps,
+                                           "solve_refine": phase[2] / args.steps},
+            },
+            "evals_per_s": evals_per_s,
+            "eval": {
+                "value": evals_per_s, "unit": "evals/s", "queries_per_gpu": nq, "ms_per_batch": ev_ms,
+                "roofline": {"bound": "hbm", "achieved": ev_bytes / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": ev_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": None},
+            },
+        }
+        if kt_sum["syrk_ms"] > 0:
+            ach = kt_sum["syrk_flop"] / (kt_sum["syrk_ms"] * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_syrk_pmc.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            line["roofline"] = {
+                "kernel": "syrk_kernel (band Cholesky trailing update, v_mfma_f64_16x16x4_f64)",
+                "bound": "mfma", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "launches": kt_sum["syrk_launches"], "avg_launch_ms": kt_sum["syrk_ms"] / max(kt_sum["syrk_launches"], 1),
+                "flop_per_launch": kt_sum["syrk_flop"] / max(kt_sum["syrk_launches"], 1),
+                "factor_ms_per_step": kt_sum["factor_ms"] / args.steps,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(nd)
+        print(json.dumps(line), flush=True)
+
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
