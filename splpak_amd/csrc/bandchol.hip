@@ -26,6 +26,7 @@
 // computed once after the factorisation, off the critical path) so that every
 // step of the forward / backward sweep is one short, fully parallel kernel.
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace splpak {
 
@@ -35,100 +36,244 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 constexpr int PNL = 64;            // potrf inner panel width
-constexpr int PLD = NBLK + 1;      // LDS leading dimension of the potrf panel
 
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
+// Cholesky of one 256x256 diagonal block: one workgroup of 4 waves, 32-column panels.
+// Per panel: (i) the 32x32 diagonal block is factored by wave 0 alone, one row per lane,
+// columns broadcast with v_readlane (no barriers); (ii) the rows below are solved one
+// row per thread against that factor (broadcast LDS reads); (iii) the rest of the block
+// is updated on the f64 matrix cores from the LDS-resident panel.  LDS stays under 80 KB
+// so the workgroup can share a CU with a trailing-update workgroup of the look-ahead.
+constexpr int IB = 32;                 // inner panel width
+constexpr int XLD = NBLK + 16;         // LDS row of the panel image (bank-half alternation, as in syrk)
+
+__device__ inline double readlane_f64(double v, int srclane)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(256)
 potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restrict__ info,
                    double *__restrict__ minpiv)
 {
-    __shared__ double P[PNL * PLD];
-    double *A = ab + (long long)k0 + (long long)k0 * lda;   // A(r,c) = A[r + c*lda], r >= c
-    const int tid = threadIdx.x;
+    __shared__ double Ls[IB * (IB + 1)];     // factor of the current diagonal 32x32: Ls[c*(IB+1) + k]
+    __shared__ double Xs[IB * XLD];          // panel image Xs[k*XLD + r], r = row inside the 256 block
+    double *A = ab + (long long)k0 + (long long)k0 * lda;    // A(r,c) = A[r + c*lda], r >= c
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    __builtin_amdgcn_s_setprio(3);           // critical path of the look-ahead: win issue arbitration
 
-    for (int c0 = 0; c0 < NBLK; c0 += PNL) {
-        for (int idx = tid; idx < PNL * NBLK; idx += 1024) {
-            const int cc = idx / NBLK, r = idx % NBLK;
-            double v = 0.0;
-            if (r >= c0 + cc) v = A[r + (long long)(c0 + cc) * lda];
-            P[cc * PLD + r] = v;
+    for (int c0 = 0; c0 < NBLK; c0 += IB) {
+        // (i) diagonal 32x32 block, in LDS, by wave 0 alone (LDS operations of one wave execute
+        // in order, so no barrier is needed inside).  lane = row + 32*half; the two halves
+        // split the columns of the rank-1 update.  Kept as compact loops on purpose: this
+        // kernel runs once per step and large unrolled bodies paid ~1 us per 64-B line of
+        // instruction-cache miss under the bulk update.
+        if (wave == 0) {
+            const int r = lane & 31, h = lane >> 5;
+            for (int c = h; c < IB; c += 2)
+                Ls[r * (IB + 1) + c] = (c <= r) ? A[(c0 + r) + (long long)(c0 + c) * lda] : 0.0;
+            double dmin = 1.0e300;
+            bool bad = false;
+            for (int j = 0; j < IB; ++j) {
+                const double d = Ls[j * (IB + 1) + j];
+                bad = bad || !(d > 0.0);
+                dmin = fmin(dmin, d);
+                const double sd = sqrt(d);
+                const double l = (r == j) ? sd : Ls[r * (IB + 1) + j] / sd;
+                if (h == 0 && r >= j) Ls[r * (IB + 1) + j] = l;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+                for (int c = j + 1 + h; c < IB; c += 2) {
+                    const double lc = Ls[c * (IB + 1) + j];
+                    if (r >= c) Ls[r * (IB + 1) + c] -= l * lc;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            for (int c = h; c < IB; c += 2)
+                if (c <= r) A[(c0 + r) + (long long)(c0 + c) * lda] = Ls[r * (IB + 1) + c];
+            if (lane == 0) {
+                if (bad) atomicCAS(info, 0, k0 + c0 + 1);
+                if (dmin < *minpiv || !(dmin == dmin)) *minpiv = dmin;
+            }
         }
         __syncthreads();
-        for (int j = 0; j < PNL; ++j) {
-            const double d = P[j * PLD + c0 + j];
-            if (tid == 0) {
-                if (!(d > 0.0)) atomicCAS(info, 0, k0 + c0 + j + 1);
-                if (d < *minpiv) *minpiv = d;
+        const int base = c0 + IB;            // first row / column of the trailing part
+        const int mrem = NBLK - base;        // rows below the diagonal block
+        // (ii) rows below: x = a L^{-T}, one row per thread
+        if (tid < mrem) {
+            const int row = base + tid;
+            double x[IB];
+#pragma unroll
+            for (int c = 0; c < IB; ++c) x[c] = A[row + (long long)(c0 + c) * lda];
+#pragma unroll
+            for (int c = 0; c < IB; ++c) {
+#pragma unroll
+                for (int k = 0; k < c; ++k) x[c] -= x[k] * Ls[c * (IB + 1) + k];
+                x[c] /= Ls[c * (IB + 1) + c];
             }
-            const double sd = sqrt(d);
-            __syncthreads();
-            if (tid < NBLK) {
-                const int r = tid;
-                if (r > c0 + j) P[j * PLD + r] /= sd;
-                else if (r == c0 + j) P[j * PLD + r] = sd;
+#pragma unroll
+            for (int c = 0; c < IB; ++c) {
+                A[row + (long long)(c0 + c) * lda] = x[c];
+                Xs[c * XLD + row] = x[c];
             }
-            __syncthreads();
-            const int ncols = PNL - 1 - j;
-            for (int idx = tid; idx < ncols * NBLK; idx += 1024) {
-                const int cc = j + 1 + idx / NBLK, r = idx % NBLK;
-                if (r >= c0 + cc) P[cc * PLD + r] -= P[j * PLD + r] * P[j * PLD + c0 + cc];
-            }
-            __syncthreads();
         }
-        for (int idx = tid; idx < PNL * NBLK; idx += 1024) {
-            const int cc = idx / NBLK, r = idx % NBLK;
-            if (r >= c0 + cc) A[r + (long long)(c0 + cc) * lda] = P[cc * PLD + r];
-        }
-        const int nrem = NBLK - c0 - PNL;       // columns right of the panel
-        for (int idx = tid; idx < nrem * NBLK; idx += 1024) {
-            const int c = c0 + PNL + idx / NBLK, r = idx % NBLK;
-            if (r >= c) {
-                double s = 0.0;
-#pragma unroll 8
-                for (int kk = 0; kk < PNL; ++kk) s += P[kk * PLD + r] * P[kk * PLD + c];
-                A[r + (long long)c * lda] -= s;
+        __syncthreads();
+        // (iii) trailing update inside the block on the matrix cores: 16x16 tiles, rt >= ct.
+        // All C tiles of this wave are fetched first (independent loads, one latency per
+        // panel instead of one per tile), then updated and stored.
+        const int nt = mrem / 16;
+        const int ntiles = nt * (nt + 1) / 2;
+        constexpr int TB = 14;               // tiles per batch and wave (2 batches cover 105 tiles / 4 waves)
+        for (int t0 = wave; t0 < ntiles; t0 += 4 * TB) {
+            d4_t cc[TB];
+            int roff[TB], coff[TB];
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                const int t = t0 + 4 * u;
+                roff[u] = -1;
+                coff[u] = 0;
+                if (t < ntiles) {
+                    int ct = 0, rem = t;
+                    while (rem >= nt - ct) { rem -= nt - ct; ++ct; }
+                    roff[u] = base + 16 * (ct + rem);
+                    coff[u] = base + 16 * ct;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        cc[u][v] = A[(roff[u] + l15) + (long long)(coff[u] + q + 4 * v) * lda];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                if (roff[u] >= 0) {
+                    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s = 0; s < IB / 4; ++s) {
+                        const double av = Xs[(4 * s + q) * XLD + coff[u] + l15];
+                        const double bv = Xs[(4 * s + q) * XLD + roff[u] + l15];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    }
+                    const int r = roff[u] + l15;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int c = coff[u] + q + 4 * v;
+                        if (r >= c) A[r + (long long)c * lda] = cc[u][v] - acc[v];
+                    }
+                }
             }
         }
         __syncthreads();
     }
 }
 
+// Inverses of the four 64x64 diagonal sub-blocks of L (column-major, inv64[p][r + 64*c]),
+// used as MFMA operands by trsm_kernel: workgroup p inverts block p, lane c owns column c
+// (forward substitution on the identity).  Compact loops, operands in LDS (see potrf).
+__global__ void __launch_bounds__(64)
+inv64_kernel(const double *__restrict__ A, long long lda, double *__restrict__ inv64)
+{
+    __shared__ double Lp[PNL * PNL];             // Lp[k*64 + r] = L(r,k)
+    __shared__ double Xc[PNL * (PNL + 1)];       // Xc[r*65 + c] = Linv(r,c)
+    __builtin_amdgcn_s_setprio(3);
+    const int p = blockIdx.x, c = threadIdx.x & 63;
+    const double *Ab = A + (long long)(PNL * p) + (long long)(PNL * p) * lda;
+    for (int k0 = 0; k0 < PNL; k0 += 16) {
+        double lv[16];                           // 16 independent loads in flight
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lv[k] = Ab[c + (long long)(k0 + k) * lda];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Lp[(k0 + k) * PNL + c] = (c >= k0 + k) ? lv[k] : 0.0;
+    }
+    __syncthreads();
+    for (int r = 0; r < PNL; ++r) {
+        double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+        int k = 0;
+        for (; k + 1 < r; k += 2) {
+            s0 -= Lp[k * PNL + r] * Xc[k * (PNL + 1) + c];
+            s1 -= Lp[(k + 1) * PNL + r] * Xc[(k + 1) * (PNL + 1) + c];
+        }
+        if (k < r) s0 -= Lp[k * PNL + r] * Xc[k * (PNL + 1) + c];
+        Xc[r * (PNL + 1) + c] = (s0 + s1) / Lp[r * PNL + r];
+    }
+    __syncthreads();
+    double *out = inv64 + (long long)p * PNL * PNL;
+    for (int cc = 0; cc < PNL; ++cc) out[cc * PNL + c] = Xc[c * (PNL + 1) + cc];   // lane = row
+}
+
 // ---------------------------------------------------------------------------
-// X = A * L^{-T} for the rows below the diagonal block: one thread per row.
+// X = A * L^{-T} for the rows below the diagonal block, on the f64 matrix cores.
+//
+// One wave owns 16 rows for the whole solve and keeps them in MFMA accumulator
+// layout (lane: row r = lane&15; register v of column tile ct: column 16ct + (lane>>4) + 4v).
+// With 64-column blocks j = 0..3 of the 256 columns,
+//     X_j = (A_j - sum_{i<j} X_i L_ji^T) Inv_jj^T ,   Inv_jj = (64x64 diagonal block of L)^{-1}.
+// Both products are computed transposed, D[c][r] = sum_k Aop[c][k] * Bop[k][r], so that
+// the accumulator registers of earlier results ARE the B operand of the next MFMA
+// (register s of a tile is k-step s): the rows never leave the register file; only
+// L / Inv elements (L2 resident, shared by all waves) are loaded, 8 bytes per lane and MFMA.
 constexpr int TCB = 32;
 __global__ void __launch_bounds__(64)
-trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long lda, int nrows)
+trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long lda,
+            const double *__restrict__ inv64, int nrows)
 {
-    // L = diagonal block (read-only here, wave-uniform addresses -> scalar loads),
-    // Xbase = first row below it; both views of the band with column stride lda
-    const int rloc = blockIdx.x * 64 + threadIdx.x;
-    if (rloc >= nrows) return;
-    double *__restrict__ X = Xbase + rloc;   // X[c*lda]
+    const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.x * 16;
+    if (r0 >= nrows) return;
+    __builtin_amdgcn_s_setprio(3);
+    double *__restrict__ Xr = Xbase + r0 + l15;          // Xr[c*lda] = X(row, c)
 
-    for (int cb = 0; cb < NBLK / TCB; ++cb) {
-        double acc[TCB];
+    d4_t X[4][4];
 #pragma unroll
-        for (int c = 0; c < TCB; ++c) acc[c] = X[(long long)(cb * TCB + c) * lda];
-        for (int kb = 0; kb < cb; ++kb) {
-            double xk[TCB];
+    for (int j = 0; j < 4; ++j) {
+        d4_t T[4];
 #pragma unroll
-            for (int k = 0; k < TCB; ++k) xk[k] = X[(long long)(kb * TCB + k) * lda];
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int k = 0; k < TCB; ++k) {
-                const double *__restrict__ Lc = L + (cb * TCB) + (long long)(kb * TCB + k) * lda;
+            for (int v = 0; v < 4; ++v) T[ct][v] = Xr[(long long)(64 * j + 16 * ct + q + 4 * v) * lda];
 #pragma unroll
-                for (int c = 0; c < TCB; ++c) acc[c] -= xk[k] * Lc[c];
+        for (int i = 0; i < j; ++i) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                double a[4][4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        a[s][ct] = -L[(64 * j + 16 * ct + l15) + (long long)(64 * i + 16 * kt + 4 * s + q) * lda];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        T[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ct], X[i][kt][s], T[ct], 0, 0, 0);
             }
         }
-        const double *__restrict__ Ld = L + (cb * TCB) + (long long)(cb * TCB) * lda;
+        const double *__restrict__ Inv = inv64 + (long long)j * 64 * 64;   // Inv[c + 64*k]
 #pragma unroll
-        for (int c = 0; c < TCB; ++c) {
+        for (int ct = 0; ct < 4; ++ct) X[j][ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < c; ++k) acc[c] -= acc[k] * Ld[c + (long long)k * lda];
-            acc[c] /= Ld[c + (long long)c * lda];
+        for (int kt = 0; kt < 4; ++kt) {
+            double a[4][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ct = kt; ct < 4; ++ct)
+                    a[s][ct] = Inv[(16 * ct + l15) + 64 * (16 * kt + 4 * s + q)];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ct = kt; ct < 4; ++ct)      // Inv is lower triangular: k-tile <= c-tile
+                    X[j][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ct], T[kt][s], X[j][ct], 0, 0, 0);
         }
 #pragma unroll
-        for (int c = 0; c < TCB; ++c) X[(long long)(cb * TCB + c) * lda] = acc[c];
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                Xr[(long long)(64 * j + 16 * ct + q + 4 * v) * lda] = X[j][ct][v];
     }
 }
 
@@ -139,15 +284,26 @@ constexpr int KC = 16;             // K chunk staged per LDS buffer
 constexpr int LDT = TS + 16;       // padded LDS row: k-rows land on alternating bank halves
 
 __global__ void __launch_bounds__(256, 2)
-syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, int tj_begin)
+syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, int tj_begin, int mode)
 {
     __shared__ double sI[2][KC * LDT];   // panel rows of the C-row block  (MFMA B operand)
     __shared__ double sJ[2][KC * LDT];   // panel rows of the C-col block  (MFMA A operand)
 
-    // block -> lower-triangular tile (ti >= tj)
-    int b = blockIdx.x, tj = tj_begin;
-    while (b >= nt - tj) { b -= nt - tj; ++tj; }
-    const int ti = tj + b;
+    // block -> lower-triangular tile (ti >= tj).
+    //   mode 0: all tiles of tile columns >= tj_begin, column-major
+    //   mode 1: the 3 tiles of the first diagonal 256x256 block
+    //   mode 2: the rest of the first two tile columns (rows >= 2)
+    int b = blockIdx.x, tj = tj_begin, ti;
+    if (mode == 0) {
+        while (b >= nt - tj) { b -= nt - tj; ++tj; }
+        ti = tj + b;
+    } else if (mode == 1) {
+        tj = (b == 2) ? 1 : 0;
+        ti = (b == 0) ? 0 : 1;
+    } else {
+        tj = b / (nt - 2);
+        ti = 2 + b % (nt - 2);
+    }
     const bool diag = (ti == tj);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -214,32 +370,54 @@ syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, in
     }
 
     if (!wave_on) return;
-    // D[i][j]: lane holds j = lane&15 (C row), i = (lane>>4) + 4*v (C column)
+    // D[i][j]: lane holds j = lane&15 (C row), i = (lane>>4) + 4*v (C column).
+    // Read-modify-write of the C tile in batches of 16 independent loads (one m slice),
+    // the next batch in flight while the current one is stored.  Loads are unconditional
+    // (the strictly-upper part of a diagonal tile aliases valid band storage of earlier
+    // columns); only the stores are masked.
     double *__restrict__ C = ab + (long long)(row0 + ti * TS) + (long long)(row0 + tj * TS) * lda;
+    d4_t cold[2][4];
+    auto cload = [&](int m, d4_t (&dst)[4]) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                dst[n][v] = C[(wi * 64 + n * 16 + l15) + (long long)(wj * 64 + m * 16 + kq + 4 * v) * lda];
+    };
+    auto cstore = [&](int m, const d4_t (&src)[4]) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int r = wi * 64 + n * 16 + l15;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int c = wj * 64 + m * 16 + kq + 4 * v;
-                if (!diag || r >= c) C[r + (long long)c * lda] -= acc[m][n][v];
+                const double val = src[n][v] - acc[m][n][v];
+                if (!diag || r >= c) C[r + (long long)c * lda] = val;
             }
         }
-    }
+    };
+    cload(0, cold[0]);
+    cload(1, cold[1]);
+    cstore(0, cold[0]);
+    cload(2, cold[0]);
+    cstore(1, cold[1]);
+    cload(3, cold[1]);
+    cstore(2, cold[0]);
+    cstore(3, cold[1]);
 }
 
 // ---------------------------------------------------------------------------
 // Inverse of every 256x256 diagonal block of L, row-major: T[r*256 + c] = Linv(r,c).
 // One workgroup per block, one thread per column of the inverse.
 __global__ void __launch_bounds__(256)
-trtri_kernel(const double *__restrict__ ab, long long lda, double *__restrict__ dinv)
+trtri_kernel(const double *__restrict__ ab, long long lda, double *__restrict__ dinv,
+             double *__restrict__ dinvt)
 {
     const int k0 = blockIdx.x * NBLK;
     const int c = threadIdx.x;
     const double *__restrict__ L = ab + ((long long)k0 + (long long)k0 * lda);
     double *__restrict__ T = dinv + (long long)blockIdx.x * NBLK * NBLK;
+    double *__restrict__ Tt = dinvt + (long long)blockIdx.x * NBLK * NBLK;   // Tt[c*256 + r] = Linv(r,c)
 
     for (int rb = 0; rb < NBLK / TCB; ++rb) {
         double acc[TCB];
@@ -265,6 +443,8 @@ trtri_kernel(const double *__restrict__ ab, long long lda, double *__restrict__ 
         }
 #pragma unroll
         for (int r = 0; r < TCB; ++r) T[(rb * TCB + r) * NBLK + c] = acc[r];
+#pragma unroll
+        for (int r = 0; r < TCB; ++r) Tt[c * NBLK + rb * TCB + r] = acc[r];
     }
 }
 
@@ -276,80 +456,96 @@ __device__ inline double wave_sum(double v)
     return v;
 }
 
-// forward step k:  y_k = Linv_k v_k  (-> yout),  v[rows below] -= L[rows, k] y_k
-// grid: max(1, nrows/64) workgroups of 256 threads; every workgroup recomputes y_k.
+// out[0..255] = M v for a row-major 256x256 block M (a diagonal-block inverse or its
+// transpose; the zero triangle is stored).  grid 16 x 256 threads: a wave dots 4 rows.
 __global__ void __launch_bounds__(256)
-fwd_step_kernel(const double *__restrict__ ab, long long lda, const double *__restrict__ dinv,
-                int k, int nrows, double *__restrict__ v, double *__restrict__ yout)
+blockmv_kernel(const double *__restrict__ M, const double *__restrict__ v, double *__restrict__ out)
 {
-    __shared__ double sv[NBLK];
-    __shared__ double sy[NBLK];
-    __shared__ double part[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k0 = k * NBLK;
-    sv[tid] = v[k0 + tid];
-    __syncthreads();
-    const double *__restrict__ T = dinv + (long long)k * NBLK * NBLK;
-    for (int r = wave; r < NBLK; r += 4) {
-        double s = 0.0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 16 + wave * 4;
+    double vv[4], s[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = lane + 64 * u;
-            if (c <= r) s += T[r * NBLK + c] * sv[c];
-        }
-        s = wave_sum(s);
-        if (lane == 0) sy[r] = s;
+    for (int u = 0; u < 4; ++u) vv[u] = v[lane + 64 * u];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s[i] = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[i] += M[(r0 + i) * NBLK + lane + 64 * u] * vv[u];
     }
-    __syncthreads();
-    if (blockIdx.x == 0) yout[k0 + tid] = sy[tid];
-    if (nrows <= 0) return;
-    // rows [blockIdx.x*64, +64) below the block: 4 column quarters per row
-    const int r = blockIdx.x * 64 + lane;
-    double s = 0.0;
-    if (r < nrows) {
-        const double *__restrict__ Lr = ab + (long long)(k0 + NBLK + r) + (long long)(k0 + wave * 64) * lda;
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) s += Lr[(long long)c * lda] * sy[wave * 64 + c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[r0 + i] = s[i];
     }
-    part[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && r < nrows)
-        v[k0 + NBLK + r] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-// backward step k:  x_k = Linv_k^T y_k (-> xout),  y[cols left] -= L[k rows, cols]^T x_k
-// grid: max(1, ncols/64) workgroups; columns jbeg .. jbeg+ncols-1 (ending at k0-1).
-__global__ void __launch_bounds__(256)
-bwd_step_kernel(const double *__restrict__ ab, long long lda, const double *__restrict__ dinv,
-                int k, int jbeg, int ncols, double *__restrict__ y, double *__restrict__ xout)
+// forward sweep, panel part:  v[rows below block k] -= L[rows, block k] y_k.
+// workgroup = 64 rows x 256 columns, 512 threads = 32 row pairs x 16 column groups.
+__global__ void __launch_bounds__(512)
+fwd_update_kernel(const double *__restrict__ Lpanel, long long lda, const double *__restrict__ yk,
+                  double *__restrict__ vbelow, int nrows)
 {
     __shared__ double sy[NBLK];
-    __shared__ double sx[NBLK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k0 = k * NBLK;
-    sy[tid] = y[k0 + tid];
+    __shared__ double part[16][64];
+    const int tid = threadIdx.x;
+    if (tid < NBLK) sy[tid] = yk[tid];
     __syncthreads();
-    const double *__restrict__ T = dinv + (long long)k * NBLK * NBLK;
-    {
-        double s = 0.0;                      // x_c = sum_{r >= c} Linv(r,c) y_r
-#pragma unroll 8
-        for (int r = tid; r < NBLK; ++r) s += T[r * NBLK + tid] * sy[r];
-        sx[tid] = s;
+    const int rp = tid & 31, cg = tid >> 5;
+    const int r = blockIdx.x * 64 + 2 * rp;
+    const double *__restrict__ Lr = Lpanel + r + (long long)(cg * 16) * lda;
+    d2_t l[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) l[c] = *reinterpret_cast<const d2_t *>(Lr + (long long)c * lda);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const double yv = sy[cg * 16 + c];
+        s0 += l[c][0] * yv;
+        s1 += l[c][1] * yv;
     }
+    part[cg][2 * rp] = s0;
+    part[cg][2 * rp + 1] = s1;
     __syncthreads();
-    if (blockIdx.x == 0) xout[k0 + tid] = sx[tid];
-    if (ncols <= 0) return;
-    // 64 columns per workgroup, 16 per wave; a wave dots one 256-row column segment
-    for (int q = 0; q < 16; ++q) {
-        const int jl = blockIdx.x * 64 + wave * 16 + q;
-        if (jl >= ncols) break;
-        const int j = jbeg + jl;
-        const double *__restrict__ Lc = ab + (long long)k0 + (long long)j * lda;
+    if (tid < 64) {
         double s = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s += Lc[lane + 64 * u] * sx[lane + 64 * u];
-        s = wave_sum(s);
-        if (lane == 0) y[j] -= s;
+        for (int g = 0; g < 16; ++g) s += part[g][tid];
+        vbelow[blockIdx.x * 64 + tid] -= s;
+    }
+}
+
+// backward sweep, panel part:  y[j] -= L[block k rows, j]^T x_k for the columns left of block k.
+// workgroup = 64 columns; a wave takes 16 of them, 4 at a time: lane = (column, 16-row segment).
+__global__ void __launch_bounds__(256)
+bwd_update_kernel(const double *__restrict__ Lrows, long long lda, const double *__restrict__ xk,
+                  double *__restrict__ yleft, int ncols)
+{
+    __shared__ double sx[NBLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    sx[tid] = xk[tid];
+    __syncthreads();
+    const int seg = lane & 15, cs = lane >> 4;
+    double xs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xs[i] = sx[seg * 16 + i];
+    d2_t l[4][8];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int j = blockIdx.x * 64 + wave * 16 + cc * 4 + cs;
+        const double *__restrict__ Lc = Lrows + (long long)j * lda + seg * 16;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) l[cc][u] = *reinterpret_cast<const d2_t *>(Lc + 2 * u);
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int j = blockIdx.x * 64 + wave * 16 + cc * 4 + cs;
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += l[cc][u][0] * xs[2 * u] + l[cc][u][1] * xs[2 * u + 1];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (seg == 0 && j < ncols) yleft[j] -= s;
     }
 }
 
@@ -398,45 +594,167 @@ size_t band_bytes(int n, int halfbw, Band *d)
     return b.bytes;
 }
 
+// Streams/events of the look-ahead pipeline (created once per process and device).
+namespace {
+struct Pipeline {
+    hipStream_t panel = nullptr, col = nullptr, upd = nullptr, res = nullptr;
+    std::vector<hipEvent_t> evP, evU, evC;
+    hipEvent_t evR[2] = {nullptr, nullptr};
+    int dev = -1;
+};
+Pipeline &pipeline(int nblk)
+{
+    static thread_local Pipeline p;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (p.panel == nullptr || p.dev != dev) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // hi = numerically lowest = highest priority
+        (void)hipStreamCreateWithPriority(&p.panel, hipStreamNonBlocking, hi);
+        // The trailing updates run on streams whose CU mask leaves one CU out, so that the
+        // latency-bound potrf workgroup of the look-ahead always finds a CU without
+        // MFMA-saturating neighbours (co-resident it ran 2.8x slower: same f64 pipes).
+        hipDeviceProp_t prop;
+        (void)hipGetDeviceProperties(&prop, dev);
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0xffffffffu);
+        mask[0] &= ~1u;
+        if (std::getenv("SPLPAK_NO_CUMASK") ||
+            hipExtStreamCreateWithCUMask(&p.upd, (uint32_t)mask.size(), mask.data()) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&p.col, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            if (!p.upd) (void)hipStreamCreateWithFlags(&p.upd, hipStreamNonBlocking);
+            if (!p.col) (void)hipStreamCreateWithPriority(&p.col, hipStreamNonBlocking, hi);
+        } else {
+            // ... and the potrf / 64x64-inverse kernels are pinned to exactly that CU
+            std::vector<uint32_t> only((size_t)(ncu + 31) / 32, 0u);
+            only[0] = 1u;
+            if (hipExtStreamCreateWithCUMask(&p.res, (uint32_t)only.size(), only.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                p.res = nullptr;
+            }
+        }
+        p.dev = dev;
+        p.evP.clear();
+        p.evU.clear();
+        p.evC.clear();
+        (void)hipEventCreateWithFlags(&p.evR[0], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&p.evR[1], hipEventDisableTiming);
+    }
+    while ((int)p.evP.size() < nblk + 1) {
+        hipEvent_t e;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        p.evP.push_back(e);
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        p.evU.push_back(e);
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        p.evC.push_back(e);
+    }
+    return p;
+}
+}  // namespace
+
+// Right-looking factorisation with one block column of look-ahead:
+//   panel stream : [update of block column k+1 by panel k] -> potrf(k+1) -> trsm(k+1)
+//   update stream: bulk trailing update by panel k (block columns >= k+2)
+// so the latency-bound panel work runs beside the MFMA-bound bulk update.
 hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipStream_t st,
                          CholStats *stats)
 {
-    hipEvent_t e0 = nullptr, e1 = nullptr, f0 = nullptr, f1 = nullptr;
     const bool timing = stats && stats->enabled;
+    Pipeline &pl = pipeline(b.nblk);
+    hipStream_t sP = pl.panel, sC = pl.col, sU = pl.upd;
+    hipStream_t sR = pl.res ? pl.res : pl.panel;     // potrf + inverses (pinned to the reserved CU)
+    hipEvent_t f0 = nullptr, f1 = nullptr;
+    std::vector<hipEvent_t> evs;
     if (timing) {
-        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&f0); (void)hipEventCreate(&f1);
+        (void)hipEventCreate(&f0);
+        (void)hipEventCreate(&f1);
         stats->syrk_launches = stats->syrk_ms = stats->syrk_flop = stats->factor_ms = 0;
         (void)hipEventRecord(f0, st);
     }
-    // per-launch event pairs are collected and read after the loop
-    std::vector<hipEvent_t> evs;
-    for (int k = 0; k < b.nblk; ++k) {
-        const int k0 = k * NBLK;
-        hipLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(1024), 0, st, b.ab, b.lda, k0, info_dev,
-                           minpiv_dev);
-        int tb = b.nblk - 1 - k;
-        if (tb > b.bw) tb = b.bw;
-        if (tb <= 0) continue;
-        const int nrows = tb * NBLK;
-        hipLaunchKernelGGL(trsm_kernel, dim3(nrows / 64), dim3(64), 0, st,
-                           (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda),
-                           b.ab + (long long)(k0 + NBLK) + (long long)k0 * b.lda, b.lda, nrows);
-        const int nt = nrows / TS;
-        const int ntiles = nt * (nt + 1) / 2;
+    auto tb_of = [&](int k) { int t = b.nblk - 1 - k; return t > b.bw ? b.bw : t; };
+    auto syrk = [&](hipStream_t s, int k, int tj_begin, int mode, int ntiles) {
+        const int k0 = k * NBLK, nt = tb_of(k) * NBLK / TS;
+        if (ntiles <= 0) return;
+        hipEvent_t a = nullptr, c = nullptr;
         if (timing) {
-            hipEvent_t a, c;
-            (void)hipEventCreate(&a); (void)hipEventCreate(&c);
-            (void)hipEventRecord(a, st);
-            hipLaunchKernelGGL(syrk_kernel, dim3(ntiles), dim3(256), 0, st, b.ab, b.lda, k0, k0 + NBLK, nt, 0);
-            (void)hipEventRecord(c, st);
-            evs.push_back(a); evs.push_back(c);
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&c);
+            (void)hipEventRecord(a, s);
+        }
+        hipLaunchKernelGGL(syrk_kernel, dim3(ntiles), dim3(256), 0, s, b.ab, b.lda, k0, k0 + NBLK, nt, tj_begin, mode);
+        if (timing) {
+            (void)hipEventRecord(c, s);
+            evs.push_back(a);
+            evs.push_back(c);
             stats->syrk_launches += 1;
             stats->syrk_flop += 2.0 * (double)ntiles * TS * TS * NBLK;
-        } else {
-            hipLaunchKernelGGL(syrk_kernel, dim3(ntiles), dim3(256), 0, st, b.ab, b.lda, k0, k0 + NBLK, nt, 0);
         }
+    };
+    auto potrf = [&](int k) {        // potrf(k) + 64x64 inverses, ordered inside the panel stream
+        const int k0 = k * NBLK;
+        if (sR != sP) {
+            (void)hipEventRecord(pl.evR[0], sP);
+            (void)hipStreamWaitEvent(sR, pl.evR[0], 0);
+        }
+        hipLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, sR, b.ab, b.lda, k0, info_dev,
+                           minpiv_dev);
+        if (sR != sP) {
+            (void)hipEventRecord(pl.evR[1], sR);
+            (void)hipStreamWaitEvent(sP, pl.evR[1], 0);
+        }
+        if (tb_of(k) > 0)
+            hipLaunchKernelGGL(inv64_kernel, dim3(4), dim3(64), 0, sP,
+                               (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda), b.lda,
+                               b.inv64 + (long long)k * 4 * 64 * 64);
+    };
+    auto trsm = [&](int k) {
+        const int k0 = k * NBLK;
+        const int nrows = tb_of(k) * NBLK;
+        if (nrows > 0)
+            hipLaunchKernelGGL(trsm_kernel, dim3(nrows / 16), dim3(64), 0, sP,
+                               (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda),
+                               b.ab + (long long)(k0 + NBLK) + (long long)k0 * b.lda, b.lda,
+                               (const double *)(b.inv64 + (long long)k * 4 * 64 * 64), nrows);
+        (void)hipEventRecord(pl.evP[k], sP);
+    };
+
+    // Dependencies per step k (panel k factored and solved = evP[k]):
+    //   sP: diag3(k) [needs bulk(k-1)] -> potrf(k+1) -> inv64(k+1) -> [colrest(k)] -> trsm(k+1)
+    //   sC: colrest(k): rest of block column k+1        [needs evP[k], bulk(k-1)]
+    //   sU: bulk(k): block columns >= k+2                [needs evP[k]]
+    (void)hipEventRecord(pl.evU[b.nblk], st);      // start after everything queued on the caller's stream
+    (void)hipStreamWaitEvent(sP, pl.evU[b.nblk], 0);
+    (void)hipStreamWaitEvent(sC, pl.evU[b.nblk], 0);
+    (void)hipStreamWaitEvent(sU, pl.evU[b.nblk], 0);
+    potrf(0);
+    trsm(0);
+    for (int k = 0; k < b.nblk; ++k) {
+        const int tb = tb_of(k);
+        if (tb <= 0) continue;
+        const int nt = tb * NBLK / TS;
+        const int ntiles = nt * (nt + 1) / 2;
+        const int ncol = nt + (nt - 1);                 // tiles of the first block column (tj = 0, 1)
+        if (k > 0) {
+            (void)hipStreamWaitEvent(sP, pl.evU[k - 1], 0);
+            (void)hipStreamWaitEvent(sC, pl.evU[k - 1], 0);
+        }
+        syrk(sP, k, 0, 1, 3);
+        potrf(k + 1);
+        (void)hipStreamWaitEvent(sC, pl.evP[k], 0);
+        syrk(sC, k, 0, 2, ncol - 3);
+        (void)hipEventRecord(pl.evC[k], sC);
+        (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
+        trsm(k + 1);
+        (void)hipStreamWaitEvent(sU, pl.evP[k], 0);
+        syrk(sU, k, 2, 0, ntiles - ncol);
+        (void)hipEventRecord(pl.evU[k], sU);
     }
-    hipLaunchKernelGGL(trtri_kernel, dim3(b.nblk), dim3(256), 0, st, b.ab, b.lda, b.dinv);
+    (void)hipStreamWaitEvent(sU, pl.evP[b.nblk - 1], 0);
+    (void)hipEventRecord(pl.evC[b.nblk], sU);      // join: the caller's stream continues after the pipeline
+    (void)hipStreamWaitEvent(st, pl.evC[b.nblk], 0);
+    hipLaunchKernelGGL(trtri_kernel, dim3(b.nblk), dim3(256), 0, st, b.ab, b.lda, b.dinv, b.dinvt);
     hipError_t err = hipGetLastError();
     if (timing) {
         (void)hipEventRecord(f1, st);
@@ -447,30 +765,43 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         for (size_t i = 0; i + 1 < evs.size(); i += 2) {
             (void)hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
             stats->syrk_ms += ms;
-            (void)hipEventDestroy(evs[i]); (void)hipEventDestroy(evs[i + 1]);
+            (void)hipEventDestroy(evs[i]);
+            (void)hipEventDestroy(evs[i + 1]);
         }
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(f0); (void)hipEventDestroy(f1);
+        (void)hipEventDestroy(f0);
+        (void)hipEventDestroy(f1);
     }
     return err;
 }
 
 hipError_t band_solve(const Band &b, double *x, double *tmp, hipStream_t st)
 {
-    // forward: x -> tmp ; backward: tmp -> x
+    // forward: x -> tmp (y), the not-yet-solved part of x is updated in place;
+    // backward: tmp -> x
     for (int k = 0; k < b.nblk; ++k) {
+        const int k0 = k * NBLK;
         int tb = b.nblk - 1 - k;
         if (tb > b.bw) tb = b.bw;
         const int nrows = tb * NBLK;
-        const int wg = nrows > 0 ? nrows / 64 : 1;
-        hipLaunchKernelGGL(fwd_step_kernel, dim3(wg), dim3(256), 0, st, b.ab, b.lda, b.dinv, k, nrows, x, tmp);
+        hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st,
+                           (const double *)(b.dinv + (long long)k * NBLK * NBLK), (const double *)(x + k0), tmp + k0);
+        if (nrows > 0)
+            hipLaunchKernelGGL(fwd_update_kernel, dim3(nrows / 64), dim3(512), 0, st,
+                               (const double *)(b.ab + (long long)(k0 + NBLK) + (long long)k0 * b.lda), b.lda,
+                               (const double *)(tmp + k0), x + k0 + NBLK, nrows);
     }
     for (int k = b.nblk - 1; k >= 0; --k) {
+        const int k0 = k * NBLK;
         int tb = k;
         if (tb > b.bw) tb = b.bw;
         const int ncols = tb * NBLK;
-        const int jbeg = k * NBLK - ncols;
-        const int wg = ncols > 0 ? ncols / 64 : 1;
-        hipLaunchKernelGGL(bwd_step_kernel, dim3(wg), dim3(256), 0, st, b.ab, b.lda, b.dinv, k, jbeg, ncols, tmp, x);
+        const int jbeg = k0 - ncols;
+        hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st,
+                           (const double *)(b.dinvt + (long long)k * NBLK * NBLK), (const double *)(tmp + k0), x + k0);
+        if (ncols > 0)
+            hipLaunchKernelGGL(bwd_update_kernel, dim3(ncols / 64), dim3(256), 0, st,
+                               (const double *)(b.ab + (long long)k0 + (long long)jbeg * b.lda), b.lda,
+                               (const double *)(x + k0), tmp + jbeg, ncols);
     }
     return hipGetLastError();
 }

@@ -56,7 +56,9 @@ hipError_t launch_constraints(const Grid &g, const double *hist, const double *s
 constexpr int NBLK = 256;     // block size of the band factorisation
 struct Band {
     double *ab;       // dense-view base: A(i,j) = ab[i + j*lda], j <= i <= j + halfbw
-    double *dinv;     // [nblk][NBLK*NBLK] inverses of the diagonal blocks of L (column-major)
+    double *dinv;     // [nblk][NBLK*NBLK] inverses of the diagonal blocks of L (row-major)
+    double *dinvt;    // [nblk][NBLK*NBLK] transposes of dinv (backward sweep)
+    double *inv64;    // [nblk][4][64*64] inverses of the 64x64 diagonal sub-blocks (column-major)
     long long lda;    // column stride of the dense view (ld - 1)
     int n;            // logical order
     int npad;         // padded to a multiple of NBLK (identity on the padding)

@@ -20,6 +20,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -191,6 +192,8 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
     band_bytes(g.ncol, g.halfbw, &p->band);
     ok = ok && dev_alloc(p, &p->band.ab, p->band.bytes / sizeof(double));
     ok = ok && dev_alloc(p, &p->band.dinv, (size_t)p->band.nblk * NBLK * NBLK);
+    ok = ok && dev_alloc(p, &p->band.dinvt, (size_t)p->band.nblk * NBLK * NBLK);
+    ok = ok && dev_alloc(p, &p->band.inv64, (size_t)p->band.nblk * 4 * 64 * 64);
     // communication buffer
     p->comm_len = comm_len_of(g);
     if (comm_buf_dev) {
@@ -361,6 +364,8 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
         ++steps;
         last_rel = (am[1] > 0.0) ? am[0] / am[1] : 0.0;
+        if (std::getenv("SPLPAK_DEBUG"))
+            fprintf(stderr, "[splpak] refinement step %d: |dx|/|x| = %.3e\n", steps, last_rel);
         if (!(last_rel == last_rel)) break;                   // NaN
         if (last_rel <= p->tol) break;
         if (last_rel > 0.5 * prev_rel && it >= 1) break;      // stagnation at the rounding floor
@@ -585,6 +590,8 @@ int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double 
     int *dinfo = nullptr;
     bool ok = dev_alloc(&holder, &b.ab, b.bytes / sizeof(double)) &&
               dev_alloc(&holder, &b.dinv, (size_t)b.nblk * NBLK * NBLK) &&
+              dev_alloc(&holder, &b.dinvt, (size_t)b.nblk * NBLK * NBLK) &&
+              dev_alloc(&holder, &b.inv64, (size_t)b.nblk * 4 * 64 * 64) &&
               dev_alloc(&holder, &dsmall, 8) && dev_alloc(&holder, &dx, (size_t)b.npad) &&
               dev_alloc(&holder, &dtmp, (size_t)b.npad) && dev_alloc(&holder, &dinfo, 2);
     int rc = 0;
