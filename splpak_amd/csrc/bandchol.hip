@@ -67,36 +67,34 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
     __builtin_amdgcn_s_setprio(3);           // critical path of the look-ahead: win issue arbitration
 
     for (int c0 = 0; c0 < NBLK; c0 += IB) {
-        // (i) diagonal 32x32 block, in LDS, by wave 0 alone (LDS operations of one wave execute
-        // in order, so no barrier is needed inside).  lane = row + 32*half; the two halves
-        // split the columns of the rank-1 update.  Kept as compact loops on purpose: this
-        // kernel runs once per step and large unrolled bodies paid ~1 us per 64-B line of
-        // instruction-cache miss under the bulk update.
+        // (i) diagonal 32x32 block: wave 0 alone, one row per lane in registers, columns
+        // broadcast with v_readlane (no barriers, no LDS round trips).  The unrolled body is
+        // large (~20 KB); the kernel is pinned to the CU that the update streams leave free,
+        // whose instruction cache therefore stays warm from step to step.
         if (wave == 0) {
-            const int r = lane & 31, h = lane >> 5;
-            for (int c = h; c < IB; c += 2)
-                Ls[r * (IB + 1) + c] = (c <= r) ? A[(c0 + r) + (long long)(c0 + c) * lda] : 0.0;
-            double dmin = 1.0e300;
+            const int r = lane & 31;
+            double a[IB];
+#pragma unroll
+            for (int c = 0; c < IB; ++c) a[c] = (c <= r) ? A[(c0 + r) + (long long)(c0 + c) * lda] : 0.0;
+            double dmin = a[0];
             bool bad = false;
+#pragma unroll
             for (int j = 0; j < IB; ++j) {
-                const double d = Ls[j * (IB + 1) + j];
+                const double d = readlane_f64(a[j], j);
                 bad = bad || !(d > 0.0);
                 dmin = fmin(dmin, d);
                 const double sd = sqrt(d);
-                const double l = (r == j) ? sd : Ls[r * (IB + 1) + j] / sd;
-                if (h == 0 && r >= j) Ls[r * (IB + 1) + j] = l;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-                for (int c = j + 1 + h; c < IB; c += 2) {
-                    const double lc = Ls[c * (IB + 1) + j];
-                    if (r >= c) Ls[r * (IB + 1) + c] -= l * lc;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                a[j] = (r == j) ? sd : a[j] / sd;
+#pragma unroll
+                for (int c = j + 1; c < IB; ++c) a[c] -= a[j] * readlane_f64(a[j], c);
             }
-            for (int c = h; c < IB; c += 2)
-                if (c <= r) A[(c0 + r) + (long long)(c0 + c) * lda] = Ls[r * (IB + 1) + c];
+            if (lane < IB) {
+#pragma unroll
+                for (int c = 0; c < IB; ++c) {
+                    Ls[r * (IB + 1) + c] = a[c];
+                    if (c <= r) A[(c0 + r) + (long long)(c0 + c) * lda] = a[c];
+                }
+            }
             if (lane == 0) {
                 if (bad) atomicCAS(info, 0, k0 + c0 + 1);
                 if (dmin < *minpiv || !(dmin == dmin)) *minpiv = dmin;
@@ -208,53 +206,54 @@ inv64_kernel(const double *__restrict__ A, long long lda, double *__restrict__ i
 // ---------------------------------------------------------------------------
 // X = A * L^{-T} for the rows below the diagonal block, on the f64 matrix cores.
 //
-// One wave owns 16 rows for the whole solve and keeps them in MFMA accumulator
-// layout (lane: row r = lane&15; register v of column tile ct: column 16ct + (lane>>4) + 4v).
-// With 64-column blocks j = 0..3 of the 256 columns,
+// One wave owns 16 rows for the whole solve.  With 64-column blocks j = 0..3 of the 256 columns,
 //     X_j = (A_j - sum_{i<j} X_i L_ji^T) Inv_jj^T ,   Inv_jj = (64x64 diagonal block of L)^{-1}.
-// Both products are computed transposed, D[c][r] = sum_k Aop[c][k] * Bop[k][r], so that
-// the accumulator registers of earlier results ARE the B operand of the next MFMA
-// (register s of a tile is k-step s): the rows never leave the register file; only
-// L / Inv elements (L2 resident, shared by all waves) are loaded, 8 bytes per lane and MFMA.
+// Both products are computed transposed, D[c][r] = sum_k Aop[c][k] * Bop[k][r]: the lane that
+// holds row r = lane&15 of an accumulator tile holds, in register s, exactly the B operand of
+// k-step s, so T = A_j - ... feeds the Inv product straight from registers.  Finished blocks
+// X_i are parked in LDS (per wave, [column][row]) so that the i / k loops stay dynamic and the
+// code compact: the kernel runs once per step on every CU with a cold instruction cache, where a
+// fully unrolled body cost more in instruction fetch than in arithmetic.
+// Only L / Inv elements (L2 resident, shared by all waves) are loaded: 8 bytes per lane and MFMA.
 constexpr int TCB = 32;
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long lda,
             const double *__restrict__ inv64, int nrows)
 {
-    const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
-    const int r0 = blockIdx.x * 16;
+    // 2 waves x 32 KB: small enough to take the place of ONE retiring trailing-update workgroup
+    __shared__ double Xs[2][NBLK * 16];                  // Xs[wave][col*16 + row]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, q = lane >> 4;
+    const int r0 = (blockIdx.x * 2 + wave) * 16;
     if (r0 >= nrows) return;
     __builtin_amdgcn_s_setprio(3);
     double *__restrict__ Xr = Xbase + r0 + l15;          // Xr[c*lda] = X(row, c)
+    double *xs = Xs[wave];
 
-    d4_t X[4][4];
-#pragma unroll
     for (int j = 0; j < 4; ++j) {
         d4_t T[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int v = 0; v < 4; ++v) T[ct][v] = Xr[(long long)(64 * j + 16 * ct + q + 4 * v) * lda];
+        for (int kb = 0; kb < 4 * j; ++kb) {             // 16-wide k blocks of the finished columns
+            double a[4][4], bq[4];
+            const double *__restrict__ Lk = L + (64 * j + l15) + (long long)(16 * kb + q) * lda;
 #pragma unroll
-        for (int i = 0; i < j; ++i) {
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                double a[4][4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        a[s][ct] = -L[(64 * j + 16 * ct + l15) + (long long)(64 * i + 16 * kt + 4 * s + q) * lda];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        T[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ct], X[i][kt][s], T[ct], 0, 0, 0);
+                for (int ct = 0; ct < 4; ++ct) a[s][ct] = -Lk[16 * ct + (long long)(4 * s) * lda];
+                bq[s] = xs[(16 * kb + 4 * s + q) * 16 + l15];
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    T[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ct], bq[s], T[ct], 0, 0, 0);
         }
         const double *__restrict__ Inv = inv64 + (long long)j * 64 * 64;   // Inv[c + 64*k]
+        d4_t Xj[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) X[j][ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int ct = 0; ct < 4; ++ct) Xj[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             double a[4][4];
@@ -267,13 +266,18 @@ trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long 
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int ct = kt; ct < 4; ++ct)      // Inv is lower triangular: k-tile <= c-tile
-                    X[j][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ct], T[kt][s], X[j][ct], 0, 0, 0);
+                    Xj[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ct], T[kt][s], Xj[ct], 0, 0, 0);
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                Xr[(long long)(64 * j + 16 * ct + q + 4 * v) * lda] = X[j][ct][v];
+            for (int v = 0; v < 4; ++v) {
+                const int c = 64 * j + 16 * ct + q + 4 * v;
+                Xr[(long long)c * lda] = Xj[ct][v];
+                xs[c * 16 + l15] = Xj[ct][v];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -293,8 +297,23 @@ syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, in
     //   mode 0: all tiles of tile columns >= tj_begin, column-major
     //   mode 1: the 3 tiles of the first diagonal 256x256 block
     //   mode 2: the rest of the first two tile columns (rows >= 2)
+    //   mode 3: as mode 0, but walked in 8x8 super-tiles that are dealt to the XCDs
+    //           (workgroup b runs on XCD b%8): the 64 workgroups an XCD has in flight share
+    //           8 + 8 panel row blocks (4 MB = its L2) instead of streaming 64 different ones
     int b = blockIdx.x, tj = tj_begin, ti;
-    if (mode == 0) {
+    if (mode == 3) {
+        const int x = b & 7, l = b >> 3;
+        int s = (l >> 6) * 8 + x;
+        const int w = l & 63;
+        const int ns = (nt - tj_begin + 7) >> 3;
+        if (s >= ns * (ns + 1) / 2) return;
+        int sj = 0;
+        while (s >= ns - sj) { s -= ns - sj; ++sj; }
+        const int si = sj + s;
+        ti = tj_begin + 8 * si + (w & 7);
+        tj = tj_begin + 8 * sj + (w >> 3);
+        if (ti >= nt || tj >= nt || ti < tj) return;
+    } else if (mode == 0) {
         while (b >= nt - tj) { b -= nt - tj; ++tj; }
         ti = tj + b;
     } else if (mode == 1) {
@@ -382,7 +401,7 @@ syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, in
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                dst[n][v] = C[(wi * 64 + n * 16 + l15) + (long long)(wj * 64 + m * 16 + kq + 4 * v) * lda];
+                dst[n][v] = __builtin_nontemporal_load(&C[(wi * 64 + n * 16 + l15) + (long long)(wj * 64 + m * 16 + kq + 4 * v) * lda]);
     };
     auto cstore = [&](int m, const d4_t (&src)[4]) {
 #pragma unroll
@@ -392,7 +411,112 @@ syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, in
             for (int v = 0; v < 4; ++v) {
                 const int c = wj * 64 + m * 16 + kq + 4 * v;
                 const double val = src[n][v] - acc[m][n][v];
-                if (!diag || r >= c) C[r + (long long)c * lda] = val;
+                if (!diag || r >= c) __builtin_nontemporal_store(val, &C[r + (long long)c * lda]);
+            }
+        }
+    };
+    cload(0, cold[0]);
+    cload(1, cold[1]);
+    cstore(0, cold[0]);
+    cload(2, cold[0]);
+    cstore(1, cold[1]);
+    cload(3, cold[1]);
+    cstore(2, cold[0]);
+    cstore(3, cold[1]);
+}
+
+// ---------------------------------------------------------------------------
+// Trailing update, register-streaming form: one wave = one 64x64 piece of C, no LDS, no
+// barriers.  The MFMA operands are loaded straight from the panel (L2 / Infinity-Cache
+// resident) in fragment shape -- lane (l15, q) reads P[row0 + 16m + l15][k + q], 16 rows
+// = one 128-B line per k -- D k-steps ahead into a rotating register queue; every loaded
+// operand feeds 4 MFMAs, so the load path carries only 16 B/clk/CU.  v_mfma_f64_16x16x4
+// occupies the pipe for 64 cycles, which leaves ample time for 8 loads per 16 MFMAs;
+// what the LDS version lost to per-chunk workgroup barriers and to the coupling of the
+// two co-resident workgroups is gone.  Two waves per SIMD (<= 256 VGPRs) overlap one
+// wave's C read-modify-write with the other's main loop.
+// SD = k-steps of look-ahead in the operand queue; WPS = waves per SIMD the register budget
+// allows; ABL = ablation switches for tools/syrk_bench (0 = the product kernel)
+template <int SD, int WPS, int ABL>
+__global__ void __launch_bounds__(64, WPS)
+syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, int ce, int rb, int re)
+{
+    // item -> (tj, ti) in 64-row units: columns [cb, ce), rows [max(tj, rb), re)
+    int it = blockIdx.x, tj = cb;
+    for (;;) {
+        const int lo = tj > rb ? tj : rb;
+        const int cnt = re - lo;
+        if (it < cnt) { it += lo; break; }
+        it -= cnt;
+        ++tj;
+    }
+    const int ti = it;
+    const bool diag = (ti == tj);
+    const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
+
+    // per-lane operand streams: element (m, step) at base + 16*m + step*4*lda
+    const double *__restrict__ pJ = ab + (long long)(row0 + tj * 64 + l15) + (long long)(k0 + q) * lda;
+    const double *__restrict__ pI = ab + (long long)(row0 + ti * 64 + l15) + (long long)(k0 + q) * lda;
+
+    d4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    double qa[SD][4], qb[SD][4];
+    auto fetch = [&](int slot, int step) {
+        const long long off = (long long)(4 * step) * lda;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            qa[slot][m] = pJ[off + 16 * m];
+            qb[slot][m] = pI[off + 16 * m];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < SD; ++d) fetch(d, d);
+    constexpr int NSTEP = NBLK / 4;
+    static_assert(NSTEP % SD == 0, "queue depth must divide the k-steps");
+    for (int ks = 0; ks < NSTEP; ks += SD) {
+#pragma unroll
+        for (int d = 0; d < SD; ++d) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+            if ((ABL & 1) == 0 && ks + d + SD < NSTEP) fetch(d, ks + d + SD);   // ABL&1: no operand refills
+        }
+    }
+    if (ABL & 2) {                                 // ABL&2: no C read-modify-write
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+        if (s == 123.456) ab[0] = s;
+        return;
+    }
+
+    // C(r, c) -= acc: lane holds r = l15 (+16n), c = q + 4v (+16m); batches of 16 loads
+    double *__restrict__ C = ab + (long long)(row0 + ti * 64) + (long long)(row0 + tj * 64) * lda;
+    d4_t cold[2][4];
+    auto cload = [&](int m, d4_t (&dst)[4]) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                dst[n][v] = __builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * lda]);
+    };
+    auto cstore = [&](int m, const d4_t (&src)[4]) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int r = n * 16 + l15;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c = m * 16 + q + 4 * v;
+                const double val = src[n][v] - acc[m][n][v];
+                if (!diag || r >= c) __builtin_nontemporal_store(val, &C[r + (long long)c * lda]);
             }
         }
     };
@@ -618,8 +742,13 @@ Pipeline &pipeline(int nblk)
         (void)hipGetDeviceProperties(&prop, dev);
         const int ncu = prop.multiProcessorCount;
         std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0xffffffffu);
-        mask[0] &= ~1u;
-        if (std::getenv("SPLPAK_NO_CUMASK") ||
+        int nres = 0;                                     // CUs left to the panel kernels (0: no masking)
+        if (const char *e = std::getenv("SPLPAK_RESERVE_CUS")) nres = std::atoi(e);
+        if (nres < 0) nres = 0;
+        if (nres > 8) nres = 8;
+        const uint32_t resbits = (1u << nres) - 1u;
+        mask[0] &= ~resbits;
+        if (nres == 0 ||
             hipExtStreamCreateWithCUMask(&p.upd, (uint32_t)mask.size(), mask.data()) != hipSuccess ||
             hipExtStreamCreateWithCUMask(&p.col, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
             (void)hipGetLastError();
@@ -628,7 +757,7 @@ Pipeline &pipeline(int nblk)
         } else {
             // ... and the potrf / 64x64-inverse kernels are pinned to exactly that CU
             std::vector<uint32_t> only((size_t)(ncu + 31) / 32, 0u);
-            only[0] = 1u;
+            only[0] = resbits;
             if (hipExtStreamCreateWithCUMask(&p.res, (uint32_t)only.size(), only.data()) != hipSuccess) {
                 (void)hipGetLastError();
                 p.res = nullptr;
@@ -664,7 +793,8 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     const bool timing = stats && stats->enabled;
     Pipeline &pl = pipeline(b.nblk);
     hipStream_t sP = pl.panel, sC = pl.col, sU = pl.upd;
-    hipStream_t sR = pl.res ? pl.res : pl.panel;     // potrf + inverses (pinned to the reserved CU)
+    hipStream_t sR = pl.res ? pl.res : pl.panel;     // potrf (pinned to the reserved CU)
+    if (std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = sC = sU = sR = st;   // diagnostics: one stream, no overlap
     hipEvent_t f0 = nullptr, f1 = nullptr;
     std::vector<hipEvent_t> evs;
     if (timing) {
@@ -674,16 +804,50 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         (void)hipEventRecord(f0, st);
     }
     auto tb_of = [&](int k) { int t = b.nblk - 1 - k; return t > b.bw ? b.bw : t; };
+    static const bool use64 = std::getenv("SPLPAK_SYRK_64") != nullptr;   // register-streaming variant (experimental)
     auto syrk = [&](hipStream_t s, int k, int tj_begin, int mode, int ntiles) {
         const int k0 = k * NBLK, nt = tb_of(k) * NBLK / TS;
         if (ntiles <= 0) return;
+        if (use64) {
+            // 64-row units: diag block = cols [0,4) rows [0,4); rest of first block column =
+            // cols [0,4) rows [4,n64); bulk = cols [4,n64)
+            const int n64 = 2 * nt;
+            int cb, ce, rb, re = n64;
+            if (mode == 1) { cb = 0; ce = 4; rb = 0; re = 4; }
+            else if (mode == 2) { cb = 0; ce = 4; rb = 4; }
+            else { cb = 2 * tj_begin; ce = n64; rb = 0; }
+            long long items = 0;
+            for (int c = cb; c < ce; ++c) items += re - (c > rb ? c : rb);
+            if (items <= 0) return;
+            hipEvent_t a = nullptr, c = nullptr;
+            if (timing) {
+                (void)hipEventCreate(&a);
+                (void)hipEventCreate(&c);
+                (void)hipEventRecord(a, s);
+            }
+            hipLaunchKernelGGL((syrk64_kernel<4, 2, 0>), dim3((unsigned)items), dim3(64), 0, s, b.ab, b.lda, k0, k0 + NBLK,
+                               cb, ce, rb, re);
+            if (timing) {
+                (void)hipEventRecord(c, s);
+                evs.push_back(a);
+                evs.push_back(c);
+                stats->syrk_launches += 1;
+                stats->syrk_flop += 2.0 * (double)items * 64 * 64 * NBLK;
+            }
+            return;
+        }
         hipEvent_t a = nullptr, c = nullptr;
         if (timing) {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&c);
             (void)hipEventRecord(a, s);
         }
-        hipLaunchKernelGGL(syrk_kernel, dim3(ntiles), dim3(256), 0, s, b.ab, b.lda, k0, k0 + NBLK, nt, tj_begin, mode);
+        int grid = ntiles;
+        if (mode == 3) {
+            const int ns = (nt - tj_begin + 7) / 8, nst = ns * (ns + 1) / 2;
+            grid = ((nst + 7) / 8) * 8 * 64;
+        }
+        hipLaunchKernelGGL(syrk_kernel, dim3(grid), dim3(256), 0, s, b.ab, b.lda, k0, k0 + NBLK, nt, tj_begin, mode);
         if (timing) {
             (void)hipEventRecord(c, s);
             evs.push_back(a);
@@ -700,20 +864,20 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         }
         hipLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, sR, b.ab, b.lda, k0, info_dev,
                            minpiv_dev);
+        if (tb_of(k) > 0)
+            hipLaunchKernelGGL(inv64_kernel, dim3(4), dim3(64), 0, sR,
+                               (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda), b.lda,
+                               b.inv64 + (long long)k * 4 * 64 * 64);
         if (sR != sP) {
             (void)hipEventRecord(pl.evR[1], sR);
             (void)hipStreamWaitEvent(sP, pl.evR[1], 0);
         }
-        if (tb_of(k) > 0)
-            hipLaunchKernelGGL(inv64_kernel, dim3(4), dim3(64), 0, sP,
-                               (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda), b.lda,
-                               b.inv64 + (long long)k * 4 * 64 * 64);
     };
     auto trsm = [&](int k) {
         const int k0 = k * NBLK;
         const int nrows = tb_of(k) * NBLK;
         if (nrows > 0)
-            hipLaunchKernelGGL(trsm_kernel, dim3(nrows / 16), dim3(64), 0, sP,
+            hipLaunchKernelGGL(trsm_kernel, dim3(nrows / 32), dim3(128), 0, sP,
                                (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda),
                                b.ab + (long long)(k0 + NBLK) + (long long)k0 * b.lda, b.lda,
                                (const double *)(b.inv64 + (long long)k * 4 * 64 * 64), nrows);
@@ -748,7 +912,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
         trsm(k + 1);
         (void)hipStreamWaitEvent(sU, pl.evP[k], 0);
-        syrk(sU, k, 2, 0, ntiles - ncol);
+        syrk(sU, k, 2, std::getenv("SPLPAK_NO_XCDMAP") ? 0 : 3, ntiles - ncol);
         (void)hipEventRecord(pl.evU[k], sU);
     }
     (void)hipStreamWaitEvent(sU, pl.evP[b.nblk - 1], 0);
