@@ -119,13 +119,9 @@ def main():
     capi.synth_points_dev(nd, rank * m, m, x, y, w, stream)
     coef = torch.zeros(ncol, dtype=torch.float64, device=dev)
 
-    comm_len = int(capi.lib().splpak_plan_comm_len(nd, capi._p(np.array(nodes, dtype=np.int32), capi._ip)))
-    comm = torch.zeros(comm_len, dtype=torch.float64, device=dev)
-    plan = capi.Plan(nd, nodes, lo, hi, 1.0, m, comm=comm)
-    if world > 1:
-        def allreduce(off, count):
-            dist.all_reduce(comm[off:off + count])
-        plan.set_allreduce(allreduce, rank, world)
+    from splpak_amd.dist import ShardedFit
+    sharded = ShardedFit(nd, nodes, lo, hi, 1.0, m, dev, dist if world > 1 else None)
+    plan = sharded.plan
     plan.enable_kernel_timing(not args.no_kernel_timing)
 
     def barrier():
