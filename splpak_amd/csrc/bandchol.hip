@@ -38,13 +38,20 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 constexpr int PNL = 64;            // potrf inner panel width
 
 // ---------------------------------------------------------------------------
-// Cholesky of one 256x256 diagonal block: one workgroup of 4 waves, 32-column panels.
-// Per panel: (i) the 32x32 diagonal block is factored by wave 0 alone, one row per lane,
-// columns broadcast with v_readlane (no barriers); (ii) the rows below are solved one
-// row per thread against that factor (broadcast LDS reads); (iii) the rest of the block
-// is updated on the f64 matrix cores from the LDS-resident panel.  LDS stays under 80 KB
-// so the workgroup can share a CU with a trailing-update workgroup of the look-ahead.
-constexpr int IB = 32;                 // inner panel width
+// Cholesky of one 256x256 diagonal block: one workgroup of 4 waves, 16-column panels.
+// Per panel: (i) the 16x16 diagonal block is factored by wave 0 alone, one row per lane in
+// registers, columns broadcast with v_readlane (no barriers); (ii) the rows below are solved
+// one row per thread against that factor (broadcast LDS reads); (iii) the rest of the block
+// is updated on the f64 matrix cores from the LDS-resident panel, four 16x16 tiles per wave
+// in flight.  All global loads of a panel are issued before phase (i) starts, so a panel
+// costs about one memory round trip.
+//
+// The kernel is on the critical path of the look-ahead, runs ONCE per step on whatever CU the
+// dispatcher finds, i.e. with a cold instruction cache beside MFMA-saturating update waves:
+// measured cost of cold code was ~0.5 us per 64-B line, which made a 60 KB fully unrolled
+// version take 700 us against 215 us alone.  Hence 16-wide panels and rolled loops: the
+// whole kernel is ~14 KB.  LDS 37 KB, <= 200 VGPRs: it fits beside trailing-update waves.
+constexpr int IB = 16;                 // inner panel width
 constexpr int XLD = NBLK + 16;         // LDS row of the panel image (bank-half alternation, as in syrk)
 
 __device__ inline double readlane_f64(double v, int srclane)
@@ -59,7 +66,7 @@ __global__ void __launch_bounds__(256)
 potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restrict__ info,
                    double *__restrict__ minpiv)
 {
-    __shared__ double Ls[IB * (IB + 1)];     // factor of the current diagonal 32x32: Ls[c*(IB+1) + k]
+    __shared__ double Ls[IB * (IB + 1)];     // factor of the current diagonal 16x16: Ls[c*(IB+1) + k]
     __shared__ double Xs[IB * XLD];          // panel image Xs[k*XLD + r], r = row inside the 256 block
     double *A = ab + (long long)k0 + (long long)k0 * lda;    // A(r,c) = A[r + c*lda], r >= c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,12 +74,21 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
     __builtin_amdgcn_s_setprio(3);           // critical path of the look-ahead: win issue arbitration
 
     for (int c0 = 0; c0 < NBLK; c0 += IB) {
-        // (i) diagonal 32x32 block: wave 0 alone, one row per lane in registers, columns
-        // broadcast with v_readlane (no barriers, no LDS round trips).  The unrolled body is
-        // large (~20 KB); the kernel is pinned to the CU that the update streams leave free,
-        // whose instruction cache therefore stays warm from step to step.
+        const int base = c0 + IB;            // first row / column of the trailing part
+        const int mrem = NBLK - base;        // rows below the diagonal block
+        const int nt = mrem / 16;
+        const int ntiles = nt * (nt + 1) / 2;
+
+        // ---- every load of this panel is issued here
+        double x[IB];                        // (ii) this thread's row of the panel
+        const int row = base + tid;
+        if (tid < mrem) {
+#pragma unroll
+            for (int c = 0; c < IB; ++c) x[c] = A[row + (long long)(c0 + c) * lda];
+        }
+        // (i) diagonal block: wave 0, one row per lane (the four 16-lane groups mirror each other)
         if (wave == 0) {
-            const int r = lane & 31;
+            const int r = l15;
             double a[IB];
 #pragma unroll
             for (int c = 0; c < IB; ++c) a[c] = (c <= r) ? A[(c0 + r) + (long long)(c0 + c) * lda] : 0.0;
@@ -101,14 +117,8 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
             }
         }
         __syncthreads();
-        const int base = c0 + IB;            // first row / column of the trailing part
-        const int mrem = NBLK - base;        // rows below the diagonal block
         // (ii) rows below: x = a L^{-T}, one row per thread
         if (tid < mrem) {
-            const int row = base + tid;
-            double x[IB];
-#pragma unroll
-            for (int c = 0; c < IB; ++c) x[c] = A[row + (long long)(c0 + c) * lda];
 #pragma unroll
             for (int c = 0; c < IB; ++c) {
 #pragma unroll
@@ -122,18 +132,14 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
             }
         }
         __syncthreads();
-        // (iii) trailing update inside the block on the matrix cores: 16x16 tiles, rt >= ct.
-        // All C tiles of this wave are fetched first (independent loads, one latency per
-        // panel instead of one per tile), then updated and stored.
-        const int nt = mrem / 16;
-        const int ntiles = nt * (nt + 1) / 2;
-        constexpr int TB = 14;               // tiles per batch and wave (2 batches cover 105 tiles / 4 waves)
-        for (int t0 = wave; t0 < ntiles; t0 += 4 * TB) {
-            d4_t cc[TB];
-            int roff[TB], coff[TB];
+        // (iii) trailing update inside the block on the matrix cores: 16x16 tiles, rt >= ct,
+        // four tiles per wave and round with all their C loads in flight together
+        for (int t0 = wave * 4; t0 < ntiles; t0 += 16) {
+            d4_t cc[4];
+            int roff[4], coff[4];
 #pragma unroll
-            for (int u = 0; u < TB; ++u) {
-                const int t = t0 + 4 * u;
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u;
                 roff[u] = -1;
                 coff[u] = 0;
                 if (t < ntiles) {
@@ -147,7 +153,7 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
                 }
             }
 #pragma unroll
-            for (int u = 0; u < TB; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 if (roff[u] >= 0) {
                     d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -216,14 +222,14 @@ inv64_kernel(const double *__restrict__ A, long long lda, double *__restrict__ i
 // fully unrolled body cost more in instruction fetch than in arithmetic.
 // Only L / Inv elements (L2 resident, shared by all waves) are loaded: 8 bytes per lane and MFMA.
 constexpr int TCB = 32;
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(64)
 trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long lda,
             const double *__restrict__ inv64, int nrows)
 {
-    // 2 waves x 32 KB: small enough to take the place of ONE retiring trailing-update workgroup
-    __shared__ double Xs[2][NBLK * 16];                  // Xs[wave][col*16 + row]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, q = lane >> 4;
-    const int r0 = (blockIdx.x * 2 + wave) * 16;
+    // one wave, 24 KB of LDS, < 200 VGPRs: takes the slot of ONE retiring trailing-update wave
+    __shared__ double Xs[1][(NBLK - 64) * 16];           // Xs[col*16 + row], columns 0..191 (X_3 is never an operand)
+    const int lane = threadIdx.x & 63, wave = 0, l15 = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.x * 16;
     if (r0 >= nrows) return;
     __builtin_amdgcn_s_setprio(3);
     double *__restrict__ Xr = Xbase + r0 + l15;          // Xr[c*lda] = X(row, c)
@@ -274,7 +280,7 @@ trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long 
             for (int v = 0; v < 4; ++v) {
                 const int c = 64 * j + 16 * ct + q + 4 * v;
                 Xr[(long long)c * lda] = Xj[ct][v];
-                xs[c * 16 + l15] = Xj[ct][v];
+                if (j < 3) xs[c * 16 + l15] = Xj[ct][v];
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -437,12 +443,42 @@ syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, in
 // wave's C read-modify-write with the other's main loop.
 // SD = k-steps of look-ahead in the operand queue; WPS = waves per SIMD the register budget
 // allows; ABL = ablation switches for tools/syrk_bench (0 = the product kernel)
+__device__ inline unsigned my_cu_id()
+{   // (XCC id, shader engine, CU) of the CU this wave runs on
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return ((xcc & 0xfu) << 16) | (hw & 0xff00u);
+}
+
+__global__ void whoami_kernel(unsigned *out) { if (threadIdx.x == 0) out[0] = my_cu_id(); }
+
+// queue[0]: next item, queue[1]: waves that stepped aside.  A wave that finds itself on the
+// CU reserved for the panel factorisation (`reserved`, ~0u = none) steps aside without taking
+// an item -- the grid carries `margin` spare waves for that -- unless the margin is used up.
 template <int SD, int WPS, int ABL>
 __global__ void __launch_bounds__(64, WPS)
-syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, int ce, int rb, int re)
+syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, int ce, int rb, int re,
+              int nitems, int margin, unsigned reserved, int *__restrict__ queue)
 {
+    int it = blockIdx.x;
+    if (queue) {
+        if (reserved != ~0u && my_cu_id() == reserved) {
+            int e = 0;
+            if (threadIdx.x == 0) e = atomicAdd(&queue[1], 1);
+            e = __builtin_amdgcn_readfirstlane(e);
+            if (e < margin) {
+                __builtin_amdgcn_s_sleep(127);       // ~8k cycles: do not drain the grid through this CU
+                __builtin_amdgcn_s_sleep(127);
+                return;
+            }
+        }
+        if (threadIdx.x == 0) it = atomicAdd(&queue[0], 1);
+        it = __builtin_amdgcn_readfirstlane(it);
+        if (it >= nitems) return;
+    }
     // item -> (tj, ti) in 64-row units: columns [cb, ce), rows [max(tj, rb), re)
-    int it = blockIdx.x, tj = cb;
+    int tj = cb;
     for (;;) {
         const int lo = tj > rb ? tj : rb;
         const int cnt = re - lo;
@@ -721,9 +757,12 @@ size_t band_bytes(int n, int halfbw, Band *d)
 // Streams/events of the look-ahead pipeline (created once per process and device).
 namespace {
 struct Pipeline {
-    hipStream_t panel = nullptr, col = nullptr, upd = nullptr, res = nullptr;
-    std::vector<hipEvent_t> evP, evU, evC;
+    hipStream_t panel = nullptr, col = nullptr, res = nullptr, upd = nullptr;
+    std::vector<hipEvent_t> evP, evU, evC, evI, evT;
     hipEvent_t evR[2] = {nullptr, nullptr};
+    unsigned reserved = ~0u;      // CU id (my_cu_id) left to the panel factorisation, ~0u = none
+    int *queues = nullptr;        // [3*nblk+8][2] item queues of the trailing-update launches
+    int nqueues = 0;
     int dev = -1;
 };
 Pipeline &pipeline(int nblk)
@@ -735,40 +774,46 @@ Pipeline &pipeline(int nblk)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // hi = numerically lowest = highest priority
         (void)hipStreamCreateWithPriority(&p.panel, hipStreamNonBlocking, hi);
-        // The trailing updates run on streams whose CU mask leaves one CU out, so that the
-        // latency-bound potrf workgroup of the look-ahead always finds a CU without
-        // MFMA-saturating neighbours (co-resident it ran 2.8x slower: same f64 pipes).
-        hipDeviceProp_t prop;
-        (void)hipGetDeviceProperties(&prop, dev);
-        const int ncu = prop.multiProcessorCount;
-        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0xffffffffu);
-        int nres = 0;                                     // CUs left to the panel kernels (0: no masking)
-        if (const char *e = std::getenv("SPLPAK_RESERVE_CUS")) nres = std::atoi(e);
-        if (nres < 0) nres = 0;
-        if (nres > 8) nres = 8;
-        const uint32_t resbits = (1u << nres) - 1u;
-        mask[0] &= ~resbits;
-        if (nres == 0 ||
-            hipExtStreamCreateWithCUMask(&p.upd, (uint32_t)mask.size(), mask.data()) != hipSuccess ||
-            hipExtStreamCreateWithCUMask(&p.col, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            if (!p.upd) (void)hipStreamCreateWithFlags(&p.upd, hipStreamNonBlocking);
-            if (!p.col) (void)hipStreamCreateWithPriority(&p.col, hipStreamNonBlocking, hi);
-        } else {
-            // ... and the potrf / 64x64-inverse kernels are pinned to exactly that CU
+        (void)hipStreamCreateWithPriority(&p.col, hipStreamNonBlocking, hi);
+        // the bulk runs on a private non-blocking stream: the caller's stream may be the legacy
+        // NULL stream, which would serialise against the (blocking) CU-masked stream below
+        (void)hipStreamCreateWithFlags(&p.upd, hipStreamNonBlocking);
+        // One CU is left to the diagonal-block factorisation: v_mfma_f64 runs on the same f64
+        // pipes as f64 VALU code, so the latency-bound potrf workgroup ran 3x slower beside
+        // trailing-update waves.  potrf is pinned to that CU through a CU-masked stream; the
+        // trailing-update waves are NOT masked (masked queues cost them ~8 %): a wave that finds
+        // itself on the reserved CU steps aside (syrk64_kernel).  The CU's id is read back once.
+        p.reserved = ~0u;
+        if (!std::getenv("SPLPAK_NO_PANEL_CU")) {
+            hipDeviceProp_t prop;
+            (void)hipGetDeviceProperties(&prop, dev);
+            const int ncu = prop.multiProcessorCount;
             std::vector<uint32_t> only((size_t)(ncu + 31) / 32, 0u);
-            only[0] = resbits;
-            if (hipExtStreamCreateWithCUMask(&p.res, (uint32_t)only.size(), only.data()) != hipSuccess) {
-                (void)hipGetLastError();
-                p.res = nullptr;
+            only[0] = 1u;
+            unsigned *d = nullptr, h = ~0u;
+            if (hipExtStreamCreateWithCUMask(&p.res, (uint32_t)only.size(), only.data()) == hipSuccess &&
+                hipMalloc(&d, sizeof(unsigned)) == hipSuccess) {
+                hipLaunchKernelGGL(whoami_kernel, dim3(1), dim3(64), 0, p.res, d);
+                if (hipStreamSynchronize(p.res) == hipSuccess &&
+                    hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess)
+                    p.reserved = h;
             }
+            if (d) (void)hipFree(d);
+            if (p.reserved == ~0u) { (void)hipGetLastError(); p.res = nullptr; }
         }
         p.dev = dev;
         p.evP.clear();
         p.evU.clear();
         p.evC.clear();
+        p.evI.clear();
+        p.evT.clear();
         (void)hipEventCreateWithFlags(&p.evR[0], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&p.evR[1], hipEventDisableTiming);
+    }
+    if (p.nqueues < 3 * nblk + 8) {
+        if (p.queues) (void)hipFree(p.queues);
+        p.nqueues = 3 * nblk + 8;
+        (void)hipMalloc(&p.queues, sizeof(int) * 2 * (size_t)p.nqueues);
     }
     while ((int)p.evP.size() < nblk + 1) {
         hipEvent_t e;
@@ -778,6 +823,10 @@ Pipeline &pipeline(int nblk)
         p.evU.push_back(e);
         (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
         p.evC.push_back(e);
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        p.evI.push_back(e);
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        p.evT.push_back(e);
     }
     return p;
 }
@@ -795,6 +844,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     hipStream_t sP = pl.panel, sC = pl.col, sU = pl.upd;
     hipStream_t sR = pl.res ? pl.res : pl.panel;     // potrf (pinned to the reserved CU)
     if (std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = sC = sU = sR = st;   // diagnostics: one stream, no overlap
+    (void)hipMemsetAsync(pl.queues, 0, sizeof(int) * 2 * (size_t)pl.nqueues, st);
     hipEvent_t f0 = nullptr, f1 = nullptr;
     std::vector<hipEvent_t> evs;
     if (timing) {
@@ -804,10 +854,11 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         (void)hipEventRecord(f0, st);
     }
     auto tb_of = [&](int k) { int t = b.nblk - 1 - k; return t > b.bw ? b.bw : t; };
-    static const bool use64 = std::getenv("SPLPAK_SYRK_64") != nullptr;   // register-streaming variant (experimental)
+    static const bool use64 = std::getenv("SPLPAK_SYRK_LDS") == nullptr;   // default: register-streaming trailing update
+    int qnext = 0;
     auto syrk = [&](hipStream_t s, int k, int tj_begin, int mode, int ntiles) {
         const int k0 = k * NBLK, nt = tb_of(k) * NBLK / TS;
-        if (ntiles <= 0) return;
+        if (ntiles <= 0 && !use64) return;
         if (use64) {
             // 64-row units: diag block = cols [0,4) rows [0,4); rest of first block column =
             // cols [0,4) rows [4,n64); bulk = cols [4,n64)
@@ -815,6 +866,8 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
             int cb, ce, rb, re = n64;
             if (mode == 1) { cb = 0; ce = 4; rb = 0; re = 4; }
             else if (mode == 2) { cb = 0; ce = 4; rb = 4; }
+            else if (mode == 4) { cb = 0; ce = 4; rb = 4; re = n64 < 8 ? n64 : 8; }
+            else if (mode == 5) { cb = 0; ce = 4; rb = 8; }
             else { cb = 2 * tj_begin; ce = n64; rb = 0; }
             long long items = 0;
             for (int c = cb; c < ce; ++c) items += re - (c > rb ? c : rb);
@@ -825,8 +878,10 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
                 (void)hipEventCreate(&c);
                 (void)hipEventRecord(a, s);
             }
-            hipLaunchKernelGGL((syrk64_kernel<4, 2, 0>), dim3((unsigned)items), dim3(64), 0, s, b.ab, b.lda, k0, k0 + NBLK,
-                               cb, ce, rb, re);
+            const int margin = pl.reserved != ~0u ? 512 : 0;
+            int *queue = pl.reserved != ~0u ? pl.queues + 2 * (qnext++) : nullptr;
+            hipLaunchKernelGGL((syrk64_kernel<16, 1, 0>), dim3((unsigned)items + margin), dim3(64), 0, s, b.ab, b.lda,
+                               k0, k0 + NBLK, cb, ce, rb, re, (int)items, margin, pl.reserved, queue);
             if (timing) {
                 (void)hipEventRecord(c, s);
                 evs.push_back(a);
@@ -856,7 +911,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
             stats->syrk_flop += 2.0 * (double)ntiles * TS * TS * NBLK;
         }
     };
-    auto potrf = [&](int k) {        // potrf(k) + 64x64 inverses, ordered inside the panel stream
+    auto potrf = [&](int k) {        // potrf(k) pinned to the reserved CU, then the 64x64 inverses
         const int k0 = k * NBLK;
         if (sR != sP) {
             (void)hipEventRecord(pl.evR[0], sP);
@@ -864,53 +919,80 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         }
         hipLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, sR, b.ab, b.lda, k0, info_dev,
                            minpiv_dev);
-        if (tb_of(k) > 0)
-            hipLaunchKernelGGL(inv64_kernel, dim3(4), dim3(64), 0, sR,
-                               (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda), b.lda,
-                               b.inv64 + (long long)k * 4 * 64 * 64);
         if (sR != sP) {
             (void)hipEventRecord(pl.evR[1], sR);
             (void)hipStreamWaitEvent(sP, pl.evR[1], 0);
         }
+        if (tb_of(k) > 0)
+            hipLaunchKernelGGL(inv64_kernel, dim3(4), dim3(64), 0, sP,
+                               (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda), b.lda,
+                               b.inv64 + (long long)k * 4 * 64 * 64);
+        (void)hipEventRecord(pl.evI[k], sP);
     };
-    auto trsm = [&](int k) {
+    // panel solve of rows [r0, r1) below the diagonal block k
+    auto trsm = [&](hipStream_t s, int k, int r0, int r1) {
         const int k0 = k * NBLK;
-        const int nrows = tb_of(k) * NBLK;
-        if (nrows > 0)
-            hipLaunchKernelGGL(trsm_kernel, dim3(nrows / 32), dim3(128), 0, sP,
+        if (r1 > r0)
+            hipLaunchKernelGGL(trsm_kernel, dim3((r1 - r0) / 16), dim3(64), 0, s,
                                (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda),
-                               b.ab + (long long)(k0 + NBLK) + (long long)k0 * b.lda, b.lda,
-                               (const double *)(b.inv64 + (long long)k * 4 * 64 * 64), nrows);
-        (void)hipEventRecord(pl.evP[k], sP);
+                               b.ab + (long long)(k0 + NBLK + r0) + (long long)k0 * b.lda, b.lda,
+                               (const double *)(b.inv64 + (long long)k * 4 * 64 * 64), r1 - r0);
     };
 
-    // Dependencies per step k (panel k factored and solved = evP[k]):
-    //   sP: diag3(k) [needs bulk(k-1)] -> potrf(k+1) -> inv64(k+1) -> [colrest(k)] -> trsm(k+1)
-    //   sC: colrest(k): rest of block column k+1        [needs evP[k], bulk(k-1)]
-    //   sU: bulk(k): block columns >= k+2                [needs evP[k]]
+    // Dependency structure per step k (X_k = solved panel k; block (I,J) = 256x256 block):
+    //   chain  (sP/sR): topA(k)  update of block (k+1,k+1) by X_k          [needs X_k row k+1 = evT[k], bulk(k-1)]
+    //                   potrf(k+1), inv64(k+1)
+    //                   trsm_top(k+1): block (k+2,k+1) -> X_{k+1} row k+2  [needs topB(k)]      -> evT[k+1]
+    //   column (sC)   : topB(k)  update of block (k+2,k+1) by X_k          [needs all of X_k = evP[k], bulk(k-1)]
+    //                   colU(k)  update of blocks (>=k+3, k+1)
+    //                   trsm_rest(k+1): rows below block row k+2           [needs inv64(k+1)]   -> evP[k+1]
+    //   bulk   (sU)   : block columns >= k+2 by X_k                        [needs evP[k]]       -> evU[k]
+    // The only cycle is the chain (~topA + potrf + inv64 + trsm of 256 rows); everything that
+    // needs the whole panel hangs off it with a step of slack.
     (void)hipEventRecord(pl.evU[b.nblk], st);      // start after everything queued on the caller's stream
     (void)hipStreamWaitEvent(sP, pl.evU[b.nblk], 0);
     (void)hipStreamWaitEvent(sC, pl.evU[b.nblk], 0);
+    if (sR != sP) (void)hipStreamWaitEvent(sR, pl.evU[b.nblk], 0);
     (void)hipStreamWaitEvent(sU, pl.evU[b.nblk], 0);
     potrf(0);
-    trsm(0);
+    trsm(sP, 0, 0, tb_of(0) * NBLK);
+    (void)hipEventRecord(pl.evP[0], sP);
+    (void)hipEventRecord(pl.evT[0], sP);
     for (int k = 0; k < b.nblk; ++k) {
         const int tb = tb_of(k);
         if (tb <= 0) continue;
         const int nt = tb * NBLK / TS;
         const int ntiles = nt * (nt + 1) / 2;
         const int ncol = nt + (nt - 1);                 // tiles of the first block column (tj = 0, 1)
+        const int nrows1 = tb_of(k + 1) * NBLK;         // rows below the diagonal block of panel k+1
         if (k > 0) {
             (void)hipStreamWaitEvent(sP, pl.evU[k - 1], 0);
             (void)hipStreamWaitEvent(sC, pl.evU[k - 1], 0);
         }
-        syrk(sP, k, 0, 1, 3);
-        potrf(k + 1);
-        (void)hipStreamWaitEvent(sC, pl.evP[k], 0);
-        syrk(sC, k, 0, 2, ncol - 3);
-        (void)hipEventRecord(pl.evC[k], sC);
-        (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
-        trsm(k + 1);
+        if (use64) {
+            syrk(sP, k, 0, 1, 0);                       // topA: cols [0,4), rows [0,4)
+            potrf(k + 1);
+            (void)hipStreamWaitEvent(sC, pl.evP[k], 0);
+            syrk(sC, k, 0, 4, 0);                       // topB: cols [0,4), rows [4,8)
+            (void)hipEventRecord(pl.evC[k], sC);
+            syrk(sC, k, 0, 5, 0);                       // colU: cols [0,4), rows [8,n64)
+            (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
+            trsm(sP, k + 1, 0, nrows1 < NBLK ? nrows1 : NBLK);
+            (void)hipEventRecord(pl.evT[k + 1], sP);
+            (void)hipStreamWaitEvent(sC, pl.evI[k + 1], 0);
+            trsm(sC, k + 1, NBLK, nrows1);
+            (void)hipStreamWaitEvent(sC, pl.evT[k + 1], 0);
+            (void)hipEventRecord(pl.evP[k + 1], sC);
+        } else {
+            syrk(sP, k, 0, 1, 3);
+            potrf(k + 1);
+            (void)hipStreamWaitEvent(sC, pl.evP[k], 0);
+            syrk(sC, k, 0, 2, ncol - 3);
+            (void)hipEventRecord(pl.evC[k], sC);
+            (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
+            trsm(sP, k + 1, 0, nrows1);
+            (void)hipEventRecord(pl.evP[k + 1], sP);
+        }
         (void)hipStreamWaitEvent(sU, pl.evP[k], 0);
         syrk(sU, k, 2, std::getenv("SPLPAK_NO_XCDMAP") ? 0 : 3, ntiles - ncol);
         (void)hipEventRecord(pl.evU[k], sU);
