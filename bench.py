@@ -14,7 +14,7 @@ the normal equations and each refinement residual are all-reduced over RCCL; the
 factorisation is replicated.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel (f64-MFMA trailing update of the band Cholesky):
+  roofline      the dominant kernel (syrk64_kernel, f64-MFMA trailing update of the band Cholesky):
                 algorithmic flop / HIP-event time measured inside the timed region
   cpu_baseline  the reference itself (oracle/_ref, 1 core; it is single-threaded)
                 on a bounded sample -- the dense reference algorithm cannot run the
@@ -218,7 +218,7 @@ def main():
                 except Exception:
                     traffic = None
             line["roofline"] = {
-                "kernel": "syrk_kernel (band Cholesky trailing update, v_mfma_f64_16x16x4_f64)",
+                "kernel": "syrk64_kernel (band Cholesky trailing update C -= P P^T, v_mfma_f64_16x16x4_f64; all launches: bulk + block-column pieces)",
                 "bound": "mfma", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "launches": kt_sum["syrk_launches"], "avg_launch_ms": kt_sum["syrk_ms"] / max(kt_sum["syrk_launches"], 1),

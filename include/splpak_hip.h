@@ -60,8 +60,8 @@ int32_t splpak_fit_f64(int32_t ndim, const double *xdata, int32_t l1xdat,
                        double *hist_out, double *info);
 
 /* real32 twin (reference built with -DREAL32, :33-34).  Storage is f32, the
- * arithmetic is f64 (converted on the device), so it is at least as accurate as
- * the REAL32 reference. */
+ * arithmetic is f64 (the arrays are widened when they are staged for upload), so it
+ * is at least as accurate as the REAL32 reference. */
 int32_t splpak_fit_f32(int32_t ndim, const float *xdata, int32_t l1xdat,
                        const float *ydata, const float *wdata, int64_t ndata,
                        const float *xmin, const float *xmax, const int32_t *nodes,
@@ -111,8 +111,8 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
 void    splpak_plan_destroy(splpak_plan *plan);
 void    splpak_plan_set_allreduce(splpak_plan *plan, splpak_allreduce_fn fn, void *user,
                                   int32_t rank, int32_t world);
-/* tuning / test knobs: max refinement steps (default 4), relative correction
- * tolerance (default 1e-13) */
+/* tuning / test knobs: max refinement steps (default 4) and the tolerance on the (estimated)
+ * remaining relative error |dx|/|x| after a step (default 1e-12; the parity bar is 1e-10) */
 void    splpak_plan_set_refine(splpak_plan *plan, int32_t max_steps, double tol);
 
 /* The fit on resident data.  xdata_dev/ydata_dev/wdata_dev (wdata_dev may be

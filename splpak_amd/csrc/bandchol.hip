@@ -441,6 +441,7 @@ syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, in
 // what the LDS version lost to per-chunk workgroup barriers and to the coupling of the
 // two co-resident workgroups is gone.  Two waves per SIMD (<= 256 VGPRs) overlap one
 // wave's C read-modify-write with the other's main loop.
+constexpr int SYRK_ABL = 4;        // product configuration of syrk64_kernel (see ABL)
 // SD = k-steps of look-ahead in the operand queue; WPS = waves per SIMD the register budget
 // allows; ABL = ablation switches for tools/syrk_bench (0 = the product kernel)
 __device__ inline unsigned my_cu_id()
@@ -494,18 +495,31 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
     const double *__restrict__ pJ = ab + (long long)(row0 + tj * 64 + l15) + (long long)(k0 + q) * lda;
     const double *__restrict__ pI = ab + (long long)(row0 + ti * 64 + l15) + (long long)(k0 + q) * lda;
 
+    // ABL&4 (product default): the accumulators START as the C tile and the products are
+    // subtracted (negated A operand), so the tile is read at the very beginning -- together with
+    // the first operands, one exposed latency -- and the epilogue is stores only.
+    constexpr bool CINIT = (ABL & 4) != 0;
+    double *__restrict__ C = ab + (long long)(row0 + ti * 64) + (long long)(row0 + tj * 64) * lda;
     d4_t acc[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int n = 0; n < 4; ++n) {
+            if (CINIT) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc[m][n][v] = __builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * lda]);
+            } else {
+                acc[m][n] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            }
+        }
 
     double qa[SD][4], qb[SD][4];
     auto fetch = [&](int slot, int step) {
         const long long off = (long long)(4 * step) * lda;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            qa[slot][m] = pJ[off + 16 * m];
+            qa[slot][m] = CINIT ? -pJ[off + 16 * m] : pJ[off + 16 * m];
             qb[slot][m] = pI[off + 16 * m];
         }
     };
@@ -534,8 +548,22 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
         return;
     }
 
-    // C(r, c) -= acc: lane holds r = l15 (+16n), c = q + 4v (+16m); batches of 16 loads
-    double *__restrict__ C = ab + (long long)(row0 + ti * 64) + (long long)(row0 + tj * 64) * lda;
+    // C(r, c) -= acc: lane holds r = l15 (+16n), c = q + 4v (+16m)
+    if (CINIT) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int r = n * 16 + l15;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = m * 16 + q + 4 * v;
+                    if (!diag || r >= c) __builtin_nontemporal_store(acc[m][n][v], &C[r + (long long)c * lda]);
+                }
+            }
+        return;
+    }
+    // batches of 16 loads
     d4_t cold[2][4];
     auto cload = [&](int m, d4_t (&dst)[4]) {
 #pragma unroll
@@ -761,7 +789,7 @@ struct Pipeline {
     std::vector<hipEvent_t> evP, evU, evC, evI, evT;
     hipEvent_t evR[2] = {nullptr, nullptr};
     unsigned reserved = ~0u;      // CU id (my_cu_id) left to the panel factorisation, ~0u = none
-    int *queues = nullptr;        // [3*nblk+8][2] item queues of the trailing-update launches
+    int *queues = nullptr;        // [4*nblk+8][2] item queues of the trailing-update launches
     int nqueues = 0;
     int dev = -1;
 };
@@ -810,9 +838,9 @@ Pipeline &pipeline(int nblk)
         (void)hipEventCreateWithFlags(&p.evR[0], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&p.evR[1], hipEventDisableTiming);
     }
-    if (p.nqueues < 3 * nblk + 8) {
+    if (p.nqueues < 4 * nblk + 8) {        // 4 queued launches per step: topA, topB, colU, bulk
         if (p.queues) (void)hipFree(p.queues);
-        p.nqueues = 3 * nblk + 8;
+        p.nqueues = 4 * nblk + 8;
         (void)hipMalloc(&p.queues, sizeof(int) * 2 * (size_t)p.nqueues);
     }
     while ((int)p.evP.size() < nblk + 1) {
@@ -878,9 +906,9 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
                 (void)hipEventCreate(&c);
                 (void)hipEventRecord(a, s);
             }
-            const int margin = pl.reserved != ~0u ? 512 : 0;
-            int *queue = pl.reserved != ~0u ? pl.queues + 2 * (qnext++) : nullptr;
-            hipLaunchKernelGGL((syrk64_kernel<16, 1, 0>), dim3((unsigned)items + margin), dim3(64), 0, s, b.ab, b.lda,
+            const int margin = (pl.reserved != ~0u && qnext < pl.nqueues) ? 512 : 0;
+            int *queue = (pl.reserved != ~0u && qnext < pl.nqueues) ? pl.queues + 2 * (qnext++) : nullptr;
+            hipLaunchKernelGGL((syrk64_kernel<16, 1, SYRK_ABL>), dim3((unsigned)items + margin), dim3(64), 0, s, b.ab, b.lda,
                                k0, k0 + NBLK, cb, ce, rb, re, (int)items, margin, pl.reserved, queue);
             if (timing) {
                 (void)hipEventRecord(c, s);

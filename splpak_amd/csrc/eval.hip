@@ -32,27 +32,41 @@ eval_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, NDeriv nd,
             const int ws = window_table(g, d, x, nd.v[d], b[d]);
             base += ws * g.colstride[d];
         }
+        // The 4 coefficients of a window row (k0 = 0..3) are contiguous: they are fetched with two
+        // 16-byte loads instead of four 8-byte ones (the kernel is bound by gather instructions,
+        // ~64 cycles of address processing per wave-load whatever its width), and summed in the
+        // reference's order (dimension 1 fastest).
         double sum = 0.0;
+        auto row4 = [&](long long idx, double scale) {
+            double c0, c1, c2, c3;
+            if constexpr (sizeof(T) == 8) {
+                typedef double d2v __attribute__((ext_vector_type(2), aligned(8)));
+                const d2v lo = *reinterpret_cast<const d2v *>(coef + idx);
+                const d2v hi = *reinterpret_cast<const d2v *>(coef + idx + 2);
+                c0 = lo[0]; c1 = lo[1]; c2 = hi[0]; c3 = hi[1];
+            } else {
+                typedef float f4v __attribute__((ext_vector_type(4), aligned(4)));
+                const f4v v = *reinterpret_cast<const f4v *>(coef + idx);
+                c0 = v[0]; c1 = v[1]; c2 = v[2]; c3 = v[3];
+            }
+            sum += c0 * (b[0][0] * scale);
+            sum += c1 * (b[0][1] * scale);
+            sum += c2 * (b[0][2] * scale);
+            sum += c3 * (b[0][3] * scale);
+        };
         if constexpr (D == 1) {
 #pragma unroll
             for (int k0 = 0; k0 < 4; ++k0) sum += (double)coef[base + k0] * b[0][k0];
         } else if constexpr (D == 2) {
             const int s1 = g.colstride[1];
 #pragma unroll
-            for (int k1 = 0; k1 < 4; ++k1)
-#pragma unroll
-                for (int k0 = 0; k0 < 4; ++k0)
-                    sum += (double)coef[base + k0 + k1 * s1] * (b[0][k0] * b[1][k1]);
+            for (int k1 = 0; k1 < 4; ++k1) row4(base + k1 * s1, b[1][k1]);
         } else if constexpr (D == 3) {
             const int s1 = g.colstride[1], s2 = g.colstride[2];
 #pragma unroll
             for (int k2 = 0; k2 < 4; ++k2)
 #pragma unroll
-                for (int k1 = 0; k1 < 4; ++k1)
-#pragma unroll
-                    for (int k0 = 0; k0 < 4; ++k0)
-                        sum += (double)coef[base + k0 + k1 * s1 + k2 * s2] *
-                               ((b[0][k0] * b[1][k1]) * b[2][k2]);
+                for (int k1 = 0; k1 < 4; ++k1) row4(base + k1 * s1 + k2 * s2, b[1][k1] * b[2][k2]);
         } else {
             const int s1 = g.colstride[1], s2 = g.colstride[2], s3 = g.colstride[3];
             for (int k3 = 0; k3 < 4; ++k3)
@@ -60,10 +74,7 @@ eval_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, NDeriv nd,
                 for (int k2 = 0; k2 < 4; ++k2)
 #pragma unroll
                     for (int k1 = 0; k1 < 4; ++k1)
-#pragma unroll
-                        for (int k0 = 0; k0 < 4; ++k0)
-                            sum += (double)coef[base + k0 + k1 * s1 + k2 * s2 + k3 * s3] *
-                                   (((b[0][k0] * b[1][k1]) * b[2][k2]) * b[3][k3]);
+                        row4(base + k1 * s1 + k2 * s2 + k3 * s3, (b[1][k1] * b[2][k2]) * b[3][k3]);
         }
         out[i] = (T)sum;
     }

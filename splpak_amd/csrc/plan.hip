@@ -104,7 +104,7 @@ struct splpak_plan {
     void *ar_user = nullptr;
     int rank = 0, world = 1;
     int max_refine = 4;
-    double tol = 1e-13;
+    double tol = 1e-12;
     CholStats stats;
     std::vector<void *> owned;
 };
@@ -351,6 +351,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     SPLPAK_HIP_TRY(band_solve(b, p->xvec, p->tmp, st), SPLPAK_E_NODEVICE);
     int steps = 0;
     double last_rel = 0.0, prev_rel = inf;
+    bool diverged = false;
     for (int it = 0; it < p->max_refine; ++it) {
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rho, st), SPLPAK_E_NODEVICE);
@@ -368,7 +369,16 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
             fprintf(stderr, "[splpak] refinement step %d: |dx|/|x| = %.3e\n", steps, last_rel);
         if (!(last_rel == last_rel)) break;                   // NaN
         if (last_rel <= p->tol) break;
-        if (last_rel > 0.5 * prev_rel && it >= 1) break;      // stagnation at the rounding floor
+        if (it >= 1) {
+            // linear convergence: after this step the error is ~ dx * rho / (1 - rho); stop as soon
+            // as that estimate is below the tolerance instead of paying for one more solve
+            const double rho = last_rel / prev_rel;
+            if (rho < 0.5 && last_rel * rho / (1.0 - rho) <= p->tol) break;
+            if (rho > 0.5) {                                  // stagnation: fine at the rounding floor,
+                diverged = last_rel > 1e-8;                   // a failure if the corrections are still large
+                break;
+            }
+        }
         prev_rel = last_rel;
     }
     SPLPAK_HIP_TRY(hipMemcpyAsync(coef_dev, p->xvec, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
@@ -379,7 +389,9 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         info[3] = last_rel;
         info[7] = std::chrono::duration<double>(t3 - t2).count();
     }
-    if (!(last_rel == last_rel)) return 107;
+    // a correction that is still large means the factor did not precondition the problem
+    // (numerically singular normal equations): the reference's "suprls failure"
+    if (!(last_rel == last_rel) || diverged) return 107;
     return 0;
 }
 

@@ -188,3 +188,56 @@ def test_fit_real32_vs_reference32():
                                 inp["nodes"], inp["xtrap"], real32=True)
     assert ierr == 0 and coef.dtype == np.float32
     assert relmax(coef, gold["coef"]) < 2e-4   # inputs rounded to f32, cond(A) ~ 1e3..1e4
+
+
+def test_plan_reuse_gives_identical_fits():
+    """A plan is reusable: consecutive fits through one plan (the bench.py pattern) must each be
+    correct.  Regression test: the trailing-update item queues of the factorisation pipeline were
+    once indexed past their allocation, which only broke the SECOND fit of a plan."""
+    import torch
+    spec = CASES["3d12"]
+    gold = load_golden("3d12")
+    inp = make_inputs(spec)
+    dev = torch.device("cuda", 0)
+    x = torch.tensor(inp["xdata"], device=dev)
+    y = torch.tensor(inp["ydata"], device=dev)
+    w = torch.tensor(inp["wdata"], device=dev)
+    ncol = int(np.prod(inp["nodes"]))
+    plan = capi.Plan(3, inp["nodes"], inp["xmin"], inp["xmax"], inp["xtrap"], x.shape[0])
+    coefs = []
+    for _ in range(3):
+        coef = torch.zeros(ncol, dtype=torch.float64, device=dev)
+        ierr, info = plan.fit(x, y, w, coef, torch.cuda.current_stream().cuda_stream)
+        assert ierr == 0
+        coefs.append(coef.cpu().numpy())
+        assert relmax(coefs[-1], gold["coef"]) < COEF_TOL
+    plan.close()
+
+
+def test_large_grid_repeated_fit_properties():
+    """Size-independent properties on a grid the dense reference cannot reach in test time
+    (3-D 24^3 = 13 824 columns, 3e5 points): (a) data sampled from a function in the spline
+    space (a plane; natural splines reproduce it, xtrap = 0) is recovered to 1e-10 at fresh
+    points, also on a second fit through the same plan; (b) splcc == splcw with unit weights."""
+    import torch
+    from splpak_amd.synth import synth_points, synth_queries
+    nd, nod, m = 3, 24, 300000
+    x, _, _ = synth_points(nd, m)
+    f = lambda p: 1.0 + 2.0 * p[:, 0] - 3.0 * p[:, 1] + 0.5 * p[:, 2]
+    dev = torch.device("cuda", 0)
+    xt = torch.tensor(x, device=dev)
+    yt = torch.tensor(f(x), device=dev)
+    wt = torch.ones(m, dtype=torch.float64, device=dev)
+    plan = capi.Plan(nd, [nod] * nd, [0.0] * nd, [1.0] * nd, 0.0, m)
+    q = synth_queries(nd, 2000, m) * 1.2 - 0.1            # also outside the grid: linear extrapolation
+    res = []
+    for wv in (None, wt, None):
+        coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
+        ierr, info = plan.fit(xt, yt, wv, coef, torch.cuda.current_stream().cuda_stream)
+        assert ierr == 0
+        c = coef.cpu().numpy()
+        v, ie = capi.evaluate(nd, q, None, c, [0.0] * nd, [1.0] * nd, [nod] * nd)
+        assert ie == 0 and np.max(np.abs(v - f(q))) < 1e-10
+        res.append(c)
+    assert relmax(res[1], res[0]) < 1e-11 and relmax(res[2], res[0]) < 1e-11
+    plan.close()

@@ -14,7 +14,7 @@ static float run64(double *ab, long long lda, int n64)
     for (int c = 4; c < n64; ++c) items += n64 - c;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, g_stream);
-    hipLaunchKernelGGL((syrk64_kernel<SD, WPS, ABL>), dim3((unsigned)items), dim3(64), 0, g_stream, ab, lda, 0, NBLK, 4, n64, 0, n64);
+    hipLaunchKernelGGL((syrk64_kernel<SD, WPS, ABL>), dim3((unsigned)items), dim3(64), 0, g_stream, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
     (void)hipEventRecord(e1, g_stream); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     return ms;
@@ -47,7 +47,7 @@ int main()
         {"lds 128x128 (2 WG/CU)", floplds, {}}, {"s64 SD4 2w/SIMD", flop64, {}}, {"s64 SD8 1w/SIMD", flop64, {}},
         {"s64 SD4 2w no-refill", flop64, {}}, {"s64 SD4 2w no-epilogue", flop64, {}}, {"s64 SD4 2w neither", flop64, {}},
         {"s64 SD2 2w", flop64, {}}, {"s64 SD8 1w no-epilogue", flop64, {}}, {"s64 SD16 1w", flop64, {}},
-        {"s64 SD16 1w no-epilogue", flop64, {}}, {"s64 SD16 1w no-refill", flop64, {}}, {"s64 SD8 1w", flop64, {}}, {"s64 SD8 2w", flop64, {}}, {"s64 SD16 2w", flop64, {}}, {"s64 SD16 2w no-epilogue", flop64, {}}, {"s64 SD32 1w", flop64, {}}};
+        {"s64 SD16 1w no-epilogue", flop64, {}}, {"s64 SD16 1w no-refill", flop64, {}}, {"s64 SD8 1w", flop64, {}}, {"s64 SD8 2w", flop64, {}}, {"s64 SD16 2w", flop64, {}}, {"s64 SD16 2w no-epilogue", flop64, {}}, {"s64 SD16 1w C-init", flop64, {}}, {"s64 SD16 2w C-init", flop64, {}}, {"s64 SD4 2w C-init", flop64, {}}, {"s64 SD8 1w C-init", flop64, {}}};
     for (int r = 0; r < rounds; ++r) {
         v[0].t.push_back(runlds(ab, lda, nt));
         v[1].t.push_back(run64<4, 2, 0>(ab, lda, n64));
@@ -64,7 +64,10 @@ int main()
         v[12].t.push_back(run64<8, 2, 0>(ab, lda, n64));
         v[13].t.push_back(run64<16, 2, 0>(ab, lda, n64));
         v[14].t.push_back(run64<16, 2, 2>(ab, lda, n64));
-        v[15].t.push_back(run64<32, 1, 0>(ab, lda, n64));
+        v[15].t.push_back(run64<16, 1, 4>(ab, lda, n64));
+        v[16].t.push_back(run64<16, 2, 4>(ab, lda, n64));
+        v[17].t.push_back(run64<4, 2, 4>(ab, lda, n64));
+        v[18].t.push_back(run64<8, 1, 4>(ab, lda, n64));
     }
     // the same two kernels on a CU-masked stream (one CU left out) and on a plain created stream
     for (int variant = 0; variant < 2; ++variant) {
@@ -83,7 +86,7 @@ int main()
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < 10; ++r)
-                hipLaunchKernelGGL((syrk64_kernel<16, 1, 0>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64);
+                hipLaunchKernelGGL((syrk64_kernel<16, 1, 0>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
             (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
             printf("   10 back-to-back s64 SD16 launches: %.3f ms each (%.1f TF)\n", ms / 10, flop64 / (ms / 10) / 1e9);
@@ -95,7 +98,7 @@ int main()
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, 0);
         for (int r = 0; r < 10; ++r)
-            hipLaunchKernelGGL((syrk64_kernel<16, 1, 0>), dim3((unsigned)items), dim3(64), 0, 0, ab, lda, 0, NBLK, 4, n64, 0, n64);
+            hipLaunchKernelGGL((syrk64_kernel<16, 1, 0>), dim3((unsigned)items), dim3(64), 0, 0, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
         (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         printf("null stream, 10 back-to-back s64 SD16 launches: %.3f ms each (%.1f TF)\n", ms / 10, flop64 / (ms / 10) / 1e9);
