@@ -162,6 +162,10 @@ int32_t splpak_synth_queries_f64(int32_t ndim, int64_t ndata_before, int64_t fir
 int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double *a_lower,
                                         const double *b, double *x);
 
+/* Releases the calling thread's internal HIP streams, events and queues (the factorisation
+ * pipeline creates them lazily and keeps them for reuse).  Optional; plans stay valid. */
+void splpak_shutdown(void);
+
 /* Human-readable text for the last negative status on this thread. */
 int32_t splpak_last_error_message(char *buf, int32_t buflen);
 

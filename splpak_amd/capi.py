@@ -29,7 +29,7 @@ SYMBOLS = [
     "splpak_plan_set_allreduce", "splpak_plan_set_refine", "splpak_plan_fit_dev",
     "splpak_plan_hist_dev", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing",
     "splpak_eval_dev_f64", "splpak_synth_points_f64", "splpak_synth_queries_f64",
-    "splpak_debug_spd_band_solve_f64", "splpak_last_error_message", "splpak_device_name",
+    "splpak_debug_spd_band_solve_f64", "splpak_shutdown", "splpak_last_error_message", "splpak_device_name",
 ]
 
 E_NODEVICE, E_NOMEM, E_BADARG, E_UNSUPPORTED, E_COMM = -1, -2, -3, -4, -5
@@ -86,11 +86,15 @@ def lib() -> C.CDLL:
     L.splpak_synth_queries_f64.argtypes = [i32, i64, i64, i64, vp, vp]
     L.splpak_debug_spd_band_solve_f64.restype = i32
     L.splpak_debug_spd_band_solve_f64.argtypes = [i32, i32, _dp, _dp, _dp]
+    L.splpak_shutdown.restype = None
+    L.splpak_shutdown.argtypes = []
     L.splpak_last_error_message.restype = i32
     L.splpak_last_error_message.argtypes = [C.c_char_p, i32]
     L.splpak_device_name.restype = i32
     L.splpak_device_name.argtypes = [C.c_char_p, i32]
     _lib = L
+    import atexit
+    atexit.register(L.splpak_shutdown)
     return L
 
 

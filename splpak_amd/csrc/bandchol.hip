@@ -64,7 +64,7 @@ __device__ inline double readlane_f64(double v, int srclane)
 
 __global__ void __launch_bounds__(256)
 potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restrict__ info,
-                   double *__restrict__ minpiv)
+                   double *__restrict__ minpiv, double *__restrict__ inv16)
 {
     __shared__ double Ls[IB * (IB + 1)];     // factor of the current diagonal 16x16: Ls[c*(IB+1) + k]
     __shared__ double Xs[IB * XLD];          // panel image Xs[k*XLD + r], r = row inside the 256 block
@@ -114,6 +114,23 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
             if (lane == 0) {
                 if (bad) atomicCAS(info, 0, k0 + c0 + 1);
                 if (dmin < *minpiv || !(dmin == dmin)) *minpiv = dmin;
+            }
+            // inverse of the 16x16 leaf (the panel solve's MFMA operand): lane c solves
+            // L x = e_c by forward substitution, L(r,k) broadcast from the lane that owns row r
+            {
+                double xi[IB];
+#pragma unroll
+                for (int rr = 0; rr < IB; ++rr) {
+                    double s = (rr == r) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < rr; ++k) s -= readlane_f64(a[k], rr) * xi[k];
+                    xi[rr] = s / readlane_f64(a[rr], rr);
+                }
+                if (lane < IB) {
+                    double *out = inv16 + (c0 / IB) * (IB * IB) + r * IB;    // column r: out[row]
+#pragma unroll
+                    for (int rr = 0; rr < IB; ++rr) out[rr] = (rr >= r) ? xi[rr] : 0.0;
+                }
             }
         }
         __syncthreads();
@@ -175,113 +192,68 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
     }
 }
 
-// Inverses of the four 64x64 diagonal sub-blocks of L (column-major, inv64[p][r + 64*c]),
-// used as MFMA operands by trsm_kernel: workgroup p inverts block p, lane c owns column c
-// (forward substitution on the identity).  Compact loops, operands in LDS (see potrf).
-__global__ void __launch_bounds__(64)
-inv64_kernel(const double *__restrict__ A, long long lda, double *__restrict__ inv64)
-{
-    __shared__ double Lp[PNL * PNL];             // Lp[k*64 + r] = L(r,k)
-    __shared__ double Xc[PNL * (PNL + 1)];       // Xc[r*65 + c] = Linv(r,c)
-    __builtin_amdgcn_s_setprio(3);
-    const int p = blockIdx.x, c = threadIdx.x & 63;
-    const double *Ab = A + (long long)(PNL * p) + (long long)(PNL * p) * lda;
-    for (int k0 = 0; k0 < PNL; k0 += 16) {
-        double lv[16];                           // 16 independent loads in flight
-#pragma unroll
-        for (int k = 0; k < 16; ++k) lv[k] = Ab[c + (long long)(k0 + k) * lda];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) Lp[(k0 + k) * PNL + c] = (c >= k0 + k) ? lv[k] : 0.0;
-    }
-    __syncthreads();
-    for (int r = 0; r < PNL; ++r) {
-        double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
-        int k = 0;
-        for (; k + 1 < r; k += 2) {
-            s0 -= Lp[k * PNL + r] * Xc[k * (PNL + 1) + c];
-            s1 -= Lp[(k + 1) * PNL + r] * Xc[(k + 1) * (PNL + 1) + c];
-        }
-        if (k < r) s0 -= Lp[k * PNL + r] * Xc[k * (PNL + 1) + c];
-        Xc[r * (PNL + 1) + c] = (s0 + s1) / Lp[r * PNL + r];
-    }
-    __syncthreads();
-    double *out = inv64 + (long long)p * PNL * PNL;
-    for (int cc = 0; cc < PNL; ++cc) out[cc * PNL + c] = Xc[c * (PNL + 1) + cc];   // lane = row
-}
-
 // ---------------------------------------------------------------------------
-// X = A * L^{-T} for the rows below the diagonal block, on the f64 matrix cores.
+// X = A * L^{-T} for rows below the diagonal block, on the f64 matrix cores.
 //
-// One wave owns 16 rows for the whole solve.  With 64-column blocks j = 0..3 of the 256 columns,
-//     X_j = (A_j - sum_{i<j} X_i L_ji^T) Inv_jj^T ,   Inv_jj = (64x64 diagonal block of L)^{-1}.
-// Both products are computed transposed, D[c][r] = sum_k Aop[c][k] * Bop[k][r]: the lane that
-// holds row r = lane&15 of an accumulator tile holds, in register s, exactly the B operand of
-// k-step s, so T = A_j - ... feeds the Inv product straight from registers.  Finished blocks
-// X_i are parked in LDS (per wave, [column][row]) so that the i / k loops stay dynamic and the
-// code compact: the kernel runs once per step on every CU with a cold instruction cache, where a
-// fully unrolled body cost more in instruction fetch than in arithmetic.
-// Only L / Inv elements (L2 resident, shared by all waves) are loaded: 8 bytes per lane and MFMA.
-constexpr int TCB = 32;
+// One wave owns 16 rows for the whole solve and walks the 256 columns in 16-column blocks:
+//     X_c = (A_c - sum_{k<c} X_k L_ck^T) Inv_cc^T ,   Inv_cc = (16x16 diagonal leaf of L)^{-1}
+// (the leaf inverses come out of potrf_block_kernel).  Both products are computed transposed,
+// D[col][row] = sum_k Aop[col][k] * Bop[k][row]: the lane that holds row = lane&15 of an
+// accumulator tile holds, in register s, exactly the B operand of k-step s, so T = A_c - ...
+// feeds the Inv product straight from registers.  Finished blocks X_k are parked in LDS
+// ([column][row], 30 KB) so the k loop stays rolled: the kernel runs once per step on every CU
+// with a cold instruction cache.  One wave, < 100 VGPRs, 30 KB LDS: it takes the slot of one
+// retiring trailing-update wave.  Only L / Inv elements (L2 resident, shared by all waves) are
+// loaded: 8 bytes per lane and MFMA.
+constexpr int TCB = 32;            // register block of trtri_kernel
 __global__ void __launch_bounds__(64)
 trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long lda,
-            const double *__restrict__ inv64, int nrows)
+            const double *__restrict__ inv16, int nrows)
 {
-    // one wave, 24 KB of LDS, < 200 VGPRs: takes the slot of ONE retiring trailing-update wave
-    __shared__ double Xs[1][(NBLK - 64) * 16];           // Xs[col*16 + row], columns 0..191 (X_3 is never an operand)
-    const int lane = threadIdx.x & 63, wave = 0, l15 = lane & 15, q = lane >> 4;
+    __shared__ double xs[(NBLK - 16) * 16];               // xs[col*16 + row], columns 0..239
+    const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
     const int r0 = blockIdx.x * 16;
     if (r0 >= nrows) return;
     __builtin_amdgcn_s_setprio(3);
     double *__restrict__ Xr = Xbase + r0 + l15;          // Xr[c*lda] = X(row, c)
-    double *xs = Xs[wave];
 
-    for (int j = 0; j < 4; ++j) {
-        d4_t T[4];
+    for (int cb = 0; cb < NBLK / 16; ++cb) {
+        d4_t T;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int v = 0; v < 4; ++v) T[v] = Xr[(long long)(16 * cb + q + 4 * v) * lda];
+        const double *__restrict__ Lc = L + (16 * cb + l15) + (long long)q * lda;   // L(16cb + l15, q + ...)
+        int kb = 0;
+        for (; kb + 1 < cb; kb += 2) {                    // two 16-wide k blocks per trip: 8 loads in flight
+            double a[8], bq[8];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) T[ct][v] = Xr[(long long)(64 * j + 16 * ct + q + 4 * v) * lda];
-        for (int kb = 0; kb < 4 * j; ++kb) {             // 16-wide k blocks of the finished columns
-            double a[4][4], bq[4];
-            const double *__restrict__ Lk = L + (64 * j + l15) + (long long)(16 * kb + q) * lda;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) a[s][ct] = -Lk[16 * ct + (long long)(4 * s) * lda];
+            for (int s = 0; s < 8; ++s) {
+                a[s] = -Lc[(long long)(16 * kb + 4 * s) * lda];
                 bq[s] = xs[(16 * kb + 4 * s + q) * 16 + l15];
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    T[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ct], bq[s], T[ct], 0, 0, 0);
+            for (int s = 0; s < 8; ++s) T = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bq[s], T, 0, 0, 0);
         }
-        const double *__restrict__ Inv = inv64 + (long long)j * 64 * 64;   // Inv[c + 64*k]
-        d4_t Xj[4];
+        if (kb < cb) {
+            double a[4], bq[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) Xj[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            double a[4][4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int ct = kt; ct < 4; ++ct)
-                    a[s][ct] = Inv[(16 * ct + l15) + 64 * (16 * kt + 4 * s + q)];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int ct = kt; ct < 4; ++ct)      // Inv is lower triangular: k-tile <= c-tile
-                    Xj[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ct], T[kt][s], Xj[ct], 0, 0, 0);
-        }
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int c = 64 * j + 16 * ct + q + 4 * v;
-                Xr[(long long)c * lda] = Xj[ct][v];
-                if (j < 3) xs[c * 16 + l15] = Xj[ct][v];
+            for (int s = 0; s < 4; ++s) {
+                a[s] = -Lc[(long long)(16 * kb + 4 * s) * lda];
+                bq[s] = xs[(16 * kb + 4 * s + q) * 16 + l15];
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) T = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bq[s], T, 0, 0, 0);
+        }
+        const double *__restrict__ Inv = inv16 + cb * 256;           // Inv[row + 16*col]
+        d4_t X = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            X = __builtin_amdgcn_mfma_f64_16x16x4f64(Inv[l15 + 16 * (4 * s + q)], T[s], X, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = 16 * cb + q + 4 * v;
+            Xr[(long long)c * lda] = X[v];
+            if (cb < NBLK / 16 - 1) xs[c * 16 + l15] = X[v];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -793,9 +765,10 @@ struct Pipeline {
     int nqueues = 0;
     int dev = -1;
 };
+thread_local Pipeline g_pipe;
 Pipeline &pipeline(int nblk)
 {
-    static thread_local Pipeline p;
+    Pipeline &p = g_pipe;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (p.panel == nullptr || p.dev != dev) {
@@ -859,6 +832,22 @@ Pipeline &pipeline(int nblk)
     return p;
 }
 }  // namespace
+
+// Releases the calling thread's pipeline streams, events and queues (splpak_shutdown).
+void band_pipeline_shutdown()
+{
+    Pipeline &p = g_pipe;
+    for (auto *v : {&p.evP, &p.evU, &p.evC, &p.evI, &p.evT}) {
+        for (hipEvent_t e : *v) (void)hipEventDestroy(e);
+        v->clear();
+    }
+    for (hipEvent_t &e : p.evR) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    for (hipStream_t *s : {&p.panel, &p.col, &p.res, &p.upd}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
+    if (p.queues) (void)hipFree(p.queues);
+    p.queues = nullptr;
+    p.nqueues = 0;
+    p.dev = -1;
+}
 
 // Right-looking factorisation with one block column of look-ahead:
 //   panel stream : [update of block column k+1 by panel k] -> potrf(k+1) -> trsm(k+1)
@@ -939,22 +928,18 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
             stats->syrk_flop += 2.0 * (double)ntiles * TS * TS * NBLK;
         }
     };
-    auto potrf = [&](int k) {        // potrf(k) pinned to the reserved CU, then the 64x64 inverses
+    auto potrf = [&](int k) {        // potrf(k) (+ the 16x16 leaf inverses) pinned to the reserved CU
         const int k0 = k * NBLK;
         if (sR != sP) {
             (void)hipEventRecord(pl.evR[0], sP);
             (void)hipStreamWaitEvent(sR, pl.evR[0], 0);
         }
         hipLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, sR, b.ab, b.lda, k0, info_dev,
-                           minpiv_dev);
+                           minpiv_dev, b.inv64 + (long long)k * 4 * 64 * 64);
         if (sR != sP) {
             (void)hipEventRecord(pl.evR[1], sR);
             (void)hipStreamWaitEvent(sP, pl.evR[1], 0);
         }
-        if (tb_of(k) > 0)
-            hipLaunchKernelGGL(inv64_kernel, dim3(4), dim3(64), 0, sP,
-                               (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda), b.lda,
-                               b.inv64 + (long long)k * 4 * 64 * 64);
         (void)hipEventRecord(pl.evI[k], sP);
     };
     // panel solve of rows [r0, r1) below the diagonal block k
@@ -969,13 +954,13 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
 
     // Dependency structure per step k (X_k = solved panel k; block (I,J) = 256x256 block):
     //   chain  (sP/sR): topA(k)  update of block (k+1,k+1) by X_k          [needs X_k row k+1 = evT[k], bulk(k-1)]
-    //                   potrf(k+1), inv64(k+1)
+    //                   potrf(k+1) (with its 16x16 leaf inverses)
     //                   trsm_top(k+1): block (k+2,k+1) -> X_{k+1} row k+2  [needs topB(k)]      -> evT[k+1]
     //   column (sC)   : topB(k)  update of block (k+2,k+1) by X_k          [needs all of X_k = evP[k], bulk(k-1)]
     //                   colU(k)  update of blocks (>=k+3, k+1)
-    //                   trsm_rest(k+1): rows below block row k+2           [needs inv64(k+1)]   -> evP[k+1]
+    //                   trsm_rest(k+1): rows below block row k+2           [needs potrf(k+1)]   -> evP[k+1]
     //   bulk   (sU)   : block columns >= k+2 by X_k                        [needs evP[k]]       -> evU[k]
-    // The only cycle is the chain (~topA + potrf + inv64 + trsm of 256 rows); everything that
+    // The only cycle is the chain (~topA + potrf + trsm of 256 rows); everything that
     // needs the whole panel hangs off it with a step of slack.
     (void)hipEventRecord(pl.evU[b.nblk], st);      // start after everything queued on the caller's stream
     (void)hipStreamWaitEvent(sP, pl.evU[b.nblk], 0);

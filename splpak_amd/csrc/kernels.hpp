@@ -58,7 +58,7 @@ struct Band {
     double *ab;       // dense-view base: A(i,j) = ab[i + j*lda], j <= i <= j + halfbw
     double *dinv;     // [nblk][NBLK*NBLK] inverses of the diagonal blocks of L (row-major)
     double *dinvt;    // [nblk][NBLK*NBLK] transposes of dinv (backward sweep)
-    double *inv64;    // [nblk][4][64*64] inverses of the 64x64 diagonal sub-blocks (column-major)
+    double *inv64;    // [nblk][16][16*16] inverses of the 16x16 diagonal leaves of L (column-major), 16 KB stride per block
     long long lda;    // column stride of the dense view (ld - 1)
     int n;            // logical order
     int npad;         // padded to a multiple of NBLK (identity on the padding)
@@ -78,6 +78,8 @@ struct CholStats {            // optional per-kernel accounting (HIP events)
 // non-positive pivot (0 = success); min pivot is tracked in minpiv_dev
 hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipStream_t st,
                          CholStats *stats);
+// release the calling thread's pipeline streams / events / queues
+void band_pipeline_shutdown();
 // x <- (L L^T)^{-1} x; x and tmp of length npad (padding entries of x must be 0)
 hipError_t band_solve(const Band &b, double *x, double *tmp, hipStream_t st);
 

@@ -635,6 +635,11 @@ int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double 
     return rc;
 }
 
+void splpak_shutdown(void)
+{
+    band_pipeline_shutdown();
+}
+
 int32_t splpak_last_error_message(char *buf, int32_t buflen)
 {
     if (!buf || buflen <= 0) return (int32_t)g_err.size();
