@@ -127,13 +127,15 @@ const double *splpak_plan_hist_dev(const splpak_plan *plan);
 
 /* Per-kernel accounting of the last splpak_plan_fit_dev call, measured with HIP
  * events on the stream the kernels ran on (bench.py's roofline object):
- *   out[0] = number of trailing-update (SYRK, f64 MFMA) launches
+ *   out[0] = number of BULK trailing-update launches (syrk64_kernel, f64 MFMA; one per step,
+ *            ~92 % of the fit's flops; the small block-column pieces are a separate instantiation)
  *   out[1] = total milliseconds in them
- *   out[2] = total floating-point operations they performed (algorithmic, 2*m*n*k/..)
+ *   out[2] = floating-point operations they performed (algorithmic: 2*64*64*256 per 64x64 item)
  *   out[3] = milliseconds in the whole factorisation
- * Timing is only collected when enabled (costs an event pair per launch). */
+ *   out[4] = floating-point operations of ALL trailing-update launches
+ * Timing is only collected when enabled (costs an event pair per bulk launch). */
 void    splpak_plan_enable_kernel_timing(splpak_plan *plan, int32_t on);
-void    splpak_plan_kernel_timing(const splpak_plan *plan, double *out4);
+void    splpak_plan_kernel_timing(const splpak_plan *plan, double *out5);
 
 /* Batched evaluation on resident data (asynchronous on `stream`; no validation
  * beyond the reference's 101..104, which is done on the host from the small

@@ -35,7 +35,7 @@ namespace {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-constexpr int PNL = 64;            // potrf inner panel width
+
 
 // ---------------------------------------------------------------------------
 // Cholesky of one 256x256 diagonal block: one workgroup of 4 waves, 16-column panels.
@@ -266,41 +266,15 @@ constexpr int KC = 16;             // K chunk staged per LDS buffer
 constexpr int LDT = TS + 16;       // padded LDS row: k-rows land on alternating bank halves
 
 __global__ void __launch_bounds__(256, 2)
-syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, int tj_begin, int mode)
+syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, int tj_begin)
 {
     __shared__ double sI[2][KC * LDT];   // panel rows of the C-row block  (MFMA B operand)
     __shared__ double sJ[2][KC * LDT];   // panel rows of the C-col block  (MFMA A operand)
 
-    // block -> lower-triangular tile (ti >= tj).
-    //   mode 0: all tiles of tile columns >= tj_begin, column-major
-    //   mode 1: the 3 tiles of the first diagonal 256x256 block
-    //   mode 2: the rest of the first two tile columns (rows >= 2)
-    //   mode 3: as mode 0, but walked in 8x8 super-tiles that are dealt to the XCDs
-    //           (workgroup b runs on XCD b%8): the 64 workgroups an XCD has in flight share
-    //           8 + 8 panel row blocks (4 MB = its L2) instead of streaming 64 different ones
-    int b = blockIdx.x, tj = tj_begin, ti;
-    if (mode == 3) {
-        const int x = b & 7, l = b >> 3;
-        int s = (l >> 6) * 8 + x;
-        const int w = l & 63;
-        const int ns = (nt - tj_begin + 7) >> 3;
-        if (s >= ns * (ns + 1) / 2) return;
-        int sj = 0;
-        while (s >= ns - sj) { s -= ns - sj; ++sj; }
-        const int si = sj + s;
-        ti = tj_begin + 8 * si + (w & 7);
-        tj = tj_begin + 8 * sj + (w >> 3);
-        if (ti >= nt || tj >= nt || ti < tj) return;
-    } else if (mode == 0) {
-        while (b >= nt - tj) { b -= nt - tj; ++tj; }
-        ti = tj + b;
-    } else if (mode == 1) {
-        tj = (b == 2) ? 1 : 0;
-        ti = (b == 0) ? 0 : 1;
-    } else {
-        tj = b / (nt - 2);
-        ti = 2 + b % (nt - 2);
-    }
+    // block -> lower-triangular tile (ti >= tj) of tile columns >= tj_begin, column-major
+    int b = blockIdx.x, tj = tj_begin;
+    while (b >= nt - tj) { b -= nt - tj; ++tj; }
+    const int ti = tj + b;
     const bool diag = (ti == tj);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -870,63 +844,42 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         stats->syrk_launches = stats->syrk_ms = stats->syrk_flop = stats->factor_ms = 0;
         (void)hipEventRecord(f0, st);
     }
+    if (stats) stats->total_flop = 0;
     auto tb_of = [&](int k) { int t = b.nblk - 1 - k; return t > b.bw ? b.bw : t; };
-    static const bool use64 = std::getenv("SPLPAK_SYRK_LDS") == nullptr;   // default: register-streaming trailing update
     int qnext = 0;
-    auto syrk = [&](hipStream_t s, int k, int tj_begin, int mode, int ntiles) {
-        const int k0 = k * NBLK, nt = tb_of(k) * NBLK / TS;
-        if (ntiles <= 0 && !use64) return;
-        if (use64) {
-            // 64-row units: diag block = cols [0,4) rows [0,4); rest of first block column =
-            // cols [0,4) rows [4,n64); bulk = cols [4,n64)
-            const int n64 = 2 * nt;
-            int cb, ce, rb, re = n64;
-            if (mode == 1) { cb = 0; ce = 4; rb = 0; re = 4; }
-            else if (mode == 2) { cb = 0; ce = 4; rb = 4; }
-            else if (mode == 4) { cb = 0; ce = 4; rb = 4; re = n64 < 8 ? n64 : 8; }
-            else if (mode == 5) { cb = 0; ce = 4; rb = 8; }
-            else { cb = 2 * tj_begin; ce = n64; rb = 0; }
-            long long items = 0;
-            for (int c = cb; c < ce; ++c) items += re - (c > rb ? c : rb);
-            if (items <= 0) return;
-            hipEvent_t a = nullptr, c = nullptr;
-            if (timing) {
-                (void)hipEventCreate(&a);
-                (void)hipEventCreate(&c);
-                (void)hipEventRecord(a, s);
-            }
-            const int margin = (pl.reserved != ~0u && qnext < pl.nqueues) ? 512 : 0;
-            int *queue = (pl.reserved != ~0u && qnext < pl.nqueues) ? pl.queues + 2 * (qnext++) : nullptr;
-            hipLaunchKernelGGL((syrk64_kernel<16, 1, SYRK_ABL>), dim3((unsigned)items + margin), dim3(64), 0, s, b.ab, b.lda,
-                               k0, k0 + NBLK, cb, ce, rb, re, (int)items, margin, pl.reserved, queue);
-            if (timing) {
-                (void)hipEventRecord(c, s);
-                evs.push_back(a);
-                evs.push_back(c);
-                stats->syrk_launches += 1;
-                stats->syrk_flop += 2.0 * (double)items * 64 * 64 * NBLK;
-            }
-            return;
-        }
+    // trailing update of the 64-row-unit range cols [cb,ce) x rows [max(col,rb), re) by panel k
+    // bulk = true: the launch that carries ~92 % of the flops; it is a separate template
+    // instantiation (ABL bit 8, no functional difference) so that profilers list it under its own
+    // name, and it alone feeds the roofline statistics
+    auto syrk = [&](hipStream_t s, int k, int cb, int ce, int rb, int re, bool bulk = false) {
+        const int k0 = k * NBLK;
+        long long items = 0;
+        for (int c = cb; c < ce; ++c) items += (re - (c > rb ? c : rb)) > 0 ? re - (c > rb ? c : rb) : 0;
+        if (items <= 0) return;
         hipEvent_t a = nullptr, c = nullptr;
-        if (timing) {
+        const bool timed = timing && bulk;
+        if (timed) {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&c);
             (void)hipEventRecord(a, s);
         }
-        int grid = ntiles;
-        if (mode == 3) {
-            const int ns = (nt - tj_begin + 7) / 8, nst = ns * (ns + 1) / 2;
-            grid = ((nst + 7) / 8) * 8 * 64;
-        }
-        hipLaunchKernelGGL(syrk_kernel, dim3(grid), dim3(256), 0, s, b.ab, b.lda, k0, k0 + NBLK, nt, tj_begin, mode);
-        if (timing) {
+        const bool queued = pl.reserved != ~0u && qnext < pl.nqueues;
+        const int margin = queued ? 512 : 0;
+        int *queue = queued ? pl.queues + 2 * (qnext++) : nullptr;
+        if (bulk)
+            hipLaunchKernelGGL((syrk64_kernel<16, 1, SYRK_ABL>), dim3((unsigned)items + margin), dim3(64), 0, s, b.ab,
+                               b.lda, k0, k0 + NBLK, cb, ce, rb, re, (int)items, margin, pl.reserved, queue);
+        else
+            hipLaunchKernelGGL((syrk64_kernel<16, 1, SYRK_ABL | 8>), dim3((unsigned)items + margin), dim3(64), 0, s, b.ab,
+                               b.lda, k0, k0 + NBLK, cb, ce, rb, re, (int)items, margin, pl.reserved, queue);
+        if (timed) {
             (void)hipEventRecord(c, s);
             evs.push_back(a);
             evs.push_back(c);
             stats->syrk_launches += 1;
-            stats->syrk_flop += 2.0 * (double)ntiles * TS * TS * NBLK;
+            stats->syrk_flop += 2.0 * (double)items * 64 * 64 * NBLK;
         }
+        if (stats) stats->total_flop += 2.0 * (double)items * 64 * 64 * NBLK;
     };
     auto potrf = [&](int k) {        // potrf(k) (+ the 16x16 leaf inverses) pinned to the reserved CU
         const int k0 = k * NBLK;
@@ -974,40 +927,27 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     for (int k = 0; k < b.nblk; ++k) {
         const int tb = tb_of(k);
         if (tb <= 0) continue;
-        const int nt = tb * NBLK / TS;
-        const int ntiles = nt * (nt + 1) / 2;
-        const int ncol = nt + (nt - 1);                 // tiles of the first block column (tj = 0, 1)
+        const int n64 = tb * NBLK / 64;                 // trailing rows / columns in 64-row units
         const int nrows1 = tb_of(k + 1) * NBLK;         // rows below the diagonal block of panel k+1
         if (k > 0) {
             (void)hipStreamWaitEvent(sP, pl.evU[k - 1], 0);
             (void)hipStreamWaitEvent(sC, pl.evU[k - 1], 0);
         }
-        if (use64) {
-            syrk(sP, k, 0, 1, 0);                       // topA: cols [0,4), rows [0,4)
-            potrf(k + 1);
-            (void)hipStreamWaitEvent(sC, pl.evP[k], 0);
-            syrk(sC, k, 0, 4, 0);                       // topB: cols [0,4), rows [4,8)
-            (void)hipEventRecord(pl.evC[k], sC);
-            syrk(sC, k, 0, 5, 0);                       // colU: cols [0,4), rows [8,n64)
-            (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
-            trsm(sP, k + 1, 0, nrows1 < NBLK ? nrows1 : NBLK);
-            (void)hipEventRecord(pl.evT[k + 1], sP);
-            (void)hipStreamWaitEvent(sC, pl.evI[k + 1], 0);
-            trsm(sC, k + 1, NBLK, nrows1);
-            (void)hipStreamWaitEvent(sC, pl.evT[k + 1], 0);
-            (void)hipEventRecord(pl.evP[k + 1], sC);
-        } else {
-            syrk(sP, k, 0, 1, 3);
-            potrf(k + 1);
-            (void)hipStreamWaitEvent(sC, pl.evP[k], 0);
-            syrk(sC, k, 0, 2, ncol - 3);
-            (void)hipEventRecord(pl.evC[k], sC);
-            (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
-            trsm(sP, k + 1, 0, nrows1);
-            (void)hipEventRecord(pl.evP[k + 1], sP);
-        }
+        syrk(sP, k, 0, 4, 0, 4);                        // topA: block (k+1,k+1)
+        potrf(k + 1);
+        (void)hipStreamWaitEvent(sC, pl.evP[k], 0);
+        syrk(sC, k, 0, 4, 4, n64 < 8 ? n64 : 8);        // topB: block (k+2,k+1)
+        (void)hipEventRecord(pl.evC[k], sC);
+        syrk(sC, k, 0, 4, 8, n64);                      // colU: blocks (>=k+3, k+1)
+        (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
+        trsm(sP, k + 1, 0, nrows1 < NBLK ? nrows1 : NBLK);
+        (void)hipEventRecord(pl.evT[k + 1], sP);
+        (void)hipStreamWaitEvent(sC, pl.evI[k + 1], 0);
+        trsm(sC, k + 1, NBLK, nrows1);
+        (void)hipStreamWaitEvent(sC, pl.evT[k + 1], 0);
+        (void)hipEventRecord(pl.evP[k + 1], sC);
         (void)hipStreamWaitEvent(sU, pl.evP[k], 0);
-        syrk(sU, k, 2, std::getenv("SPLPAK_NO_XCDMAP") ? 0 : 3, ntiles - ncol);
+        syrk(sU, k, 4, n64, 0, n64, true);              // bulk: block columns >= k+2
         (void)hipEventRecord(pl.evU[k], sU);
     }
     (void)hipStreamWaitEvent(sU, pl.evP[b.nblk - 1], 0);

@@ -72,7 +72,8 @@ hipError_t launch_expand(const Grid &g, const double *nst, const Band &b, hipStr
 
 struct CholStats {            // optional per-kernel accounting (HIP events)
     bool enabled = false;
-    double syrk_launches = 0, syrk_ms = 0, syrk_flop = 0, factor_ms = 0;
+    double syrk_launches = 0, syrk_ms = 0, syrk_flop = 0, factor_ms = 0;   // bulk trailing-update launches
+    double total_flop = 0;                                                 // all trailing-update launches
 };
 // in-place L L^T; *info_dev (device int) is set to 1 + column of the first
 // non-positive pivot (0 = success); min pivot is tracked in minpiv_dev

@@ -264,6 +264,7 @@ void splpak_plan_kernel_timing(const splpak_plan *p, double *out4)
     out4[1] = p->stats.syrk_ms;
     out4[2] = p->stats.syrk_flop;
     out4[3] = p->stats.factor_ms;
+    out4[4] = p->stats.total_flop;
 }
 
 const double *splpak_plan_hist_dev(const splpak_plan *p) { return p ? p->hist : nullptr; }

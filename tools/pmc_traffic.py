@@ -23,9 +23,7 @@ res = {
     "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
     "bulk_launches": nfb, "bulk_fetch_kb_raw": fb, "bulk_write_kb": wb,
     "bulk_hbm_bytes_per_launch": (2.0 * fb + wb) * 1024.0,
-    "note": "FETCH_SIZE doubled per the gfx950 correction for 16-B/lane streaming reads (panel loads); the C-tile "
-            "reads are 8 B/lane in 128-B segments, for which the doubling is an upper bound: WRITE_SIZE equals the "
-            "C-tile bytes exactly, so the C read is the same amount and the rest of FETCH_SIZE is panel misses.",
+    "note": "FETCH_SIZE x 2 is the gfx950 correction for wide streaming reads; for the 8-B/lane loads of syrk64_kernel it is an upper bound (see profiles/r01_syrk_pmc.json)",
 }
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))

@@ -24,7 +24,7 @@ static float runlds(double *ab, long long lda, int nt)
     const int ntiles = nt * (nt + 1) / 2 - (nt + nt - 1);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, g_stream);
-    hipLaunchKernelGGL(syrk_kernel, dim3(ntiles), dim3(256), 0, g_stream, ab, lda, 0, NBLK, nt, 2, 0);
+    hipLaunchKernelGGL(syrk_kernel, dim3(ntiles), dim3(256), 0, g_stream, ab, lda, 0, NBLK, nt, 2);
     (void)hipEventRecord(e1, g_stream); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     return ms;
