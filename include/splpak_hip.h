@@ -49,10 +49,12 @@ extern "C" {
  * `nwrk` is only used for the reference's 106 check (:772-781); the GPU path does
  * not use the caller's `work` array, except that when `hist_out` != NULL and
  * xtrap != 0 it receives the sparse-area histogram the reference leaves in
- * work(1:ncol) (:879-907).  `info` (optional, 8 doubles) receives diagnostics:
+ * work(1:ncol) (:879-907).  `info` (optional, 10 doubles) receives diagnostics:
  *   [0] data rows used, [1] constraint rows, [2] refinement steps taken,
  *   [3] |last correction|_inf / |coef|_inf, [4] min Cholesky pivot,
- *   [5] seconds in assembly, [6] seconds in factorisation, [7] seconds in solve+refine */
+ *   [5] seconds in assembly, [6] seconds in factorisation, [7] seconds in solve+refine,
+ *   [8] residual norm ||rows*coef - rhs||_2 over data and constraint rows -- the `reserr` that the
+ *       reference computes (suprls :1693) and drops (splcw :690, :1052), [9] reserved */
 int32_t splpak_fit_f64(int32_t ndim, const double *xdata, int32_t l1xdat,
                        const double *ydata, const double *wdata, int64_t ndata,
                        const double *xmin, const double *xmax, const int32_t *nodes,

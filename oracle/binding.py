@@ -138,6 +138,8 @@ class Port(_Base):
         L.oracle_splde.argtypes = [C.c_int, _dp, _ip, _dp, _dp, _dp, _ip, _ip]
         L.oracle_splde_many.restype = C.c_int
         L.oracle_splde_many.argtypes = [C.c_int, C.c_long, _dp, C.c_int, _ip, _dp, _dp, _dp, _ip, _dp]
+        L.oracle_last_reserr.restype = C.c_double
+        L.oracle_last_reserr.argtypes = []
         L.oracle_bascmp.restype = C.c_double
         L.oracle_bascmp.argtypes = [C.c_int, _dp, _ip, _ip, _dp, _dp, _ip, _ip]
 
@@ -162,6 +164,7 @@ class Port(_Base):
                                      _ptr(wdata, _dp), ndata, _ptr(xmin, _dp), _ptr(xmax, _dp),
                                      _ptr(nodes, _ip), float(xtrap), _ptr(coef, _dp), ncf,
                                      _ptr(work, _dp), nwrk, 1 if quiet else 0)
+        self.last_reserr = float(self.lib.oracle_last_reserr())
         return coef, ierr, work
 
     def evaluate(self, ndim, xq, nderiv, coef, xmin, xmax, nodes):

@@ -359,6 +359,11 @@ static void say(int quiet, int ierr, const char *m)
 
 #define MAXD 16
 
+/* the residual norm suprls returns (:1693) and splcw discards (:690): kept so that the
+ * GPU path's diagnostic can be checked against it */
+static double g_last_reserr = 0.0;
+double oracle_last_reserr(void) { return g_last_reserr; }
+
 int oracle_splcw(int ndim, const double *xdata, int l1xdat, const double *ydata,
                  const double *wdata, int ndata, const double *xmin, const double *xmax,
                  const int *nodes, double xtrap, double *coef, int ncf,
@@ -510,6 +515,7 @@ int oracle_splcw(int ndim, const double *xdata, int l1xdat, const double *ydata,
     /* ---- solve (:1051-1058) ---- */
     double reserr = 0.0;
     if (rls_solve(&S, coef, &reserr)) { ierror = 107; say(quiet, 107, fail107); }
+    g_last_reserr = reserr;
     rls_free(&S);
     return ierror;
 }

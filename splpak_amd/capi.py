@@ -153,7 +153,7 @@ def fit(ndim, xdata, ydata, wdata, xmin, xmax, nodes, xtrap, ncf=None, nwrk=-1, 
         ncf = ncol
     coef = np.zeros(max(ncf, 1), dtype=dt)
     hist = np.zeros(max(ncol, 1), dtype=dt) if want_hist else None
-    info = np.zeros(8)
+    info = np.zeros(10)
     fn = lib().splpak_fit_f32 if real32 else lib().splpak_fit_f64
     xt = C.c_float(xtrap) if real32 else C.c_double(xtrap)
     rc = _check(fn(ndim, _p(xdata, rp), l1xdat, _p(ydata, rp), _p(wdata, rp), ndata, _p(xmin, rp),
@@ -247,7 +247,7 @@ class Plan:
     def fit(self, xdata, ydata, wdata, coef, stream=0):
         """All arguments are torch float64 device tensors; xdata is (ndata, l1xdat) row-major
         (= the reference's column-major xdata(l1xdat, ndata)).  Returns (ierror, info)."""
-        info = np.zeros(8)
+        info = np.zeros(10)
         ndata, l1 = xdata.shape
         rc = self._L.splpak_plan_fit_dev(self._h, xdata.data_ptr(), int(l1), ydata.data_ptr(),
                                          None if wdata is None else wdata.data_ptr(), int(ndata),

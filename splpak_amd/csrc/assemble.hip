@@ -265,7 +265,7 @@ template <int D>
 __global__ void __launch_bounds__(ResCfg<D>::NT)
 residual_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
                 const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
-                const double *__restrict__ xvec, double *__restrict__ rho)
+                const double *__restrict__ xvec, double *__restrict__ rho, double *__restrict__ ssq)
 {
     using C = ResCfg<D>;
     constexpr int NB = C::NB, NT = C::NT, PCH = C::PCH, LDB = NB + 1;
@@ -288,7 +288,7 @@ residual_kernel(Grid g, const int *__restrict__ offset, const double *__restrict
         mycol = local_col<D>(g, colbase, tid);
         xloc[tid] = xvec[mycol];
     }
-    double racc = 0.0;
+    double racc = 0.0, e2 = 0.0;
     for (long long p0 = beg; p0 < end; p0 += PCH) {
         const int np = (int)((end - p0 < PCH) ? (end - p0) : PCH);
         stage_points<D, NB, LDB, NT>(g, xs, ys, ws, cap, p0, np, tab, bw, wy, wt);
@@ -297,6 +297,7 @@ residual_kernel(Grid g, const int *__restrict__ offset, const double *__restrict
             double dot = 0.0;
             for (int c = 0; c < NB; ++c) dot += bw[p * LDB + c] * xloc[c];
             wy[p] = wy[p] - dot;
+            e2 += wy[p] * wy[p];
         }
         __syncthreads();
         if (tid < NB)
@@ -304,6 +305,10 @@ residual_kernel(Grid g, const int *__restrict__ offset, const double *__restrict
         __syncthreads();
     }
     if (tid < NB) atomicAdd(&rho[mycol], racc);
+    if (ssq) {                                   // sum of squared row residuals (the reference's errsum)
+        e2 = wave_sum(e2);
+        if ((tid & 63) == 0 && e2 != 0.0) atomicAdd(ssq, e2);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -312,7 +317,7 @@ template <int D>
 __global__ void __launch_bounds__(256)
 constraint_kernel(Grid g, const double *__restrict__ hist, const double *__restrict__ scal,
                   double xtrap, double *__restrict__ nst, const double *__restrict__ xvec,
-                  double *__restrict__ rho, double *__restrict__ scal_out)
+                  double *__restrict__ rho, double *__restrict__ scal_out, double *__restrict__ ssq)
 {
 #pragma clang fp contract(off)
     constexpr int NE = (D == 1) ? 3 : (D == 2) ? 9 : (D == 3) ? 27 : 81;
@@ -402,6 +407,7 @@ constraint_kernel(Grid g, const double *__restrict__ hist, const double *__restr
                     t = wave_sum(t);
                     for (int e = lane; e < NE; e += 64)
                         if (cv[e] != 0.0) atomicAdd(&rho[cl[e]], -cv[e] * t);
+                    if (ssq && lane == 0) atomicAdd(ssq, t * t);     // constraint rows have rhs 0
                 }
             }
         }
@@ -497,23 +503,23 @@ hipError_t launch_gram(const Grid &g, const SortScratch &s, double *nst, double 
 }
 
 hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rho,
-                           hipStream_t st)
+                           double *ssq, hipStream_t st)
 {
     DISPATCH_D(g.ndim, {
         using C = ResCfg<D>;
         hipLaunchKernelGGL(residual_kernel<D>, dim3((unsigned)g.ncell), dim3(C::NT), 0, st, g,
-                           s.offset, s.xs, s.ys, s.ws, s.cap, xvec, rho);
+                           s.offset, s.xs, s.ys, s.ws, s.cap, xvec, rho, ssq);
     });
     return hipGetLastError();
 }
 
 hipError_t launch_constraints(const Grid &g, const double *hist, const double *scal, double xtrap,
                               double *nst, const double *xvec, double *rho, double *scal_out,
-                              hipStream_t st)
+                              double *ssq, hipStream_t st)
 {
     dim3 gr((unsigned)((g.ncol + 3) / 4)), bl(256);
     DISPATCH_D(g.ndim, hipLaunchKernelGGL(constraint_kernel<D>, gr, bl, 0, st, g, hist, scal, xtrap,
-                                          nst, xvec, rho, scal_out));
+                                          nst, xvec, rho, scal_out, ssq));
     return hipGetLastError();
 }
 

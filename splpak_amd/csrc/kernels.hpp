@@ -42,15 +42,16 @@ hipError_t launch_scan_scatter(const Grid &g, long long m, const double *x, int 
 hipError_t launch_gram(const Grid &g, const SortScratch &s, double *nst, double *rhs,
                        hipStream_t st);
 // data part of the refinement residual: rho += A^T W (W y - W A x)
+// ssq != NULL: also accumulate the sum of squared row residuals
 hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rho,
-                           hipStream_t st);
+                           double *ssq, hipStream_t st);
 // derivative-constraint rows of the data-sparse nodes (:921-1046).
 //   nst != NULL : add c c^T of every constraint row to the normal equations and
 //                 count the rows into scal[SC_NROWS_CONS]
 //   xvec != NULL: rho -= c (c . x) for every constraint row (residual mode)
 hipError_t launch_constraints(const Grid &g, const double *hist, const double *scal, double xtrap,
                               double *nst, const double *xvec, double *rho, double *scal_out,
-                              hipStream_t st);
+                              double *ssq, hipStream_t st);
 
 // ---- bandchol.hip
 constexpr int NBLK = 256;     // block size of the band factorisation

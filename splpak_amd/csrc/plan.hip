@@ -114,7 +114,7 @@ static long long comm_len_of(const Grid &g)
     const long long npad = ((g.ncol + NBLK - 1) / NBLK) * (long long)NBLK;
     return (long long)g.ncol * g.hstencil + g.ncol + SC_COUNT   // G: nst, rhs, scalG
            + (long long)g.ncol + SC_COUNT                        // H: hist, scalH
-           + npad;                                               // R: rho
+           + npad + SC_COUNT;                                    // R: rho, scalR (residual sum of squares)
 }
 
 template <typename T>
@@ -217,7 +217,7 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
     }
     p->lenG = (long long)g.ncol * g.hstencil + g.ncol + SC_COUNT;
     p->lenH = (long long)g.ncol + SC_COUNT;
-    p->lenR = p->band.npad;
+    p->lenR = p->band.npad + SC_COUNT;
     p->nst = p->comm;
     p->rhs = p->nst + (long long)g.ncol * g.hstencil;
     p->scalG = p->rhs + g.ncol;
@@ -299,7 +299,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     SPLPAK_HIP_TRY(launch_gram(g, p->s, p->nst, p->rhs, st), SPLPAK_E_NODEVICE);
     if (int r = do_allreduce(p, p->hist, p->lenH, st)) return r;
     if (smooth && p->rank == 0)
-        SPLPAK_HIP_TRY(launch_constraints(g, p->hist, p->scalH, p->xtrap, p->nst, nullptr, nullptr, p->scalG, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_constraints(g, p->hist, p->scalH, p->xtrap, p->nst, nullptr, nullptr, p->scalG, nullptr, st), SPLPAK_E_NODEVICE);
     if (int r = do_allreduce(p, p->nst, p->lenG, st)) return r;
 
     double hs[2 * SC_COUNT];
@@ -311,7 +311,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     const double rows_cons = hs[SC_NROWS_CONS];
     auto t1 = clk::now();
     if (info) {
-        for (int i = 0; i < 8; ++i) info[i] = 0.0;
+        for (int i = 0; i < 10; ++i) info[i] = 0.0;
         info[0] = rows_data;
         info[1] = rows_cons;
         info[5] = std::chrono::duration<double>(t1 - t0).count();
@@ -355,9 +355,9 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     bool diverged = false;
     for (int it = 0; it < p->max_refine; ++it) {
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rho, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rho, nullptr, st), SPLPAK_E_NODEVICE);
         if (smooth && p->rank == 0)
-            SPLPAK_HIP_TRY(launch_constraints(g, p->hist, p->scalH, p->xtrap, nullptr, p->xvec, p->rho, nullptr, st), SPLPAK_E_NODEVICE);
+            SPLPAK_HIP_TRY(launch_constraints(g, p->hist, p->scalH, p->xtrap, nullptr, p->xvec, p->rho, nullptr, nullptr, st), SPLPAK_E_NODEVICE);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
         SPLPAK_HIP_TRY(band_solve(b, p->rho, p->tmp, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(launch_axpy_absmax(g.ncol, p->xvec, p->rho, p->small, st), SPLPAK_E_NODEVICE);
@@ -383,12 +383,25 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         prev_rel = last_rel;
     }
     SPLPAK_HIP_TRY(hipMemcpyAsync(coef_dev, p->xvec, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
+    // residual norm of the fitted system, ||rows * coef - rhs||_2 over data AND constraint rows: what
+    // the reference computes as `reserr` (suprls :1693) and then drops (splcw :690, :1052)
+    double ssq = 0.0;
+    if (info) {
+        double *scalR = p->rho + b.npad;
+        SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rho, scalR, st), SPLPAK_E_NODEVICE);
+        if (smooth && p->rank == 0)
+            SPLPAK_HIP_TRY(launch_constraints(g, p->hist, p->scalH, p->xtrap, nullptr, p->xvec, p->rho, nullptr, scalR, st), SPLPAK_E_NODEVICE);
+        if (int r = do_allreduce(p, scalR, SC_COUNT, st)) return r;
+        SPLPAK_HIP_TRY(hipMemcpyAsync(&ssq, scalR, sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+    }
     SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
     auto t3 = clk::now();
     if (info) {
         info[2] = steps;
         info[3] = last_rel;
         info[7] = std::chrono::duration<double>(t3 - t2).count();
+        info[8] = std::sqrt(ssq);
     }
     // a correction that is still large means the factor did not precondition the problem
     // (numerically singular normal equations): the reference's "suprls failure"

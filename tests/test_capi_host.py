@@ -70,4 +70,4 @@ def test_comm_len_formula():
     nodes = np.array([8, 8, 8], dtype=np.int32)
     n = 512
     npad = 512
-    assert capi.lib().splpak_plan_comm_len(3, capi._p(nodes, capi._ip)) == n * 172 + n + 8 + n + 8 + npad
+    assert capi.lib().splpak_plan_comm_len(3, capi._p(nodes, capi._ip)) == n * 172 + n + 8 + n + 8 + npad + 8

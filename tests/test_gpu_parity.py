@@ -241,3 +241,59 @@ def test_large_grid_repeated_fit_properties():
         res.append(c)
     assert relmax(res[1], res[0]) < 1e-11 and relmax(res[2], res[0]) < 1e-11
     plan.close()
+
+
+@pytest.mark.parametrize("name", ["c1_1d16", "2d16", "2d16_sparse", "3d8_cc_clust", "4d4"])
+def test_residual_norm_matches_reference_algorithm(port, name):
+    """info[8] = ||rows*coef - rhs||_2 over data and constraint rows: the `reserr` the reference
+    computes in suprls (:1693) and drops in splcw (:690).  Checked against the oracle's value."""
+    inp = make_inputs(CASES[name])
+    _, ierr, _, info = capi.fit(inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"],
+                                inp["nodes"], inp["xtrap"])
+    _, e0, _ = port.fit(inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"],
+                        inp["nodes"], inp["xtrap"])
+    assert ierr == e0 == 0
+    assert abs(info[8] - port.last_reserr) <= 1e-9 * max(port.last_reserr, 1e-300)
+
+
+def test_fit_is_linear_in_ydata_and_idempotent():
+    """Size-independent properties of the least-squares fit (same xdata, wdata, grid):
+    coef(a*y1 + b*y2) = a*coef(y1) + b*coef(y2); and fitting data sampled FROM a spline of the
+    grid with xtrap = 0 returns that spline (projection is idempotent)."""
+    inp = make_inputs(CASES["3d8"])
+    nd, x, w = inp["ndim"], inp["xdata"], inp["wdata"]
+    rng = np.random.default_rng(5)
+    y1, y2 = inp["ydata"], np.cos(7.0 * x.sum(axis=1)) + rng.standard_normal(x.shape[0])
+    args = (inp["xmin"], inp["xmax"], inp["nodes"], inp["xtrap"])
+    c1 = capi.fit(nd, x, y1, w, *args)[0]
+    c2 = capi.fit(nd, x, y2, w, *args)[0]
+    c12 = capi.fit(nd, x, 2.5 * y1 - 0.75 * y2, w, *args)[0]
+    assert relmax(c12, 2.5 * c1 - 0.75 * c2) < 1e-10
+    # idempotence: y := spline(c1) at the data points, no smoothing rows
+    ys, _ = capi.evaluate(nd, x, None, c1, inp["xmin"], inp["xmax"], inp["nodes"])
+    c3, ierr, _, _ = capi.fit(nd, x, ys, w, inp["xmin"], inp["xmax"], inp["nodes"], 0.0)
+    assert ierr == 0 and relmax(c3, c1) < 1e-9
+
+
+def test_ragged_and_degenerate_batches():
+    """One point, all points in one cell, duplicated points, a huge batch of one repeated query."""
+    lo, hi, nodes = [0.0, 0.0], [1.0, 1.0], [6, 6]
+    # a single data point cannot determine 36 coefficients without smoothing rows ...
+    assert capi.fit(2, np.array([[0.3, 0.4]]), np.array([1.0]), None, lo, hi, nodes, 0.0)[1] == 107
+    # ... with them the fit exists; it must agree with the reference algorithm
+    from oracle.binding import Port
+    P = Port()
+    x1 = np.array([[0.3, 0.4]])
+    c, ierr, _, _ = capi.fit(2, x1, np.array([1.0]), None, lo, hi, nodes, 1.0)
+    c0, e0, _ = P.fit(2, x1, np.array([1.0]), None, lo, hi, nodes, 1.0)
+    assert ierr == e0 == 0 and relmax(c, c0[:36]) < 1e-10
+    # many coincident points in a single window + a few elsewhere
+    rng = np.random.default_rng(3)
+    x = np.vstack([np.tile([[0.52, 0.47]], (500, 1)), rng.random((200, 2))])
+    y = np.sin(3 * x[:, 0]) + x[:, 1]
+    c, ierr, _, _ = capi.fit(2, x, y, None, lo, hi, nodes, 1.0)
+    c0, e0, _ = P.fit(2, x, y, None, lo, hi, nodes, 1.0)
+    assert ierr == e0 == 0 and relmax(c, c0[:36]) < 1e-10
+    q = np.tile([[0.25, 0.75]], (100000, 1))
+    v, rc = capi.evaluate(2, q, [1, 1], c, lo, hi, nodes)
+    assert rc == 0 and np.all(v == v[0])
