@@ -403,7 +403,7 @@ __global__ void whoami_kernel(unsigned *out) { if (threadIdx.x == 0) out[0] = my
 // queue[0]: next item, queue[1]: waves that stepped aside.  A wave that finds itself on the
 // CU reserved for the panel factorisation (`reserved`, ~0u = none) steps aside without taking
 // an item -- the grid carries `margin` spare waves for that -- unless the margin is used up.
-template <int SD, int WPS, int ABL>
+template <int SD, int WPS, int ABL, int KTOT = NBLK>
 __global__ void __launch_bounds__(64, WPS)
 syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, int ce, int rb, int re,
               int nitems, int margin, unsigned reserved, int *__restrict__ queue)
@@ -425,15 +425,31 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
         if (it >= nitems) return;
     }
     // item -> (tj, ti) in 64-row units: columns [cb, ce), rows [max(tj, rb), re)
-    int tj = cb;
-    for (;;) {
-        const int lo = tj > rb ? tj : rb;
-        const int cnt = re - lo;
-        if (it < cnt) { it += lo; break; }
-        it -= cnt;
-        ++tj;
+    int tj = cb, ti;
+    if (ABL & 16) {
+        // experiment: 16x16 super-blocks of items dealt to the XCDs (item index = workgroup id,
+        // workgroup b runs on XCD b%8): the ~256 waves an XCD has in flight share 16+16 panel
+        // row blocks (4 MB = its L2)
+        const int x = it & 7, l = it >> 3;
+        int s = (l >> 8) * 8 + x;
+        const int w = l & 255;
+        const int ns = (re - cb + 15) >> 4;
+        if (s >= ns * (ns + 1) / 2) return;
+        int sj = 0;
+        while (s >= ns - sj) { s -= ns - sj; ++sj; }
+        ti = cb + 16 * (sj + s) + (w & 15);
+        tj = cb + 16 * sj + (w >> 4);
+        if (ti >= re || tj >= ce || ti < tj) return;
+    } else {
+        for (;;) {
+            const int lo = tj > rb ? tj : rb;
+            const int cnt = re - lo;
+            if (it < cnt) { it += lo; break; }
+            it -= cnt;
+            ++tj;
+        }
+        ti = it;
     }
-    const int ti = it;
     const bool diag = (ti == tj);
     const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
 
@@ -471,7 +487,7 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
     };
 #pragma unroll
     for (int d = 0; d < SD; ++d) fetch(d, d);
-    constexpr int NSTEP = NBLK / 4;
+    constexpr int NSTEP = KTOT / 4;             // KTOT = panel width applied per pass
     static_assert(NSTEP % SD == 0, "queue depth must divide the k-steps");
     for (int ks = 0; ks < NSTEP; ks += SD) {
 #pragma unroll

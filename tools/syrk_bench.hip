@@ -7,14 +7,15 @@ using namespace splpak;
 namespace splpak { void set_error(const std::string &) {} bool hip_ok(hipError_t e, const char *) { return e == hipSuccess; } }
 
 static hipStream_t g_stream = nullptr;
-template <int SD, int WPS, int ABL>
+template <int SD, int WPS, int ABL, int KTOT = NBLK>
 static float run64(double *ab, long long lda, int n64)
 {
     long long items = 0;
     for (int c = 4; c < n64; ++c) items += n64 - c;
+    if (ABL & 16) { const int ns = (n64 - 4 + 15) / 16, nsb = ns * (ns + 1) / 2; items = (long long)((nsb + 7) / 8) * 8 * 256; }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, g_stream);
-    hipLaunchKernelGGL((syrk64_kernel<SD, WPS, ABL>), dim3((unsigned)items), dim3(64), 0, g_stream, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+    hipLaunchKernelGGL((syrk64_kernel<SD, WPS, ABL, KTOT>), dim3((unsigned)items), dim3(64), 0, g_stream, ab, lda, 0, KTOT, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
     (void)hipEventRecord(e1, g_stream); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     return ms;
@@ -33,7 +34,7 @@ int main()
 {
     const int tb = 49, nrows = tb * NBLK, nt = nrows / 128, n64 = nrows / 64;
     const long long lda = (long long)(tb + 1) * NBLK + 16;
-    const size_t ncols = (size_t)NBLK + nrows;
+    const size_t ncols = (size_t)2 * NBLK + nrows;
     const size_t elems = (size_t)(lda + 1) * ncols + 4096;
     double *ab; (void)hipMalloc(&ab, elems * sizeof(double));
     std::vector<double> h(1 << 20);
@@ -47,7 +48,7 @@ int main()
         {"lds 128x128 (2 WG/CU)", floplds, {}}, {"s64 SD4 2w/SIMD", flop64, {}}, {"s64 SD8 1w/SIMD", flop64, {}},
         {"s64 SD4 2w no-refill", flop64, {}}, {"s64 SD4 2w no-epilogue", flop64, {}}, {"s64 SD4 2w neither", flop64, {}},
         {"s64 SD2 2w", flop64, {}}, {"s64 SD8 1w no-epilogue", flop64, {}}, {"s64 SD16 1w", flop64, {}},
-        {"s64 SD16 1w no-epilogue", flop64, {}}, {"s64 SD16 1w no-refill", flop64, {}}, {"s64 SD8 1w", flop64, {}}, {"s64 SD8 2w", flop64, {}}, {"s64 SD16 2w", flop64, {}}, {"s64 SD16 2w no-epilogue", flop64, {}}, {"s64 SD16 1w C-init", flop64, {}}, {"s64 SD16 2w C-init", flop64, {}}, {"s64 SD4 2w C-init", flop64, {}}, {"s64 SD8 1w C-init", flop64, {}}};
+        {"s64 SD16 1w no-epilogue", flop64, {}}, {"s64 SD16 1w no-refill", flop64, {}}, {"s64 SD8 1w", flop64, {}}, {"s64 SD8 2w", flop64, {}}, {"s64 SD16 2w", flop64, {}}, {"s64 SD16 2w no-epilogue", flop64, {}}, {"s64 SD16 1w C-init", flop64, {}}, {"s64 SD16 2w C-init", flop64, {}}, {"s64 SD4 2w C-init", flop64, {}}, {"s64 SD8 1w C-init", flop64, {}}, {"s64 SD16 1w C-init K=512", 2 * flop64, {}}, {"s64 SD16 1w K=512", 2 * flop64, {}}, {"s64 SD16 1w xcd-blocked", flop64, {}}, {"s64 SD16 1w K=512 xcd-blocked", 2 * flop64, {}}};
     for (int r = 0; r < rounds; ++r) {
         v[0].t.push_back(runlds(ab, lda, nt));
         v[1].t.push_back(run64<4, 2, 0>(ab, lda, n64));
@@ -68,6 +69,10 @@ int main()
         v[16].t.push_back(run64<16, 2, 4>(ab, lda, n64));
         v[17].t.push_back(run64<4, 2, 4>(ab, lda, n64));
         v[18].t.push_back(run64<8, 1, 4>(ab, lda, n64));
+        v[19].t.push_back(run64<16, 1, 4, 512>(ab, lda, n64));
+        v[20].t.push_back(run64<16, 1, 0, 512>(ab, lda, n64));
+        v[21].t.push_back(run64<16, 1, 16>(ab, lda, n64));
+        v[22].t.push_back(run64<16, 1, 16, 512>(ab, lda, n64));
     }
     // the same two kernels on a CU-masked stream (one CU left out) and on a plain created stream
     for (int variant = 0; variant < 2; ++variant) {
