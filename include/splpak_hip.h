@@ -166,9 +166,19 @@ int32_t splpak_synth_queries_f64(int32_t ndim, int64_t ndata_before, int64_t fir
 int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double *a_lower,
                                         const double *b, double *x);
 
-/* Releases the calling thread's internal HIP streams, events and queues (the factorisation
- * pipeline creates them lazily and keeps them for reuse).  Optional; plans stay valid. */
+/* Releases the calling thread's internal HIP streams, events, queues and evaluation scratch
+ * (created lazily and kept for reuse).  Optional; plans stay valid. */
 void splpak_shutdown(void);
+
+/* Evaluation strategy of the calling thread (results are bit-identical either way):
+ *   mode 0  automatic: batches of >= 2^20 queries on 3-D and 4-D grids of more than 32768 nodes
+ *           take the binned path, everything else the direct one
+ *   mode 1  direct: one thread per query, coefficients gathered from global memory
+ *   mode 2  binned: queries are sorted by grid region, `chunk` queries at a time (0 = 2^24), and
+ *           each region is evaluated from a copy of its coefficients in LDS; needs
+ *           chunk*(8*ndim+4) bytes of device scratch, kept until splpak_shutdown
+ * There is no counterpart in the reference (splde evaluates one point per call, :1089-1240). */
+int32_t splpak_set_eval_mode(int32_t mode, int64_t chunk);
 
 /* Human-readable text for the last negative status on this thread. */
 int32_t splpak_last_error_message(char *buf, int32_t buflen);

@@ -29,7 +29,8 @@ SYMBOLS = [
     "splpak_plan_set_allreduce", "splpak_plan_set_refine", "splpak_plan_fit_dev",
     "splpak_plan_hist_dev", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing",
     "splpak_eval_dev_f64", "splpak_synth_points_f64", "splpak_synth_queries_f64",
-    "splpak_debug_spd_band_solve_f64", "splpak_shutdown", "splpak_last_error_message", "splpak_device_name",
+    "splpak_debug_spd_band_solve_f64", "splpak_shutdown", "splpak_set_eval_mode",
+    "splpak_last_error_message", "splpak_device_name",
 ]
 
 E_NODEVICE, E_NOMEM, E_BADARG, E_UNSUPPORTED, E_COMM = -1, -2, -3, -4, -5
@@ -88,6 +89,8 @@ def lib() -> C.CDLL:
     L.splpak_debug_spd_band_solve_f64.argtypes = [i32, i32, _dp, _dp, _dp]
     L.splpak_shutdown.restype = None
     L.splpak_shutdown.argtypes = []
+    L.splpak_set_eval_mode.restype = i32
+    L.splpak_set_eval_mode.argtypes = [i32, i64]
     L.splpak_last_error_message.restype = i32
     L.splpak_last_error_message.argtypes = [C.c_char_p, i32]
     L.splpak_device_name.restype = i32
@@ -266,6 +269,14 @@ def evaluate_dev(ndim, xq, nderiv, coef, xmin, xmax, nodes, out, stream=0):
     return _check(lib().splpak_eval_dev_f64(ndim, int(nq), xq.data_ptr(), int(ldx), _p(nd, _ip),
                                             coef.data_ptr(), _p(xmin, _dp), _p(xmax, _dp),
                                             _p(nodes, _ip), out.data_ptr(), C.c_void_p(stream)))
+
+
+EVAL_AUTO, EVAL_DIRECT, EVAL_BINNED = 0, 1, 2
+
+
+def set_eval_mode(mode=EVAL_AUTO, chunk=0):
+    """Evaluation strategy of this thread (bit-identical results): auto / direct gathers / LDS-binned."""
+    return _check(lib().splpak_set_eval_mode(int(mode), int(chunk)))
 
 
 def synth_points_dev(ndim, first_point, ndata, xdata, ydata, wdata, stream=0):

@@ -699,6 +699,159 @@ bwd_update_kernel(const double *__restrict__ Lrows, long long lda, const double 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Coupling blocks of the one-kernel-per-step band sweeps.  With
+//   M_k = Linv_{k+1} L_{k+1,k}          (forward)      N_k = Linv_k^T L_{k+1,k}^T     (backward)
+// the next solved block is  y_{k+1} = Linv_{k+1} v'_{k+1} - M_k y_k  (v' = right-hand side updated by
+// the steps before k only), so a step no longer waits for the panel update of the previous one:
+// the 256x512 product [Linv | -M] [v'; y_k] and the panel update by y_k run in the same launch.
+// grid (2*(nblk-1), 16): x = block pair and direction, y = 64x64 tile; a wave owns 16 rows.
+__global__ void __launch_bounds__(256)
+sweepmat_kernel(const double *__restrict__ ab, long long lda, const double *__restrict__ dinv,
+                const double *__restrict__ dinvt, double *__restrict__ mfwd, double *__restrict__ mbwd,
+                int npairs)
+{
+    const bool back = (int)blockIdx.x >= npairs;
+    const int k = back ? blockIdx.x - npairs : blockIdx.x;          // couples blocks k and k+1
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, q = lane >> 4;
+    const int r0 = (blockIdx.y >> 2) * 64 + wave * 16, c0 = (blockIdx.y & 3) * 64;
+    // Out[r][c] = sum_j A[r][j] * B(j, c);  forward: A = Linv_{k+1}, B(j,c) = L(j,c);
+    // backward: A = Linv_k^T (dinvt), B(j,c) = L(c,j)   with L = block (k+1,k)
+    const double *__restrict__ A = (back ? dinvt + (long long)k * NBLK * NBLK
+                                         : dinv + (long long)(k + 1) * NBLK * NBLK) + (long long)(r0 + l15) * NBLK + q;
+    const double *__restrict__ L = ab + (long long)(k + 1) * NBLK + (long long)k * NBLK * lda;
+    const long long bj = back ? lda : 1, bc = back ? 1 : lda;      // address of B(j,c) = L + j*bj + c*bc
+    const double *__restrict__ B = L + (long long)q * bj + (long long)(c0 + l15) * bc;
+    d4_t acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int j0 = 0; j0 < NBLK; j0 += 4) {
+        const double a = A[j0];
+        double bv[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bv[n] = B[(long long)j0 * bj + (long long)(16 * n) * bc];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[n], acc[n], 0, 0, 0);
+    }
+    double *__restrict__ O = (back ? mbwd : mfwd) + (long long)k * NBLK * NBLK;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) O[(long long)(r0 + q + 4 * v) * NBLK + c0 + 16 * n + l15] = acc[n][v];
+}
+
+// rows [r0, r0+R) of  out = T v - M y  for row-major 256x256 blocks T, M; one wave, R rows
+template <int R>
+__device__ inline void coupled_rows(const double *__restrict__ T, const double *__restrict__ M,
+                                    const double *__restrict__ v, const double *__restrict__ y,
+                                    double *__restrict__ out, int r0, int lane)
+{
+    double vv[4], yy[4], s[R];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        vv[u] = v[lane + 64 * u];
+        yy[u] = y[lane + 64 * u];
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a += T[(r0 + i) * NBLK + lane + 64 * u] * vv[u];
+            b += M[(r0 + i) * NBLK + lane + 64 * u] * yy[u];
+        }
+        s[i] = a - b;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) s[i] = wave_sum(s[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) out[r0 + i] = s[i];
+    }
+}
+
+// Forward step k: workgroups 0..15 solve block k+1 (y1 = Linv1 v1 - Mk yk), the others apply
+// the panel update of y_k to the rows from block k+2 on (as fwd_update_kernel).
+__global__ void __launch_bounds__(512)
+fwd_step_kernel(const double *__restrict__ Linv1, const double *__restrict__ Mk,
+                const double *__restrict__ Lpanel2, long long lda, const double *__restrict__ yk,
+                const double *__restrict__ v1, double *__restrict__ y1, double *__restrict__ vbelow2)
+{
+    __shared__ double sy[NBLK];
+    __shared__ double part[16][64];
+    const int tid = threadIdx.x;
+    if (blockIdx.x < 16) {
+        coupled_rows<2>(Linv1, Mk, v1, yk, y1, blockIdx.x * 16 + (tid >> 6) * 2, tid & 63);
+        return;
+    }
+    const int wg = blockIdx.x - 16;
+    if (tid < NBLK) sy[tid] = yk[tid];
+    __syncthreads();
+    const int rp = tid & 31, cg = tid >> 5;
+    const int r = wg * 64 + 2 * rp;
+    const double *__restrict__ Lr = Lpanel2 + r + (long long)(cg * 16) * lda;
+    d2_t l[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) l[c] = *reinterpret_cast<const d2_t *>(Lr + (long long)c * lda);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const double yv = sy[cg * 16 + c];
+        s0 += l[c][0] * yv;
+        s1 += l[c][1] * yv;
+    }
+    part[cg][2 * rp] = s0;
+    part[cg][2 * rp + 1] = s1;
+    __syncthreads();
+    if (tid < 64) {
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += part[g][tid];
+        vbelow2[wg * 64 + tid] -= s;
+    }
+}
+
+// Backward step k: workgroups 0..15 solve block k-1 (x0 = Linv0^T y0 - N x_k), the others apply
+// L[block k rows, j]^T x_k to the columns left of block k-1 (as bwd_update_kernel).
+__global__ void __launch_bounds__(256)
+bwd_step_kernel(const double *__restrict__ Linvt0, const double *__restrict__ Nk,
+                const double *__restrict__ Lrows, long long lda, const double *__restrict__ xk,
+                const double *__restrict__ y0, double *__restrict__ x0, double *__restrict__ yleft)
+{
+    __shared__ double sx[NBLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x < 16) {
+        coupled_rows<4>(Linvt0, Nk, y0, xk, x0, blockIdx.x * 16 + wave * 4, lane);
+        return;
+    }
+    const int wg = blockIdx.x - 16;
+    sx[tid] = xk[tid];
+    __syncthreads();
+    const int seg = lane & 15, cs = lane >> 4;
+    double xs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xs[i] = sx[seg * 16 + i];
+    d2_t l[4][8];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int j = wg * 64 + wave * 16 + cc * 4 + cs;
+        const double *__restrict__ Lc = Lrows + (long long)j * lda + seg * 16;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) l[cc][u] = *reinterpret_cast<const d2_t *>(Lc + 2 * u);
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int j = wg * 64 + wave * 16 + cc * 4 + cs;
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += l[cc][u][0] * xs[2 * u] + l[cc][u][1] * xs[2 * u + 1];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (seg == 0) yleft[j] -= s;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 axpy_absmax_kernel(int n, double *__restrict__ x, const double *__restrict__ dx,
                    unsigned long long *__restrict__ absmax2)
@@ -970,6 +1123,9 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     (void)hipEventRecord(pl.evC[b.nblk], sU);      // join: the caller's stream continues after the pipeline
     (void)hipStreamWaitEvent(st, pl.evC[b.nblk], 0);
     hipLaunchKernelGGL(trtri_kernel, dim3(b.nblk), dim3(256), 0, st, b.ab, b.lda, b.dinv, b.dinvt);
+    if (b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1)
+        hipLaunchKernelGGL(sweepmat_kernel, dim3(2 * (b.nblk - 1), 16), dim3(256), 0, st, (const double *)b.ab, b.lda,
+                           (const double *)b.dinv, (const double *)b.dinvt, b.mfwd, b.mbwd, b.nblk - 1);
     hipError_t err = hipGetLastError();
     if (timing) {
         (void)hipEventRecord(f1, st);
@@ -993,6 +1149,37 @@ hipError_t band_solve(const Band &b, double *x, double *tmp, hipStream_t st)
 {
     // forward: x -> tmp (y), the not-yet-solved part of x is updated in place;
     // backward: tmp -> x
+    if (b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1) {
+        // one launch per block step (coupling blocks M_k, N_k from sweepmat_kernel)
+        const long long nb2 = (long long)NBLK * NBLK;
+        hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st, (const double *)b.dinv, (const double *)x, tmp);
+        for (int k = 0; k + 1 < b.nblk; ++k) {
+            const int k0 = k * NBLK;
+            int tb = b.nblk - 1 - k;
+            if (tb > b.bw) tb = b.bw;
+            const int nrows2 = (tb - 1) * NBLK;
+            hipLaunchKernelGGL(fwd_step_kernel, dim3(16 + nrows2 / 64), dim3(512), 0, st,
+                               (const double *)(b.dinv + (k + 1) * nb2), (const double *)(b.mfwd + k * nb2),
+                               (const double *)(b.ab + (long long)(k0 + 2 * NBLK) + (long long)k0 * b.lda), b.lda,
+                               (const double *)(tmp + k0), (const double *)(x + k0 + NBLK), tmp + k0 + NBLK,
+                               x + k0 + 2 * NBLK);
+        }
+        const int last = (b.nblk - 1) * NBLK;
+        hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st, (const double *)(b.dinvt + (b.nblk - 1) * nb2),
+                           (const double *)(tmp + last), x + last);
+        for (int k = b.nblk - 1; k >= 1; --k) {
+            const int k0 = k * NBLK;
+            int tb = k;
+            if (tb > b.bw) tb = b.bw;
+            const int ncols2 = (tb - 1) * NBLK;
+            const int jbeg = k0 - tb * NBLK;
+            hipLaunchKernelGGL(bwd_step_kernel, dim3(16 + ncols2 / 64), dim3(256), 0, st,
+                               (const double *)(b.dinvt + (k - 1) * nb2), (const double *)(b.mbwd + (k - 1) * nb2),
+                               (const double *)(b.ab + (long long)k0 + (long long)jbeg * b.lda), b.lda,
+                               (const double *)(x + k0), (const double *)(tmp + k0 - NBLK), x + k0 - NBLK, tmp + jbeg);
+        }
+        return hipGetLastError();
+    }
     for (int k = 0; k < b.nblk; ++k) {
         const int k0 = k * NBLK;
         int tb = b.nblk - 1 - k;

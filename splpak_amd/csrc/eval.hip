@@ -8,8 +8,9 @@
 // so results differ from the reference only by FMA contraction.
 //
 // HBM roofline: 8*(ndim+1) algorithmic bytes per query (ndim coordinates in, one
-// value out); the coefficient gathers (2 MB at 64^3) are L2 / Infinity-Cache
-// resident.
+// value out).  Two paths with identical arithmetic: the direct kernel gathers the
+// coefficients from global memory (L2-bound for scattered queries), the binned
+// path sorts large batches by grid region and gathers from LDS (see below).
 #include "basis.hpp"
 #include "kernels.hpp"
 
@@ -17,6 +18,45 @@ namespace splpak {
 
 struct NDeriv { int v[MAXD]; };
 
+// Sum of the 4^D window products in the reference's order (dimension 1 fastest, :1228-1232).
+// load4(k1, k2, k3, c) delivers the 4 coefficients of the window row (k0 = 0..3).  Shared by the
+// direct and the binned kernels so that both produce bit-identical values.
+template <int D, typename L4>
+__device__ inline double window_sum(const double (&b)[D][4], L4 &&load4)
+{
+    double sum = 0.0;
+    auto row = [&](int k1, int k2, int k3, double scale) {
+        double c[4];
+        load4(k1, k2, k3, c);
+        sum = fma(c[0], b[0][0] * scale, sum);
+        sum = fma(c[1], b[0][1] * scale, sum);
+        sum = fma(c[2], b[0][2] * scale, sum);
+        sum = fma(c[3], b[0][3] * scale, sum);
+    };
+    if constexpr (D == 1) {
+        double c[4];
+        load4(0, 0, 0, c);
+#pragma unroll
+        for (int k0 = 0; k0 < 4; ++k0) sum = fma(c[k0], b[0][k0], sum);
+    } else if constexpr (D == 2) {
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) row(k1, 0, 0, b[1][k1]);
+    } else if constexpr (D == 3) {
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2)
+#pragma unroll
+            for (int k1 = 0; k1 < 4; ++k1) row(k1, k2, 0, b[1][k1] * b[2][k2]);
+    } else {
+        for (int k3 = 0; k3 < 4; ++k3)
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2)
+#pragma unroll
+                for (int k1 = 0; k1 < 4; ++k1) row(k1, k2, k3, (b[1][k1] * b[2][k2]) * b[3][k3]);
+    }
+    return sum;
+}
+
+// ---- direct path: one thread per query, coefficient gathers from global memory (L2) -------------
 template <int D, typename T>
 __global__ void __launch_bounds__(256)
 eval_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, NDeriv nd,
@@ -32,52 +72,352 @@ eval_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, NDeriv nd,
             const int ws = window_table(g, d, x, nd.v[d], b[d]);
             base += ws * g.colstride[d];
         }
-        // The 4 coefficients of a window row (k0 = 0..3) are contiguous: they are fetched with two
-        // 16-byte loads instead of four 8-byte ones (the kernel is bound by gather instructions,
-        // ~64 cycles of address processing per wave-load whatever its width), and summed in the
-        // reference's order (dimension 1 fastest).
-        double sum = 0.0;
-        auto row4 = [&](long long idx, double scale) {
-            double c0, c1, c2, c3;
+        // The 4 coefficients of a window row are contiguous: two 16-byte loads instead of four
+        // 8-byte ones (the kernel is bound by gather instructions / L2 lines, not bytes).
+        const int s1 = D > 1 ? g.colstride[1] : 0, s2 = D > 2 ? g.colstride[2] : 0, s3 = D > 3 ? g.colstride[3] : 0;
+        const double sum = window_sum<D>(b, [&](int k1, int k2, int k3, double (&c)[4]) {
+            const long long idx = base + k1 * s1 + k2 * s2 + k3 * s3;
             if constexpr (sizeof(T) == 8) {
                 typedef double d2v __attribute__((ext_vector_type(2), aligned(8)));
                 const d2v lo = *reinterpret_cast<const d2v *>(coef + idx);
                 const d2v hi = *reinterpret_cast<const d2v *>(coef + idx + 2);
-                c0 = lo[0]; c1 = lo[1]; c2 = hi[0]; c3 = hi[1];
+                c[0] = lo[0]; c[1] = lo[1]; c[2] = hi[0]; c[3] = hi[1];
             } else {
                 typedef float f4v __attribute__((ext_vector_type(4), aligned(4)));
                 const f4v v = *reinterpret_cast<const f4v *>(coef + idx);
-                c0 = v[0]; c1 = v[1]; c2 = v[2]; c3 = v[3];
+                c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
             }
-            sum += c0 * (b[0][0] * scale);
-            sum += c1 * (b[0][1] * scale);
-            sum += c2 * (b[0][2] * scale);
-            sum += c3 * (b[0][3] * scale);
-        };
-        if constexpr (D == 1) {
-#pragma unroll
-            for (int k0 = 0; k0 < 4; ++k0) sum += (double)coef[base + k0] * b[0][k0];
-        } else if constexpr (D == 2) {
-            const int s1 = g.colstride[1];
-#pragma unroll
-            for (int k1 = 0; k1 < 4; ++k1) row4(base + k1 * s1, b[1][k1]);
-        } else if constexpr (D == 3) {
-            const int s1 = g.colstride[1], s2 = g.colstride[2];
-#pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2)
-#pragma unroll
-                for (int k1 = 0; k1 < 4; ++k1) row4(base + k1 * s1 + k2 * s2, b[1][k1] * b[2][k2]);
-        } else {
-            const int s1 = g.colstride[1], s2 = g.colstride[2], s3 = g.colstride[3];
-            for (int k3 = 0; k3 < 4; ++k3)
-#pragma unroll
-                for (int k2 = 0; k2 < 4; ++k2)
-#pragma unroll
-                    for (int k1 = 0; k1 < 4; ++k1)
-                        row4(base + k1 * s1 + k2 * s2 + k3 * s3, (b[1][k1] * b[2][k2]) * b[3][k3]);
-        }
+        });
         out[i] = (T)sum;
     }
+}
+
+// ---- binned path ---------------------------------------------------------------------------------
+// Random queries make every window row a separate 128-byte L2 line (~19 lines = 2.4 KB of L2
+// traffic per 3-D query, for 512 useful bytes): the direct kernel sits at the L2 gather ceiling.
+// The binned path sorts a chunk of queries by REGION -- a box of window starts whose
+// coefficients (box + 3 nodes per dimension, 4096 doubles = 32 KB) fit in LDS -- and evaluates
+// every region's queries from an LDS copy of its coefficients: the gathers become LDS reads, the
+// global traffic per query is its coordinates, a permutation index and the result.
+//   pass A  bin_count_kernel    region histogram of the chunk (LDS histogram per workgroup)
+//           bin_scan_kernel     offsets, cursors and workgroups per region
+//   pass B  bin_scatter_kernel  coordinates + original index copied into region order
+//   pass C  eval_binned_kernel  one workgroup per (region, 2048 queries)
+// The arithmetic per query is window_table + window_sum exactly as in the direct kernel, so both
+// paths return identical bits; only the order in which queries are processed differs.
+template <int D> struct TileShape;
+template <> struct TileShape<2> { static constexpr int T[4] = {64, 64, 1, 1}; };
+template <> struct TileShape<3> { static constexpr int T[4] = {16, 16, 16, 1}; };
+template <> struct TileShape<4> { static constexpr int T[4] = {8, 8, 8, 8}; };
+constexpr int TILE_ELEMS = 4096;
+constexpr int BIN_MAX = 2048;          // regions per grid handled by the LDS histograms
+constexpr int BIN_QPT = 16;            // queries per thread in pass A
+constexpr int EVAL_QPW = 2048;         // queries per workgroup in pass C
+
+struct Regions { int nreg[MAXD]; int nbins; };
+
+template <int D>
+__device__ inline int region_of(const Grid &g, const Regions &rg, const double *__restrict__ x)
+{
+    int r = 0, m = 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        int lo, hi;
+        const int ws = window_start(g, d, x[d], lo, hi);
+        r += (ws / (TileShape<D>::T[d] - 3)) * m;
+        m *= rg.nreg[d];
+    }
+    return r;
+}
+
+template <int D>
+__global__ void __launch_bounds__(256)
+bin_count_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int ldxq, int *__restrict__ hist)
+{
+    __shared__ int lh[BIN_MAX];
+    for (int b = threadIdx.x; b < rg.nbins; b += 256) lh[b] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * (256 * BIN_QPT);
+#pragma unroll 4
+    for (int j = 0; j < BIN_QPT; ++j) {
+        const int i = base + j * 256 + threadIdx.x;
+        if (i < n) {
+            double x[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) x[d] = xq[(long long)i * ldxq + d];
+            atomicAdd(&lh[region_of<D>(g, rg, x)], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < rg.nbins; b += 256)
+        if (lh[b]) atomicAdd(&hist[b], lh[b]);
+}
+
+// ints: hist[nbins] | off[nbins+1] | cursor[nbins] | wgoff[nbins+1]
+__global__ void __launch_bounds__(256)
+bin_scan_kernel(int nbins, const int *__restrict__ hist, int *__restrict__ off, int *__restrict__ cursor,
+                int *__restrict__ wgoff)
+{
+    __shared__ int sq[256], sw[256];
+    const int per = (nbins + 255) / 256;
+    const int b0 = threadIdx.x * per;
+    int q = 0, w = 0;
+    for (int b = b0; b < b0 + per && b < nbins; ++b) {
+        q += hist[b];
+        w += (hist[b] + EVAL_QPW - 1) / EVAL_QPW;
+    }
+    sq[threadIdx.x] = q;
+    sw[threadIdx.x] = w;
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+        const int aq = threadIdx.x >= s ? sq[threadIdx.x - s] : 0;
+        const int aw = threadIdx.x >= s ? sw[threadIdx.x - s] : 0;
+        __syncthreads();
+        sq[threadIdx.x] += aq;
+        sw[threadIdx.x] += aw;
+        __syncthreads();
+    }
+    q = sq[threadIdx.x] - q;          // exclusive
+    w = sw[threadIdx.x] - w;
+    for (int b = b0; b < b0 + per && b < nbins; ++b) {
+        off[b] = q;
+        cursor[b] = q;
+        wgoff[b] = w;
+        q += hist[b];
+        w += (hist[b] + EVAL_QPW - 1) / EVAL_QPW;
+    }
+    if (threadIdx.x == 255) {
+        off[nbins] = sq[255];
+        wgoff[nbins] = sw[255];
+    }
+}
+
+// Pass B.  The workgroup sorts its queries by region in LDS first, so that the copy to global
+// memory walks every region's run with consecutive lanes on consecutive addresses (the
+// straightforward per-query scatter issued one 8-byte store request per coordinate and was
+// bound by the request rate, not by bytes).
+template <int D> struct ScatterShape { static constexpr int QPT = D == 4 ? 4 : 8; };   // queries per thread
+template <int D>
+__global__ void __launch_bounds__(256)
+bin_scatter_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int ldxq,
+                   int *__restrict__ cursor, double *__restrict__ xs, int *__restrict__ perm)
+{
+    constexpr int QPT = ScatterShape<D>::QPT, QPW = 256 * QPT;
+    __shared__ double sx[QPW * D];
+    __shared__ int sidx[QPW];
+    __shared__ unsigned short srid[QPW];
+    __shared__ int lh[BIN_MAX], lbase[BIN_MAX];
+    __shared__ int sscan[256];
+    for (int b = threadIdx.x; b < rg.nbins; b += 256) lh[b] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * QPW;
+    int rid[QPT], rank[QPT];
+    double xr[QPT][D];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        const int i = base + j * 256 + threadIdx.x;
+        rid[j] = -1;
+        rank[j] = 0;
+        if (i < n) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) xr[j][d] = xq[(long long)i * ldxq + d];
+            rid[j] = region_of<D>(g, rg, xr[j]);
+            rank[j] = atomicAdd(&lh[rid[j]], 1);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the local counts; lh[b] <- local start, lbase[b] <- global start - local start
+    const int per = (rg.nbins + 255) / 256;
+    const int b0 = threadIdx.x * per;
+    int q = 0;
+    for (int b = b0; b < b0 + per && b < rg.nbins; ++b) q += lh[b];
+    sscan[threadIdx.x] = q;
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+        const int aq = threadIdx.x >= s ? sscan[threadIdx.x - s] : 0;
+        __syncthreads();
+        sscan[threadIdx.x] += aq;
+        __syncthreads();
+    }
+    q = sscan[threadIdx.x] - q;
+    for (int b = b0; b < b0 + per && b < rg.nbins; ++b) {
+        const int c = lh[b];
+        lh[b] = q;
+        lbase[b] = (c ? atomicAdd(&cursor[b], c) : 0) - q;
+        q += c;
+    }
+    const int total = sscan[255];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        if (rid[j] < 0) continue;
+        const int i = base + j * 256 + threadIdx.x;
+        const int lp = lh[rid[j]] + rank[j];
+#pragma unroll
+        for (int d = 0; d < D; ++d) sx[lp * D + d] = xr[j][d];
+        sidx[lp] = i;
+        srid[lp] = (unsigned short)rid[j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total * D; e += 256) {
+        const int lp = e / D, d = e - lp * D;
+        const long long gpos = lp + lbase[srid[lp]];
+        xs[gpos * D + d] = sx[e];
+    }
+    for (int lp = threadIdx.x; lp < total; lp += 256) perm[lp + lbase[srid[lp]]] = sidx[lp];
+}
+
+template <int D>
+__global__ void __launch_bounds__(256)
+eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coef,
+                   const double *__restrict__ xs, const int *__restrict__ perm,
+                   const int *__restrict__ off, const int *__restrict__ wgoff, double *__restrict__ out)
+{
+    __shared__ double tile[TILE_ELEMS];
+    using TS = TileShape<D>;
+    const int wg = blockIdx.x;
+    if (wg >= wgoff[rg.nbins]) return;
+    int lo = 0, hi = rg.nbins;               // wgoff[lo] <= wg < wgoff[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (wgoff[mid] <= wg) lo = mid; else hi = mid;
+    }
+    const int r = lo;                         // wgoff[r] <= wg < wgoff[r+1]: a non-empty region
+    const int part = wg - wgoff[r];
+    int a[D];                                  // first node of the region's tile
+    {
+        int rr = r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            a[d] = (rr % rg.nreg[d]) * (TS::T[d] - 3);
+            rr /= rg.nreg[d];
+        }
+    }
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += 256) {
+        int rem = e, idx = 0;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int l = rem % TS::T[d];
+            rem /= TS::T[d];
+            const int node = a[d] + l;
+            ok = ok && node < g.nodes[d];
+            idx += node * g.colstride[d];
+        }
+        tile[e] = ok ? coef[idx] : 0.0;
+    }
+    __syncthreads();
+    const int qb = off[r] + part * EVAL_QPW;
+    const int qe = min(off[r + 1], qb + EVAL_QPW);
+    constexpr int t1 = TS::T[0], t2 = TS::T[0] * TS::T[1], t3 = TS::T[0] * TS::T[1] * TS::T[2];
+    for (int j = qb + threadIdx.x; j < qe; j += 256) {
+        double b[D][4];
+        int base = 0, m = 1;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const double x = xs[(long long)j * D + d];
+            const int ws = window_table(g, d, x, nd.v[d], b[d]);
+            base += (ws - a[d]) * m;
+            m *= TS::T[d];
+        }
+        const double sum = window_sum<D>(b, [&](int k1, int k2, int k3, double (&c)[4]) {
+            // four ds_read_b64 (2 LDS cycles each, 64 banks) instead of the two ds_read2_b64 the
+            // compiler would merge them into (8 cycles each, 32 banks): volatile keeps them apart
+            typedef const volatile __attribute__((address_space(3))) double *lds_cvd;
+            lds_cvd p = (lds_cvd)tile + (base + k1 * t1 + k2 * t2 + k3 * t3);
+            c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3];
+        });
+        out[perm[j]] = sum;
+    }
+}
+
+// scratch of the binned path: per thread, grown on demand, released by splpak_shutdown
+namespace {
+struct EvalScratch {
+    double *xs = nullptr;
+    int *perm = nullptr;
+    int *ints = nullptr;          // hist | off | cursor | wgoff
+    long long cap = 0;            // queries per chunk the buffers hold
+    int capd = 0;
+    hipEvent_t last = nullptr;    // end of the previous use (another stream must wait for it)
+    int dev = -1;
+};
+thread_local EvalScratch g_scratch;
+thread_local int g_eval_mode = 0;             // 0 auto, 1 direct, 2 binned
+thread_local long long g_eval_chunk = 0;      // queries per chunk, 0 = default
+}  // namespace
+
+void eval_scratch_shutdown()
+{
+    EvalScratch &s = g_scratch;
+    if (s.xs) (void)hipFree(s.xs);
+    if (s.perm) (void)hipFree(s.perm);
+    if (s.ints) (void)hipFree(s.ints);
+    if (s.last) (void)hipEventDestroy(s.last);
+    s = EvalScratch();
+}
+
+void set_eval_mode(int mode, long long chunk)
+{
+    g_eval_mode = mode;
+    g_eval_chunk = chunk;
+}
+
+template <int D>
+static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, const double *xq, int ldxq,
+                              const NDeriv &nd, const double *coef, double *out, hipStream_t st)
+{
+    long long chunk = g_eval_chunk > 0 ? g_eval_chunk : (1LL << 24);
+    if (chunk > (1LL << 28)) chunk = 1LL << 28;
+    if (chunk > nq) chunk = nq;
+    EvalScratch &s = g_scratch;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (s.dev != dev || s.cap < chunk || s.capd < D) {
+        eval_scratch_shutdown();
+        hipError_t e = hipMalloc(&s.xs, sizeof(double) * (size_t)chunk * D);
+        if (e == hipSuccess) e = hipMalloc(&s.perm, sizeof(int) * (size_t)chunk);
+        if (e == hipSuccess) e = hipMalloc(&s.ints, sizeof(int) * (4 * BIN_MAX + 8));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.last, hipEventDisableTiming);
+        if (e != hipSuccess) { eval_scratch_shutdown(); return e; }
+        s.cap = chunk;
+        s.capd = D;
+        s.dev = dev;
+    } else {
+        (void)hipStreamWaitEvent(st, s.last, 0);
+    }
+    int *hist = s.ints, *off = hist + BIN_MAX, *cursor = off + BIN_MAX + 1, *wgoff = cursor + BIN_MAX;
+    for (long long c0 = 0; c0 < nq; c0 += chunk) {
+        const int n = (int)(nq - c0 < chunk ? nq - c0 : chunk);
+        const double *xc = xq + c0 * ldxq;
+        const unsigned nb = (unsigned)((n + 256 * BIN_QPT - 1) / (256 * BIN_QPT));
+        hipError_t e = hipMemsetAsync(hist, 0, sizeof(int) * rg.nbins, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((bin_count_kernel<D>), dim3(nb), dim3(256), 0, st, g, rg, n, xc, ldxq, hist);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, st, rg.nbins, (const int *)hist, off, cursor, wgoff);
+        const unsigned nbs = (unsigned)((n + 256 * ScatterShape<D>::QPT - 1) / (256 * ScatterShape<D>::QPT));
+        hipLaunchKernelGGL((bin_scatter_kernel<D>), dim3(nbs), dim3(256), 0, st, g, rg, n, xc, ldxq, cursor, s.xs, s.perm);
+        const unsigned nw = (unsigned)(n / EVAL_QPW + rg.nbins + 1);
+        hipLaunchKernelGGL((eval_binned_kernel<D>), dim3(nw), dim3(256), 0, st, g, rg, nd, coef,
+                           (const double *)s.xs, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
+    }
+    (void)hipEventRecord(s.last, st);
+    return hipGetLastError();
+}
+
+// regions of the grid for dimension count D; false when the binned path does not apply
+template <int D>
+static bool make_regions(const Grid &g, Regions &rg)
+{
+    long long nb = 1;
+    for (int d = 0; d < MAXD; ++d) rg.nreg[d] = 1;
+    for (int d = 0; d < D; ++d) {
+        const int R = TileShape<D>::T[d] - 3;
+        rg.nreg[d] = (g.nodes[d] - 3 + R - 1) / R;
+        nb *= rg.nreg[d];
+    }
+    rg.nbins = (int)nb;
+    return nb >= 1 && nb <= BIN_MAX;
 }
 
 template <typename T>
@@ -89,6 +429,22 @@ static hipError_t launch_eval_t(const Grid &g, long long nq, const T *xq, int ld
     for (int d = 0; d < MAXD; ++d) {
         int v = (nderiv && d < g.ndim) ? nderiv[d] : 0;
         nd.v[d] = v < 0 ? 0 : (v > 2 ? 2 : v);
+    }
+    if constexpr (sizeof(T) == 8) {
+        // binned path: large batches on grids whose coefficients are far beyond the L1 (auto), or forced
+        Regions rg;
+        bool can = false;
+        if (g.ndim == 2) can = make_regions<2>(g, rg);
+        if (g.ndim == 3) can = make_regions<3>(g, rg);
+        if (g.ndim == 4) can = make_regions<4>(g, rg);
+        // auto: 2-D windows are 4 rows (4-5 L2 lines) and the direct kernel wins; from 3-D on (16+ rows)
+        // the sort pays for itself once the batch is large and the coefficients are far beyond L1
+        const bool want = g_eval_mode == 2 || (g_eval_mode == 0 && g.ndim >= 3 && nq >= (1LL << 20) && g.ncol > 32768);
+        if (can && want) {
+            if (g.ndim == 2) return eval_binned<2>(g, rg, nq, xq, ldxq, nd, coef, out, st);
+            if (g.ndim == 3) return eval_binned<3>(g, rg, nq, xq, ldxq, nd, coef, out, st);
+            return eval_binned<4>(g, rg, nq, xq, ldxq, nd, coef, out, st);
+        }
     }
     const int threads = 256;
     long long blocks = (nq + threads - 1) / threads;

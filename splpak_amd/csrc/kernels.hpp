@@ -8,6 +8,10 @@ namespace splpak {
 // ---- eval.hip
 hipError_t launch_eval(const Grid &g, long long nq, const double *xq, int ldxq, const int *nderiv,
                        const double *coef, double *out, hipStream_t st);
+// evaluation path of the calling thread: 0 auto, 1 direct (global gathers), 2 binned (LDS tiles);
+// chunk = queries sorted per pass of the binned path (0 = default)
+void set_eval_mode(int mode, long long chunk);
+void eval_scratch_shutdown();
 hipError_t launch_eval_f32(const Grid &g, long long nq, const float *xq, int ldxq, const int *nderiv,
                            const float *coef, float *out, hipStream_t st);
 
@@ -59,6 +63,8 @@ struct Band {
     double *ab;       // dense-view base: A(i,j) = ab[i + j*lda], j <= i <= j + halfbw
     double *dinv;     // [nblk][NBLK*NBLK] inverses of the diagonal blocks of L (row-major)
     double *dinvt;    // [nblk][NBLK*NBLK] transposes of dinv (backward sweep)
+    double *mfwd;     // [nblk-1][NBLK*NBLK] Linv_{k+1} L_{k+1,k} (row-major): forward-sweep coupling blocks; NULL = two-kernel sweeps
+    double *mbwd;     // [nblk-1][NBLK*NBLK] Linv_k^T L_{k+1,k}^T: backward-sweep coupling blocks
     double *inv64;    // [nblk][16][16*16] inverses of the 16x16 diagonal leaves of L (column-major), 16 KB stride per block
     long long lda;    // column stride of the dense view (ld - 1)
     int n;            // logical order

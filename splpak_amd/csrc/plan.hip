@@ -194,6 +194,8 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
     ok = ok && dev_alloc(p, &p->band.dinv, (size_t)p->band.nblk * NBLK * NBLK);
     ok = ok && dev_alloc(p, &p->band.dinvt, (size_t)p->band.nblk * NBLK * NBLK);
     ok = ok && dev_alloc(p, &p->band.inv64, (size_t)p->band.nblk * 4 * 64 * 64);
+    ok = ok && dev_alloc(p, &p->band.mfwd, (size_t)p->band.nblk * NBLK * NBLK);
+    ok = ok && dev_alloc(p, &p->band.mbwd, (size_t)p->band.nblk * NBLK * NBLK);
     // communication buffer
     p->comm_len = comm_len_of(g);
     if (comm_buf_dev) {
@@ -618,6 +620,8 @@ int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double 
               dev_alloc(&holder, &b.dinv, (size_t)b.nblk * NBLK * NBLK) &&
               dev_alloc(&holder, &b.dinvt, (size_t)b.nblk * NBLK * NBLK) &&
               dev_alloc(&holder, &b.inv64, (size_t)b.nblk * 4 * 64 * 64) &&
+              dev_alloc(&holder, &b.mfwd, (size_t)b.nblk * NBLK * NBLK) &&
+              dev_alloc(&holder, &b.mbwd, (size_t)b.nblk * NBLK * NBLK) &&
               dev_alloc(&holder, &dsmall, 8) && dev_alloc(&holder, &dx, (size_t)b.npad) &&
               dev_alloc(&holder, &dtmp, (size_t)b.npad) && dev_alloc(&holder, &dinfo, 2);
     int rc = 0;
@@ -652,6 +656,14 @@ int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double 
 void splpak_shutdown(void)
 {
     band_pipeline_shutdown();
+    eval_scratch_shutdown();
+}
+
+int32_t splpak_set_eval_mode(int32_t mode, int64_t chunk)
+{
+    if (mode < 0 || mode > 2 || chunk < 0) { set_error("bad evaluation mode"); return SPLPAK_E_BADARG; }
+    set_eval_mode(mode, chunk);
+    return 0;
 }
 
 int32_t splpak_last_error_message(char *buf, int32_t buflen)

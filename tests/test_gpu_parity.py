@@ -103,6 +103,39 @@ def test_eval_real32():
     assert np.max(np.abs(v - v64)) <= 1e-6 * np.max(np.abs(v64))
 
 
+@pytest.mark.parametrize("nodes", [(150, 70), (20, 17, 30), (12, 9, 8, 14), (64, 64)])
+def test_eval_binned_path_is_bit_identical_to_direct(port, nodes):
+    """The LDS-binned evaluation (queries sorted by grid region) must return the bits of the direct
+    kernel, for every derivative pattern, with queries outside the grid, padded rows and a ragged
+    last chunk; one pattern is also anchored to the reference algorithm (oracle)."""
+    nd = len(nodes)
+    rng = np.random.default_rng(nd * 1000 + nodes[0])
+    coef = rng.standard_normal(int(np.prod(nodes)))
+    lo = -1.0 + rng.random(nd)
+    hi = lo + 1.0 + 3.0 * rng.random(nd)
+    nq = 20011
+    q = np.full((nq, nd + 1), 1e300)
+    q[:, :nd] = lo + (hi - lo) * (-0.2 + 1.4 * rng.random((nq, nd)))     # ~30 % outside the grid
+    q[:50, :nd] = lo + (hi - lo) * rng.integers(0, 2, (50, nd))            # corners / edges exactly
+    try:
+        for p in [None] + nderiv_patterns(nd):
+            capi.set_eval_mode(capi.EVAL_DIRECT)
+            vd, rc = capi.evaluate(nd, q, p, coef, lo, hi, nodes)
+            assert rc == 0
+            capi.set_eval_mode(capi.EVAL_BINNED, 4099)
+            vb, rc = capi.evaluate(nd, q, p, coef, lo, hi, nodes)
+            assert rc == 0
+            assert np.array_equal(vd, vb), (nodes, p)
+        capi.set_eval_mode(capi.EVAL_BINNED, 0)
+        vb, _ = capi.evaluate(nd, q, None, coef, lo, hi, nodes)
+        vo, _ = port.evaluate(nd, q[:2000], None, coef, lo, hi, nodes)
+        assert np.max(np.abs(vb[:2000] - vo)) <= EVAL_TOL * np.max(np.abs(vo))
+    finally:
+        capi.set_eval_mode(capi.EVAL_AUTO)
+    with pytest.raises(capi.SplpakError):
+        capi.set_eval_mode(7)
+
+
 # ---------------------------------------------------------------------------
 # fit
 # ---------------------------------------------------------------------------
