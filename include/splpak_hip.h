@@ -128,16 +128,19 @@ int32_t splpak_plan_fit_dev(splpak_plan *plan, const double *xdata_dev, int32_t 
 const double *splpak_plan_hist_dev(const splpak_plan *plan);
 
 /* Per-kernel accounting of the last splpak_plan_fit_dev call, measured with HIP
- * events on the stream the kernels ran on (bench.py's roofline object):
- *   out[0] = number of BULK trailing-update launches (syrk64_kernel, f64 MFMA; one per step,
- *            ~92 % of the fit's flops; the small block-column pieces are a separate instantiation)
+ * events on the stream the kernels ran on (bench.py's roofline object).  Every BULK
+ * trailing-update launch (syrk64_kernel, f64 MFMA; one bulk launch per block step carries
+ * ~96 % of the factorisation's flops, the small block-column pieces are a separate
+ * instantiation) carries a start/stop event pair in its dispatch (hipExtLaunchKernelGGL):
+ *   out[0] = number of timed bulk launches
  *   out[1] = total milliseconds in them
  *   out[2] = floating-point operations they performed (algorithmic: 2*64*64*256 per 64x64 item)
  *   out[3] = milliseconds in the whole factorisation
  *   out[4] = floating-point operations of ALL trailing-update launches
- * Timing is only collected when enabled (costs an event pair per bulk launch). */
+ *   out[5] = number of bulk launches, out[6] = their floating-point operations
+ * Timing is only collected when enabled. */
 void    splpak_plan_enable_kernel_timing(splpak_plan *plan, int32_t on);
-void    splpak_plan_kernel_timing(const splpak_plan *plan, double *out5);
+void    splpak_plan_kernel_timing(const splpak_plan *plan, double *out7);
 
 /* Batched evaluation on resident data (asynchronous on `stream`; no validation
  * beyond the reference's 101..104, which is done on the host from the small

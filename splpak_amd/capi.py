@@ -243,9 +243,10 @@ class Plan:
         self._L.splpak_plan_enable_kernel_timing(self._h, 1 if on else 0)
 
     def kernel_timing(self):
-        out = np.zeros(5)
+        out = np.zeros(7)
         self._L.splpak_plan_kernel_timing(self._h, _p(out, _dp))
-        return dict(syrk_launches=out[0], syrk_ms=out[1], syrk_flop=out[2], factor_ms=out[3], total_flop=out[4])
+        return dict(syrk_launches=out[0], syrk_ms=out[1], syrk_flop=out[2], factor_ms=out[3], total_flop=out[4],
+                    bulk_launches=out[5], bulk_flop=out[6])
 
     def fit(self, xdata, ydata, wdata, coef, stream=0):
         """All arguments are torch float64 device tensors; xdata is (ndata, l1xdat) row-major

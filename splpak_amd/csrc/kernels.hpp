@@ -79,7 +79,8 @@ hipError_t launch_expand(const Grid &g, const double *nst, const Band &b, hipStr
 
 struct CholStats {            // optional per-kernel accounting (HIP events)
     bool enabled = false;
-    double syrk_launches = 0, syrk_ms = 0, syrk_flop = 0, factor_ms = 0;   // bulk trailing-update launches
+    double syrk_launches = 0, syrk_ms = 0, syrk_flop = 0, factor_ms = 0;   // timed bulk trailing-update launches
+    double bulk_launches = 0, bulk_flop = 0;                               // all bulk launches
     double total_flop = 0;                                                 // all trailing-update launches
 };
 // in-place L L^T; *info_dev (device int) is set to 1 + column of the first

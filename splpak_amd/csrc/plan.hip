@@ -262,6 +262,8 @@ void splpak_plan_enable_kernel_timing(splpak_plan *p, int32_t on)
 void splpak_plan_kernel_timing(const splpak_plan *p, double *out4)
 {
     if (!p || !out4) return;
+    out4[5] = p->stats.bulk_launches;
+    out4[6] = p->stats.bulk_flop;
     out4[0] = p->stats.syrk_launches;
     out4[1] = p->stats.syrk_ms;
     out4[2] = p->stats.syrk_flop;
