@@ -198,62 +198,75 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
 //
 // One wave owns 16 rows for the whole solve and walks the 256 columns in 16-column blocks:
 //     X_c = (A_c - sum_{k<c} X_k L_ck^T) Inv_cc^T ,   Inv_cc = (16x16 diagonal leaf of L)^{-1}
-// (the leaf inverses come out of potrf_block_kernel).  Both products are computed transposed,
+// (the leaf inverses come out of potrf_block_kernel; -X_k is what is parked, so the sum is
+// accumulated into A_c directly).  Both products are computed transposed,
 // D[col][row] = sum_k Aop[col][k] * Bop[k][row]: the lane that holds row = lane&15 of an
 // accumulator tile holds, in register s, exactly the B operand of k-step s, so T = A_c - ...
 // feeds the Inv product straight from registers.  Finished blocks X_k are parked in LDS
-// ([column][row], 30 KB) so the k loop stays rolled: the kernel runs once per step on every CU
-// with a cold instruction cache.  One wave, < 100 VGPRs, 30 KB LDS: it takes the slot of one
-// retiring trailing-update wave.  Only L / Inv elements (L2 resident, shared by all waves) are
-// loaded: 8 bytes per lane and MFMA.
+// ([column][row], 30 KB) so the block-row loop stays rolled: the kernel runs once per step on
+// every CU with a cold instruction cache.  Single-wave workgroups of < 200 registers: a wave
+// takes the place of one retiring trailing-update wave (252 registers, two per SIMD) beside the
+// other one.  Only L / Inv elements (L2 resident, shared by all waves) and the wave's own rows
+// are loaded.
 constexpr int TCB = 32;            // register block of trtri_kernel
+// The L operands of block row cb+1 and its right-hand side are fetched while block row cb is
+// being computed (lb[] is refilled slot by slot as soon as the MFMA that read the slot has been
+// issued): one exposed L2 round trip per block row instead of one per two k blocks took the
+// in-pipeline kernel from 162 to 103 us.  Measured alternatives that lost: 32 rows per wave
+// (257 registers: no longer fits beside a trailing-update wave, 380 us), unguarded refills
+// (exactly counted waits, but 76 % more loads through the L1 that the update waves stream
+// their operands through: 127 us).
 __global__ void __launch_bounds__(64)
 trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long lda,
             const double *__restrict__ inv16, int nrows)
 {
-    __shared__ double xs[(NBLK - 16) * 16];               // xs[col*16 + row], columns 0..239
+    __shared__ double xs[(NBLK - 16) * 16];               // xs[col*16 + row] = -X(row, col), columns 0..239
     const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
     const int r0 = blockIdx.x * 16;
     if (r0 >= nrows) return;
     __builtin_amdgcn_s_setprio(3);
     double *__restrict__ Xr = Xbase + r0 + l15;          // Xr[c*lda] = X(row, c)
+    constexpr int NCB = NBLK / 16;
 
-    for (int cb = 0; cb < NBLK / 16; ++cb) {
-        d4_t T;
+    double lb[NCB - 1][4];        // lb[kb][s] = L(16 cb + l15, 16 kb + 4 s + q), block row cb (then cb+1)
+    d4_t Tn;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) T[v] = Xr[(long long)(16 * cb + q + 4 * v) * lda];
-        const double *__restrict__ Lc = L + (16 * cb + l15) + (long long)q * lda;   // L(16cb + l15, q + ...)
-        int kb = 0;
-        for (; kb + 1 < cb; kb += 2) {                    // two 16-wide k blocks per trip: 8 loads in flight
-            double a[8], bq[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                a[s] = -Lc[(long long)(16 * kb + 4 * s) * lda];
-                bq[s] = xs[(16 * kb + 4 * s + q) * 16 + l15];
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) T = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bq[s], T, 0, 0, 0);
-        }
-        if (kb < cb) {
-            double a[4], bq[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                a[s] = -Lc[(long long)(16 * kb + 4 * s) * lda];
-                bq[s] = xs[(16 * kb + 4 * s + q) * 16 + l15];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) T = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bq[s], T, 0, 0, 0);
-        }
+    for (int v = 0; v < 4; ++v) Tn[v] = Xr[(long long)(q + 4 * v) * lda];
+#pragma unroll 1
+    for (int cb = 0; cb < NCB; ++cb) {          // stays rolled: the code must stay small (cold I-cache)
+        d4_t T = Tn;
+        const bool more = cb + 1 < NCB;
         const double *__restrict__ Inv = inv16 + cb * 256;           // Inv[row + 16*col]
+        double iv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) iv[s] = Inv[l15 + 16 * (4 * s + q)];
+        if (more) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Tn[v] = Xr[(long long)(16 * (cb + 1) + q + 4 * v) * lda];
+        }
+        const double *__restrict__ Ln = L + (16 * (cb + 1) + l15) + (long long)q * lda;   // block row cb+1
+#pragma unroll
+        for (int kb = 0; kb < NCB - 1; ++kb) {
+            if (kb < cb) {
+                double bq[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bq[s] = xs[(16 * kb + 4 * s + q) * 16 + l15];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) T = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[kb][s], bq[s], T, 0, 0, 0);
+            }
+            if (kb <= cb && more) {                    // slot kb is free: tile (cb+1, kb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) lb[kb][s] = Ln[(long long)(16 * kb + 4 * s) * lda];
+            }
+        }
         d4_t X = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            X = __builtin_amdgcn_mfma_f64_16x16x4f64(Inv[l15 + 16 * (4 * s + q)], T[s], X, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) X = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[s], T[s], X, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int c = 16 * cb + q + 4 * v;
             Xr[(long long)c * lda] = X[v];
-            if (cb < NBLK / 16 - 1) xs[c * 16 + l15] = X[v];
+            if (more) xs[c * 16 + l15] = -X[v];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1074,11 +1087,11 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     // panel solve of rows [r0, r1) below the diagonal block k
     auto trsm = [&](hipStream_t s, int k, int r0, int r1) {
         const int k0 = k * NBLK;
-        if (r1 > r0)
-            hipLaunchKernelGGL(trsm_kernel, dim3((r1 - r0) / 16), dim3(64), 0, s,
-                               (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda),
-                               b.ab + (long long)(k0 + NBLK + r0) + (long long)k0 * b.lda, b.lda,
-                               (const double *)(b.inv64 + (long long)k * 4 * 64 * 64), r1 - r0);
+        if (r1 <= r0) return;
+        const double *Lk = b.ab + (long long)k0 + (long long)k0 * b.lda;
+        double *Xk = b.ab + (long long)(k0 + NBLK + r0) + (long long)k0 * b.lda;
+        const double *ik = b.inv64 + (long long)k * 4 * 64 * 64;
+        hipLaunchKernelGGL(trsm_kernel, dim3((r1 - r0) / 16), dim3(64), 0, s, Lk, Xk, b.lda, ik, r1 - r0);
     };
 
     // Dependency structure per step k (X_k = solved panel k; block (I,J) = 256x256 block):
