@@ -199,6 +199,39 @@ def test_fit_error_codes():
     assert capi.fit(2, xc, xc.sum(axis=1), None, [0.0, 0.0], [1.0, 1.0], [8, 8], 0.0)[1] == 107
 
 
+def test_grid_beyond_one_gpu_is_a_clean_error():
+    """BASELINE config 5's 32^4 grid: the band factor alone is 852 GB (half bandwidth 101 475):
+    the plan must be refused with the library's out-of-memory status, not crash."""
+    with pytest.raises(capi.SplpakError) as e:
+        capi.Plan(4, [32] * 4, [0.0] * 4, [1.0] * 4, 1.0, 1000)
+    assert "-2" in str(e.value) or "memory" in str(e.value).lower()
+    # the host-pointer entry reports the same failure as a negative ierror
+    x = np.random.default_rng(1).random((100, 4))
+    with pytest.raises(capi.SplpakError):
+        capi.fit(4, x, x.sum(axis=1), None, [0.0] * 4, [1.0] * 4, [32] * 4, 1.0)
+
+
+def test_eval_4d_32_real32_vs_real64_sweep():
+    """BASELINE config 5, evaluation half: 4-D 32^4 coefficients, values and derivatives, real32
+    against real64 (the reference's REAL32 build evaluates in single precision throughout)."""
+    nodes = [32] * 4
+    rng = np.random.default_rng(5)
+    coef = rng.standard_normal(32 ** 4)
+    q = rng.random((200_000, 4))
+    lo, hi = [0.0] * 4, [1.0] * 4
+    for p, tol in ((None, 2e-6), ([1, 0, 0, 0], 2e-6), ([0, 2, 0, 1], 2e-6)):
+        v64, rc = capi.evaluate(4, q, p, coef, lo, hi, nodes)
+        assert rc == 0
+        v32, rc = capi.evaluate(4, q.astype(np.float32), p, coef.astype(np.float32), lo, hi, nodes, real32=True)
+        assert rc == 0 and v32.dtype == np.float32
+        # same inputs rounded to single, evaluated in double: isolates the storage rounding
+        v64r, _ = capi.evaluate(4, q.astype(np.float32).astype(np.float64), p,
+                                coef.astype(np.float32).astype(np.float64), lo, hi, nodes)
+        scale = np.max(np.abs(v64))
+        assert np.max(np.abs(v32 - v64r)) <= tol * scale, p
+        assert np.max(np.abs(v64r - v64)) <= 1e-3 * scale, p        # input rounding amplified by 31/box derivatives
+
+
 def test_reference_known_answer_linear_on_gpu():
     """test/splpak_test_linear.f90:65-89 through the HIP path: slope 2 within 1e-12."""
     inp = make_inputs(CASES["ref_linear"])
