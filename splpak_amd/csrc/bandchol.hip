@@ -417,13 +417,36 @@ __global__ void whoami_kernel(unsigned *out) { if (threadIdx.x == 0) out[0] = my
 // queue[0]: next item, queue[1]: waves that stepped aside.  A wave that finds itself on the
 // CU reserved for the panel factorisation (`reserved`, ~0u = none) steps aside without taking
 // an item -- the grid carries `margin` spare waves for that -- unless the margin is used up.
+__device__ unsigned long long *g_syrk_clock_probe = nullptr;   // tools/syrk_bench only (ABL & 128)
 template <int SD, int WPS, int ABL, int KTOT = NBLK>
-__global__ void __launch_bounds__(64, WPS)
+__global__ void __launch_bounds__((ABL & 256) ? 256 : 64, WPS)
 syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, int ce, int rb, int re,
               int nitems, int margin, unsigned reserved, int *__restrict__ queue)
 {
-    int it = blockIdx.x;
-    if (queue) {
+    // ABL&256: workgroups of 4 waves take 4 consecutive items (same tile column: the waves stream the
+    // same 64 panel rows of the column operand, which the L1 can then serve three times out of four)
+    int it = (ABL & 256) ? (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x;
+    if ((ABL & 256) && !queue && it >= nitems) return;
+    if (queue && (ABL & 256)) {
+        __shared__ int s_base;
+        if (threadIdx.x == 0) {
+            int base = -1;
+            bool aside = false;
+            if (reserved != ~0u && my_cu_id() == reserved) aside = atomicAdd(&queue[1], 1) < margin;
+            if (aside) {
+                __builtin_amdgcn_s_sleep(127);       // ~8k cycles: do not drain the grid through this CU
+                __builtin_amdgcn_s_sleep(127);
+            } else {
+                base = atomicAdd(&queue[0], 4);
+            }
+            s_base = base;
+        }
+        __syncthreads();
+        const int base = s_base;
+        if (base < 0) return;
+        it = base + (int)(threadIdx.x >> 6);
+        if (it >= nitems) return;
+    } else if (queue) {
         if (reserved != ~0u && my_cu_id() == reserved) {
             int e = 0;
             if (threadIdx.x == 0) e = atomicAdd(&queue[1], 1);
@@ -438,6 +461,8 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
         it = __builtin_amdgcn_readfirstlane(it);
         if (it >= nitems) return;
     }
+    unsigned long long pt0 = 0, pr0 = 0;
+    if (ABL & 128) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     // item -> (tj, ti) in 64-row units: columns [cb, ce), rows [max(tj, rb), re)
     int tj = cb, ti;
     if (ABL & 16) {
@@ -503,6 +528,28 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
     for (int d = 0; d < SD; ++d) fetch(d, d);
     constexpr int NSTEP = KTOT / 4;             // KTOT = panel width applied per pass
     static_assert(NSTEP % SD == 0, "queue depth must divide the k-steps");
+    if (ABL & 64) {
+        // rolled form: refills are unconditional in the main loop, the last SD steps are peeled
+#pragma unroll 1
+        for (int ks = 0; ks < NSTEP - SD; ks += SD) {
+#pragma unroll
+            for (int d = 0; d < SD; ++d) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+                fetch(d, ks + d + SD);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < SD; ++d)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+    } else
     for (int ks = 0; ks < NSTEP; ks += SD) {
 #pragma unroll
         for (int d = 0; d < SD; ++d) {
@@ -537,6 +584,10 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
                     if (!diag || r >= c) __builtin_nontemporal_store(acc[m][n][v], &C[r + (long long)c * lda]);
                 }
             }
+        if ((ABL & 128) && threadIdx.x == 0 && g_syrk_clock_probe) {     // shader cycles and 100 MHz ticks of this wave
+            g_syrk_clock_probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - pt0;
+            g_syrk_clock_probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - pr0;
+        }
         return;
     }
     // batches of 16 loads
