@@ -71,7 +71,7 @@ int32_t splpak_fit_f32(int32_t ndim, const float *xdata, int32_t l1xdat,
                        float *hist_out, double *info);
 
 /* Replaces a loop of splde (:1089) calls; nderiv == NULL gives splfe (:1258).
- * Query i is the `ndim` doubles at xq + i*ldxq.  Error semantics per query are
+ * Query i is the `ndim` doubles at xq + i*ldxq (ldxq >= ndim, else SPLPAK_E_BADARG).  Error semantics per query are
  * the reference's: 101/102/103 return without computing (out is set to 0),
  * 104 (nderiv outside 0..2) is reported but the values are still computed with
  * nderiv clamped to 0..2 (the reference computes on, :1190-1194). */

@@ -441,9 +441,12 @@ static hipError_t launch_eval_t(const Grid &g, long long nq, const T *xq, int ld
         // the sort pays for itself once the batch is large and the coefficients are far beyond L1
         const bool want = g_eval_mode == 2 || (g_eval_mode == 0 && g.ndim >= 3 && nq >= (1LL << 20) && g.ncol > 32768);
         if (can && want) {
-            if (g.ndim == 2) return eval_binned<2>(g, rg, nq, xq, ldxq, nd, coef, out, st);
-            if (g.ndim == 3) return eval_binned<3>(g, rg, nq, xq, ldxq, nd, coef, out, st);
-            return eval_binned<4>(g, rg, nq, xq, ldxq, nd, coef, out, st);
+            hipError_t e = g.ndim == 2   ? eval_binned<2>(g, rg, nq, xq, ldxq, nd, coef, out, st)
+                           : g.ndim == 3 ? eval_binned<3>(g, rg, nq, xq, ldxq, nd, coef, out, st)
+                                         : eval_binned<4>(g, rg, nq, xq, ldxq, nd, coef, out, st);
+            // no room for the sort scratch: the binned path is an optimisation, fall through to the direct one
+            if (e != hipErrorOutOfMemory) return e;
+            (void)hipGetLastError();
         }
     }
     const int threads = 256;

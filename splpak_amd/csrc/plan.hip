@@ -526,6 +526,7 @@ int32_t splpak_eval_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int3
     }
     if (nq <= 0) return v;
     if (!xq_dev || !coef_dev || !out_dev) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (ldxq < ndim) { set_error("ldxq smaller than ndim"); return SPLPAK_E_BADARG; }
     if (int r = device_ready()) return r;
     SPLPAK_HIP_TRY(launch_eval(g, nq, xq_dev, ldxq, nderiv, coef_dev, out_dev, (hipStream_t)stream), SPLPAK_E_NODEVICE);
     return v;
@@ -550,6 +551,7 @@ static int32_t eval_host(int32_t ndim, int64_t nq, const T *xq, int32_t ldxq, co
     }
     if (nq <= 0) return v;
     if (!xq || !coef || !out) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (ldxq < ndim) { set_error("ldxq smaller than ndim"); return SPLPAK_E_BADARG; }
     if (int r = device_ready()) return r;
     T *dq = nullptr, *dc = nullptr, *dout = nullptr;
     splpak_plan holder;   // only used as an allocation owner

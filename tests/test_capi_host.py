@@ -54,6 +54,15 @@ def test_eval_validation_without_gpu():
     assert e(xmax=[0.0])[1] == 103
 
 
+def test_eval_rejects_short_leading_dimension():
+    """xq(ldxq, nq) with ldxq < ndim cannot hold a query: argument error before any device work."""
+    with pytest.raises(capi.SplpakError) as e:
+        capi.evaluate(2, np.array([[0.3], [0.4]]), None, np.ones(16), [0.0, 0.0], [1.0, 1.0], [4, 4])
+    assert "-3" in str(e.value)
+    assert capi.lib().splpak_set_eval_mode(9, 0) == capi.E_BADARG
+    assert capi.lib().splpak_set_eval_mode(0, 0) == 0
+
+
 def test_no_cpu_fallback_without_gpu():
     """On a box without a GPU the compute path must fail loudly, not fall back."""
     import torch

@@ -167,19 +167,21 @@ int main()
         hipStream_t st;
         (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         long long items = 0; for (int c = 4; c < n64; ++c) items += n64 - c;
-        for (int variant = 0; variant < 2; ++variant) {
+        for (int variant = 0; variant < 3; ++variant) {
             const int reps = 30;
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < reps; ++r) {
                 if (variant == 0)
                     hipLaunchKernelGGL((syrk64_kernel<16, 1, 4>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
-                else
+                else if (variant == 1)
                     hipLaunchKernelGGL((syrk64_kernel<16, 1, 4 | 256>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+                else
+                    hipLaunchKernelGGL(syrk_kernel, dim3(nt * (nt + 1) / 2 - (nt + nt - 1)), dim3(256), 0, st, ab, lda, 0, NBLK, nt, 2);
             }
             (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-            printf("sustained 30 launches, %s: %.3f ms per launch (%.1f TF)\n", variant == 0 ? "single-wave workgroups" : "4-wave workgroups    ", ms / reps, flop64 / (ms / reps) / 1e9);
+            printf("sustained 30 launches, %s: %.3f ms per launch (%.1f TF)\n", variant == 0 ? "single-wave workgroups" : variant == 1 ? "4-wave workgroups    " : "LDS 128x128 tiles     ", ms / reps, (variant == 2 ? floplds : flop64) / (ms / reps) / 1e9);
         }
     }
     for (auto &x : v) {
