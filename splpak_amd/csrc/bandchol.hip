@@ -893,17 +893,22 @@ bwd_step_kernel(const double *__restrict__ Linvt0, const double *__restrict__ Nk
     const int wg = blockIdx.x - 16;
     sx[tid] = xk[tid];
     __syncthreads();
+    // lane = (column cs, row pair seg): rows 2 seg + 32 u (+1), so that the 16 lanes of a column read
+    // 256 contiguous bytes per load
     const int seg = lane & 15, cs = lane >> 4;
     double xs[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) xs[i] = sx[seg * 16 + i];
+    for (int u = 0; u < 8; ++u) {
+        xs[2 * u] = sx[2 * seg + 32 * u];
+        xs[2 * u + 1] = sx[2 * seg + 32 * u + 1];
+    }
     d2_t l[4][8];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
         const int j = wg * 64 + wave * 16 + cc * 4 + cs;
-        const double *__restrict__ Lc = Lrows + (long long)j * lda + seg * 16;
+        const double *__restrict__ Lc = Lrows + (long long)j * lda + 2 * seg;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) l[cc][u] = *reinterpret_cast<const d2_t *>(Lc + 2 * u);
+        for (int u = 0; u < 8; ++u) l[cc][u] = *reinterpret_cast<const d2_t *>(Lc + 32 * u);
     }
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
