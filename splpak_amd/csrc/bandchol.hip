@@ -26,6 +26,7 @@
 // computed once after the factorisation, off the critical path) so that every
 // step of the forward / backward sweep is one short, fully parallel kernel.
 #include "kernels.hpp"
+#include <chrono>
 #include <hip/hip_ext.h>
 #include <cstdlib>
 
@@ -1070,6 +1071,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
                          CholStats *stats)
 {
     const bool timing = stats && stats->enabled;
+    const auto t_enq = std::chrono::steady_clock::now();
     Pipeline &pl = pipeline(b.nblk);
     hipStream_t sP = pl.panel, sC = pl.col, sU = pl.upd;
     hipStream_t sR = pl.res ? pl.res : pl.panel;     // potrf (pinned to the reserved CU)
@@ -1198,6 +1200,9 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     (void)hipStreamWaitEvent(sU, pl.evP[b.nblk - 1], 0);
     (void)hipEventRecord(pl.evC[b.nblk], sU);      // join: the caller's stream continues after the pipeline
     (void)hipStreamWaitEvent(st, pl.evC[b.nblk], 0);
+    if (std::getenv("SPLPAK_DEBUG"))
+        std::fprintf(stderr, "[splpak] band_cholesky: host enqueue of %d steps took %.1f ms\n", b.nblk,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
     hipLaunchKernelGGL(trtri_kernel, dim3(b.nblk), dim3(256), 0, st, b.ab, b.lda, b.dinv, b.dinvt);
     if (b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1)
         hipLaunchKernelGGL(sweepmat_kernel, dim3(2 * (b.nblk - 1), 16), dim3(256), 0, st, (const double *)b.ab, b.lda,
