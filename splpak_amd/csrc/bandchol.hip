@@ -1034,7 +1034,7 @@ Pipeline &pipeline(int nblk)
         hipEvent_t e;
         (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
         p.evP.push_back(e);
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        (void)hipEventCreate(&e);                 // evU[k] is also the stop event of bulk launch k (timing statistics)
         p.evU.push_back(e);
         (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
         p.evC.push_back(e);
@@ -1093,6 +1093,8 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     // bulk = true: the launch that carries ~92 % of the flops; it is a separate template
     // instantiation (ABL bit 8, no functional difference) so that profilers list it under its own
     // name, and it alone feeds the roofline statistics
+    const bool bulk_stop_event = std::getenv("SPLPAK_NO_STOPEV") == nullptr;
+    std::vector<bool> evs_owned;
     auto syrk = [&](hipStream_t s, int k, int cb, int ce, int rb, int re, bool bulk = false) {
         const int k0 = k * NBLK;
         long long items = 0;
@@ -1103,10 +1105,10 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         // start/stop are taken from the kernel's own dispatch packet), so timing adds no packet to
         // the stream; events recorded around the launch cost ~4 us each between two launches.
         const bool timed = timing && bulk;
-        if (timed) {
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&c);
-        }
+        if (timed) (void)hipEventCreate(&a);
+        // the bulk launch's completion IS evU[k]: no separate event record behind it in the stream
+        if (bulk && bulk_stop_event) c = pl.evU[k];
+        else if (timed) (void)hipEventCreate(&c);
         const bool queued = pl.reserved != ~0u && qnext < pl.nqueues;
         const int margin = queued ? 512 : 0;
         int *queue = queued ? pl.queues + 2 * (qnext++) : nullptr;
@@ -1119,6 +1121,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         if (timed) {
             evs.push_back(a);
             evs.push_back(c);
+            evs_owned.push_back(!(bulk && bulk_stop_event));
             stats->syrk_launches += 1;
             stats->syrk_flop += 2.0 * (double)items * 64 * 64 * NBLK;
         }
@@ -1195,7 +1198,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         (void)hipEventRecord(pl.evP[k + 1], sC);
         (void)hipStreamWaitEvent(sU, pl.evP[k], 0);
         syrk(sU, k, 4, n64, 0, n64, true);              // bulk: block columns >= k+2
-        (void)hipEventRecord(pl.evU[k], sU);
+        if (!bulk_stop_event) (void)hipEventRecord(pl.evU[k], sU);
     }
     (void)hipStreamWaitEvent(sU, pl.evP[b.nblk - 1], 0);
     (void)hipEventRecord(pl.evC[b.nblk], sU);      // join: the caller's stream continues after the pipeline
@@ -1218,7 +1221,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
             (void)hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
             stats->syrk_ms += ms;
             (void)hipEventDestroy(evs[i]);
-            (void)hipEventDestroy(evs[i + 1]);
+            if (evs_owned[i / 2]) (void)hipEventDestroy(evs[i + 1]);
         }
         (void)hipEventDestroy(f0);
         (void)hipEventDestroy(f1);
