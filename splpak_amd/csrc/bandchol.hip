@@ -978,14 +978,20 @@ struct Pipeline {
     int *queues = nullptr;        // [4*nblk+8][2] item queues of the trailing-update launches
     int nqueues = 0;
     int dev = -1;
+    hipEvent_t done = nullptr;    // end of the previous factorisation that used this pipeline
+    bool used = false;
 };
 thread_local Pipeline g_pipe;
+}  // namespace
+void band_pipeline_shutdown();
+namespace {
 Pipeline &pipeline(int nblk)
 {
     Pipeline &p = g_pipe;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (p.panel == nullptr || p.dev != dev) {
+        if (p.panel != nullptr) band_pipeline_shutdown();     // the thread moved to another device
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // hi = numerically lowest = highest priority
         (void)hipStreamCreateWithPriority(&p.panel, hipStreamNonBlocking, hi);
@@ -1022,6 +1028,8 @@ Pipeline &pipeline(int nblk)
         p.evC.clear();
         p.evI.clear();
         p.evT.clear();
+        (void)hipEventCreateWithFlags(&p.done, hipEventDisableTiming);
+        p.used = false;
         (void)hipEventCreateWithFlags(&p.evR[0], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&p.evR[1], hipEventDisableTiming);
     }
@@ -1056,6 +1064,9 @@ void band_pipeline_shutdown()
         v->clear();
     }
     for (hipEvent_t &e : p.evR) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (p.done) (void)hipEventDestroy(p.done);
+    p.done = nullptr;
+    p.used = false;
     for (hipStream_t *s : {&p.panel, &p.col, &p.res, &p.upd}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
     if (p.queues) (void)hipFree(p.queues);
     p.queues = nullptr;
@@ -1075,7 +1086,10 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     Pipeline &pl = pipeline(b.nblk);
     hipStream_t sP = pl.panel, sC = pl.col, sU = pl.upd;
     hipStream_t sR = pl.res ? pl.res : pl.panel;     // potrf (pinned to the reserved CU)
-    if (std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = sC = sU = sR = st;   // diagnostics: one stream, no overlap
+    if (!sP || !sC || !sU || std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = sC = sU = sR = st;   // no streams / diagnostics: no overlap
+    // the item queues and events belong to the pipeline, not to the caller's stream: a factorisation
+    // enqueued from another stream must not clear them while the previous one is still running
+    if (pl.used && pl.done) (void)hipStreamWaitEvent(st, pl.done, 0);
     (void)hipMemsetAsync(pl.queues, 0, sizeof(int) * 2 * (size_t)pl.nqueues, st);
     hipEvent_t f0 = nullptr, f1 = nullptr;
     std::vector<hipEvent_t> evs;
@@ -1210,6 +1224,10 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     if (b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1)
         hipLaunchKernelGGL(sweepmat_kernel, dim3(2 * (b.nblk - 1), 16), dim3(256), 0, st, (const double *)b.ab, b.lda,
                            (const double *)b.dinv, (const double *)b.dinvt, b.mfwd, b.mbwd, b.nblk - 1);
+    if (pl.done) {
+        (void)hipEventRecord(pl.done, st);
+        pl.used = true;
+    }
     hipError_t err = hipGetLastError();
     if (timing) {
         (void)hipEventRecord(f1, st);
