@@ -367,7 +367,7 @@ template <int D>
 static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, const double *xq, int ldxq,
                               const NDeriv &nd, const double *coef, double *out, hipStream_t st)
 {
-    long long chunk = g_eval_chunk > 0 ? g_eval_chunk : (1LL << 24);
+    long long chunk = g_eval_chunk > 0 ? g_eval_chunk : (1LL << 26);
     if (chunk > (1LL << 28)) chunk = 1LL << 28;
     if (chunk > nq) chunk = nq;
     EvalScratch &s = g_scratch;
