@@ -89,6 +89,30 @@ def cpu_baseline(ndim):
     }
 
 
+def pin_to_gpu_numa_node(local_rank):
+    """Run this process on the CPUs of the NUMA node the GPU hangs off (HIP events and completion
+    signals live in host memory: a remote socket costs ~1 % of the fit).  Best effort."""
+    try:
+        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(local_rank), "pci_domain_id", 0)
+        dev = getattr(torch.cuda.get_device_properties(local_rank), "pci_device_id", 0)
+        path = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{dev:02x}.0/numa_node"
+        node = int(open(path).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -96,6 +120,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the splpak HIP path has no CPU fallback")
+    numa_node = pin_to_gpu_numa_node(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -199,7 +224,7 @@ def main():
             "config": {
                 "workload": (f"C3: {nd}-D splcw least-squares spline fit, {m} weighted scattered points per GPU "
                              f"(Park-Miller stream, seed 42), {'x'.join(map(str, nodes))} nodes, xtrap=1, real64"),
-                "ncol": ncol, "points_per_gpu": m, "points_total": world * m,
+                "ncol": ncol, "points_per_gpu": m, "points_total": world * m, "host_numa_node": numa_node,
                 "parallelism": "points sharded per GPU; RCCL all-reduce of histogram, normal equations and "
                                "refinement residuals; band Cholesky replicated" if world > 1 else "single GPU",
                 "refine_steps": int(info[2]), "last_correction_rel": float(info[3]),
