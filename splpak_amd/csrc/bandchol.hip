@@ -11,20 +11,22 @@
 // that lda is a multiple of 16 doubles (128-B lines) but not of a large power of
 // two (HBM channel spread).
 //
-// Right-looking blocked algorithm with NBLK = 256 columns per step:
-//   potrf_block_kernel  256x256 diagonal block, one workgroup, LDS-resident
-//                       64-column panels
-//   trsm_kernel         panel below the diagonal block, one thread per row,
-//                       exact forward substitution (L_kk read through the scalar
-//                       cache)
-//   syrk_kernel         trailing update C -= P P^T on the f64 matrix cores
-//                       (v_mfma_f64_16x16x4_f64), 128x128 tile per workgroup,
-//                       LDS double-buffered K-chunks of the panel.  This kernel
-//                       carries ~n*p^2 of the flops (4.1e13 at 64^3 nodes) and
-//                       is the MFMA-bound roofline kernel of the fit.
-// Solves use explicit inverses of the 256x256 diagonal blocks of L (trtri_kernel,
-// computed once after the factorisation, off the critical path) so that every
-// step of the forward / backward sweep is one short, fully parallel kernel.
+// Right-looking blocked algorithm with NBLK = 256 columns per step (band_cholesky):
+//   potrf_block_kernel  256x256 diagonal block: one workgroup, 16-column panels, leaf in
+//                       registers (v_readlane), in-block update on the matrix cores; also
+//                       writes the inverses of the 16x16 diagonal leaves
+//   trsm_kernel         panel below the diagonal block: one wave per 16 rows, 16-column
+//                       blocks on the matrix cores against the leaf inverses
+//   syrk64_kernel       trailing update C -= P P^T on the f64 matrix cores
+//                       (v_mfma_f64_16x16x4_f64): one wave per 64x64 item, operands streamed
+//                       from L2 into a register queue, no LDS.  This kernel carries ~n*p^2
+//                       of the flops (4.1e13 at 64^3 nodes) and is the roofline kernel of the
+//                       fit.  syrk_kernel is the earlier LDS-tiled
+//                       128x128 form, kept for tools/syrk_bench.hip only.
+// The steps are pipelined over four HIP streams with one block column of look-ahead.
+// Solves (band_solve) use explicit inverses of the 256x256 diagonal blocks of L
+// (trtri_kernel) and the coupling blocks of sweepmat_kernel, computed once after the
+// factorisation, so that every step of the forward / backward sweep is ONE short launch.
 #include "kernels.hpp"
 #include <chrono>
 #include <hip/hip_ext.h>
