@@ -50,10 +50,11 @@ keys_kernel(Grid g, long long m, const double *__restrict__ x, int ldx,
             double xv[D];
             k = 0;
 #pragma unroll
+            for (int d = 0; d < D; ++d) xv[d] = x[i * ldx + d];        // caller's dimension order
+#pragma unroll
             for (int d = 0; d < D; ++d) {
-                xv[d] = x[i * ldx + d];
                 int lo, hi;
-                k += window_start(g, d, xv[d], lo, hi) * g.cellstride[d];
+                k += window_start(g, d, xv[g.perm[d]], lo, hi) * g.cellstride[d];
             }
             lrows += 1.0;
             if (hist) {
@@ -116,7 +117,7 @@ scatter_kernel(Grid g, long long m, const double *__restrict__ x, int ldx,
         if (k >= g.ncell) continue;
         const long long pos = (long long)offset[k] + atomicAdd(&cursor[k], 1);
 #pragma unroll
-        for (int d = 0; d < D; ++d) xs[(long long)d * cap + pos] = x[i * ldx + d];
+        for (int d = 0; d < D; ++d) xs[(long long)d * cap + pos] = x[i * ldx + g.perm[d]];
         ys[pos] = y[i];
         ws[pos] = w ? w[i] : 1.0;
     }
@@ -346,7 +347,10 @@ constraint_kernel(Grid g, const double *__restrict__ hist, const double *__restr
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (in[d] == 0 || in[d] == g.nodes[d] - 1) expect = 0.5 * expect;   // :928
-        const double have = hist[node];
+        int refnode = 0;                                              // the histogram is in the caller's order
+#pragma unroll
+        for (int d = 0; d < D; ++d) refnode += in[d] * g.refstride[d];
+        const double have = hist[refnode];
         sparse = have < 0.75 * expect;                                // spcrit, :696, :936
         dcwght = expect - have;                                       // :938
         dcwght = xtrap * dcwght;                                      // :960
@@ -463,6 +467,25 @@ inline unsigned grid_for(long long n, int threads, long long maxblocks = 256LL *
     case 3: { constexpr int D = 3; CALL; } break; \
     default: { constexpr int D = 4; CALL; } break; \
     }
+
+__global__ void __launch_bounds__(256)
+to_reference_order_kernel(Grid g, const double *__restrict__ xvec, double *__restrict__ coef)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= g.ncol) return;
+    int ref = 0;
+    for (int d = 0; d < g.ndim; ++d) ref += ((col / g.colstride[d]) % g.nodes[d]) * g.refstride[d];
+    coef[ref] = xvec[col];
+}
+
+hipError_t launch_to_reference_order(const Grid &g, const double *xvec, double *coef, hipStream_t st)
+{
+    bool identity = true;
+    for (int d = 0; d < g.ndim; ++d) identity = identity && g.perm[d] == d;
+    if (identity) return hipMemcpyAsync(coef, xvec, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(to_reference_order_kernel, dim3((g.ncol + 255) / 256), dim3(256), 0, st, g, xvec, coef);
+    return hipGetLastError();
+}
 
 hipError_t launch_keys(const Grid &g, long long m, const double *x, int ldx, const double *w,
                        const SortScratch &s, double *hist, double *scal, hipStream_t st)

@@ -138,13 +138,14 @@ __host__ __device__ inline int window_table(const Grid &g, int d, double x, int 
 __host__ __device__ inline int nearest_node_address(const Grid &g, const double *x)
 {
 #pragma clang fp contract(off)
+    // x and the Horner order are the caller's (reference) dimension order
     int iin = 0;
     for (int dc = 0; dc < g.ndim; ++dc) {
         const int d = g.ndim - 1 - dc;
-        const double t = g.dxin[d] * (x[d] - g.xmin[d]) + 0.5;
+        const double t = g.ref_dxin[d] * (x[d] - g.ref_xmin[d]) + 0.5;
         const int inidim = (t >= 2.0e9) ? 2000000000 : (t <= -2.0e9 ? -2000000000 : (int)t);
-        if (inidim < 0 || inidim > g.nodes[d] - 1) continue;
-        iin = g.nodes[d] * iin + inidim;
+        if (inidim < 0 || inidim > g.ref_nodes[d] - 1) continue;
+        iin = g.ref_nodes[d] * iin + inidim;
     }
     return iin;
 }

@@ -26,6 +26,14 @@ struct Grid {
     int nb;                // 4^ndim basis functions per window
     int hstencil;          // (7^ndim+1)/2 stored entries per row of the normal equations
     int halfbw;            // 3*sum colstride_d : half bandwidth of the normal equations
+    // A fit plan orders the dimensions by ascending node count (largest slowest): the half bandwidth
+    // 3 (1 + n_a + n_a n_b) then involves the two SMALLEST dimensions.  Everything above is in that
+    // internal order; the caller's (reference) order only matters where data enters or leaves:
+    int perm[MAXD];        // internal dimension d = reference dimension perm[d]
+    int refstride[MAXD];   // reference column stride of internal dimension d (coef / histogram address)
+    int ref_nodes[MAXD];   // reference-order copies for the nearest-node histogram address (:894-902)
+    double ref_xmin[MAXD];
+    double ref_dxin[MAXD];
 };
 
 // half-stencil slot of the column offset o_d in [-3,3] (dim 0 fastest); valid

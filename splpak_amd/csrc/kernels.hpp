@@ -57,6 +57,9 @@ hipError_t launch_constraints(const Grid &g, const double *hist, const double *s
                               double *nst, const double *xvec, double *rho, double *scal_out,
                               double *ssq, hipStream_t st);
 
+// coef[reference column] = xvec[internal column] (a plain copy when the plan did not reorder the dimensions)
+hipError_t launch_to_reference_order(const Grid &g, const double *xvec, double *coef, hipStream_t st);
+
 // ---- bandchol.hip
 constexpr int NBLK = 256;     // block size of the band factorisation
 struct Band {

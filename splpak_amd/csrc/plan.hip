@@ -42,24 +42,42 @@ bool hip_ok(hipError_t e, const char *what)
 // reference-order validation shared by fit and evaluation (:716-750, :1166-1210).
 // returns 0 or 101/102/103
 static int build_grid(int ndim, const int *nodes, const double *xmin, const double *xmax, Grid &g,
-                      long long *ncol_out)
+                      long long *ncol_out, bool reorder = false)
 {
     std::memset(&g, 0, sizeof(g));
     if (ndim < 1) return 101;
     if (ndim > MAXD) return SPLPAK_E_UNSUPPORTED;
     g.ndim = ndim;
+    // checks in the reference's order (first failing dimension wins), reference-order copies
+    long long rs = 1;
+    int refstride_of[MAXD] = {0, 0, 0, 0};
+    for (int d = 0; d < ndim; ++d) {
+        if (nodes[d] < 4) return 102;
+        const double xrng = xmax[d] - xmin[d];
+        if (xrng == 0.0) return 103;
+        g.ref_nodes[d] = nodes[d];
+        g.ref_xmin[d] = xmin[d];
+        g.ref_dxin[d] = 1.0 / (xrng / (double)(nodes[d] - 1));
+        refstride_of[d] = (int)rs;
+        rs *= nodes[d];
+        if (rs > (1LL << 30)) { if (ncol_out) *ncol_out = rs; return SPLPAK_E_UNSUPPORTED; }
+    }
+    for (int d = 0; d < MAXD; ++d) g.perm[d] = d;
+    if (reorder)        // ascending node counts, stable: identity for isotropic grids
+        for (int i = 1; i < ndim; ++i)
+            for (int j = i; j > 0 && nodes[g.perm[j]] < nodes[g.perm[j - 1]]; --j) std::swap(g.perm[j], g.perm[j - 1]);
     long long ncol = 1, ncell = 1, cs = 1, ls = 1;
     int nb = 1, h = 1, hb = 0;
     for (int d = 0; d < ndim; ++d) {
-        const int nod = nodes[d];
-        if (nod < 4) return 102;
-        const double xrng = xmax[d] - xmin[d];
-        if (xrng == 0.0) return 103;
+        const int r = g.perm[d];
+        const int nod = nodes[r];
+        const double xrng = xmax[r] - xmin[r];
         g.nodes[d] = nod;
-        g.xmin[d] = xmin[d];
+        g.xmin[d] = xmin[r];
         g.dx[d] = xrng / (double)(nod - 1);        // :747
         g.dxin[d] = 1.0 / g.dx[d];                 // :748
         g.colstride[d] = (int)cs;
+        g.refstride[d] = refstride_of[r];
         g.cells[d] = nod - 3;
         g.cellstride[d] = (int)ls;
         hb += 3 * (int)cs;
@@ -69,9 +87,11 @@ static int build_grid(int ndim, const int *nodes, const double *xmin, const doub
         ncell *= (nod - 3);
         nb *= 4;
         h *= 7;
-        if (ncol > (1LL << 30)) { if (ncol_out) *ncol_out = ncol; return SPLPAK_E_UNSUPPORTED; }
     }
-    for (int d = ndim; d < MAXD; ++d) { g.nodes[d] = 4; g.dx[d] = g.dxin[d] = 1.0; g.cells[d] = 1; }
+    for (int d = ndim; d < MAXD; ++d) {
+        g.nodes[d] = 4; g.dx[d] = g.dxin[d] = 1.0; g.cells[d] = 1;
+        g.ref_nodes[d] = 4; g.ref_dxin[d] = 1.0;
+    }
     g.ncol = (int)ncol;
     g.ncell = (int)ncell;
     g.nb = nb;
@@ -166,7 +186,7 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
     *plan = nullptr;
     Grid g;
     long long ncol = 0;
-    const int v = build_grid(ndim, nodes, xmin, xmax, g, &ncol);
+    const int v = build_grid(ndim, nodes, xmin, xmax, g, &ncol, std::getenv("SPLPAK_NO_REORDER") == nullptr);
     if (v != 0) {
         if (v == SPLPAK_E_UNSUPPORTED) set_error("ndim > 4 or more than 2^30 nodes is not supported");
         return v;
@@ -386,7 +406,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         }
         prev_rel = last_rel;
     }
-    SPLPAK_HIP_TRY(hipMemcpyAsync(coef_dev, p->xvec, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(launch_to_reference_order(g, p->xvec, coef_dev, st), SPLPAK_E_NODEVICE);   // internal -> caller's dimension order
     // residual norm of the fitted system, ||rows * coef - rhs||_2 over data AND constraint rows: what
     // the reference computes as `reserr` (suprls :1693) and then drops (splcw :690, :1052)
     double ssq = 0.0;

@@ -171,6 +171,32 @@ def test_fit_fresh_inputs_vs_oracle(port):
             assert relmax(h1[:n], w0[:n]) < 1e-12
 
 
+def test_fit_dimension_reordering_vs_oracle(port):
+    """A plan orders the dimensions by node count internally (smallest fastest) to minimise the
+    bandwidth; coefficients and the histogram must come back in the caller's order.  Descending
+    and mixed node counts, a different box per dimension, points outside the box."""
+    rng = np.random.default_rng(23)
+    for nd, nodes in [(2, [11, 6]), (3, [9, 6, 4]), (3, [4, 8, 5]), (4, [6, 4, 5, 4])]:
+        m = 1200
+        lo = -1.0 + rng.random(nd)
+        hi = lo + 0.5 + 2.0 * rng.random(nd)
+        x = lo + (hi - lo) * (rng.random((m, nd)) * 1.2 - 0.1)
+        y = np.cos(((x - lo) / (hi - lo) * np.arange(1, nd + 1)).sum(axis=1) * 2.0) + 0.05 * rng.standard_normal(m)
+        w = 0.5 + rng.random(m)
+        for xtrap in (1.0, 0.0):
+            c0, e0, w0 = port.fit(nd, x, y, w, lo, hi, nodes, xtrap)
+            c1, e1, h1, _ = capi.fit(nd, x, y, w, lo, hi, nodes, xtrap, want_hist=True)
+            n = int(np.prod(nodes))
+            assert e0 == e1 == 0, (nodes, xtrap, e0, e1)
+            assert relmax(c1[:n], c0[:n]) < COEF_TOL, (nodes, xtrap)
+            if xtrap != 0.0:
+                assert relmax(h1[:n], w0[:n]) < 1e-12, (nodes, xtrap)
+            q = lo + (hi - lo) * rng.random((500, nd))
+            v1, _ = capi.evaluate(nd, q, None, c1, lo, hi, nodes)
+            v0, _ = port.evaluate(nd, q, None, c0, lo, hi, nodes)
+            assert np.max(np.abs(v1 - v0)) <= 1e-9 * np.max(np.abs(v0))
+
+
 def test_fit_l1xdat_and_negative_first_weight(port):
     """xdata(l1xdat, ndata) with l1xdat > ndim (:521-525); wdata(1) < 0 means unweighted (:581-588)."""
     inp = make_inputs(CASES["2d8"])
