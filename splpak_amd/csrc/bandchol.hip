@@ -43,6 +43,8 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------
 // Cholesky of one 256x256 diagonal block: one workgroup of 4 waves, 16-column panels.
+// (The inverses of the sixteen 16x16 leaves, needed by the panel solve, are computed together at the
+// end: every 16-lane group takes one leaf -- 290 -> 250 us for the kernel, tools/potrf_probe.hip.)
 // Per panel: (i) the 16x16 diagonal block is factored by wave 0 alone, one row per lane in
 // registers, columns broadcast with v_readlane (no barriers); (ii) the rows below are solved
 // one row per thread against that factor (broadcast LDS reads); (iii) the rest of the block
@@ -66,6 +68,12 @@ __device__ inline double readlane_f64(double v, int srclane)
     return __hiloint2double(hi, lo);
 }
 
+#ifdef SPLPAK_POTRF_STAMPS        // tools/potrf_probe.hip: cycle stamps of wave 0 at the phase boundaries
+__device__ unsigned long long g_potrf_stamps[16 * 8];
+#define POTRF_STAMP(i) do { if (tid == 0) g_potrf_stamps[(c0 / IB) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define POTRF_STAMP(i) do { } while (0)
+#endif
 __global__ void __launch_bounds__(256)
 potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restrict__ info,
                    double *__restrict__ minpiv, double *__restrict__ inv16)
@@ -83,6 +91,7 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
         const int nt = mrem / 16;
         const int ntiles = nt * (nt + 1) / 2;
 
+        POTRF_STAMP(0);
         // ---- every load of this panel is issued here
         double x[IB];                        // (ii) this thread's row of the panel
         const int row = base + tid;
@@ -96,6 +105,7 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
             double a[IB];
 #pragma unroll
             for (int c = 0; c < IB; ++c) a[c] = (c <= r) ? A[(c0 + r) + (long long)(c0 + c) * lda] : 0.0;
+            POTRF_STAMP(1);
             double dmin = a[0];
             bool bad = false;
 #pragma unroll
@@ -108,6 +118,7 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
 #pragma unroll
                 for (int c = j + 1; c < IB; ++c) a[c] -= a[j] * readlane_f64(a[j], c);
             }
+            POTRF_STAMP(2);
             if (lane < IB) {
 #pragma unroll
                 for (int c = 0; c < IB; ++c) {
@@ -119,25 +130,10 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
                 if (bad) atomicCAS(info, 0, k0 + c0 + 1);
                 if (dmin < *minpiv || !(dmin == dmin)) *minpiv = dmin;
             }
-            // inverse of the 16x16 leaf (the panel solve's MFMA operand): lane c solves
-            // L x = e_c by forward substitution, L(r,k) broadcast from the lane that owns row r
-            {
-                double xi[IB];
-#pragma unroll
-                for (int rr = 0; rr < IB; ++rr) {
-                    double s = (rr == r) ? 1.0 : 0.0;
-#pragma unroll
-                    for (int k = 0; k < rr; ++k) s -= readlane_f64(a[k], rr) * xi[k];
-                    xi[rr] = s / readlane_f64(a[rr], rr);
-                }
-                if (lane < IB) {
-                    double *out = inv16 + (c0 / IB) * (IB * IB) + r * IB;    // column r: out[row]
-#pragma unroll
-                    for (int rr = 0; rr < IB; ++rr) out[rr] = (rr >= r) ? xi[rr] : 0.0;
-                }
-            }
         }
+        POTRF_STAMP(3);
         __syncthreads();
+        POTRF_STAMP(4);
         // (ii) rows below: x = a L^{-T}, one row per thread
         if (tid < mrem) {
 #pragma unroll
@@ -152,7 +148,9 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
                 Xs[c * XLD + row] = x[c];
             }
         }
+        POTRF_STAMP(5);
         __syncthreads();
+        POTRF_STAMP(6);
         // (iii) trailing update inside the block on the matrix cores: 16x16 tiles, rt >= ct,
         // four tiles per wave and round with all their C loads in flight together
         for (int t0 = wave * 4; t0 < ntiles; t0 += 16) {
@@ -192,7 +190,29 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
                 }
             }
         }
+        POTRF_STAMP(7);
         __syncthreads();
+    }
+    // Inverses of the sixteen 16x16 diagonal leaves (the panel solve's MFMA operands), all at once:
+    // every 16-lane group of every wave takes one leaf; lane c of a group solves L x = e_c by
+    // forward substitution, L(rr,k) comes from the lane of the group that holds row rr.
+    {
+        const int leaf = wave * 4 + q, r = l15;
+        const int d0 = leaf * IB;
+        double a[IB];
+#pragma unroll
+        for (int c = 0; c < IB; ++c) a[c] = (c <= r) ? A[(d0 + r) + (long long)(d0 + c) * lda] : 0.0;
+        double xi[IB];
+#pragma unroll
+        for (int rr = 0; rr < IB; ++rr) {
+            double sacc = (rr == r) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < rr; ++k) sacc -= __shfl(a[k], rr, 16) * xi[k];
+            xi[rr] = sacc / __shfl(a[rr], rr, 16);
+        }
+        double *out = inv16 + leaf * (IB * IB) + r * IB;    // column r: out[row]
+#pragma unroll
+        for (int rr = 0; rr < IB; ++rr) out[rr] = (rr >= r) ? xi[rr] : 0.0;
     }
 }
 
