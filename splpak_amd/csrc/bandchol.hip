@@ -58,6 +58,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // version take 700 us against 215 us alone.  Hence 16-wide panels and rolled loops: the
 // whole kernel is ~14 KB.  LDS 37 KB, <= 200 VGPRs: it fits beside trailing-update waves.
 constexpr int IB = 16;                 // inner panel width
+constexpr int PTB = 4;                 // 16x16 tiles of the in-block update per wave and round
 constexpr int XLD = NBLK + 16;         // LDS row of the panel image (bank-half alternation, as in syrk)
 
 __device__ inline double readlane_f64(double v, int srclane)
@@ -81,7 +82,8 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
     __shared__ double Ls[IB * (IB + 1)];     // factor of the current diagonal 16x16: Ls[c*(IB+1) + k]
     __shared__ double Xs[IB * XLD];          // panel image Xs[k*XLD + r], r = row inside the 256 block
     double *A = ab + (long long)k0 + (long long)k0 * lda;    // A(r,c) = A[r + c*lda], r >= c
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile bookkeeping stays scalar
     const int l15 = lane & 15, q = lane >> 4;
     __builtin_amdgcn_s_setprio(3);           // critical path of the look-ahead: win issue arbitration
 
@@ -152,42 +154,72 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
         __syncthreads();
         POTRF_STAMP(6);
         // (iii) trailing update inside the block on the matrix cores: 16x16 tiles, rt >= ct,
-        // four tiles per wave and round with all their C loads in flight together
-        for (int t0 = wave * 4; t0 < ntiles; t0 += 16) {
-            d4_t cc[4];
-            int roff[4], coff[4];
+        // PTB tiles per wave and round with all their C loads in flight together.  The kernel has a
+        // SIMD per wave to itself, so every instruction is exposed: tile addresses are wave-uniform
+        // (scalar) bases plus one 32-bit per-lane offset, the tile index advances incrementally and
+        // only diagonal tiles take the predicated store path.
+        {
+            const unsigned voff = (unsigned)(l15 + (long long)q * lda) * 8u;      // bytes; q*lda*8 < 2^20
+            int ct = 0, rem = wave * PTB;                                        // tile t -> (ct, ct + rem)
+            while (rem >= nt - ct && ct < nt) { rem -= nt - ct; ++ct; }
+            // a round = PTB tiles of this wave; the C tiles of the next round are loaded before the
+            // current one is computed (two register sets, loop unrolled by two)
+            auto load_round = [&](int t0, d4_t (&cc)[PTB], int (&roff)[PTB], int (&coff)[PTB]) {
+                int ctu = ct, remu = rem;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = t0 + u;
-                roff[u] = -1;
-                coff[u] = 0;
-                if (t < ntiles) {
-                    int ct = 0, rem = t;
-                    while (rem >= nt - ct) { rem -= nt - ct; ++ct; }
-                    roff[u] = base + 16 * (ct + rem);
-                    coff[u] = base + 16 * ct;
+                for (int u = 0; u < PTB; ++u) {
+                    roff[u] = -1;
+                    coff[u] = 0;
+                    if (t0 + u < ntiles) {
+                        roff[u] = base + 16 * (ctu + remu);
+                        coff[u] = base + 16 * ctu;
+                        const char *tile = reinterpret_cast<const char *>(A + roff[u] + (long long)coff[u] * lda);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        cc[u][v] = A[(roff[u] + l15) + (long long)(coff[u] + q + 4 * v) * lda];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (roff[u] >= 0) {
-                    d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int s = 0; s < IB / 4; ++s) {
-                        const double av = Xs[(4 * s + q) * XLD + coff[u] + l15];
-                        const double bv = Xs[(4 * s + q) * XLD + roff[u] + l15];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                        for (int v = 0; v < 4; ++v)
+                            cc[u][v] = *reinterpret_cast<const double *>(tile + (long long)(4 * v) * lda * 8 + voff);
                     }
-                    const int r = roff[u] + l15;
+                    if (++remu >= nt - ctu) { remu = 0; ++ctu; }
+                }
+                rem += 4 * PTB;                      // this wave's next round
+                while (ct < nt && rem >= nt - ct) { rem -= nt - ct; ++ct; }
+            };
+            auto compute_round = [&](d4_t (&cc)[PTB], int (&roff)[PTB], int (&coff)[PTB]) {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int c = coff[u] + q + 4 * v;
-                        if (r >= c) A[r + (long long)c * lda] = cc[u][v] - acc[v];
+                for (int u = 0; u < PTB; ++u) {
+                    if (roff[u] >= 0) {
+                        d4_t acc = cc[u];                 // C - X X^T accumulated in place (negated operand)
+#pragma unroll
+                        for (int s4 = 0; s4 < IB / 4; ++s4) {
+                            const double av = -Xs[(4 * s4 + q) * XLD + coff[u] + l15];
+                            const double bv = Xs[(4 * s4 + q) * XLD + roff[u] + l15];
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                        }
+                        char *tile = reinterpret_cast<char *>(A + roff[u] + (long long)coff[u] * lda);
+                        if (roff[u] != coff[u]) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                *reinterpret_cast<double *>(tile + (long long)(4 * v) * lda * 8 + voff) = acc[v];
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (l15 >= q + 4 * v)
+                                    *reinterpret_cast<double *>(tile + (long long)(4 * v) * lda * 8 + voff) = acc[v];
+                        }
                     }
                 }
+            };
+            d4_t ccA[PTB], ccB[PTB];
+            int roA[PTB], coA[PTB], roB[PTB], coB[PTB];
+            int tA = wave * PTB;
+            if (tA < ntiles) load_round(tA, ccA, roA, coA);
+            while (tA < ntiles) {
+                const int tB = tA + 4 * PTB;
+                if (tB < ntiles) load_round(tB, ccB, roB, coB);
+                compute_round(ccA, roA, coA);
+                if (tB >= ntiles) break;
+                tA = tB + 4 * PTB;
+                if (tA < ntiles) load_round(tA, ccA, roA, coA);
+                compute_round(ccB, roB, coB);
             }
         }
         POTRF_STAMP(7);
