@@ -1139,7 +1139,10 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     const auto t_enq = std::chrono::steady_clock::now();
     Pipeline &pl = pipeline(b.nblk);
     hipStream_t sP = pl.panel, sC = pl.col, sU = pl.upd;
-    hipStream_t sR = pl.res ? pl.res : pl.panel;     // potrf (pinned to the reserved CU)
+    // potrf is pinned to the reserved CU (own stream, two event hops per step) when the trailing update is
+    // heavy enough to starve it; with a narrow band the step is bound by the chain itself and the hops cost more
+    const int pin_bw = std::getenv("SPLPAK_PIN_BW") ? atoi(std::getenv("SPLPAK_PIN_BW")) : 24;
+    hipStream_t sR = (pl.res && b.bw >= pin_bw) ? pl.res : pl.panel;
     if (!sP || !sC || !sU || std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = sC = sU = sR = st;   // no streams / diagnostics: no overlap
     // the item queues and events belong to the pipeline, not to the caller's stream: a factorisation
     // enqueued from another stream must not clear them while the previous one is still running
