@@ -150,6 +150,23 @@ int32_t splpak_eval_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int3
                             const double *coef_dev, const double *xmin, const double *xmax,
                             const int32_t *nodes, double *out_dev, void *stream);
 
+/* Value, gradient and (order 2) Hessian of the spline at a batch of points in one pass over the
+ * window -- SURVEY 8f: what a caller otherwise obtains from 1 + ndim (+ ndim(ndim+1)/2) splde calls
+ * (:1089-1240) per point.  order = 1 or 2.  Row i of `out` (ldout apart, ldout >= number of entries):
+ *   [ f, df/dx_1 .. df/dx_ndim, (order 2:) d2f/dx_1dx_1, d2f/dx_1dx_2, .., d2f/dx_1dx_ndim, d2f/dx_2dx_2, .. ]
+ * i.e. the upper triangle of the Hessian row by row.  Each entry equals splde with the matching nderiv.
+ * Status: 0, 101/102/103 as splde (`out` is zeroed), or a negative library status. */
+int32_t splpak_eval_derivs_f64(int32_t ndim, int64_t nq, const double *xq, int32_t ldxq, int32_t order,
+                               const double *coef, const double *xmin, const double *xmax,
+                               const int32_t *nodes, double *out, int32_t ldout);
+int32_t splpak_eval_derivs_f32(int32_t ndim, int64_t nq, const float *xq, int32_t ldxq, int32_t order,
+                               const float *coef, const float *xmin, const float *xmax,
+                               const int32_t *nodes, float *out, int32_t ldout);
+/* the same on resident data (asynchronous on `stream`) */
+int32_t splpak_eval_derivs_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int32_t ldxq, int32_t order,
+                                   const double *coef_dev, const double *xmin, const double *xmax,
+                                   const int32_t *nodes, double *out_dev, int32_t ldout, void *stream);
+
 /* Device-side synthetic inputs of SURVEY 8d (Park-Miller stream, seed 42):
  * points first_point .. first_point+ndata-1; any of the outputs may be NULL.
  * xdata_dev is written with leading dimension ndim.  Queries continue the stream

@@ -28,7 +28,8 @@ SYMBOLS = [
     "splpak_plan_comm_len", "splpak_plan_create", "splpak_plan_destroy",
     "splpak_plan_set_allreduce", "splpak_plan_set_refine", "splpak_plan_fit_dev",
     "splpak_plan_hist_dev", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing",
-    "splpak_eval_dev_f64", "splpak_synth_points_f64", "splpak_synth_queries_f64",
+    "splpak_eval_dev_f64", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
+    "splpak_synth_points_f64", "splpak_synth_queries_f64",
     "splpak_debug_spd_band_solve_f64", "splpak_shutdown", "splpak_set_eval_mode",
     "splpak_last_error_message", "splpak_device_name",
 ]
@@ -81,6 +82,12 @@ def lib() -> C.CDLL:
     L.splpak_plan_kernel_timing.argtypes = [vp, _dp]
     L.splpak_eval_dev_f64.restype = i32
     L.splpak_eval_dev_f64.argtypes = [i32, i64, vp, i32, _ip, vp, _dp, _dp, _ip, vp, vp]
+    L.splpak_eval_derivs_f64.restype = i32
+    L.splpak_eval_derivs_f64.argtypes = [i32, i64, _dp, i32, i32, _dp, _dp, _dp, _ip, _dp, i32]
+    L.splpak_eval_derivs_f32.restype = i32
+    L.splpak_eval_derivs_f32.argtypes = [i32, i64, _fp, i32, i32, _fp, _fp, _fp, _ip, _fp, i32]
+    L.splpak_eval_derivs_dev_f64.restype = i32
+    L.splpak_eval_derivs_dev_f64.argtypes = [i32, i64, vp, i32, i32, vp, _dp, _dp, _ip, vp, i32, vp]
     L.splpak_synth_points_f64.restype = i32
     L.splpak_synth_points_f64.argtypes = [i32, i64, i64, vp, vp, vp, vp]
     L.splpak_synth_queries_f64.restype = i32
@@ -181,6 +188,37 @@ def evaluate(ndim, xq, nderiv, coef, xmin, xmax, nodes, real32=False):
     rc = _check(fn(ndim, nq, _p(xq, rp), ldx, _p(nd, _ip), _p(coef, rp), _p(xmin, rp), _p(xmax, rp),
                    _p(nodes, _ip), _p(out, rp)))
     return out, rc
+
+
+def derivs_nout(ndim, order):
+    return 1 + ndim + (ndim * (ndim + 1) // 2 if order == 2 else 0)
+
+
+def evaluate_derivs(ndim, xq, order, coef, xmin, xmax, nodes, real32=False):
+    """Value, gradient (order 1) and Hessian upper triangle (order 2) per query -> (array (nq, nout), ierror)."""
+    dt = np.float32 if real32 else np.float64
+    rp = _fp if real32 else _dp
+    xq = np.ascontiguousarray(xq, dtype=dt)
+    if xq.ndim == 1:
+        xq = xq.reshape(-1, 1)
+    nq, ldx = xq.shape
+    coef = np.ascontiguousarray(coef, dtype=dt)
+    xmin, xmax, nodes = _grid(ndim, xmin, xmax, nodes, dt)
+    nout = derivs_nout(max(ndim, 1), order) if order in (1, 2) else 1
+    out = np.zeros((nq, nout), dtype=dt)
+    fn = lib().splpak_eval_derivs_f32 if real32 else lib().splpak_eval_derivs_f64
+    rc = _check(fn(ndim, nq, _p(xq, rp), ldx, int(order), _p(coef, rp), _p(xmin, rp), _p(xmax, rp),
+                   _p(nodes, _ip), _p(out, rp), nout))
+    return out, rc
+
+
+def evaluate_derivs_dev(ndim, xq, order, coef, xmin, xmax, nodes, out, stream=0):
+    """Same on torch device tensors; `out` is (nq, >= nout) float64."""
+    xmin, xmax, nodes = _grid(ndim, xmin, xmax, nodes)
+    nq, ldx = xq.shape
+    return _check(lib().splpak_eval_derivs_dev_f64(ndim, int(nq), xq.data_ptr(), int(ldx), int(order),
+                                                   coef.data_ptr(), _p(xmin, _dp), _p(xmax, _dp), _p(nodes, _ip),
+                                                   out.data_ptr(), int(out.shape[1]), C.c_void_p(stream)))
 
 
 # ---------------------------------------------------------------------------

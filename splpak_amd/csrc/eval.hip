@@ -420,6 +420,120 @@ static bool make_regions(const Grid &g, Regions &rg)
     return nb >= 1 && nb <= BIN_MAX;
 }
 
+// ---- fused value + gradient (+ Hessian) ------------------------------------------------------------
+// all derivative patterns of total order <= ORDER from ONE pass over the window, instead
+// of one splde call (:1089-1240) per pattern.  Output per query, ldout apart:
+//   [ f, df/dx_1 .. df/dx_D, (ORDER 2:) d2f/dx_1dx_1, d2f/dx_1dx_2, .., d2f/dx_1dx_D, d2f/dx_2dx_2, .. ]
+// Each entry is the reference's sum  sum_window coef * prod_d bas1(nderiv_d; x_d)  for its nderiv
+// pattern; the 1-D factors come from the same window_table as everywhere else.
+template <int D, int ORDER, typename T>
+__global__ void __launch_bounds__(256)
+eval_derivs_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, const T *__restrict__ coef,
+                   T *__restrict__ out, int ldout)
+{
+    constexpr int NOUT = 1 + D + (ORDER == 2 ? D * (D + 1) / 2 : 0);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {
+        double b[ORDER + 1][D][4];
+        int base = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const double x = (double)xq[i * ldxq + d];
+            int ws = 0;
+#pragma unroll
+            for (int a = 0; a <= ORDER; ++a) ws = window_table(g, d, x, a, b[a][d]);
+            base += ws * g.colstride[d];
+        }
+        double acc[NOUT];
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
+        constexpr int NW = D == 1 ? 4 : (D == 2 ? 16 : (D == 3 ? 64 : 256));
+        for (int e = 0; e < NW; ++e) {
+            int k[D], off = 0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                k[d] = (e >> (2 * d)) & 3;
+                off += k[d] * g.colstride[d];
+            }
+            const double c = (double)coef[base + off];
+            double v0[D], v1[D], pex[D];          // pex[d] = prod_{f != d} v0[f]
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                v0[d] = b[0][d][k[d]];
+                v1[d] = b[1][d][k[d]];
+            }
+            double full = 1.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                full *= v0[d];
+                double pd = 1.0;
+#pragma unroll
+                for (int f = 0; f < D; ++f)
+                    if (f != d) pd *= v0[f];
+                pex[d] = pd;
+            }
+            acc[0] = fma(c, full, acc[0]);
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[1 + d] = fma(c, v1[d] * pex[d], acc[1 + d]);
+            if constexpr (ORDER == 2) {
+                int j = 1 + D;
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+#pragma unroll
+                    for (int f = d; f < D; ++f) {
+                        double term;
+                        if (f == d) {
+                            term = b[2][d][k[d]] * pex[d];
+                        } else {
+                            double pdf = 1.0;
+#pragma unroll
+                            for (int h = 0; h < D; ++h)
+                                if (h != d && h != f) pdf *= v0[h];
+                            term = v1[d] * v1[f] * pdf;
+                        }
+                        acc[j] = fma(c, term, acc[j]);
+                        ++j;
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) out[i * ldout + j] = (T)acc[j];
+    }
+}
+
+template <typename T>
+static hipError_t launch_eval_derivs_t(const Grid &g, long long nq, const T *xq, int ldxq, int order,
+                                       const T *coef, T *out, int ldout, hipStream_t st)
+{
+    if (nq <= 0) return hipSuccess;
+    long long blocks = (nq + 255) / 256;
+    if (blocks > 256LL * 32) blocks = 256LL * 32;
+    dim3 gr((unsigned)blocks), bl(256);
+#define SPLPAK_DERIVS(DD)                                                                                         \
+    if (order == 1) hipLaunchKernelGGL((eval_derivs_kernel<DD, 1, T>), gr, bl, 0, st, g, nq, xq, ldxq, coef, out, ldout); \
+    else hipLaunchKernelGGL((eval_derivs_kernel<DD, 2, T>), gr, bl, 0, st, g, nq, xq, ldxq, coef, out, ldout);
+    switch (g.ndim) {
+    case 1: SPLPAK_DERIVS(1) break;
+    case 2: SPLPAK_DERIVS(2) break;
+    case 3: SPLPAK_DERIVS(3) break;
+    default: SPLPAK_DERIVS(4) break;
+    }
+#undef SPLPAK_DERIVS
+    return hipGetLastError();
+}
+
+hipError_t launch_eval_derivs(const Grid &g, long long nq, const double *xq, int ldxq, int order,
+                              const double *coef, double *out, int ldout, hipStream_t st)
+{
+    return launch_eval_derivs_t<double>(g, nq, xq, ldxq, order, coef, out, ldout, st);
+}
+
+hipError_t launch_eval_derivs_f32(const Grid &g, long long nq, const float *xq, int ldxq, int order,
+                                  const float *coef, float *out, int ldout, hipStream_t st)
+{
+    return launch_eval_derivs_t<float>(g, nq, xq, ldxq, order, coef, out, ldout, st);
+}
+
 template <typename T>
 static hipError_t launch_eval_t(const Grid &g, long long nq, const T *xq, int ldxq,
                                 const int *nderiv, const T *coef, T *out, hipStream_t st)

@@ -8,6 +8,11 @@ namespace splpak {
 // ---- eval.hip
 hipError_t launch_eval(const Grid &g, long long nq, const double *xq, int ldxq, const int *nderiv,
                        const double *coef, double *out, hipStream_t st);
+// value + gradient (order 1) (+ Hessian upper triangle, order 2) per query, ldout apart
+hipError_t launch_eval_derivs(const Grid &g, long long nq, const double *xq, int ldxq, int order,
+                              const double *coef, double *out, int ldout, hipStream_t st);
+hipError_t launch_eval_derivs_f32(const Grid &g, long long nq, const float *xq, int ldxq, int order,
+                                  const float *coef, float *out, int ldout, hipStream_t st);
 // evaluation path of the calling thread: 0 auto, 1 direct (global gathers), 2 binned (LDS tiles);
 // chunk = queries sorted per pass of the binned path (0 = default)
 void set_eval_mode(int mode, long long chunk);

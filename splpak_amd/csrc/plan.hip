@@ -552,6 +552,29 @@ int32_t splpak_eval_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int3
     return v;
 }
 
+static int derivs_nout(int ndim, int order) { return 1 + ndim + (order == 2 ? ndim * (ndim + 1) / 2 : 0); }
+
+int32_t splpak_eval_derivs_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int32_t ldxq, int32_t order,
+                                   const double *coef_dev, const double *xmin, const double *xmax,
+                                   const int32_t *nodes, double *out_dev, int32_t ldout, void *stream)
+{
+    if (!nodes || !xmin || !xmax) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    Grid g;
+    const int v = eval_validate(ndim, nullptr, xmin, xmax, nodes, g);
+    if (v != 0) {
+        if (v > 0 && out_dev && nq > 0 && ldout > 0)
+            (void)hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)nq * (size_t)ldout, (hipStream_t)stream);
+        return v;
+    }
+    if (order < 1 || order > 2) { set_error("order must be 1 (gradient) or 2 (gradient and Hessian)"); return SPLPAK_E_BADARG; }
+    if (ldxq < ndim || ldout < derivs_nout(ndim, order)) { set_error("ldxq or ldout too small"); return SPLPAK_E_BADARG; }
+    if (nq <= 0) return 0;
+    if (!xq_dev || !coef_dev || !out_dev) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (int r = device_ready()) return r;
+    SPLPAK_HIP_TRY(launch_eval_derivs(g, nq, xq_dev, ldxq, order, coef_dev, out_dev, ldout, (hipStream_t)stream), SPLPAK_E_NODEVICE);
+    return 0;
+}
+
 }  // extern "C"
 
 template <typename T>
@@ -595,7 +618,64 @@ static int32_t eval_host(int32_t ndim, int64_t nq, const T *xq, int32_t ldxq, co
     return rc;
 }
 
+template <typename T>
+static int32_t eval_derivs_host(int32_t ndim, int64_t nq, const T *xq, int32_t ldxq, int32_t order, const T *coef,
+                                const T *xmin_t, const T *xmax_t, const int32_t *nodes, T *out, int32_t ldout)
+{
+    if (!nodes || !xmin_t || !xmax_t) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (ndim < 1) return 101;
+    if (ndim > MAXD) return SPLPAK_E_UNSUPPORTED;
+    double xmin[MAXD], xmax[MAXD];
+    for (int d = 0; d < ndim; ++d) { xmin[d] = (double)xmin_t[d]; xmax[d] = (double)xmax_t[d]; }
+    Grid g;
+    const int v = eval_validate(ndim, nullptr, xmin, xmax, nodes, g);
+    if (v != 0) {
+        if (v > 0 && out && ldout > 0) for (int64_t i = 0; i < nq * ldout; ++i) out[i] = (T)0;
+        return v;
+    }
+    if (order < 1 || order > 2) { set_error("order must be 1 (gradient) or 2 (gradient and Hessian)"); return SPLPAK_E_BADARG; }
+    if (ldxq < ndim || ldout < derivs_nout(ndim, order)) { set_error("ldxq or ldout too small"); return SPLPAK_E_BADARG; }
+    if (nq <= 0) return 0;
+    if (!xq || !coef || !out) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (int r = device_ready()) return r;
+    T *dq = nullptr, *dc = nullptr, *dout = nullptr;
+    splpak_plan holder;   // only used as an allocation owner
+    bool ok = dev_alloc(&holder, &dq, (size_t)nq * ldxq) && dev_alloc(&holder, &dc, (size_t)g.ncol) &&
+              dev_alloc(&holder, &dout, (size_t)nq * ldout);
+    int rc = 0;
+    if (!ok) rc = SPLPAK_E_NOMEM;
+    if (ok) {
+        hipError_t e = hipMemcpy(dq, xq, sizeof(T) * (size_t)nq * ldxq, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dc, coef, sizeof(T) * (size_t)g.ncol, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(dout, 0, sizeof(T) * (size_t)nq * ldout);
+        if (e == hipSuccess) {
+            if constexpr (sizeof(T) == 8)
+                e = launch_eval_derivs(g, nq, (const double *)dq, ldxq, order, (const double *)dc, (double *)dout, ldout, nullptr);
+            else
+                e = launch_eval_derivs_f32(g, nq, (const float *)dq, ldxq, order, (const float *)dc, (float *)dout, ldout, nullptr);
+        }
+        if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(T) * (size_t)nq * ldout, hipMemcpyDeviceToHost);
+        if (!hip_ok(e, "evaluation")) rc = SPLPAK_E_NODEVICE;
+    }
+    for (void *q : holder.owned) (void)hipFree(q);
+    return rc;
+}
+
 extern "C" {
+
+int32_t splpak_eval_derivs_f64(int32_t ndim, int64_t nq, const double *xq, int32_t ldxq, int32_t order,
+                               const double *coef, const double *xmin, const double *xmax,
+                               const int32_t *nodes, double *out, int32_t ldout)
+{
+    return eval_derivs_host<double>(ndim, nq, xq, ldxq, order, coef, xmin, xmax, nodes, out, ldout);
+}
+
+int32_t splpak_eval_derivs_f32(int32_t ndim, int64_t nq, const float *xq, int32_t ldxq, int32_t order,
+                               const float *coef, const float *xmin, const float *xmax,
+                               const int32_t *nodes, float *out, int32_t ldout)
+{
+    return eval_derivs_host<float>(ndim, nq, xq, ldxq, order, coef, xmin, xmax, nodes, out, ldout);
+}
 
 int32_t splpak_eval_f64(int32_t ndim, int64_t nq, const double *xq, int32_t ldxq,
                         const int32_t *nderiv, const double *coef, const double *xmin,

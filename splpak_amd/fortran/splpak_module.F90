@@ -14,7 +14,8 @@
 !!    not enforced, because the GPU path does not need the ncol*(ncol+1) array (550 GB
 !!    at 64^3 nodes).  After a successful fit with xtrap /= 0 `work(1:ncol)` holds the
 !!    sparse-area histogram exactly as the reference leaves it (:879-907).
-!!  * additive: `evaluate_many` evaluates a batch of points in one kernel launch.
+!!  * additive: `evaluate_many` evaluates a batch of points in one kernel launch,
+!!    `evaluate_derivatives` value + gradient (+ Hessian) of a batch in one pass.
 !!
 !! Build with -DREAL32 for single precision storage (as the reference, :33-41);
 !! REAL128 has no GPU path and is rejected at compile time.
@@ -45,6 +46,7 @@ module splpak_module
         generic,public   :: initialize    => splcc, splcw        !! fit
         generic,public   :: evaluate      => splfe, splde        !! one point
         generic,public   :: evaluate_many => splfe_many, splde_many  !! batch of points (additive)
+        procedure,public :: evaluate_derivatives => splpak_derivs_many !! value + gradient (+ Hessian) of a batch (additive)
         procedure,public :: destroy       => destroy_splpak
         procedure,private :: splcc
         procedure,private :: splcw
@@ -52,6 +54,7 @@ module splpak_module
         procedure,private :: splde
         procedure,private :: splfe_many
         procedure,private :: splde_many
+        procedure,private :: splpak_derivs_many
     end type splpak_type
 
     interface
@@ -80,6 +83,18 @@ module splpak_module
             integer(c_int64_t),value :: nq
             type(c_ptr),value :: xq, nderiv, coef, xmin, xmax, nodes, out
         end function c_eval
+#ifdef REAL32
+        integer(c_int32_t) function c_eval_derivs(ndim,nq,xq,ldxq,order,coef,xmin,xmax,nodes,out,ldout) &
+                                                  bind(C,name='splpak_eval_derivs_f32')
+#else
+        integer(c_int32_t) function c_eval_derivs(ndim,nq,xq,ldxq,order,coef,xmin,xmax,nodes,out,ldout) &
+                                                  bind(C,name='splpak_eval_derivs_f64')
+#endif
+            import :: c_int32_t, c_int64_t, c_ptr
+            integer(c_int32_t),value :: ndim, ldxq, order, ldout
+            integer(c_int64_t),value :: nq
+            type(c_ptr),value :: xq, coef, xmin, xmax, nodes, out
+        end function c_eval_derivs
         integer(c_int32_t) function c_last_error(buf,buflen) bind(C,name='splpak_last_error_message')
             import :: c_int32_t, c_char
             character(kind=c_char) :: buf(*)
@@ -274,6 +289,35 @@ module splpak_module
         call eval_common(me,ndim,int(nq,c_int64_t),c_loc(x),ldx,c_loc(nderiv),c_loc(coef),c_loc(xmin), &
                          c_loc(xmax),c_loc(nodes),c_loc(f),ierror)
     end subroutine splde_many
+
+    !> Value, gradient and (order = 2) Hessian of a batch of points in one pass: column i of
+    !! f(ldf,nq) holds [ f, df/dx_1..df/dx_ndim, then for order 2 the upper triangle of the Hessian
+    !! row by row ] at x(:,i) -- what 1 + ndim (+ ndim(ndim+1)/2) `evaluate` calls with the
+    !! matching nderiv would return (splde, reference :1089-1240).
+    subroutine splpak_derivs_many(me,ndim,nq,x,ldx,order,coef,xmin,xmax,nodes,f,ldf,ierror)
+        class(splpak_type),intent(inout) :: me
+        integer,intent(in) :: ndim, nq, ldx, order, ldf
+        real(wp),intent(in),target :: x(ldx,*)
+        real(wp),intent(in),target :: coef(*)
+        real(wp),intent(in),target :: xmin(*), xmax(*)
+        integer,intent(in),target :: nodes(*)
+        real(wp),intent(out),target :: f(ldf,*)
+        integer,intent(out) :: ierror
+        integer(c_int32_t) :: rc
+        me%mdim = ndim
+        rc = c_eval_derivs(int(ndim,c_int32_t), int(nq,c_int64_t), c_loc(x), int(ldx,c_int32_t), &
+                           int(order,c_int32_t), c_loc(coef), c_loc(xmin), c_loc(xmax), c_loc(nodes), &
+                           c_loc(f), int(ldf,c_int32_t))
+        ierror = int(rc)
+        select case (ierror)
+        case (0)
+        case (101); call report(ierror,' splfe or splde - NDIM is less than 1')
+        case (102); call report(ierror,' splfe or splde - NODES(IDIM) is less than  4for some IDIM')
+        case (103); call report(ierror,' splfe or splde - XMIN(IDIM) = XMAX(IDIM) for some IDIM')
+        case default
+            if (ierror < 0) call report_library_failure(ierror,'evaluate_derivatives')
+        end select
+    end subroutine splpak_derivs_many
 
     subroutine eval_common(me,ndim,nq,x,ldx,nderiv,coef,xmin,xmax,nodes,f,ierror)
         class(splpak_type),intent(inout) :: me

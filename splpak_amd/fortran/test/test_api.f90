@@ -6,7 +6,7 @@ program test_api
     integer,parameter :: m = 2000
     integer :: nodes(2), ierror, i, nbad
     real(wp) :: xdata(2,m), ydata(m), xmin(2), xmax(2), coef(64), work(64*65), x(2), f, fx, u
-    real(wp) :: xs(2,50), fs(50)
+    real(wp) :: xs(2,50), fs(50), jet(6,50)
     integer(8) :: s
     type(splpak_type) :: solver
 
@@ -47,6 +47,19 @@ program test_api
     end do
     call solver%evaluate_many(2,50,xs,2,[0,1],coef,xmin,xmax,nodes,fs,ierror); call expect(ierror,0)
     if (maxval(abs(fs + 3.0_wp)) > 1.0e-9_wp) call fail('evaluate_many derivative')
+
+    ! value + gradient + Hessian in one pass: plane -> gradient (2,-3), zero Hessian; columns = splde patterns
+    call solver%evaluate_derivatives(2,50,xs,2,2,coef,xmin,xmax,nodes,jet,6,ierror); call expect(ierror,0)
+    if (maxval(abs(jet(2,:) - 2.0_wp)) > 1.0e-9_wp .or. maxval(abs(jet(3,:) + 3.0_wp)) > 1.0e-9_wp) &
+        call fail('evaluate_derivatives gradient')
+    if (maxval(abs(jet(4:6,:))) > 1.0e-6_wp) call fail('evaluate_derivatives Hessian of a plane')
+    do i = 1, 50, 7
+        f = solver%evaluate(2,xs(:,i),coef,xmin,xmax,nodes,ierror)
+        if (abs(jet(1,i) - f) > 1.0e-12_wp*max(1.0_wp,abs(f))) call fail('evaluate_derivatives value')
+        fx = solver%evaluate(2,xs(:,i),[1,1],coef,xmin,xmax,nodes,ierror)
+        if (abs(jet(5,i) - fx) > 1.0e-9_wp) call fail('evaluate_derivatives mixed derivative')
+    end do
+    call solver%evaluate_derivatives(2,50,xs,2,1,coef,xmin,xmin,nodes,jet,6,ierror); call expect(ierror,103)
 
     if (nbad /= 0) error stop 'test_api FAILED'
     write(*,*) 'PASS test_api'

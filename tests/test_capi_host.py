@@ -63,6 +63,18 @@ def test_eval_rejects_short_leading_dimension():
     assert capi.lib().splpak_set_eval_mode(0, 0) == 0
 
 
+def test_eval_derivs_validation_without_gpu():
+    q = np.array([[0.3, 0.4]])
+    c = np.ones(16)
+    assert capi.evaluate_derivs(0, q, 1, c, [0.0, 0.0], [1.0, 1.0], [4, 4])[1] == 101
+    assert capi.evaluate_derivs(2, q, 1, c, [0.0, 0.0], [1.0, 1.0], [4, 3])[1] == 102
+    assert capi.evaluate_derivs(2, q, 1, c, [0.0, 0.0], [1.0, 0.0], [4, 4])[1] == 103
+    with pytest.raises(capi.SplpakError) as e:
+        capi.evaluate_derivs(2, q, 0, c, [0.0, 0.0], [1.0, 1.0], [4, 4])
+    assert "-3" in str(e.value)
+    assert capi.derivs_nout(3, 1) == 4 and capi.derivs_nout(3, 2) == 10 and capi.derivs_nout(4, 2) == 15
+
+
 def test_no_cpu_fallback_without_gpu():
     """On a box without a GPU the compute path must fail loudly, not fall back."""
     import torch

@@ -136,6 +136,43 @@ def test_eval_binned_path_is_bit_identical_to_direct(port, nodes):
         capi.set_eval_mode(7)
 
 
+@pytest.mark.parametrize("name", ["c1_1d16", "2d16", "3d8", "3d_aniso", "4d6"])
+def test_eval_derivs_matches_splde_patterns(port, name):
+    """Fused value / gradient / Hessian evaluation: every output column equals splde with the
+    matching nderiv pattern -- against the reference's golden values where they exist, the GPU's
+    single-pattern path and the oracle otherwise."""
+    spec = CASES[name]
+    gold = load_golden(name)
+    inp = make_inputs(spec)
+    nd, nodes, lo, hi = inp["ndim"], inp["nodes"], inp["xmin"], inp["xmax"]
+    q = make_queries(spec)
+    coef = gold["coef"]
+    dxin = (np.array(spec["nodes"]) - 1) / (hi - lo)
+    cmax = np.max(np.abs(coef))
+    for order in (1, 2):
+        out, rc = capi.evaluate_derivs(nd, q, order, coef, lo, hi, nodes)
+        assert rc == 0 and out.shape == (q.shape[0], capi.derivs_nout(nd, order))
+        pats = [[0] * nd] + [[int(e == d) for e in range(nd)] for d in range(nd)]
+        if order == 2:
+            pats += [[int(e == d) + int(e == f) for e in range(nd)] for d in range(nd) for f in range(d, nd)]
+        for j, p in enumerate(pats):
+            ref, rc1 = capi.evaluate(nd, q, p, coef, lo, hi, nodes)
+            scale = max(np.max(np.abs(ref)), cmax * float(np.prod(dxin ** np.array(p))))
+            assert np.max(np.abs(out[:, j] - ref)) <= EVAL_TOL * scale, (name, order, p)
+            vo, _ = port.evaluate(nd, q[:200], p, coef, lo, hi, nodes)
+            assert np.max(np.abs(out[:200, j] - vo)) <= EVAL_TOL * scale, (name, order, p)
+    # real32 twin and argument errors
+    o32, rc = capi.evaluate_derivs(nd, q.astype(np.float32), 1, coef.astype(np.float32), lo, hi, nodes, real32=True)
+    assert rc == 0 and o32.dtype == np.float32
+    o64, _ = capi.evaluate_derivs(nd, q.astype(np.float32).astype(np.float64), 1,
+                                  coef.astype(np.float32).astype(np.float64), lo, hi, nodes)
+    assert np.max(np.abs(o32 - o64)) <= 2e-5 * max(np.max(np.abs(o64)), 1e-30)
+    with pytest.raises(capi.SplpakError):
+        capi.evaluate_derivs(nd, q, 3, coef, lo, hi, nodes)
+    z, rc = capi.evaluate_derivs(nd, q, 1, coef, lo, lo, nodes)      # xmin == xmax: 103, zeros
+    assert rc == 103 and not z.any()
+
+
 # ---------------------------------------------------------------------------
 # fit
 # ---------------------------------------------------------------------------
