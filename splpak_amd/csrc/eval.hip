@@ -447,34 +447,56 @@ eval_derivs_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, con
         double acc[NOUT];
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
-        constexpr int NW = D == 1 ? 4 : (D == 2 ? 16 : (D == 3 ? 64 : 256));
-        for (int e = 0; e < NW; ++e) {
+        // window rows (k_0 = 0..3 contiguous): contract dimension 1 with its value / first / second
+        // derivative factors first, then combine with the factors of the other dimensions
+        constexpr int NROW = D == 1 ? 1 : (D == 2 ? 4 : (D == 3 ? 16 : 64));
+        for (int e = 0; e < NROW; ++e) {
             int k[D], off = 0;
+            k[0] = 0;
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                k[d] = (e >> (2 * d)) & 3;
+            for (int d = 1; d < D; ++d) {
+                k[d] = (e >> (2 * (d - 1))) & 3;
                 off += k[d] * g.colstride[d];
             }
-            const double c = (double)coef[base + off];
-            double v0[D], v1[D], pex[D];          // pex[d] = prod_{f != d} v0[f]
+            double c[4];
+            if constexpr (sizeof(T) == 8) {
+                typedef double d2v __attribute__((ext_vector_type(2), aligned(8)));
+                const d2v lo2 = *reinterpret_cast<const d2v *>(coef + base + off);
+                const d2v hi2 = *reinterpret_cast<const d2v *>(coef + base + off + 2);
+                c[0] = lo2[0]; c[1] = lo2[1]; c[2] = hi2[0]; c[3] = hi2[1];
+            } else {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
+                for (int k0 = 0; k0 < 4; ++k0) c[k0] = (double)coef[base + off + k0];
+            }
+            double r[ORDER + 1];                  // r[a] = sum_k0 c[k0] * (a-th derivative factor of dim 1)
+#pragma unroll
+            for (int a = 0; a <= ORDER; ++a) {
+                double t = 0.0;
+#pragma unroll
+                for (int k0 = 0; k0 < 4; ++k0) t = fma(c[k0], b[a][0][k0], t);
+                r[a] = t;
+            }
+            double v0[D], v1[D], pex[D];          // dims >= 1: pex[d] = prod_{f >= 1, f != d} v0[f]
+            double full = 1.0;                    // prod_{f >= 1} v0[f]
+            v0[0] = v1[0] = pex[0] = 1.0;
+#pragma unroll
+            for (int d = 1; d < D; ++d) {
                 v0[d] = b[0][d][k[d]];
                 v1[d] = b[1][d][k[d]];
-            }
-            double full = 1.0;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
                 full *= v0[d];
+            }
+#pragma unroll
+            for (int d = 1; d < D; ++d) {
                 double pd = 1.0;
 #pragma unroll
-                for (int f = 0; f < D; ++f)
+                for (int f = 1; f < D; ++f)
                     if (f != d) pd *= v0[f];
                 pex[d] = pd;
             }
-            acc[0] = fma(c, full, acc[0]);
+            acc[0] = fma(r[0], full, acc[0]);
+            acc[1] = fma(r[1], full, acc[1]);
 #pragma unroll
-            for (int d = 0; d < D; ++d) acc[1 + d] = fma(c, v1[d] * pex[d], acc[1 + d]);
+            for (int d = 1; d < D; ++d) acc[1 + d] = fma(r[0], v1[d] * pex[d], acc[1 + d]);
             if constexpr (ORDER == 2) {
                 int j = 1 + D;
 #pragma unroll
@@ -482,16 +504,20 @@ eval_derivs_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, con
 #pragma unroll
                     for (int f = d; f < D; ++f) {
                         double term;
-                        if (f == d) {
-                            term = b[2][d][k[d]] * pex[d];
+                        if (d == 0 && f == 0) {
+                            term = r[2] * full;
+                        } else if (d == 0) {
+                            term = r[1] * (v1[f] * pex[f]);
+                        } else if (f == d) {
+                            term = r[0] * (b[2][d][k[d]] * pex[d]);
                         } else {
                             double pdf = 1.0;
 #pragma unroll
-                            for (int h = 0; h < D; ++h)
+                            for (int h = 1; h < D; ++h)
                                 if (h != d && h != f) pdf *= v0[h];
-                            term = v1[d] * v1[f] * pdf;
+                            term = r[0] * (v1[d] * v1[f] * pdf);
                         }
-                        acc[j] = fma(c, term, acc[j]);
+                        acc[j] += term;
                         ++j;
                     }
             }
