@@ -120,6 +120,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the splpak HIP path has no CPU fallback")
+    # rehearsal aids for a one-GPU box: all ranks on device 0 and/or a gloo process group
+    if os.environ.get("SPLPAK_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     numa_node = pin_to_gpu_numa_node(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -127,7 +130,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("SPLPAK_BENCH_BACKEND", "nccl")          # nccl = RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from splpak_amd import capi
 
