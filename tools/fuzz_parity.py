@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""One-off randomized parity sweep of the HIP fit / evaluation against the CPU oracle (not part of the
+test tier): random dimensions, node counts, boxes, weights, xtrap, points outside the box."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from splpak_amd import capi
+from oracle import binding
+
+port = binding.Port()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2026)
+worst, fails = 0.0, 0
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
+    nd = int(rng.integers(1, 5))
+    hi_nodes = {1: 40, 2: 14, 3: 8, 4: 6}[nd]
+    nodes = [int(rng.integers(4, hi_nodes + 1)) for _ in range(nd)]
+    ncol = int(np.prod(nodes))
+    m = int(rng.integers(max(ncol // 2, 8), 6 * ncol + 50))
+    lo = rng.normal(size=nd)
+    hi = lo + 0.2 + 3.0 * rng.random(nd)
+    spread = 1.0 + 0.3 * rng.random()
+    x = lo + (hi - lo) * (0.5 + spread * (rng.random((m, nd)) - 0.5))
+    if rng.random() < 0.3:                       # clustered data -> sparse areas
+        x[: m // 2] = lo + (hi - lo) * 0.3 * rng.random((m // 2, nd))
+    y = np.sin(3.0 * ((x - lo) / (hi - lo)).sum(axis=1)) + 0.1 * rng.standard_normal(m)
+    w = None if rng.random() < 0.3 else 0.2 + rng.random(m)
+    if w is not None and rng.random() < 0.5:
+        w[rng.random(m) < 0.1] = 0.0
+    xtrap = float(rng.choice([0.0, 0.3, 1.0, 2.5]))
+    # generous workspace: the reference's own size check (suprls 32 -> 107, :1443-1454) is not under test
+    c0, e0, w0 = port.fit(nd, x, y, w, lo, hi, nodes, xtrap, nwrk=ncol * (ncol + 1) + 64)
+    c1, e1, h1, _ = capi.fit(nd, x, y, w, lo, hi, nodes, xtrap, want_hist=True)
+    tag = f"trial {trial:3d} nd={nd} nodes={nodes} m={m} xtrap={xtrap} weighted={w is not None}"
+    if e0 != e1:
+        # the reference reports 107 only on an EXACT zero pivot and otherwise returns whatever a numerically
+        # singular system gives (documented deviation): accept hip = 107 when the oracle's coefficients blew up
+        singular = e0 == 0 and e1 == 107 and np.max(np.abs(c0[:ncol])) > 1e4 * np.max(np.abs(y))
+        print(tag, f"ierror oracle {e0} hip {e1}", "(numerically singular: oracle max|coef| = %.1e)" % np.max(np.abs(c0[:ncol])) if singular else "<-- FAIL")
+        fails += 0 if singular else 1
+        continue
+    if e0 != 0:
+        continue
+    rel = np.max(np.abs(c1[:ncol] - c0[:ncol])) / max(np.max(np.abs(c0[:ncol])), 1e-300)
+    q = lo + (hi - lo) * (rng.random((300, nd)) * 1.4 - 0.2)
+    p = [int(rng.integers(0, 3)) for _ in range(nd)]
+    v1, _ = capi.evaluate(nd, q, p, c0, lo, hi, nodes)
+    v0, _ = port.evaluate(nd, q, p, c0, lo, hi, nodes)
+    dxin = (np.array(nodes) - 1) / (hi - lo)
+    scale = max(np.max(np.abs(v0)), np.max(np.abs(c0)) * float(np.prod(dxin ** np.array(p))))
+    erel = np.max(np.abs(v1 - v0)) / scale
+    # coefficients far larger than the data: an ill-conditioned (or numerically singular, non-unique) problem,
+    # where the reference's own result is only accurate to cond*eps -- compare residual-equivalent answers loosely
+    illposed = np.max(np.abs(c0[:ncol])) > 100.0 * np.max(np.abs(y))
+    if illposed:
+        print(tag, f"ill-conditioned (oracle max|coef| {np.max(np.abs(c0[:ncol])):.1e}): coef rel {rel:.2e} not judged")
+        rel = 0.0
+    worst = max(worst, rel)
+    bad = rel > 1e-10 or erel > 1e-12 or (xtrap != 0 and np.max(np.abs(h1[:ncol] - w0[:ncol])) > 1e-12 * max(np.max(np.abs(w0[:ncol])), 1))
+    if bad:
+        fails += 1
+        print(tag, f"coef rel {rel:.2e} eval rel {erel:.2e}  <-- FAIL")
+print(f"worst coefficient deviation {worst:.2e}; failures {fails}")
+sys.exit(1 if fails else 0)
