@@ -1100,9 +1100,9 @@ Pipeline &pipeline(int nblk)
         p.evU.push_back(e);
         (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
         p.evC.push_back(e);
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        (void)hipEventCreate(&e);                 // evI[k], evT[k]: completion (stop event) of potrf(k) / the top panel solve
         p.evI.push_back(e);
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        (void)hipEventCreate(&e);
         p.evT.push_back(e);
     }
     return p;
@@ -1208,22 +1208,22 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
             (void)hipEventRecord(pl.evR[0], sP);
             (void)hipStreamWaitEvent(sR, pl.evR[0], 0);
         }
-        hipLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, sR, b.ab, b.lda, k0, info_dev,
-                           minpiv_dev, b.inv64 + (long long)k * 4 * 64 * 64);
-        if (sR != sP) {
-            (void)hipEventRecord(pl.evR[1], sR);
-            (void)hipStreamWaitEvent(sP, pl.evR[1], 0);
-        }
-        (void)hipEventRecord(pl.evI[k], sP);
+        // the kernel's completion is evI[k] (stop event of the dispatch): no separate record packets
+        hipExtLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, sR, nullptr, pl.evI[k], 0, b.ab, b.lda, k0,
+                              info_dev, minpiv_dev, b.inv64 + (long long)k * 4 * 64 * 64);
+        if (sR != sP) (void)hipStreamWaitEvent(sP, pl.evI[k], 0);
     };
     // panel solve of rows [r0, r1) below the diagonal block k
-    auto trsm = [&](hipStream_t s, int k, int r0, int r1) {
+    auto trsm = [&](hipStream_t s, int k, int r0, int r1, hipEvent_t done = nullptr) {
         const int k0 = k * NBLK;
-        if (r1 <= r0) return;
+        if (r1 <= r0) {
+            if (done) (void)hipEventRecord(done, s);
+            return;
+        }
         const double *Lk = b.ab + (long long)k0 + (long long)k0 * b.lda;
         double *Xk = b.ab + (long long)(k0 + NBLK + r0) + (long long)k0 * b.lda;
         const double *ik = b.inv64 + (long long)k * 4 * 64 * 64;
-        hipLaunchKernelGGL(trsm_kernel, dim3((r1 - r0) / 16), dim3(64), 0, s, Lk, Xk, b.lda, ik, r1 - r0);
+        hipExtLaunchKernelGGL(trsm_kernel, dim3((r1 - r0) / 16), dim3(64), 0, s, nullptr, done, 0, Lk, Xk, b.lda, ik, r1 - r0);
     };
 
     // Dependency structure per step k (X_k = solved panel k; block (I,J) = 256x256 block):
@@ -1242,9 +1242,8 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     if (sR != sP) (void)hipStreamWaitEvent(sR, pl.evU[b.nblk], 0);
     (void)hipStreamWaitEvent(sU, pl.evU[b.nblk], 0);
     potrf(0);
-    trsm(sP, 0, 0, tb_of(0) * NBLK);
+    trsm(sP, 0, 0, tb_of(0) * NBLK, pl.evT[0]);
     (void)hipEventRecord(pl.evP[0], sP);
-    (void)hipEventRecord(pl.evT[0], sP);
     for (int k = 0; k < b.nblk; ++k) {
         const int tb = tb_of(k);
         if (tb <= 0) continue;
@@ -1261,8 +1260,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         (void)hipEventRecord(pl.evC[k], sC);
         syrk(sC, k, 0, 4, 8, n64);                      // colU: blocks (>=k+3, k+1)
         (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
-        trsm(sP, k + 1, 0, nrows1 < NBLK ? nrows1 : NBLK);
-        (void)hipEventRecord(pl.evT[k + 1], sP);
+        trsm(sP, k + 1, 0, nrows1 < NBLK ? nrows1 : NBLK, pl.evT[k + 1]);
         (void)hipStreamWaitEvent(sC, pl.evI[k + 1], 0);
         trsm(sC, k + 1, NBLK, nrows1);
         (void)hipStreamWaitEvent(sC, pl.evT[k + 1], 0);
