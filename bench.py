@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--neval", type=int, default=50_000_000, help="evaluation queries per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the C2 and host-pointer (PCIe-inclusive) legs")
     return ap.parse_args()
 
 
@@ -113,11 +114,73 @@ def pin_to_gpu_numa_node(local_rank):
     return None
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes, one rank per GPU
+    (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment), BEFORE this process has touched the
+    GPU -- nothing is ever exec'ed from a process that initialised HIP.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(p.wait() for p in procs)
+
+
+def bench_c2(capi, dev, stream, steps):
+    """BASELINE config 2 (2-D, 1e6 scattered points, 64x64 nodes, equal weights = splcc), resident data."""
+    import torch
+    nd, nodes, m = 2, [64, 64], 1_000_000
+    x = torch.empty((m, nd), dtype=torch.float64, device=dev)
+    y = torch.empty(m, dtype=torch.float64, device=dev)
+    capi.synth_points_dev(nd, 0, m, x, y, None, stream)
+    coef = torch.zeros(64 * 64, dtype=torch.float64, device=dev)
+    plan = capi.Plan(nd, nodes, [0.0] * nd, [1.0] * nd, 1.0, m)
+    for _ in range(3):
+        ierr, info = plan.fit(x, y, None, coef, stream)
+        assert ierr == 0, f"C2 fit failed with ierror {ierr}"
+    torch.cuda.synchronize()
+    n = max(steps, 10)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ierr, info = plan.fit(x, y, None, coef, stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    plan.close()
+    assert ierr == 0 and info[9] < 1e-9, f"C2: ierror {ierr}, optimality residual {info[9]:.2e}"
+    return {"workload": "C2: 2-D splcc fit, 1e6 scattered points (same stream), 64x64 nodes, xtrap=1, real64, resident data",
+            "value": m / dt, "unit": "points/s", "ms_per_fit": 1e3 * dt, "fits_timed": n,
+            "refine_steps": int(info[2]), "optimality_residual": float(info[9])}
+
+
+def bench_incl_h2d(capi, x, y, w, lo, hi, nodes):
+    """The host-pointer entry (what the Fortran module binds): pageable host arrays in, coefficients
+    out, PCIe transfers included.  Never `value`."""
+    xh, yh, wh = x.cpu().numpy(), y.cpu().numpy(), w.cpu().numpy()
+    nd = xh.shape[1]
+    capi.fit(nd, xh, yh, wh, lo, hi, nodes, 1.0)              # first call: plan allocation (cached afterwards)
+    t0 = time.perf_counter()
+    coef, ierr, _, info = capi.fit(nd, xh, yh, wh, lo, hi, nodes, 1.0)
+    dt = time.perf_counter() - t0
+    assert ierr == 0
+    return {"value": xh.shape[0] / dt, "unit": "points/s", "seconds": dt,
+            "what": "splpak_fit_f64 on host arrays: H2D of xdata/ydata/wdata + fit + D2H of coef, second call of the process"}
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the splpak HIP path has no CPU fallback")
     # rehearsal aids for a one-GPU box: all ranks on device 0 and/or a gloo process group
@@ -179,6 +242,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert ierr == 0, f"fit failed with ierror {ierr}"
+    # parity gate at the size that is timed: the MEASURED optimality residual of the returned coefficients
+    # (gradient of the least-squares functional, relative to |A^T W^2 y|) must be at rounding level
+    assert info[9] < 1e-9, f"optimality residual {info[9]:.2e} of the timed fit exceeds 1e-9"
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,7 +282,8 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "fitted points/sec (splcw) + evals/sec (splfe), 3-D 1e7 pts 64^3 nodes",
+            "metric": (f"fitted points/sec (splcw) + evals/sec (splfe), {nd}-D {m:.0e} pts {nod}^{nd} nodes"
+                       .replace("e+0", "e").replace("e+", "e")),
             "value": value,
             "unit": "points/s",
             "n_gpus": world,
@@ -235,6 +302,7 @@ def main():
                 "parallelism": "points sharded per GPU; RCCL all-reduce of histogram, normal equations and "
                                "refinement residuals; band Cholesky replicated" if world > 1 else "single GPU",
                 "refine_steps": int(info[2]), "last_correction_rel": float(info[3]),
+                "optimality_residual": float(info[9]), "residual_norm": float(info[8]),
                 "data_rows": float(info[0]), "constraint_rows": float(info[1]),
                 "phase_seconds_per_step": {"assembly": phase[0] / args.steps, "factor": phase[1] / args.steps,
                                            "solve_refine": phase[2] / args.steps},
@@ -270,6 +338,9 @@ def main():
                 "flop_share_of_factorisation": kt_sum["bulk_flop"] / max(kt_sum["total_flop"], 1.0),
                 "factorisation_tflops": kt_sum["total_flop"] / max(kt_sum["factor_ms"], 1e-9) / 1e9,
             }
+        if world == 1 and not args.no_side_legs:
+            line["c2"] = bench_c2(capi, dev, stream, args.steps)
+            line["fit_incl_h2d"] = bench_incl_h2d(capi, x, y, w, lo, hi, nodes)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nd)
         print(json.dumps(line), flush=True)

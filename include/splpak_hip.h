@@ -54,7 +54,17 @@ extern "C" {
  *   [3] |last correction|_inf / |coef|_inf, [4] min Cholesky pivot,
  *   [5] seconds in assembly, [6] seconds in factorisation, [7] seconds in solve+refine,
  *   [8] residual norm ||rows*coef - rhs||_2 over data and constraint rows -- the `reserr` that the
- *       reference computes (suprls :1693) and drops (splcw :690, :1052), [9] reserved */
+ *       reference computes (suprls :1693) and drops (splcw :690, :1052),
+ *   [9] measured optimality residual of the returned coefficients: the gradient
+ *       rho = A^T W (W y - W A x) - C^T C x of the least-squares functional (data rows A, constraint rows C),
+ *       recomputed from the rows, as the componentwise backward error
+ *       max_i |rho_i| / ((|N| |x|)_i + |A^T W^2 y|_i), N = A^T W^2 A + C^T C; 0 at the minimiser the reference
+ *       computes, ~1e-14 when the fit is converged, ~cond(N) eps for plain normal equations.
+ * The band-Cholesky solution is refined against the rows until the estimated remaining error
+ * |dx|/|x| is below 1e-12 (2-3 steps at 64^3); a solve that is still contracting after the nominal
+ * number of steps continues (up to 16), and one that then still misses 1e-10, or whose corrections
+ * stop contracting while above 1e-8, is reported as 107 ("suprls failure") with an explanatory
+ * splpak_last_error_message -- never as a silent success. */
 int32_t splpak_fit_f64(int32_t ndim, const double *xdata, int32_t l1xdat,
                        const double *ydata, const double *wdata, int64_t ndata,
                        const double *xmin, const double *xmax, const int32_t *nodes,
@@ -102,9 +112,13 @@ typedef int32_t (*splpak_allreduce_fn)(void *dev_buf, int64_t count, void *strea
 /* Validates exactly like splcw (:716-781; 105/106 are checked at fit time) and
  * allocates every device buffer the fit of a grid needs (band factor, stencil
  * normal equations, sort scratch for up to `max_ndata` points per call).
+ * `max_ndata` (points per call on THIS GPU) is limited to 2^31 - 1025 (32-bit binning offsets);
+ * larger values return SPLPAK_E_UNSUPPORTED.
  * `comm_buf_dev`/`comm_len`: optional caller-owned device buffer (doubles) the
  * all-reduced quantities live in -- pass a torch tensor's data_ptr so the
- * callback can all-reduce views of it; NULL lets the plan allocate it.
+ * callback can all-reduce views of it; NULL lets the plan allocate it.  It must be ordinary
+ * (coarse-grained) device memory from hipMalloc: the assembly kernels add into it with hardware
+ * f64 atomics, which are not defined on fine-grained or host-mapped memory.
  * `splpak_plan_comm_len` tells the required length. */
 int64_t splpak_plan_comm_len(int32_t ndim, const int32_t *nodes);
 int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmin,
@@ -113,13 +127,16 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
 void    splpak_plan_destroy(splpak_plan *plan);
 void    splpak_plan_set_allreduce(splpak_plan *plan, splpak_allreduce_fn fn, void *user,
                                   int32_t rank, int32_t world);
-/* tuning / test knobs: max refinement steps (default 4) and the tolerance on the (estimated)
- * remaining relative error |dx|/|x| after a step (default 1e-12; the parity bar is 1e-10) */
+/* tuning / test knobs: nominal refinement steps (default 4; 0 = none; a solve that still contracts goes on
+ * up to max(steps, 16)) and the tolerance on the (estimated) remaining relative error |dx|/|x| after a
+ * step (default 1e-12; the parity bar is 1e-10) */
 void    splpak_plan_set_refine(splpak_plan *plan, int32_t max_steps, double tol);
 
 /* The fit on resident data.  xdata_dev/ydata_dev/wdata_dev (wdata_dev may be
- * NULL) hold THIS rank's `ndata` points; coef_dev receives ncol coefficients
- * (identical on every rank).  Synchronises `stream` before returning (the error
+ * NULL) hold THIS rank's `ndata` points (with more than one rank a rank may hold none: ndata = 0,
+ * pointers ignored); coef_dev receives ncol coefficients (identical on every rank).  A rank whose
+ * arguments are rejected still takes part in the first reduction, which carries an error flag: that
+ * rank returns its status, the others SPLPAK_E_COMM -- nobody is left waiting in a collective.  Synchronises `stream` before returning (the error
  * flag and the refinement's convergence test are read back).  info as above. */
 int32_t splpak_plan_fit_dev(splpak_plan *plan, const double *xdata_dev, int32_t l1xdat,
                             const double *ydata_dev, const double *wdata_dev,

@@ -17,6 +17,8 @@ Inputs are NOT stored: they are regenerated from the seeded generator
     python oracle/gen_golden.py            # all fast cases
     python oracle/gen_golden.py --slow     # also the ~1 h 64x64 case
     python oracle/gen_golden.py NAME...    # selected cases
+    python oracle/gen_golden.py --real32   # <case>_r32.npz from the REAL32 build of the reference
+                                           # (oracle/_ref/libsplpak_ref32.so, src/splpak.F90:33-41)
 """
 import os
 import sys
@@ -55,8 +57,38 @@ def run_case(R, name, spec, outdir):
           f"|coef|max={np.abs(coef[:ncol]).max():.3e}", flush=True)
 
 
+R32_CASES = ["2d8", "3d8", "4d4"]
+
+
+def run_case_r32(R32, name, spec, outdir):
+    """The reference compiled with -DREAL32 on the inputs rounded to single precision: coefficients,
+    histogram and `evaluate` values for every nderiv pattern, all real32."""
+    inp = make_inputs(spec)
+    nd = inp["ndim"]
+    f32 = lambda a: None if a is None else np.asarray(a, dtype=np.float32)
+    coef, ierr, work = R32.fit(nd, f32(inp["xdata"]), f32(inp["ydata"]), f32(inp["wdata"]), inp["xmin"],
+                               inp["xmax"], inp["nodes"], inp["xtrap"])
+    ncol = int(np.prod(inp["nodes"]))
+    q = f32(make_queries(spec))
+    pats = np.array(nderiv_patterns(nd), dtype=np.int32)
+    vals = np.zeros((len(pats), q.shape[0]), dtype=np.float32)
+    for i, p in enumerate(pats):
+        vals[i], _ = R32.evaluate(nd, q, p, coef, inp["xmin"], inp["xmax"], inp["nodes"])
+    hist = work[:ncol].copy() if inp["xtrap"] != 0.0 else np.zeros(0, dtype=np.float32)
+    np.savez_compressed(os.path.join(outdir, name + "_r32.npz"), coef=coef[:ncol], ierror=np.int32(ierr),
+                        hist=hist, patterns=pats, values=vals)
+    print(f"{name + '_r32':16s} ncol={ncol:5d} m={spec['m']:6d} ierror={ierr} "
+          f"|coef|max={np.abs(coef[:ncol]).max():.3e}", flush=True)
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("-")]
+    if "--real32" in sys.argv:
+        outdir = os.path.join(ROOT, "tests", "golden")
+        R32 = Reference(real32=True)
+        for name in (args or R32_CASES):
+            run_case_r32(R32, name, CASES[name], outdir)
+        return
     slow = "--slow" in sys.argv
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)

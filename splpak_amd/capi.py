@@ -267,8 +267,16 @@ class Plan:
         base = self.comm.data_ptr()
 
         def _cb(ptr, count, stream, user):
+            # The C ABI's contract: the reduction is ordered ON `stream` (the stream the fit was
+            # enqueued on).  torch.distributed orders a collective against torch's CURRENT stream, so
+            # make the library's stream current for the duration of the call.
             try:
-                fn((int(ptr) - base) // 8, int(count))
+                import torch
+                if torch.cuda.is_available():
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0))):
+                        fn((int(ptr) - base) // 8, int(count))
+                else:
+                    fn((int(ptr) - base) // 8, int(count))
                 return 0
             except Exception as exc:  # pragma: no cover - surfaced as SPLPAK_E_COMM
                 print("all-reduce callback failed:", exc, flush=True)

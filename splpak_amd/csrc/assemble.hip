@@ -9,17 +9,29 @@
 // nst[ncol][(7^ndim+1)/2] (row i, columns i+offset with offset tuple in
 // [-3,3]^ndim, lower triangle only).
 //
-// Kernels (all HBM-bound streaming passes; algorithmic bytes 8*(ndim+1+[weighted])
-// per point and pass):
-//   keys_kernel        window key per point, per-cell counts, nearest-node
-//                      sparse-area histogram (:886-907) and total weight
-//   scan_kernel        exclusive scan of the counts
-//   scatter_kernel     counting-sort scatter into cell-ordered SoA copies
-//   gram_kernel        per-cell Gram block: point tables staged in LDS, register
-//                      tiled rank-1 updates, f64 atomics into the half stencil
-//   residual_kernel    rho += A^T W (W y - W A x) for iterative refinement
-//   constraint_kernel  derivative-constraint rows of data-sparse nodes (:921-1046)
-//   expand_kernel      half stencil -> band storage of the Cholesky factorisation
+// No floating-point atomics on this path: every sum has ONE owner and a fixed order, so the normal
+// equations, the sparse-area histogram and every refinement residual are bitwise reproducible from
+// run to run, and the assembly runs at streaming rates instead of the rate of
+// scattered 8-byte atomics (round 1: 3.8 GB of them at 64^3, 19.8 ms).
+//
+//   keys_kernel            window key per point + per-cell counts (integer atomics only)
+//   scan_kernel            exclusive scan of the counts
+//   scatter_kernel         counting-sort scatter into cell-ordered SoA copies (+ original index)
+//   cell_order_kernel      orders the points INSIDE every cell by original index: the scatter's
+//                          cursor order is not reproducible, the per-cell sums below must be
+//   gram_block_kernel      per cell: point tables staged in LDS, register-tiled rank-1 updates;
+//                          the 4^d x 4^d Gram block (packed lower triangle), B^T W^2 y and the
+//                          cell's share of the nearest-node histogram (:886-907) are written with
+//                          plain stores into a scratch image (the not-yet-used band storage)
+//   stencil_gather_kernel  one wave per node: sums the <= 4^d blocks that contain the node, in a
+//                          fixed order, into its stencil row, right-hand side and histogram entry
+//   constraint_rows_kernel derivative-constraint rows of data-sparse nodes (:921-1046), gathered
+//                          per stencil row from the <= 3^d sparse neighbours
+//   residual_block_kernel / constraint_dots_kernel / rho_gather_kernel
+//                          rho = A^T W (W y - W A x) - C^T C x for iterative refinement, same
+//                          owner-gathers structure
+//   expand_kernel          half stencil -> band storage of the Cholesky factorisation
+// HBM roofline: 8*(ndim+1+[weighted]) algorithmic bytes per point and streaming pass.
 #include "basis.hpp"
 #include "kernels.hpp"
 
@@ -39,43 +51,33 @@ template <int D>
 __global__ void __launch_bounds__(256)
 keys_kernel(Grid g, long long m, const double *__restrict__ x, int ldx,
             const double *__restrict__ w, int *__restrict__ key, int *__restrict__ count,
-            double *__restrict__ hist, double *__restrict__ scal)
+            double *__restrict__ scal)
 {
-    double lw = 0.0, lrows = 0.0;
+    double lrows = 0.0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
         const double wv = w ? w[i] : 1.0;
         int k = g.ncell;                       // zero weight: ignored (:799, :891)
         if (wv != 0.0) {
-            double xv[D];
             k = 0;
-#pragma unroll
-            for (int d = 0; d < D; ++d) xv[d] = x[i * ldx + d];        // caller's dimension order
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 int lo, hi;
-                k += window_start(g, d, xv[g.perm[d]], lo, hi) * g.cellstride[d];
+                k += window_start(g, d, x[i * ldx + g.perm[d]], lo, hi) * g.cellstride[d];
             }
             lrows += 1.0;
-            if (hist) {
-                atomicAdd(&hist[nearest_node_address(g, xv)], wv);   // :905
-                lw += wv;                                            // :906
-            }
         }
         key[i] = k;
         atomicAdd(&count[k], 1);
     }
-    lw = wave_sum(lw);
     lrows = wave_sum(lrows);
-    __shared__ double red[2][4];
+    __shared__ double red[4];
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
-    if (lane == 0) { red[0][wv_id] = lw; red[1][wv_id] = lrows; }
+    if (lane == 0) red[wv_id] = lrows;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        const double b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        if (a != 0.0) atomicAdd(&scal[SC_TOTLWT], a);
-        if (b != 0.0) atomicAdd(&scal[SC_NROWS_DATA], b);
+        const double b = red[0] + red[1] + red[2] + red[3];
+        if (b != 0.0) atomicAdd(&scal[SC_NROWS_DATA], b);      // integer-valued: exact in any order
     }
 }
 
@@ -109,7 +111,7 @@ scatter_kernel(Grid g, long long m, const double *__restrict__ x, int ldx,
                const double *__restrict__ y, const double *__restrict__ w,
                const int *__restrict__ key, const int *__restrict__ offset,
                int *__restrict__ cursor, double *__restrict__ xs, double *__restrict__ ys,
-               double *__restrict__ ws, long long cap)
+               double *__restrict__ ws, int *__restrict__ idx, long long cap)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
@@ -120,33 +122,108 @@ scatter_kernel(Grid g, long long m, const double *__restrict__ x, int ldx,
         for (int d = 0; d < D; ++d) xs[(long long)d * cap + pos] = x[i * ldx + g.perm[d]];
         ys[pos] = y[i];
         ws[pos] = w ? w[i] : 1.0;
+        idx[pos] = (int)i;
     }
+}
+
+// Orders the points inside every cell by original index.  The scatter places them in the order in
+// which its atomic cursor was served, which differs from run to run; the per-cell sums of the Gram
+// and residual kernels are taken in storage order, so this is what makes the whole fit reproducible
+// bit for bit.  One workgroup per cell; cells with more than ORDER_CAP points (the image does not fit
+// in LDS) keep the scatter's order -- their sums are still correct, only not reproducible.
+constexpr int ORDER_CAP = 1024;
+template <int D>
+__global__ void __launch_bounds__(256)
+cell_order_kernel(const int *__restrict__ offset, double *__restrict__ xs, double *__restrict__ ys,
+                  double *__restrict__ ws, int *__restrict__ idx, long long cap)
+{
+    __shared__ int sidx[ORDER_CAP];
+    __shared__ double sv[ORDER_CAP * (D + 2)];
+    const int cell = blockIdx.x;
+    const long long beg = offset[cell];
+    const int n = (int)(offset[cell + 1] - beg);
+    if (n < 2 || n > ORDER_CAP) return;
+    const int tid = threadIdx.x;
+    for (int p = tid; p < n; p += 256) {
+        sidx[p] = idx[beg + p];
+#pragma unroll
+        for (int d = 0; d < D; ++d) sv[d * ORDER_CAP + p] = xs[(long long)d * cap + beg + p];
+        sv[D * ORDER_CAP + p] = ys[beg + p];
+        sv[(D + 1) * ORDER_CAP + p] = ws[beg + p];
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += 256) {
+        const int me = sidx[p];
+        int rank = 0;
+        for (int q = 0; q < n; ++q) rank += sidx[q] < me;
+        const long long pos = beg + rank;
+#pragma unroll
+        for (int d = 0; d < D; ++d) xs[(long long)d * cap + pos] = sv[d * ORDER_CAP + p];
+        ys[pos] = sv[D * ORDER_CAP + p];
+        ws[pos] = sv[(D + 1) * ORDER_CAP + p];
+        idx[pos] = me;
+    }
+}
+
+// nearest-node histogram slot of a point INSIDE its cell's window (local index, dim 0 fastest), or -1
+// when the reference's address (:894-902) is not a node of the window: a coordinate so far outside
+// the grid that its dimension is skipped in the Horner address (the :899 quirk).  x is in the plan's
+// internal dimension order; per dimension the arithmetic is the reference's.
+template <int D>
+__device__ inline int nearest_slot(const Grid &g, const double *x)
+{
+#pragma clang fp contract(off)
+    int slot = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const double t = g.dxin[d] * (x[d] - g.xmin[d]) + 0.5;
+        const int inidim = (t >= 2.0e9) ? 2000000000 : (t <= -2.0e9 ? -2000000000 : (int)t);
+        if (inidim < 0 || inidim > g.nodes[d] - 1) return -1;
+        int lo, hi;
+        const int l = inidim - window_start(g, d, x[d], lo, hi);
+        if (l < 0 || l > 3) return -1;
+        slot += l << (2 * d);
+    }
+    return slot;
 }
 
 // ---------------------------------------------------------------------------
 // Per-cell staging shared by the Gram and the residual kernels: for `np` points
 // starting at sorted position `p0`, fill bw[p*LDB + c] = w * ((b0*b1)*b2...) --
 // the row of the weighted least-squares matrix restricted to the cell's window
-// (:833-837) -- and wy[p] = w*y (:806).
+// (:833-837) -- and wy[p] = w*y (:806).  hslot != NULL: also the point's histogram slot
+// (nearest_slot; points whose address lies outside the window are added to `hist` directly).
 template <int D, int NB, int LDB, int NT>
 __device__ inline void stage_points(const Grid &g, const double *__restrict__ xs,
                                     const double *__restrict__ ys,
                                     const double *__restrict__ ws, long long cap, long long p0,
                                     int np, double *tab /*[PCH][D][4]*/, double *bw, double *wy,
-                                    double *wt)
+                                    double *wt, int *hslot, double *__restrict__ hist)
 {
     const int tid = threadIdx.x;
     for (int p = tid; p < np; p += NT) {
         const double wv = ws[p0 + p];
+        double xv[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             double b[4];
-            window_table(g, d, xs[(long long)d * cap + p0 + p], 0, b);
+            xv[d] = xs[(long long)d * cap + p0 + p];
+            window_table(g, d, xv[d], 0, b);
 #pragma unroll
             for (int k = 0; k < 4; ++k) tab[(p * D + d) * 4 + k] = b[k];
         }
         wy[p] = wv * ys[p0 + p];
         wt[p] = wv;
+        if (hslot) {
+            const int sl = nearest_slot<D>(g, xv);
+            hslot[p] = sl;
+            if (sl < 0) {                       // rare: far outside the grid (:899); the only atomic left
+                double xr[MAXD] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int d = 0; d < D; ++d) xr[g.perm[d]] = xv[d];
+                atomicAdd(&hist[nearest_node_address(g, xr)], wv);       // :905
+            }
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < np * NB; idx += NT) {
@@ -177,41 +254,49 @@ template <> struct GramCfg<2> { static constexpr int NB = 16,  TR = 1, TC = 1, N
 template <> struct GramCfg<3> { static constexpr int NB = 64,  TR = 4, TC = 4, NTY = 16, NTX = 16, NT = 256,  PCH = 64; };
 template <> struct GramCfg<4> { static constexpr int NB = 256, TR = 4, TC = 4, NTY = 64, NTX = 16, NT = 1024, PCH = 16; };
 
+// scratch image of the per-cell blocks: [ncell][TRI] packed lower triangles (row-major: entry (r,c),
+// c <= r, at r(r+1)/2 + c), then [ncell][NB] right-hand sides, then [ncell][NB] histogram shares
+__host__ __device__ inline long long gram_tri(int nb) { return (long long)nb * (nb + 1) / 2; }
+
 template <int D>
 __global__ void __launch_bounds__(GramCfg<D>::NT)
-gram_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
-            const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
-            double *__restrict__ nst, double *__restrict__ rhs)
+gram_block_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
+                  const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
+                  double *__restrict__ blk, double *__restrict__ rblk, double *__restrict__ hblk,
+                  double *__restrict__ hist)
 {
     using C = GramCfg<D>;
     constexpr int NB = C::NB, TR = C::TR, TC = C::TC, NT = C::NT, PCH = C::PCH;
     constexpr int CW = C::NTX * TC;            // columns handled by this workgroup
+    constexpr long long TRI = (long long)NB * (NB + 1) / 2;
     const int cell = blockIdx.x;
     const int cpass = blockIdx.y;
     const long long beg = offset[cell], end = offset[cell + 1];
-    if (beg == end) return;
+    if (beg == end) return;                    // the gather skips empty cells
 
     __shared__ double tab[PCH * D * 4];
     __shared__ double bw[PCH * NB];
     __shared__ double wy[PCH];
     __shared__ double wt[PCH];
+    __shared__ int hslot[PCH];
 
     const int tid = threadIdx.x;
     const int ty = tid / C::NTX, tx = tid % C::NTX;
     const int r0 = ty * TR, c0 = cpass * CW + tx * TC;
     const bool tile_on = (tid < C::NTY * C::NTX) && (r0 + TR - 1 >= c0);
-    const bool rhs_on = (cpass == 0) && (tid < NB);
+    const bool vec_on = (cpass == 0) && (tid < NB);
+    const bool hist_on = hblk != nullptr && cpass == 0;
 
     double acc[TR][TC];
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
         for (int j = 0; j < TC; ++j) acc[i][j] = 0.0;
-    double racc = 0.0;
+    double racc = 0.0, hacc = 0.0;
 
     for (long long p0 = beg; p0 < end; p0 += PCH) {
         const int np = (int)((end - p0 < PCH) ? (end - p0) : PCH);
-        stage_points<D, NB, NB, NT>(g, xs, ys, ws, cap, p0, np, tab, bw, wy, wt);
+        stage_points<D, NB, NB, NT>(g, xs, ys, ws, cap, p0, np, tab, bw, wy, wt, hist_on ? hslot : nullptr, hist);
         if (tile_on) {
             for (int p = 0; p < np; ++p) {
                 double a[TR], b[TC];
@@ -225,34 +310,136 @@ gram_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ x
                     for (int j = 0; j < TC; ++j) acc[i][j] += a[i] * b[j];
             }
         }
-        if (rhs_on)
+        if (vec_on) {
             for (int p = 0; p < np; ++p) racc += bw[p * NB + tid] * wy[p];
+            if (hist_on)
+                for (int p = 0; p < np; ++p) hacc += (hslot[p] == tid) ? wt[p] : 0.0;       // :905, in storage order
+        }
         __syncthreads();
     }
 
-    // window -> first node column
-    int colbase = 0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) colbase += ((cell / g.cellstride[d]) % g.cells[d]) * g.colstride[d];
-
     if (tile_on) {
+        double *__restrict__ out = blk + (long long)cell * TRI;
 #pragma unroll
         for (int i = 0; i < TR; ++i) {
             const int r = r0 + i;
-            const int rowcol = local_col<D>(g, colbase, r);
 #pragma unroll
             for (int j = 0; j < TC; ++j) {
                 const int c = c0 + j;
-                if (c > r) continue;           // lower triangle only
-                int o[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d) o[d] = ((c >> (2 * d)) & 3) - ((r >> (2 * d)) & 3);
-                const int code = stencil_code(o, D);
-                atomicAdd(&nst[(long long)rowcol * g.hstencil + code], acc[i][j]);
+                if (c <= r) out[(long long)r * (r + 1) / 2 + c] = acc[i][j];
             }
         }
     }
-    if (rhs_on) atomicAdd(&rhs[local_col<D>(g, colbase, tid)], racc);
+    if (vec_on) {
+        rblk[(long long)cell * NB + tid] = racc;
+        if (hist_on) hblk[(long long)cell * NB + tid] = hacc;
+    }
+}
+
+// Cells whose window contains node `in`: window starts ws_d in [max(in_d - 3, 0), min(in_d, cells_d - 1)],
+// enumerated with dimension 0 fastest -- THE fixed summation order of every gather below.
+template <int D>
+struct CellRange {
+    int lo[D], cnt[D], total;
+    __device__ CellRange(const Grid &g, const int *in)
+    {
+        total = 1;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            lo[d] = in[d] - 3 > 0 ? in[d] - 3 : 0;
+            const int hi = in[d] < g.cells[d] - 1 ? in[d] : g.cells[d] - 1;
+            cnt[d] = hi - lo[d] + 1;
+            total *= cnt[d];
+        }
+    }
+    // e-th cell: its linear index, and the node's local basis index r inside that cell's window
+    __device__ void get(const Grid &g, const int *in, int e, int &cell, int &r) const
+    {
+        cell = 0;
+        r = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int wsd = lo[d] + e % cnt[d];
+            e /= cnt[d];
+            cell += wsd * g.cellstride[d];
+            r += (in[d] - wsd) << (2 * d);
+        }
+    }
+};
+
+// One wave per node i: stencil row nst[i][*], rhs[i] and the node's histogram entry as the sums of
+// the per-cell blocks, cell after cell in CellRange order.  Entry (r, c) of a block, c <= r, belongs
+// to column offset c - r (digit-wise), i.e. stencil code sum_d (c_d - r_d + 3) 7^d; for one cell the
+// lanes c = 0..r hit distinct codes, so the wave accumulates in an LDS row without conflicts.
+template <int D>
+__global__ void __launch_bounds__(256)
+stencil_gather_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ blk,
+                      const double *__restrict__ rblk, const double *__restrict__ hblk,
+                      double *__restrict__ nst, double *__restrict__ rhs, double *__restrict__ hist)
+{
+    constexpr int NB = 1 << (2 * D);
+    constexpr long long TRI = (long long)NB * (NB + 1) / 2;
+    constexpr int HS = (D == 1) ? 4 : (D == 2) ? 25 : (D == 3) ? 172 : 1201;
+    __shared__ double sacc[4][HS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int node = blockIdx.x * 4 + wave;
+    if (node >= g.ncol) return;                // whole waves leave; no workgroup barrier below
+    double *acc = sacc[wave];
+    for (int e = lane; e < HS; e += 64) acc[e] = 0.0;
+    int in[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) in[d] = (node / g.colstride[d]) % g.nodes[d];
+    const CellRange<D> cr(g, in);
+    double racc = 0.0, hacc = 0.0;
+    for (int e = 0; e < cr.total; ++e) {
+        int cell, r;
+        cr.get(g, in, e, cell, r);
+        if (offset[cell] == offset[cell + 1]) continue;
+        const double *__restrict__ row = blk + (long long)cell * TRI + (long long)r * (r + 1) / 2;
+        for (int c = lane; c <= r; c += 64) {
+            int code = 0, m7 = 1;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                code += (((c >> (2 * d)) & 3) - ((r >> (2 * d)) & 3) + 3) * m7;
+                m7 *= 7;
+            }
+            acc[code] += row[c];
+        }
+        if (lane == 0) {
+            racc += rblk[(long long)cell * NB + r];
+            if (hblk) hacc += hblk[(long long)cell * NB + r];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double *__restrict__ out = nst + (long long)node * g.hstencil;
+    for (int e = lane; e < HS; e += 64) out[e] = acc[e];
+    if (lane == 0) {
+        rhs[node] = racc;
+        if (hblk) {
+            int refnode = 0;                   // the histogram is kept in the caller's dimension order
+#pragma unroll
+            for (int d = 0; d < D; ++d) refnode += in[d] * g.refstride[d];
+            hist[refnode] += hacc;             // on top of the out-of-window points added by gram_block_kernel
+        }
+    }
+}
+
+// totlwt (:906) = the sum of the histogram (every counted point is in it), in a fixed order
+__global__ void __launch_bounds__(1024)
+hist_total_kernel(const double *__restrict__ hist, int n, double *__restrict__ scal)
+{
+    __shared__ double part[1024];
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int i = t; i < n; i += 1024) s += hist[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (t < o) part[t] += part[t + o];
+        __syncthreads();
+    }
+    if (t == 0) scal[SC_TOTLWT] = part[0];
 }
 
 template <int D>
@@ -262,11 +449,12 @@ template <> struct ResCfg<2> { static constexpr int NB = 16,  NT = 256, PCH = 12
 template <> struct ResCfg<3> { static constexpr int NB = 64,  NT = 256, PCH = 64; };
 template <> struct ResCfg<4> { static constexpr int NB = 256, NT = 256, PCH = 16; };
 
+// per-cell share of rho = A^T W (W y - W A x): rcell[cell][c] (plain stores; empty cells are skipped by the gather)
 template <int D>
 __global__ void __launch_bounds__(ResCfg<D>::NT)
-residual_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
-                const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
-                const double *__restrict__ xvec, double *__restrict__ rho, double *__restrict__ ssq)
+residual_block_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
+                      const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
+                      const double *__restrict__ xvec, double *__restrict__ rcell, double *__restrict__ ssq)
 {
     using C = ResCfg<D>;
     constexpr int NB = C::NB, NT = C::NT, PCH = C::PCH, LDB = NB + 1;
@@ -284,15 +472,11 @@ residual_kernel(Grid g, const int *__restrict__ offset, const double *__restrict
     int colbase = 0;
 #pragma unroll
     for (int d = 0; d < D; ++d) colbase += ((cell / g.cellstride[d]) % g.cells[d]) * g.colstride[d];
-    int mycol = 0;
-    if (tid < NB) {
-        mycol = local_col<D>(g, colbase, tid);
-        xloc[tid] = xvec[mycol];
-    }
+    if (tid < NB) xloc[tid] = xvec[local_col<D>(g, colbase, tid)];
     double racc = 0.0, e2 = 0.0;
     for (long long p0 = beg; p0 < end; p0 += PCH) {
         const int np = (int)((end - p0 < PCH) ? (end - p0) : PCH);
-        stage_points<D, NB, LDB, NT>(g, xs, ys, ws, cap, p0, np, tab, bw, wy, wt);
+        stage_points<D, NB, LDB, NT>(g, xs, ys, ws, cap, p0, np, tab, bw, wy, wt, nullptr, nullptr);
         // e_p = w y - (w b) . x   (row residual)
         for (int p = tid; p < np; p += NT) {
             double dot = 0.0;
@@ -305,117 +489,291 @@ residual_kernel(Grid g, const int *__restrict__ offset, const double *__restrict
             for (int p = 0; p < np; ++p) racc += bw[p * LDB + tid] * wy[p];
         __syncthreads();
     }
-    if (tid < NB) atomicAdd(&rho[mycol], racc);
-    if (ssq) {                                   // sum of squared row residuals (the reference's errsum)
+    if (tid < NB) rcell[(long long)cell * NB + tid] = racc;
+    if (ssq) {                                   // sum of squared row residuals (the reference's errsum; a diagnostic)
         e2 = wave_sum(e2);
         if ((tid & 63) == 0 && e2 != 0.0) atomicAdd(ssq, e2);
     }
 }
 
 // ---------------------------------------------------------------------------
-// Derivative-constraint rows (:921-1046): one wave per node.
+// Derivative-constraint rows (:921-1046).  A data-sparse node n (histogram below spcrit = 0.75 of the
+// expected weight, :936) emits D(D+1)/2 rows, one per pair idm <= jdm, whose entries sit on the 3^D
+// nodes around n:  row(n, pair)[j] = rowwt * prod_d bas1(nderiv_d; x_n; node j).
+struct SparseNode {
+    bool sparse;
+    double dcwght;
+};
+
 template <int D>
-__global__ void __launch_bounds__(256)
-constraint_kernel(Grid g, const double *__restrict__ hist, const double *__restrict__ scal,
-                  double xtrap, double *__restrict__ nst, const double *__restrict__ xvec,
-                  double *__restrict__ rho, double *__restrict__ scal_out, double *__restrict__ ssq)
+__device__ inline SparseNode sparse_node(const Grid &g, const int *in, const double *__restrict__ hist,
+                                         double totlwt, double xtrap)
 {
 #pragma clang fp contract(off)
+    long long nrect = 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) nrect *= (g.nodes[d] - 1);
+    const double wtprrc = totlwt / (double)nrect;                 // :910
+    double expect = wtprrc;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (in[d] == 0 || in[d] == g.nodes[d] - 1) expect = 0.5 * expect;     // :928
+    int refnode = 0;                                              // the histogram is in the caller's order
+#pragma unroll
+    for (int d = 0; d < D; ++d) refnode += in[d] * g.refstride[d];
+    const double have = hist[refnode];
+    SparseNode s;
+    s.sparse = have < 0.75 * expect;                              // spcrit, :696, :936
+    s.dcwght = xtrap * (expect - have);                           // :938, :960
+    return s;
+}
+
+// derivative orders and weight of constraint row `pair` (idm <= jdm enumerated row by row) of node `in`
+template <int D>
+__device__ inline double constraint_pattern(const Grid &g, const int *in, int idm, int jdm, double dcwght, int *nder)
+{
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int d = 0; d < D; ++d) nder[d] = 0;
+    bool boundary = true;
+    double rowwt = 2.0 * dcwght;                                  // :983
+    if (jdm == idm) {
+        rowwt = dcwght;
+        nder[jdm] = 2;
+        if (in[idm] != 0 && in[idm] != g.nodes[idm] - 1) boundary = false;
+    }
+    if (boundary) { nder[idm] = 1; nder[jdm] = 1; }                // :998-999
+    return rowwt;
+}
+
+// entry of the constraint row of node n (coordinates nn) at node j = nn + off (off_d in [-1,1]); 0 outside the grid
+template <int D>
+__device__ inline double constraint_entry(const Grid &g, const int *nn, const int *off, const int *nder, double rowwt)
+{
+#pragma clang fp contract(off)
+    double basm = 1.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int ib = nn[d] + off[d];
+        if (ib < 0 || ib > g.nodes[d] - 1) return 0.0;
+        const double xnode = g.xmin[d] + (double)nn[d] * g.dx[d];         // :943
+        const double xb = g.xmin[d] + (double)ib * g.dx[d];
+        basm *= basis_1d(basis_kind(ib, g.nodes[d]), nder[d], xnode, xb, g.dxin[d]);
+    }
+    return rowwt * basm;                                          // :1011
+}
+
+// One wave per stencil row i: nst[i][code(j - i)] += sum over the sparse nodes n within one node of
+// both i and j, and over n's rows, of row[i] * row[j] -- neighbours and rows in a fixed order, the
+// row's owner adds with plain read-modify-writes.  Also counts the rows (scal_out[SC_NROWS_CONS]).
+template <int D>
+__global__ void __launch_bounds__(256)
+constraint_rows_kernel(Grid g, const double *__restrict__ hist, const double *__restrict__ scal,
+                       double xtrap, double *__restrict__ nst, double *__restrict__ scal_out)
+{
     constexpr int NE = (D == 1) ? 3 : (D == 2) ? 9 : (D == 3) ? 27 : 81;
-    __shared__ double cv_s[4][NE];
-    __shared__ int col_s[4][NE];
+    constexpr int HS = (D == 1) ? 4 : (D == 2) ? 25 : (D == 3) ? 172 : 1201;
+    __shared__ double sacc[4][HS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int node = blockIdx.x * 4 + wave;
-    const bool in_range = node < g.ncol;
-    double *cv = cv_s[wave];
-    int *cl = col_s[wave];
-
+    if (node >= g.ncol) return;
+    double *acc = sacc[wave];
+    for (int e = lane; e < HS; e += 64) acc[e] = 0.0;
     int in[D];
-    double xnode[D];
-    bool sparse = false;
-    double dcwght = 0.0;
-    if (in_range) {
-        long long nrect = 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) in[d] = (node / g.colstride[d]) % g.nodes[d];
+    const double totlwt = scal[SC_TOTLWT];
+    bool any = false;
+    for (int ne = 0; ne < NE; ++ne) {            // neighbour n = i + offn, offn_d in [-1,1], dim 0 fastest
+        int nn[D], offi[D], t = ne;
+        bool ok = true;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            in[d] = (node / g.colstride[d]) % g.nodes[d];
-            xnode[d] = g.xmin[d] + (double)in[d] * g.dx[d];          // :943
-            nrect *= (g.nodes[d] - 1);
+            const int o = t % 3 - 1;
+            t /= 3;
+            nn[d] = in[d] + o;
+            offi[d] = -o;                        // i = n + offi
+            ok = ok && nn[d] >= 0 && nn[d] <= g.nodes[d] - 1;
         }
-        const double wtprrc = scal[SC_TOTLWT] / (double)nrect;        // :910
-        double expect = wtprrc;
+        if (!ok) continue;
+        const SparseNode sn = sparse_node<D>(g, nn, hist, totlwt, xtrap);
+        if (!sn.sparse) continue;
+        any = true;
+        if (ne == NE / 2 && lane == 0) atomicAdd(&scal_out[SC_NROWS_CONS], (double)(D * (D + 1) / 2));   // integer-valued
+        for (int idm = 0; idm < D; ++idm)
+            for (int jdm = idm; jdm < D; ++jdm) {
+                int nder[D];
+                const double rowwt = constraint_pattern<D>(g, nn, idm, jdm, sn.dcwght, nder);
+                const double ci = constraint_entry<D>(g, nn, offi, nder, rowwt);
+                if (ci == 0.0) continue;         // wave-uniform
+                for (int je = lane; je < NE; je += 64) {
+                    int offj[D], tt = je, code = 0, m7 = 1;
+                    bool lower = true, decided = false;
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (in[d] == 0 || in[d] == g.nodes[d] - 1) expect = 0.5 * expect;   // :928
-        int refnode = 0;                                              // the histogram is in the caller's order
+                    for (int d = 0; d < D; ++d) { offj[d] = tt % 3 - 1; tt /= 3; }
+                    // column j = n + offj must not exceed row i = n + offi in the linear order
+                    // (highest dimension most significant)
 #pragma unroll
-        for (int d = 0; d < D; ++d) refnode += in[d] * g.refstride[d];
-        const double have = hist[refnode];
-        sparse = have < 0.75 * expect;                                // spcrit, :696, :936
-        dcwght = expect - have;                                       // :938
-        dcwght = xtrap * dcwght;                                      // :960
-    } else {
+                    for (int d = D - 1; d >= 0; --d) {
+                        if (!decided && offj[d] != offi[d]) { lower = offj[d] < offi[d]; decided = true; }
+                    }
 #pragma unroll
-        for (int d = 0; d < D; ++d) { in[d] = 0; xnode[d] = 0.0; }
-    }
-    if (sparse && lane == 0 && nst)
-        atomicAdd(&scal_out[SC_NROWS_CONS], (double)(D * (D + 1) / 2));
-
-    for (int idm = 0; idm < D; ++idm) {
-        for (int jdm = idm; jdm < D; ++jdm) {
-            int nder[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) nder[d] = 0;
-            bool boundary = true;
-            double rowwt = 2.0 * dcwght;                              // :983
-            if (jdm == idm) {
-                rowwt = dcwght;
-                nder[jdm] = 2;
-                if (in[idm] != 0 && in[idm] != g.nodes[idm] - 1) boundary = false;
+                    for (int d = 0; d < D; ++d) { code += (offj[d] - offi[d] + 3) * m7; m7 *= 7; }
+                    if (!lower) continue;
+                    const double cj = constraint_entry<D>(g, nn, offj, nder, rowwt);
+                    if (cj != 0.0) acc[code] += ci * cj;
+                }
             }
-            if (boundary) { nder[idm] = 1; nder[jdm] = 1; }            // :998-999
-            __syncthreads();
-            for (int e = lane; e < NE; e += 64) {
-                int ee = e, col = 0;
-                bool ok = sparse;
-                double basm = 1.0;
+    }
+    if (!any) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double *__restrict__ out = nst + (long long)node * g.hstencil;
+    for (int e = lane; e < HS; e += 64)
+        if (acc[e] != 0.0) out[e] += acc[e];
+}
+
+// residual mode, step 1: t[n][pair] = row(n, pair) . x for every sparse node (0 otherwise); one wave per node
+template <int D>
+__global__ void __launch_bounds__(256)
+constraint_dots_kernel(Grid g, const double *__restrict__ hist, const double *__restrict__ scal,
+                       double xtrap, const double *__restrict__ xvec, double *__restrict__ tbuf,
+                       double *__restrict__ ssq)
+{
+    constexpr int NE = (D == 1) ? 3 : (D == 2) ? 9 : (D == 3) ? 27 : 81;
+    constexpr int NP = D * (D + 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int node = blockIdx.x * 4 + wave;
+    if (node >= g.ncol) return;
+    int nn[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) nn[d] = (node / g.colstride[d]) % g.nodes[d];
+    const SparseNode sn = sparse_node<D>(g, nn, hist, scal[SC_TOTLWT], xtrap);
+    double *__restrict__ out = tbuf + (long long)node * NP;
+    if (!sn.sparse) {
+        if (lane < NP) out[lane] = 0.0;
+        return;
+    }
+    int pair = 0;
+    double e2 = 0.0;
+    for (int idm = 0; idm < D; ++idm)
+        for (int jdm = idm; jdm < D; ++jdm, ++pair) {
+            int nder[D];
+            const double rowwt = constraint_pattern<D>(g, nn, idm, jdm, sn.dcwght, nder);
+            double t = 0.0;
+            for (int je = lane; je < NE; je += 64) {
+                int offj[D], tt = je, col = 0;
+                bool ok = true;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    const int ib = in[d] - 1 + (ee % 3);
-                    ee /= 3;
-                    if (ib < 0 || ib > g.nodes[d] - 1) { ok = false; continue; }
+                    offj[d] = tt % 3 - 1;
+                    tt /= 3;
+                    const int ib = nn[d] + offj[d];
+                    ok = ok && ib >= 0 && ib <= g.nodes[d] - 1;
                     col += ib * g.colstride[d];
-                    const double xb = g.xmin[d] + (double)ib * g.dx[d];
-                    basm *= basis_1d(basis_kind(ib, g.nodes[d]), nder[d], xnode[d], xb, g.dxin[d]);
                 }
-                cv[e] = ok ? rowwt * basm : 0.0;                      // :1011
-                cl[e] = ok ? col : 0;
+                if (ok) t += constraint_entry<D>(g, nn, offj, nder, rowwt) * xvec[col];
             }
-            __syncthreads();
-            if (sparse) {
-                if (nst) {
-                    for (int q = lane; q < NE * NE; q += 64) {
-                        const int e1 = q / NE, e2 = q % NE;
-                        if (e2 > e1) continue;
-                        const double v = cv[e1] * cv[e2];
-                        if (v == 0.0) continue;
-                        int o[D], a = e1, b = e2;
+            t = wave_sum(t);
+            if (lane == 0) out[pair] = t;
+            e2 += t * t;                         // constraint rows have rhs 0
+        }
+    if (ssq && lane == 0 && e2 != 0.0) atomicAdd(ssq, e2);
+}
+
+// rho[i] = sum over the cells that contain node i of their share (CellRange order)
+//          - sum over sparse neighbours n and their rows of row(n,pair)[i] * t[n][pair]   (tbuf != NULL)
+template <int D>
+__global__ void __launch_bounds__(256)
+rho_gather_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ rcell,
+                  const double *__restrict__ hist, const double *__restrict__ scal, double xtrap,
+                  const double *__restrict__ tbuf, double *__restrict__ rho)
+{
+    constexpr int NB = 1 << (2 * D);
+    constexpr int NE = (D == 1) ? 3 : (D == 2) ? 9 : (D == 3) ? 27 : 81;
+    constexpr int NP = D * (D + 1) / 2;
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= g.ncol) return;
+    int in[D];
 #pragma unroll
-                        for (int d = 0; d < D; ++d) { o[d] = (b % 3) - (a % 3); a /= 3; b /= 3; }
-                        atomicAdd(&nst[(long long)cl[e1] * g.hstencil + stencil_code(o, D)], v);
-                    }
-                }
-                if (xvec) {
-                    double t = 0.0;
-                    for (int e = lane; e < NE; e += 64) t += cv[e] * xvec[cl[e]];
-                    t = wave_sum(t);
-                    for (int e = lane; e < NE; e += 64)
-                        if (cv[e] != 0.0) atomicAdd(&rho[cl[e]], -cv[e] * t);
-                    if (ssq && lane == 0) atomicAdd(ssq, t * t);     // constraint rows have rhs 0
-                }
+    for (int d = 0; d < D; ++d) in[d] = (node / g.colstride[d]) % g.nodes[d];
+    const CellRange<D> cr(g, in);
+    double acc = 0.0;
+    for (int e = 0; e < cr.total; ++e) {
+        int cell, r;
+        cr.get(g, in, e, cell, r);
+        if (offset[cell] != offset[cell + 1]) acc += rcell[(long long)cell * NB + r];
+    }
+    if (tbuf) {
+        const double totlwt = scal[SC_TOTLWT];
+        for (int ne = 0; ne < NE; ++ne) {
+            int nn[D], offi[D], t = ne, ncol_n = 0;
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int o = t % 3 - 1;
+                t /= 3;
+                nn[d] = in[d] + o;
+                offi[d] = -o;
+                ok = ok && nn[d] >= 0 && nn[d] <= g.nodes[d] - 1;
+                ncol_n += nn[d] * g.colstride[d];
             }
+            if (!ok) continue;
+            const SparseNode sn = sparse_node<D>(g, nn, hist, totlwt, xtrap);
+            if (!sn.sparse) continue;
+            int pair = 0;
+            for (int idm = 0; idm < D; ++idm)
+                for (int jdm = idm; jdm < D; ++jdm, ++pair) {
+                    int nder[D];
+                    const double rowwt = constraint_pattern<D>(g, nn, idm, jdm, sn.dcwght, nder);
+                    const double ci = constraint_entry<D>(g, nn, offi, nder, rowwt);
+                    if (ci != 0.0) acc -= ci * tbuf[(long long)ncol_n * NP + pair];
+                }
         }
     }
+    rho[node] = acc;
+}
+
+// Componentwise backward error of the returned coefficients with respect to the rows:
+//   omega = max_i |rho_i| / ((|N| |x|)_i + |r_i|),   rho = A^T W (W y - W A x) - C^T C x  (from the rows),
+// N = the assembled normal equations (half stencil, both triangles visited), r = A^T W^2 y.  The
+// denominator is the size of the terms whose sum rho_i is (the basis functions are non-negative, so
+// |A|^T |A| = N on the data rows): omega is at rounding level exactly when x minimises the
+// least-squares functional to working precision, whatever the grading of the constraint weights.
+template <int D>
+__global__ void __launch_bounds__(256)
+backward_error_kernel(Grid g, const double *__restrict__ nst, const double *__restrict__ xvec,
+                      const double *__restrict__ rho, const double *__restrict__ rhs,
+                      unsigned long long *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double om = 0.0;
+    if (i < g.ncol) {
+        int in[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) in[d] = (i / g.colstride[d]) % g.nodes[d];
+        const int centre = g.hstencil - 1;
+        double s = fabs(nst[(long long)i * g.hstencil + centre] * xvec[i]) + fabs(rhs[i]);
+        for (int code = 0; code < centre; ++code) {
+            int c = code, jl = i, ju = i;
+            bool okl = true, oku = true;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int o = c % 7 - 3;
+                c /= 7;
+                okl = okl && in[d] + o >= 0 && in[d] + o <= g.nodes[d] - 1;
+                oku = oku && in[d] - o >= 0 && in[d] - o <= g.nodes[d] - 1;
+                jl += o * g.colstride[d];
+                ju -= o * g.colstride[d];
+            }
+            if (okl) s += fabs(nst[(long long)i * g.hstencil + code] * xvec[jl]);       // N(i, jl), jl < i
+            if (oku) s += fabs(nst[(long long)ju * g.hstencil + code] * xvec[ju]);      // N(i, ju) = N(ju, i), ju > i
+        }
+        om = s > 0.0 ? fabs(rho[i]) / s : fabs(rho[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) om = fmax(om, __shfl_xor(om, o, 64));
+    if ((threadIdx.x & 63) == 0 && om > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(om));
 }
 
 // ---------------------------------------------------------------------------
@@ -487,62 +845,88 @@ hipError_t launch_to_reference_order(const Grid &g, const double *xvec, double *
     return hipGetLastError();
 }
 
-hipError_t launch_keys(const Grid &g, long long m, const double *x, int ldx, const double *w,
-                       const SortScratch &s, double *hist, double *scal, hipStream_t st)
+long long gram_scratch_doubles(const Grid &g)
+{
+    return (long long)g.ncell * (gram_tri(g.nb) + 2LL * g.nb);
+}
+
+hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ldx, const double *y,
+                             const double *w, const SortScratch &s, double *scal, hipStream_t st)
 {
     hipError_t e = hipMemsetAsync(s.count, 0, sizeof(int) * (size_t)(g.ncell + 2), st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(s.cursor, 0, sizeof(int) * (size_t)(g.ncell + 1), st);
     if (e != hipSuccess) return e;
-    if (m <= 0) return hipSuccess;
-    dim3 gr(grid_for(m, 256)), bl(256);
-    DISPATCH_D(g.ndim, hipLaunchKernelGGL(keys_kernel<D>, gr, bl, 0, st, g, m, x, ldx, w, s.key,
-                                          s.count, hist, scal));
-    return hipGetLastError();
-}
-
-hipError_t launch_scan_scatter(const Grid &g, long long m, const double *x, int ldx,
-                               const double *y, const double *w, const SortScratch &s,
-                               hipStream_t st)
-{
+    if (m > 0) {
+        dim3 gr(grid_for(m, 256)), bl(256);
+        DISPATCH_D(g.ndim, hipLaunchKernelGGL(keys_kernel<D>, gr, bl, 0, st, g, m, x, ldx, w, s.key, s.count, scal));
+    }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, s.count, s.offset, g.ncell + 1);
     if (m > 0) {
         dim3 gr(grid_for(m, 256)), bl(256);
         DISPATCH_D(g.ndim, hipLaunchKernelGGL(scatter_kernel<D>, gr, bl, 0, st, g, m, x, ldx, y, w,
-                                              s.key, s.offset, s.cursor, s.xs, s.ys, s.ws, s.cap));
+                                              s.key, s.offset, s.cursor, s.xs, s.ys, s.ws, s.idx, s.cap));
+        DISPATCH_D(g.ndim, hipLaunchKernelGGL(cell_order_kernel<D>, dim3((unsigned)g.ncell), dim3(256), 0, st,
+                                              (const int *)s.offset, s.xs, s.ys, s.ws, s.idx, s.cap));
     }
     return hipGetLastError();
 }
 
-hipError_t launch_gram(const Grid &g, const SortScratch &s, double *nst, double *rhs, hipStream_t st)
+hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, bool smooth, double *nst,
+                       double *rhs, double *hist, double *scalH, hipStream_t st)
 {
+    const long long tri = gram_tri(g.nb);
+    double *blk = scratch;
+    double *rblk = blk + (long long)g.ncell * tri;
+    double *hblk = smooth ? rblk + (long long)g.ncell * g.nb : nullptr;
     DISPATCH_D(g.ndim, {
         using C = GramCfg<D>;
         dim3 gr((unsigned)g.ncell, (unsigned)(C::NB / (C::NTX * C::TC)));
-        hipLaunchKernelGGL(gram_kernel<D>, gr, dim3(C::NT), 0, st, g, s.offset, s.xs, s.ys, s.ws,
-                           s.cap, nst, rhs);
+        hipLaunchKernelGGL(gram_block_kernel<D>, gr, dim3(C::NT), 0, st, g, (const int *)s.offset, (const double *)s.xs,
+                           (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist);
+        hipLaunchKernelGGL(stencil_gather_kernel<D>, dim3((unsigned)((g.ncol + 3) / 4)), dim3(256), 0, st, g,
+                           (const int *)s.offset, (const double *)blk, (const double *)rblk, (const double *)hblk,
+                           nst, rhs, hist);
     });
+    if (smooth) hipLaunchKernelGGL(hist_total_kernel, dim3(1), dim3(1024), 0, st, (const double *)hist, g.ncol, scalH);
     return hipGetLastError();
 }
 
-hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rho,
-                           double *ssq, hipStream_t st)
-{
-    DISPATCH_D(g.ndim, {
-        using C = ResCfg<D>;
-        hipLaunchKernelGGL(residual_kernel<D>, dim3((unsigned)g.ncell), dim3(C::NT), 0, st, g,
-                           s.offset, s.xs, s.ys, s.ws, s.cap, xvec, rho, ssq);
-    });
-    return hipGetLastError();
-}
-
-hipError_t launch_constraints(const Grid &g, const double *hist, const double *scal, double xtrap,
-                              double *nst, const double *xvec, double *rho, double *scal_out,
-                              double *ssq, hipStream_t st)
+hipError_t launch_constraint_rows(const Grid &g, const double *hist, const double *scal, double xtrap,
+                                  double *nst, double *scal_out, hipStream_t st)
 {
     dim3 gr((unsigned)((g.ncol + 3) / 4)), bl(256);
-    DISPATCH_D(g.ndim, hipLaunchKernelGGL(constraint_kernel<D>, gr, bl, 0, st, g, hist, scal, xtrap,
-                                          nst, xvec, rho, scal_out, ssq));
+    DISPATCH_D(g.ndim, hipLaunchKernelGGL(constraint_rows_kernel<D>, gr, bl, 0, st, g, hist, scal, xtrap, nst, scal_out));
+    return hipGetLastError();
+}
+
+hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rcell,
+                           const double *hist, const double *scal, double xtrap, bool constraints,
+                           double *tbuf, double *rho, double *ssq, hipStream_t st)
+{
+    dim3 gn((unsigned)((g.ncol + 3) / 4)), bl(256);
+    DISPATCH_D(g.ndim, {
+        using C = ResCfg<D>;
+        hipLaunchKernelGGL(residual_block_kernel<D>, dim3((unsigned)g.ncell), dim3(C::NT), 0, st, g,
+                           (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
+                           s.cap, xvec, rcell, ssq);
+        if (constraints)
+            hipLaunchKernelGGL(constraint_dots_kernel<D>, gn, bl, 0, st, g, hist, scal, xtrap, xvec, tbuf, ssq);
+        hipLaunchKernelGGL(rho_gather_kernel<D>, dim3((unsigned)((g.ncol + 255) / 256)), bl, 0, st, g,
+                           (const int *)s.offset, (const double *)rcell, hist, scal, xtrap,
+                           constraints ? (const double *)tbuf : (const double *)nullptr, rho);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_backward_error(const Grid &g, const double *nst, const double *xvec, const double *rho,
+                                 const double *rhs, double *out, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+    if (e != hipSuccess) return e;
+    dim3 gr((unsigned)((g.ncol + 255) / 256)), bl(256);
+    DISPATCH_D(g.ndim, hipLaunchKernelGGL(backward_error_kernel<D>, gr, bl, 0, st, g, nst, xvec, rho, rhs,
+                                          reinterpret_cast<unsigned long long *>(out)));
     return hipGetLastError();
 }
 

@@ -1002,6 +1002,28 @@ axpy_absmax_kernel(int n, double *__restrict__ x, const double *__restrict__ dx,
     }
 }
 
+// absmax2[0] = max |a[i]|, absmax2[1] = max |b[i]|
+__global__ void __launch_bounds__(256)
+absmax2_kernel(int n, const double *__restrict__ a, const double *__restrict__ b,
+               unsigned long long *__restrict__ absmax2)
+{
+    double ma = 0.0, mb = 0.0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        ma = fmax(ma, fabs(a[i]));
+        mb = fmax(mb, fabs(b[i]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ma = fmax(ma, __shfl_xor(ma, o, 64));
+        mb = fmax(mb, __shfl_xor(mb, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&absmax2[0], (unsigned long long)__double_as_longlong(ma));
+        atomicMax(&absmax2[1], (unsigned long long)__double_as_longlong(mb));
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1034,18 +1056,18 @@ struct Pipeline {
     int dev = -1;
     hipEvent_t done = nullptr;    // end of the previous factorisation that used this pipeline
     bool used = false;
+    std::vector<hipEvent_t> evA;  // start events of the timed bulk launches (kernel timing only)
+    hipEvent_t f0 = nullptr, f1 = nullptr;
 };
-thread_local Pipeline g_pipe;
-}  // namespace
-void band_pipeline_shutdown();
-namespace {
-Pipeline &pipeline(int nblk)
+void pipeline_release(Pipeline &p);
+Pipeline &pipeline(void *&slot, int nblk)
 {
-    Pipeline &p = g_pipe;
+    if (!slot) slot = new Pipeline();
+    Pipeline &p = *static_cast<Pipeline *>(slot);
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (p.panel == nullptr || p.dev != dev) {
-        if (p.panel != nullptr) band_pipeline_shutdown();     // the thread moved to another device
+        if (p.panel != nullptr) pipeline_release(p);          // the owner moved to another device
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // hi = numerically lowest = highest priority
         (void)hipStreamCreateWithPriority(&p.panel, hipStreamNonBlocking, hi);
@@ -1109,23 +1131,32 @@ Pipeline &pipeline(int nblk)
 }
 }  // namespace
 
-// Releases the calling thread's pipeline streams, events and queues (splpak_shutdown).
-void band_pipeline_shutdown()
+namespace {
+void pipeline_release(Pipeline &p)
 {
-    Pipeline &p = g_pipe;
-    for (auto *v : {&p.evP, &p.evU, &p.evC, &p.evI, &p.evT}) {
+    for (auto *v : {&p.evP, &p.evU, &p.evC, &p.evI, &p.evT, &p.evA}) {
         for (hipEvent_t e : *v) (void)hipEventDestroy(e);
         v->clear();
     }
     for (hipEvent_t &e : p.evR) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    if (p.done) (void)hipEventDestroy(p.done);
-    p.done = nullptr;
+    for (hipEvent_t *e : {&p.done, &p.f0, &p.f1}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
     p.used = false;
     for (hipStream_t *s : {&p.panel, &p.col, &p.res, &p.upd}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
     if (p.queues) (void)hipFree(p.queues);
     p.queues = nullptr;
     p.nqueues = 0;
     p.dev = -1;
+}
+}  // namespace
+
+// The look-ahead pipeline (streams, events, item queues) belongs to whoever owns the Band (a plan):
+// created on the first factorisation, released with it.
+void band_pipeline_destroy(void *slot)
+{
+    if (!slot) return;
+    Pipeline *p = static_cast<Pipeline *>(slot);
+    pipeline_release(*p);
+    delete p;
 }
 
 // Right-looking factorisation with one block column of look-ahead:
@@ -1137,7 +1168,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
 {
     const bool timing = stats && stats->enabled;
     const auto t_enq = std::chrono::steady_clock::now();
-    Pipeline &pl = pipeline(b.nblk);
+    Pipeline &pl = pipeline(b.pipe, b.nblk);
     hipStream_t sP = pl.panel, sC = pl.col, sU = pl.upd;
     // potrf is pinned to the reserved CU (own stream, two event hops per step) when the trailing update is
     // heavy enough to starve it; with a narrow band the step is bound by the chain itself and the hops cost more
@@ -1148,14 +1179,18 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     // enqueued from another stream must not clear them while the previous one is still running
     if (pl.used && pl.done) (void)hipStreamWaitEvent(st, pl.done, 0);
     (void)hipMemsetAsync(pl.queues, 0, sizeof(int) * 2 * (size_t)pl.nqueues, st);
-    hipEvent_t f0 = nullptr, f1 = nullptr;
     std::vector<hipEvent_t> evs;
     if (timing) {
-        (void)hipEventCreate(&f0);
-        (void)hipEventCreate(&f1);
+        // the timing events live in the pipeline: nothing is created or destroyed inside a timed fit
+        if (!pl.f0) { (void)hipEventCreate(&pl.f0); (void)hipEventCreate(&pl.f1); }
+        while ((int)pl.evA.size() < b.nblk + 1) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            pl.evA.push_back(e);
+        }
         stats->syrk_launches = stats->syrk_ms = stats->syrk_flop = stats->factor_ms = 0;
         stats->bulk_launches = stats->bulk_flop = 0;
-        (void)hipEventRecord(f0, st);
+        (void)hipEventRecord(pl.f0, st);
     }
     if (stats) stats->total_flop = stats->bulk_launches = stats->bulk_flop = 0;
     auto tb_of = [&](int k) { int t = b.nblk - 1 - k; return t > b.bw ? b.bw : t; };
@@ -1165,7 +1200,6 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     // instantiation (ABL bit 8, no functional difference) so that profilers list it under its own
     // name, and it alone feeds the roofline statistics
     const bool bulk_stop_event = std::getenv("SPLPAK_NO_STOPEV") == nullptr;
-    std::vector<bool> evs_owned;
     auto syrk = [&](hipStream_t s, int k, int cb, int ce, int rb, int re, bool bulk = false) {
         const int k0 = k * NBLK;
         long long items = 0;
@@ -1175,11 +1209,10 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         // Timed bulk launches carry their HIP events in the dispatch itself (hipExtLaunchKernelGGL:
         // start/stop are taken from the kernel's own dispatch packet), so timing adds no packet to
         // the stream; events recorded around the launch cost ~4 us each between two launches.
-        const bool timed = timing && bulk;
-        if (timed) (void)hipEventCreate(&a);
+        const bool timed = timing && bulk && bulk_stop_event;
+        if (timed) a = pl.evA[k];
         // the bulk launch's completion IS evU[k]: no separate event record behind it in the stream
         if (bulk && bulk_stop_event) c = pl.evU[k];
-        else if (timed) (void)hipEventCreate(&c);
         const bool queued = pl.reserved != ~0u && qnext < pl.nqueues;
         const int margin = queued ? 512 : 0;
         int *queue = queued ? pl.queues + 2 * (qnext++) : nullptr;
@@ -1192,7 +1225,6 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
         if (timed) {
             evs.push_back(a);
             evs.push_back(c);
-            evs_owned.push_back(!(bulk && bulk_stop_event));
             stats->syrk_launches += 1;
             stats->syrk_flop += 2.0 * (double)items * 64 * 64 * NBLK;
         }
@@ -1285,19 +1317,15 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     }
     hipError_t err = hipGetLastError();
     if (timing) {
-        (void)hipEventRecord(f1, st);
-        (void)hipEventSynchronize(f1);
+        (void)hipEventRecord(pl.f1, st);
+        (void)hipEventSynchronize(pl.f1);
         float ms = 0;
-        (void)hipEventElapsedTime(&ms, f0, f1);
+        (void)hipEventElapsedTime(&ms, pl.f0, pl.f1);
         stats->factor_ms = ms;
         for (size_t i = 0; i + 1 < evs.size(); i += 2) {
             (void)hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
             stats->syrk_ms += ms;
-            (void)hipEventDestroy(evs[i]);
-            if (evs_owned[i / 2]) (void)hipEventDestroy(evs[i + 1]);
         }
-        (void)hipEventDestroy(f0);
-        (void)hipEventDestroy(f1);
     }
     return err;
 }
@@ -1372,6 +1400,17 @@ hipError_t launch_axpy_absmax(int n, double *x, const double *dx, double *absmax
     int blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(axpy_absmax_kernel, dim3(blocks), dim3(256), 0, st, n, x, dx,
+                       reinterpret_cast<unsigned long long *>(absmax2));
+    return hipGetLastError();
+}
+
+hipError_t launch_absmax2(int n, const double *a, const double *b, double *absmax2, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(absmax2, 0, 2 * sizeof(double), st);
+    if (e != hipSuccess) return e;
+    int blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(absmax2_kernel, dim3(blocks), dim3(256), 0, st, n, a, b,
                        reinterpret_cast<unsigned long long *>(absmax2));
     return hipGetLastError();
 }

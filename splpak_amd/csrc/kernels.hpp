@@ -28,39 +28,42 @@ hipError_t launch_synth_queries(int ndim, long long skip_draws, long long nq, do
 
 // ---- assemble.hip
 // scalars (device doubles) written by the assembly kernels
-enum { SC_TOTLWT = 0, SC_NROWS_DATA = 1, SC_NROWS_CONS = 2, SC_COUNT = 8 };
+enum { SC_TOTLWT = 0, SC_NROWS_DATA = 1, SC_NROWS_CONS = 2, SC_ERRFLAG = 3, SC_COUNT = 8 };
 
 struct SortScratch {
     int *key;        // [max_ndata] cell key per point (ncell = zero-weight sentinel)
     int *count;      // [ncell + 2]
     int *offset;     // [ncell + 2] exclusive scan of count
     int *cursor;     // [ncell + 1]
-    double *xs;      // [ndim][cap] sorted coordinates, SoA
+    double *xs;      // [ndim][cap] sorted coordinates, SoA (internal dimension order)
     double *ys;      // [cap]
     double *ws;      // [cap]
+    int *idx;        // [cap] original index of the sorted points (orders the points inside a cell)
     long long cap;   // max_ndata
 };
 
-// keys + per-cell counts + (xtrap != 0) nearest-node histogram + scalars
-hipError_t launch_keys(const Grid &g, long long m, const double *x, int ldx, const double *w,
-                       const SortScratch &s, double *hist, double *scal, hipStream_t st);
-hipError_t launch_scan_scatter(const Grid &g, long long m, const double *x, int ldx,
-                               const double *y, const double *w, const SortScratch &s,
-                               hipStream_t st);
-// per-cell Gram blocks -> half-stencil normal equations nst[ncol][hstencil], rhs[ncol]
-hipError_t launch_gram(const Grid &g, const SortScratch &s, double *nst, double *rhs,
-                       hipStream_t st);
-// data part of the refinement residual: rho += A^T W (W y - W A x)
-// ssq != NULL: also accumulate the sum of squared row residuals
-hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rho,
-                           double *ssq, hipStream_t st);
-// derivative-constraint rows of the data-sparse nodes (:921-1046).
-//   nst != NULL : add c c^T of every constraint row to the normal equations and
-//                 count the rows into scal[SC_NROWS_CONS]
-//   xvec != NULL: rho -= c (c . x) for every constraint row (residual mode)
-hipError_t launch_constraints(const Grid &g, const double *hist, const double *scal, double xtrap,
-                              double *nst, const double *xvec, double *rho, double *scal_out,
-                              double *ssq, hipStream_t st);
+// binning: window keys + per-cell counts + scalars -> scan -> counting-sort scatter -> points of every
+// cell ordered by original index
+hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ldx, const double *y,
+                             const double *w, const SortScratch &s, double *scal, hipStream_t st);
+// doubles of scratch launch_gram needs (per-cell Gram blocks, right-hand sides, histogram shares)
+long long gram_scratch_doubles(const Grid &g);
+// per-cell Gram blocks -> (owner gathers) half-stencil normal equations nst[ncol][hstencil], rhs[ncol] and,
+// when smooth, the nearest-node histogram hist[ncol] (caller's order; must be zero on entry) + its total
+hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, bool smooth, double *nst,
+                       double *rhs, double *hist, double *scalH, hipStream_t st);
+// derivative-constraint rows of the data-sparse nodes (:921-1046): nst += C^T C, rows counted into
+// scal_out[SC_NROWS_CONS]
+hipError_t launch_constraint_rows(const Grid &g, const double *hist, const double *scal, double xtrap,
+                                  double *nst, double *scal_out, hipStream_t st);
+// refinement residual rho = A^T W (W y - W A x) [- C^T C x when `constraints`]; rcell: [ncell][nb] scratch,
+// tbuf: [ncol][ndim(ndim+1)/2] scratch; ssq != NULL: also accumulate the sum of squared row residuals
+hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rcell,
+                           const double *hist, const double *scal, double xtrap, bool constraints,
+                           double *tbuf, double *rho, double *ssq, hipStream_t st);
+// out[0] = max_i |rho_i| / ((|N||x|)_i + |rhs_i|): componentwise backward error with respect to the rows
+hipError_t launch_backward_error(const Grid &g, const double *nst, const double *xvec, const double *rho,
+                                 const double *rhs, double *out, hipStream_t st);
 
 // coef[reference column] = xvec[internal column] (a plain copy when the plan did not reorder the dimensions)
 hipError_t launch_to_reference_order(const Grid &g, const double *xvec, double *coef, hipStream_t st);
@@ -80,6 +83,8 @@ struct Band {
     int nblk;         // npad / NBLK
     int bw;           // block half-bandwidth: ceil(halfbw / NBLK)
     size_t bytes;     // allocation size of ab
+    mutable void *pipe = nullptr;   // look-ahead pipeline of band_cholesky (streams, events, queues): created on first
+                                    // use, released by band_pipeline_destroy -- owned by whoever owns the Band
 };
 size_t band_bytes(int n, int halfbw, Band *desc);
 // zero the band, put 1 on the padded diagonal, scatter the half-stencil into it
@@ -95,12 +100,14 @@ struct CholStats {            // optional per-kernel accounting (HIP events)
 // non-positive pivot (0 = success); min pivot is tracked in minpiv_dev
 hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipStream_t st,
                          CholStats *stats);
-// release the calling thread's pipeline streams / events / queues
-void band_pipeline_shutdown();
+// release a Band's pipeline (streams / events / queues); NULL is fine
+void band_pipeline_destroy(void *pipe);
 // x <- (L L^T)^{-1} x; x and tmp of length npad (padding entries of x must be 0)
 hipError_t band_solve(const Band &b, double *x, double *tmp, hipStream_t st);
 
 // small vector helpers (vecops in bandchol.hip)
 hipError_t launch_axpy_absmax(int n, double *x, const double *dx, double *absmax2, hipStream_t st);
+// absmax2[0] = max |a|, absmax2[1] = max |b| (device doubles, non-negative => ordered like their bit patterns)
+hipError_t launch_absmax2(int n, const double *a, const double *b, double *absmax2, hipStream_t st);
 
 }  // namespace splpak

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <vector>
 
 namespace splpak {
@@ -118,12 +119,17 @@ struct splpak_plan {
     double *nst = nullptr, *rhs = nullptr, *scalG = nullptr, *hist = nullptr, *scalH = nullptr,
            *rho = nullptr;
     long long lenG = 0, lenH = 0, lenR = 0;
-    double *xvec = nullptr, *tmp = nullptr, *small = nullptr;   // small: [absmax(2) | minpiv(1) | pad]
+    double *xvec = nullptr, *tmp = nullptr, *small = nullptr;   // small: [absmax(2) | minpiv(1) | backward error(1) | pad]
+    double *gscratch = nullptr;   // per-cell Gram blocks: the band storage itself when it is large enough (it is only
+                                  // filled after the gather), a buffer of its own otherwise
+    double *rcell = nullptr;      // [ncell][nb] per-cell shares of the refinement residual
+    double *tbuf = nullptr;       // [ncol][ndim(ndim+1)/2] constraint-row dot products of the refinement residual
     int *info = nullptr;
     splpak_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
     int rank = 0, world = 1;
-    int max_refine = 4;
+    int max_refine = 4;           // nominal number of refinement steps; a solve that is still contracting goes on (max_refine_hard)
+    int max_refine_hard = 16;
     double tol = 1e-12;
     CholStats stats;
     std::vector<void *> owned;
@@ -192,6 +198,11 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
         return v;
     }
     if (max_ndata < 1) return 105;
+    if (max_ndata > (int64_t)std::numeric_limits<int32_t>::max() - 1024) {
+        // the binning (keys, per-cell offsets and cursors, the scan) is 32-bit
+        set_error("max_ndata per plan (= per GPU) is limited to 2^31 - 1025 points; shard the points over more plans");
+        return SPLPAK_E_UNSUPPORTED;
+    }
     if (int r = device_ready()) return r;
 
     splpak_plan *p = new splpak_plan();
@@ -208,9 +219,14 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
     ok = ok && dev_alloc(p, &p->s.xs, (size_t)max_ndata * g.ndim);
     ok = ok && dev_alloc(p, &p->s.ys, (size_t)max_ndata);
     ok = ok && dev_alloc(p, &p->s.ws, (size_t)max_ndata);
+    ok = ok && dev_alloc(p, &p->s.idx, (size_t)max_ndata);
+    ok = ok && dev_alloc(p, &p->rcell, (size_t)g.ncell * g.nb);
+    ok = ok && dev_alloc(p, &p->tbuf, (size_t)g.ncol * (g.ndim * (g.ndim + 1) / 2));
     // band
     band_bytes(g.ncol, g.halfbw, &p->band);
     ok = ok && dev_alloc(p, &p->band.ab, p->band.bytes / sizeof(double));
+    if ((size_t)gram_scratch_doubles(g) * sizeof(double) <= p->band.bytes) p->gscratch = p->band.ab;
+    else ok = ok && dev_alloc(p, &p->gscratch, (size_t)gram_scratch_doubles(g));
     ok = ok && dev_alloc(p, &p->band.dinv, (size_t)p->band.nblk * NBLK * NBLK);
     ok = ok && dev_alloc(p, &p->band.dinvt, (size_t)p->band.nblk * NBLK * NBLK);
     ok = ok && dev_alloc(p, &p->band.inv64, (size_t)p->band.nblk * 4 * 64 * 64);
@@ -253,6 +269,7 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
 void splpak_plan_destroy(splpak_plan *p)
 {
     if (!p) return;
+    band_pipeline_destroy(p->band.pipe);
     for (void *q : p->owned) (void)hipFree(q);
     delete p;
 }
@@ -271,6 +288,7 @@ void splpak_plan_set_refine(splpak_plan *p, int32_t max_steps, double tol)
 {
     if (!p) return;
     p->max_refine = max_steps < 0 ? 0 : max_steps;
+    p->max_refine_hard = p->max_refine == 0 ? 0 : (p->max_refine > 16 ? p->max_refine : 16);
     p->tol = tol;
 }
 
@@ -305,28 +323,47 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
                             const double *w, int64_t ndata, double *coef_dev, void *stream,
                             double *info)
 {
-    if (!p || !x || !y || !coef_dev) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (!p || !coef_dev) { set_error("null argument"); return SPLPAK_E_BADARG; }
     if (ndata < 1 && p->world <= 1) return 105;                       // :759-764
-    if (ndata > p->max_ndata) { set_error("ndata exceeds the plan's max_ndata"); return SPLPAK_E_BADARG; }
-    if (l1xdat < p->g.ndim) { set_error("l1xdat < ndim"); return SPLPAK_E_BADARG; }
+    // A failure of ONE rank's arguments must not leave the others waiting in a collective: with more
+    // than one rank it is carried through the first reduction as a flag and every rank returns.
+    int lerr = 0;
+    if (ndata < 0) ndata = 0;
+    if (ndata > 0 && (!x || !y)) { set_error("null data pointer"); lerr = SPLPAK_E_BADARG; }
+    else if (ndata > p->max_ndata) { set_error("ndata exceeds the plan's max_ndata"); lerr = SPLPAK_E_BADARG; }
+    else if (l1xdat < p->g.ndim) { set_error("l1xdat < ndim"); lerr = SPLPAK_E_BADARG; }
+    if (lerr != 0 && p->world <= 1) return lerr;
+    if (lerr != 0) ndata = 0;
     hipStream_t st = (hipStream_t)stream;
     const Grid &g = p->g;
     const Band &b = p->band;
     const bool smooth = p->xtrap != 0.0;                              // swght, :769
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
+    if (info) for (int i = 0; i < 10; ++i) info[i] = 0.0;
 
     // ---- assembly -------------------------------------------------------
     SPLPAK_HIP_TRY(hipMemsetAsync(p->comm, 0, sizeof(double) * (size_t)(p->lenG + p->lenH), st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(launch_keys(g, ndata, x, l1xdat, w, p->s, smooth ? p->hist : nullptr, p->scalH, st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(launch_scan_scatter(g, ndata, x, l1xdat, y, w, p->s, st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(launch_gram(g, p->s, p->nst, p->rhs, st), SPLPAK_E_NODEVICE);
-    if (int r = do_allreduce(p, p->hist, p->lenH, st)) return r;
+    SPLPAK_HIP_TRY(launch_bin_points(g, ndata, x, l1xdat, y, w, p->s, p->scalH, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(launch_gram(g, p->s, p->gscratch, smooth, p->nst, p->rhs, p->hist, p->scalH, st), SPLPAK_E_NODEVICE);
+    double hs[2 * SC_COUNT];
+    if (p->world > 1) {
+        const double one = 1.0;
+        if (lerr != 0)
+            SPLPAK_HIP_TRY(hipMemcpyAsync(p->scalH + SC_ERRFLAG, &one, sizeof(double), hipMemcpyHostToDevice, st), SPLPAK_E_NODEVICE);
+        if (int r = do_allreduce(p, p->hist, p->lenH, st)) return r;
+        SPLPAK_HIP_TRY(hipMemcpyAsync(hs + SC_COUNT, p->scalH, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+        if (hs[SC_COUNT + SC_ERRFLAG] != 0.0) {
+            if (lerr != 0) return lerr;
+            set_error("another rank of the sharded fit rejected its arguments");
+            return SPLPAK_E_COMM;
+        }
+    }
     if (smooth && p->rank == 0)
-        SPLPAK_HIP_TRY(launch_constraints(g, p->hist, p->scalH, p->xtrap, p->nst, nullptr, nullptr, p->scalG, nullptr, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_constraint_rows(g, p->hist, p->scalH, p->xtrap, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
     if (int r = do_allreduce(p, p->nst, p->lenG, st)) return r;
 
-    double hs[2 * SC_COUNT];
     SPLPAK_HIP_TRY(hipMemcpyAsync(hs, p->scalG, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
     // scalG and scalH are not adjacent (hist sits between): fetch scalH separately
     SPLPAK_HIP_TRY(hipMemcpyAsync(hs + SC_COUNT, p->scalH, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
@@ -335,7 +372,6 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     const double rows_cons = hs[SC_NROWS_CONS];
     auto t1 = clk::now();
     if (info) {
-        for (int i = 0; i < 10; ++i) info[i] = 0.0;
         info[0] = rows_data;
         info[1] = rows_cons;
         info[5] = std::chrono::duration<double>(t1 - t0).count();
@@ -344,6 +380,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     if (rows_data + rows_cons < (double)g.ncol) {
         SPLPAK_HIP_TRY(hipMemsetAsync(coef_dev, 0, sizeof(double) * (size_t)g.ncol, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+        set_error("fewer rows than coefficients (suprls 33)");
         return 107;
     }
 
@@ -367,6 +404,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         // not positive definite: the reference's "system is singular" (suprls 34 -> 107)
         SPLPAK_HIP_TRY(hipMemsetAsync(coef_dev, 0, sizeof(double) * (size_t)g.ncol, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+        set_error("normal equations not positive definite (suprls 34)");
         return 107;
     }
 
@@ -375,13 +413,17 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     SPLPAK_HIP_TRY(hipMemcpyAsync(p->xvec, p->rhs, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
     SPLPAK_HIP_TRY(band_solve(b, p->xvec, p->tmp, st), SPLPAK_E_NODEVICE);
     int steps = 0;
-    double last_rel = 0.0, prev_rel = inf;
-    bool diverged = false;
-    for (int it = 0; it < p->max_refine; ++it) {
+    double last_rel = 0.0, prev_rel = inf, ratio = 0.0;
+    // converged: the (estimated) remaining error is below tol, or the corrections sit at the rounding
+    // floor; diverged: they stopped contracting while still large.  A solve that is still contracting
+    // after the nominal number of steps goes on up to max_refine_hard; if even that leaves an estimated
+    // error above the parity bar the fit is reported as failed (107) instead of returning coefficients
+    // that silently miss it.
+    bool converged = p->max_refine == 0, diverged = false;
+    for (int it = 0; it < p->max_refine_hard && !converged; ++it) {
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rho, nullptr, st), SPLPAK_E_NODEVICE);
-        if (smooth && p->rank == 0)
-            SPLPAK_HIP_TRY(launch_constraints(g, p->hist, p->scalH, p->xtrap, nullptr, p->xvec, p->rho, nullptr, nullptr, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->hist, p->scalH, p->xtrap, smooth && p->rank == 0,
+                                       p->tbuf, p->rho, nullptr, st), SPLPAK_E_NODEVICE);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
         SPLPAK_HIP_TRY(band_solve(b, p->rho, p->tmp, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(launch_axpy_absmax(g.ncol, p->xvec, p->rho, p->small, st), SPLPAK_E_NODEVICE);
@@ -393,31 +435,44 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         if (std::getenv("SPLPAK_DEBUG"))
             fprintf(stderr, "[splpak] refinement step %d: |dx|/|x| = %.3e\n", steps, last_rel);
         if (!(last_rel == last_rel)) break;                   // NaN
-        if (last_rel <= p->tol) break;
+        if (last_rel <= p->tol) { converged = true; break; }
         if (it >= 1) {
-            // linear convergence: after this step the error is ~ dx * rho / (1 - rho); stop as soon
+            // linear convergence: after this step the error is ~ dx * ratio / (1 - ratio); stop as soon
             // as that estimate is below the tolerance instead of paying for one more solve
-            const double rho = last_rel / prev_rel;
-            if (rho < 0.5 && last_rel * rho / (1.0 - rho) <= p->tol) break;
-            if (rho > 0.5) {                                  // stagnation: fine at the rounding floor,
+            ratio = last_rel / prev_rel;
+            if (ratio < 0.5 && last_rel * ratio / (1.0 - ratio) <= p->tol) { converged = true; break; }
+            if (ratio > 0.5) {                                // stagnation: fine at the rounding floor,
                 diverged = last_rel > 1e-8;                   // a failure if the corrections are still large
+                converged = !diverged;
                 break;
             }
         }
         prev_rel = last_rel;
+        if (it + 1 >= p->max_refine && it + 1 < p->max_refine_hard && std::getenv("SPLPAK_DEBUG"))
+            fprintf(stderr, "[splpak] still contracting after %d steps: continuing\n", it + 1);
     }
+    // estimated error left after the last step (exact 0 when it met the tolerance outright)
+    double est_err = last_rel;
+    if (steps >= 2 && ratio > 0.0 && ratio < 1.0) est_err = last_rel * ratio / (1.0 - ratio);
+    const bool unconverged = !converged && !diverged && last_rel == last_rel && est_err > 1e-10;
     SPLPAK_HIP_TRY(launch_to_reference_order(g, p->xvec, coef_dev, st), SPLPAK_E_NODEVICE);   // internal -> caller's dimension order
-    // residual norm of the fitted system, ||rows * coef - rhs||_2 over data AND constraint rows: what
-    // the reference computes as `reserr` (suprls :1693) and then drops (splcw :690, :1052)
-    double ssq = 0.0;
+    // Diagnostics from one more pass over the rows at the returned coefficients:
+    //  * residual norm ||rows * coef - rhs||_2 over data AND constraint rows: what the reference computes
+    //    as `reserr` (suprls :1693) and then drops (splcw :690, :1052)
+    //  * optimality residual: the gradient rho = A^T W (W y - W A x) - C^T C x of the least-squares functional,
+    //    recomputed from the rows, as a componentwise backward error max_i |rho_i| / ((|N||x|)_i + |A^T W^2 y|_i)
+    //    -- 0 at the minimiser the reference computes; a MEASURED statement about the returned
+    //    coefficients (the refinement's stopping rule is an estimate)
+    double ssq = 0.0, omega = 0.0;
     if (info) {
         double *scalR = p->rho + b.npad;
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rho, scalR, st), SPLPAK_E_NODEVICE);
-        if (smooth && p->rank == 0)
-            SPLPAK_HIP_TRY(launch_constraints(g, p->hist, p->scalH, p->xtrap, nullptr, p->xvec, p->rho, nullptr, scalR, st), SPLPAK_E_NODEVICE);
-        if (int r = do_allreduce(p, scalR, SC_COUNT, st)) return r;
+        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->hist, p->scalH, p->xtrap, smooth && p->rank == 0,
+                                       p->tbuf, p->rho, scalR, st), SPLPAK_E_NODEVICE);
+        if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
+        SPLPAK_HIP_TRY(launch_backward_error(g, p->nst, p->xvec, p->rho, p->rhs, p->small + 3, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(hipMemcpyAsync(&ssq, scalR, sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(hipMemcpyAsync(&omega, p->small + 3, sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
     }
     SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
     auto t3 = clk::now();
@@ -426,16 +481,50 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         info[3] = last_rel;
         info[7] = std::chrono::duration<double>(t3 - t2).count();
         info[8] = std::sqrt(ssq);
+        info[9] = omega;
     }
     // a correction that is still large means the factor did not precondition the problem
     // (numerically singular normal equations): the reference's "suprls failure"
-    if (!(last_rel == last_rel) || diverged) return 107;
+    if (!(last_rel == last_rel) || diverged) {
+        set_error("iterative refinement diverged: numerically singular normal equations");
+        return 107;
+    }
+    if (unconverged) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "iterative refinement did not converge in %d steps: last correction %.2e, contraction %.2f, "
+                 "estimated error %.1e > 1e-10", steps, last_rel, ratio, est_err);
+        set_error(buf);
+        return 107;
+    }
     return 0;
 }
 
 // ---------------------------------------------------------------------------
 // one-shot host entry points
 // ---------------------------------------------------------------------------
+
+// The one-shot entry keeps its plan (band factor storage, sort scratch, staging buffers: 28 GB at
+// 64^3) between calls: a caller that fits the same grid again -- the reference's usage pattern is one
+// `initialize` per data set -- pays the allocation once.  Released by splpak_shutdown(); disabled by
+// SPLPAK_NO_PLAN_CACHE.  Calls from several threads are serialised.
+namespace {
+struct HostFitCache {
+    std::mutex mu;
+    splpak_plan *plan = nullptr;
+    int ndim = 0, nodes[MAXD] = {0, 0, 0, 0}, dev = -1;
+    double xmin[MAXD] = {0, 0, 0, 0}, xmax[MAXD] = {0, 0, 0, 0}, xtrap = 0.0;
+    double *dx = nullptr, *dy = nullptr, *dw = nullptr, *dc = nullptr;
+    long long cap_x = 0, cap_y = 0, cap_w = 0, cap_c = 0;
+    void release()
+    {
+        for (double **q : {&dx, &dy, &dw, &dc}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        cap_x = cap_y = cap_w = cap_c = 0;
+        if (plan) splpak_plan_destroy(plan);
+        plan = nullptr;
+    }
+};
+HostFitCache g_hostfit;
+}  // namespace
 
 static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const double *ydata,
                         const double *wdata, int64_t ndata, const double *xmin, const double *xmax,
@@ -454,28 +543,51 @@ static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const
         if (nwrk - nwrk1 + 1 < 1) return 106;
     }
     if (!xdata || !ydata || !coef) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (l1xdat < ndim) { set_error("l1xdat < ndim"); return SPLPAK_E_BADARG; }
     if (wdata && wdata[0] < 0.0) wdata = nullptr;                      // :581-588, :796
     if (int r = device_ready()) return r;
 
-    splpak_plan *p = nullptr;
-    int rc = splpak_plan_create(ndim, nodes, xmin, xmax, xtrap, ndata, nullptr, 0, &p);
-    if (rc != 0) return rc;
-    double *dx = nullptr, *dy = nullptr, *dw = nullptr, *dc = nullptr;
-    bool ok = dev_alloc(p, &dx, (size_t)ndata * l1xdat) && dev_alloc(p, &dy, (size_t)ndata) &&
-              dev_alloc(p, &dc, (size_t)ncol) && (!wdata || dev_alloc(p, &dw, (size_t)ndata));
-    if (!ok) { splpak_plan_destroy(p); return SPLPAK_E_NOMEM; }
-    hipError_t e = hipMemcpy(dx, xdata, sizeof(double) * (size_t)ndata * l1xdat, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dy, ydata, sizeof(double) * (size_t)ndata, hipMemcpyHostToDevice);
-    if (e == hipSuccess && wdata) e = hipMemcpy(dw, wdata, sizeof(double) * (size_t)ndata, hipMemcpyHostToDevice);
-    if (!hip_ok(e, "hipMemcpy H2D")) { splpak_plan_destroy(p); return SPLPAK_E_NODEVICE; }
-    rc = splpak_plan_fit_dev(p, dx, l1xdat, dy, dw, ndata, dc, nullptr, info);
+    HostFitCache &hc = g_hostfit;
+    std::lock_guard<std::mutex> lock(hc.mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool same = hc.plan && hc.dev == dev && hc.ndim == ndim && hc.xtrap == xtrap && hc.plan->max_ndata >= ndata;
+    for (int d = 0; same && d < ndim; ++d)
+        same = hc.nodes[d] == nodes[d] && hc.xmin[d] == xmin[d] && hc.xmax[d] == xmax[d];
+    if (!same) {
+        hc.release();
+        int rc = splpak_plan_create(ndim, nodes, xmin, xmax, xtrap, ndata, nullptr, 0, &hc.plan);
+        if (rc != 0) { hc.plan = nullptr; return rc; }
+        hc.dev = dev;
+        hc.ndim = ndim;
+        hc.xtrap = xtrap;
+        for (int d = 0; d < ndim; ++d) { hc.nodes[d] = nodes[d]; hc.xmin[d] = xmin[d]; hc.xmax[d] = xmax[d]; }
+    }
+    splpak_plan *p = hc.plan;
+    auto grow = [&](double **q, long long &cap, long long need) {
+        if (*q && cap >= need) return true;
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+        cap = 0;
+        if (!hip_ok(hipMalloc((void **)q, sizeof(double) * (size_t)need), "hipMalloc of the staging buffers")) return false;
+        cap = need;
+        return true;
+    };
+    const bool ok = grow(&hc.dx, hc.cap_x, (long long)ndata * l1xdat) && grow(&hc.dy, hc.cap_y, ndata) &&
+                    (!wdata || grow(&hc.dw, hc.cap_w, ndata)) && grow(&hc.dc, hc.cap_c, ncol);
+    if (!ok) { hc.release(); return SPLPAK_E_NOMEM; }
+    hipError_t e = hipMemcpy(hc.dx, xdata, sizeof(double) * (size_t)ndata * l1xdat, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(hc.dy, ydata, sizeof(double) * (size_t)ndata, hipMemcpyHostToDevice);
+    if (e == hipSuccess && wdata) e = hipMemcpy(hc.dw, wdata, sizeof(double) * (size_t)ndata, hipMemcpyHostToDevice);
+    if (!hip_ok(e, "hipMemcpy H2D")) { hc.release(); return SPLPAK_E_NODEVICE; }
+    int rc = splpak_plan_fit_dev(p, hc.dx, l1xdat, hc.dy, wdata ? hc.dw : nullptr, ndata, hc.dc, nullptr, info);
     if (rc == 0 || rc == 107) {
-        e = hipMemcpy(coef, dc, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost);
+        e = hipMemcpy(coef, hc.dc, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost);
         if (e == hipSuccess && hist_out && xtrap != 0.0)
             e = hipMemcpy(hist_out, p->hist, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost);
         if (!hip_ok(e, "hipMemcpy D2H")) rc = SPLPAK_E_NODEVICE;
     }
-    splpak_plan_destroy(p);
+    if (rc < 0 || std::getenv("SPLPAK_NO_PLAN_CACHE")) hc.release();
     return rc;
 }
 
@@ -753,13 +865,17 @@ int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double 
             if (hinfo != 0) rc = 107;
         }
     }
+    band_pipeline_destroy(b.pipe);
     for (void *q : holder.owned) (void)hipFree(q);
     return rc;
 }
 
 void splpak_shutdown(void)
 {
-    band_pipeline_shutdown();
+    {
+        std::lock_guard<std::mutex> lock(g_hostfit.mu);
+        g_hostfit.release();
+    }
     eval_scratch_shutdown();
 }
 

@@ -5,8 +5,11 @@
 !!
 !! Argument lists, `ierror` codes and the text printed on `output_unit` follow the
 !! reference (splcw :512-513, splcc :421-422, splde :1089, splfe :1258, cfaerr :399-407).
-!! All numerical work is done on the GPU; there is no host fallback: without a GPU
-!! the calls fail with a negative `ierror` and the library's message is printed.
+!! The fit and every batched evaluation run on the GPU; there is no host fallback: without a GPU
+!! those calls fail with a negative `ierror` and the library's message is printed.  The SCALAR
+!! `evaluate` (one point per call, the reference's splfe/splde) is computed on the host by this
+!! module itself (SURVEY 7.2 H6: one kernel launch per point would cost 10^4 x its arithmetic);
+!! `evaluate_many` is the GPU path.
 !!
 !! Differences a caller can observe (documented in INTEGRATION.md):
 !!  * `work` is not used as scratch.  The reference's 106 check on `nwrk` is kept; the
@@ -15,7 +18,9 @@
 !!    at 64^3 nodes).  After a successful fit with xtrap /= 0 `work(1:ncol)` holds the
 !!    sparse-area histogram exactly as the reference leaves it (:879-907).
 !!  * additive: `evaluate_many` evaluates a batch of points in one kernel launch,
-!!    `evaluate_derivatives` value + gradient (+ Hessian) of a batch in one pass.
+!!    `evaluate_derivatives` value + gradient (+ Hessian) of a batch in one pass,
+!!    `last_fit_info` returns the diagnostics of the last fit (the residual norm `reserr` that the
+!!    reference computes, suprls :1693, and drops, splcw :690; row counts; refinement steps).
 !!
 !! Build with -DREAL32 for single precision storage (as the reference, :33-41);
 !! REAL128 has no GPU path and is rejected at compile time.
@@ -41,6 +46,7 @@ module splpak_module
     type,public :: splpak_type
         private
         integer :: mdim = 0    !! dimension of the last call (the reference keeps scratch here, :95-111)
+        real(real64) :: info(10) = 0.0_real64   !! diagnostics of the last fit (include/splpak_hip.h, `info`)
     contains
         private
         generic,public   :: initialize    => splcc, splcw        !! fit
@@ -48,6 +54,7 @@ module splpak_module
         generic,public   :: evaluate_many => splfe_many, splde_many  !! batch of points (additive)
         procedure,public :: evaluate_derivatives => splpak_derivs_many !! value + gradient (+ Hessian) of a batch (additive)
         procedure,public :: destroy       => destroy_splpak
+        procedure,public :: last_fit_info => splpak_last_fit_info   !! reserr, row counts, ... of the last fit (additive)
         procedure,private :: splcc
         procedure,private :: splcw
         procedure,private :: splfe
@@ -95,6 +102,8 @@ module splpak_module
             integer(c_int64_t),value :: nq
             type(c_ptr),value :: xq, coef, xmin, xmax, nodes, out
         end function c_eval_derivs
+        subroutine c_shutdown() bind(C,name='splpak_shutdown')
+        end subroutine c_shutdown
         integer(c_int32_t) function c_last_error(buf,buflen) bind(C,name='splpak_last_error_message')
             import :: c_int32_t, c_char
             character(kind=c_char) :: buf(*)
@@ -104,13 +113,37 @@ module splpak_module
 
     contains
 
-    !> Release the object's state (the reference reallocates scratch here, :136-165).
+    !> Release the object's state (the reference reallocates scratch here, :136-165).  Called
+    !! without `ndim` it also releases the device memory the library keeps between fits of the same
+    !! grid (band factor storage, staging buffers); the next fit simply allocates again.
     subroutine destroy_splpak(me,ndim)
         class(splpak_type),intent(inout) :: me
         integer,intent(in),optional :: ndim
         me%mdim = 0
-        if (present(ndim)) me%mdim = ndim
+        me%info = 0.0_real64
+        if (present(ndim)) then
+            me%mdim = ndim
+        else
+            call c_shutdown()
+        end if
     end subroutine destroy_splpak
+
+    !> Diagnostics of the last `initialize` of this object.  `reserr` is the residual norm
+    !! ||rows*coef - rhs||_2 over data and constraint rows that the reference computes in suprls
+    !! (:1693) and drops in splcw (:690, :1052).
+    subroutine splpak_last_fit_info(me,reserr,ndata_rows,nconstraint_rows,refine_steps,optimality)
+        class(splpak_type),intent(in) :: me
+        real(wp),intent(out),optional :: reserr        !! residual norm of the fitted system
+        integer,intent(out),optional :: ndata_rows       !! data rows used (non-zero weight)
+        integer,intent(out),optional :: nconstraint_rows !! derivative-constraint rows of data-sparse nodes (:921-1046)
+        integer,intent(out),optional :: refine_steps     !! iterative-refinement steps taken
+        real(wp),intent(out),optional :: optimality      !! componentwise backward error of coef w.r.t. the rows
+        if (present(reserr)) reserr = real(me%info(9),wp)
+        if (present(ndata_rows)) ndata_rows = int(me%info(1))
+        if (present(nconstraint_rows)) nconstraint_rows = int(me%info(2))
+        if (present(refine_steps)) refine_steps = int(me%info(3))
+        if (present(optimality)) optimality = real(me%info(10),wp)
+    end subroutine splpak_last_fit_info
 
     !> ` IERR=nnnnn` + message on output_unit, as the reference's cfaerr (:399-407).
     subroutine report(ierr,mess)
@@ -198,7 +231,7 @@ module splpak_module
 
     subroutine fit_common(me,ndim,xdata,l1xdat,ydata,wdata,ndata,xmin,xmax,nodes,xtrap,coef,ncf, &
                           work,nwrk,ierror)
-        class(splpak_type),intent(inout) :: me
+        class(splpak_type),intent(inout),target :: me
         integer,intent(in) :: ndim, l1xdat, ncf, nwrk, ndata
         type(c_ptr),intent(in) :: xdata, ydata, wdata, xmin, xmax
         integer,intent(in),target :: nodes(*)
@@ -219,7 +252,7 @@ module splpak_module
         if (ndim >= 1 .and. xtrap /= 0.0_wp .and. int(nwrk,c_int64_t) >= ncol) hist = c_loc(work)
         rc = c_fit(int(ndim,c_int32_t), xdata, int(l1xdat,c_int32_t), ydata, wdata, &
                    int(ndata,c_int64_t), xmin, xmax, c_loc(nodes), xtrap, c_loc(coef), &
-                   int(ncf,c_int64_t), int(nwrk,c_int64_t), hist, c_null_ptr)
+                   int(ncf,c_int64_t), int(nwrk,c_int64_t), hist, c_loc(me%info))
         ierror = int(rc)
         if (rc > 0) then
             call report_fit(ierror)
@@ -228,38 +261,194 @@ module splpak_module
         end if
     end subroutine fit_common
 
-    !> Spline value at one point; same arguments as the reference's splfe (:1258).
+    !> Spline value at one point; same arguments as the reference's splfe (:1258).  Host computation.
     function splfe(me,ndim,x,coef,xmin,xmax,nodes,ierror)
         class(splpak_type),intent(inout) :: me
         real(wp) :: splfe
         integer,intent(in) :: ndim
-        real(wp),intent(in),target :: x(*)
-        real(wp),intent(out),target :: coef(*)     ! intent as in the reference (:1264); only read
-        real(wp),intent(in),target :: xmin(*), xmax(*)
-        integer,intent(in),target :: nodes(*)
+        real(wp),intent(in) :: x(*)
+        real(wp),intent(out) :: coef(*)            ! intent as in the reference (:1264); only read
+        real(wp),intent(in) :: xmin(*), xmax(*)
+        integer,intent(in) :: nodes(*)
         integer,intent(out) :: ierror
-        real(wp),target :: f(1)
-        call eval_common(me,ndim,1_c_int64_t,c_loc(x),max(ndim,1),c_null_ptr,c_loc(coef),c_loc(xmin), &
-                         c_loc(xmax),c_loc(nodes),c_loc(f),ierror)
-        splfe = f(1)
+        integer :: nderiv(max(ndim,1))
+        nderiv = 0
+        splfe = eval_point(me,ndim,x,nderiv,coef,xmin,xmax,nodes,ierror)
     end function splfe
 
-    !> Partial derivative at one point; same arguments as the reference's splde (:1089).
+    !> Partial derivative at one point; same arguments as the reference's splde (:1089).  Host computation.
     function splde(me,ndim,x,nderiv,coef,xmin,xmax,nodes,ierror)
         class(splpak_type),intent(inout) :: me
         real(wp) :: splde
         integer,intent(in) :: ndim
-        real(wp),intent(in),target :: x(*)
-        integer,intent(in),target :: nderiv(*)
-        real(wp),intent(out),target :: coef(*)
-        real(wp),intent(in),target :: xmin(*), xmax(*)
-        integer,intent(in),target :: nodes(*)
+        real(wp),intent(in) :: x(*)
+        integer,intent(in) :: nderiv(*)
+        real(wp),intent(out) :: coef(*)
+        real(wp),intent(in) :: xmin(*), xmax(*)
+        integer,intent(in) :: nodes(*)
         integer,intent(out) :: ierror
-        real(wp),target :: f(1)
-        call eval_common(me,ndim,1_c_int64_t,c_loc(x),max(ndim,1),c_loc(nderiv),c_loc(coef),c_loc(xmin), &
-                         c_loc(xmax),c_loc(nodes),c_loc(f),ierror)
-        splde = f(1)
+        splde = eval_point(me,ndim,x,nderiv,coef,xmin,xmax,nodes,ierror)
     end function splde
+
+    !> One 1-D factor of the tensor-product basis: the natural-spline basis function centred on node
+    !! `ib` of a dimension with `nod` nodes, spacing 1/s, or its first / second derivative, at `xx`.
+    !! Closed forms of SURVEY appendix A (reference bascmp :231-381): interior functions are the
+    !! cubic "chapeau" B-splines, the two functions at either end are cubic inside and straight lines
+    !! outside (natural boundary, linear extrapolation).  Strict inequalities as in the reference.
+    pure function basis_factor(ib,nod,ider,xx,xnode,s) result(b)
+        integer,intent(in) :: ib, nod, ider
+        real(real64),intent(in) :: xx, xnode, s
+        real(real64) :: b, z, z1, f
+        b = 0.0_real64
+        if (ib >= 2 .and. ib <= nod-3) then                 ! chapeau (:253-300)
+            select case (ider)
+            case (0)
+                z = abs(s*(xx-xnode)) - 2.0_real64
+                if (z < 0.0_real64) then
+                    b = -0.25_real64*z**3
+                    z1 = z + 1.0_real64
+                    if (z1 < 0.0_real64) b = b + z1**3
+                end if
+            case (1)
+                f = s
+                if (xx-xnode < 0.0_real64) f = -s
+                z = f*(xx-xnode) - 2.0_real64
+                if (z < 0.0_real64) then
+                    b = -0.75_real64*z**2
+                    z1 = z + 1.0_real64
+                    if (z1 < 0.0_real64) b = b + 3.0_real64*z1**2
+                    b = b*f
+                end if
+            case default
+                z = s*abs(xx-xnode) - 2.0_real64
+                if (z < 0.0_real64) then
+                    b = -1.5_real64*z
+                    z1 = z + 1.0_real64
+                    if (z1 < 0.0_real64) b = b + 6.0_real64*z1
+                    b = b*s*s
+                end if
+            end select
+            return
+        end if
+        f = s                                               ! end functions: left (ib <= 1) mirrors right (:302-379)
+        if (ib <= 1) f = -s
+        z = f*(xx-xnode) + 2.0_real64
+        select case (ider)
+        case (0)
+            if (z > 0.0_real64) then
+                if (z < 2.0_real64) then
+                    b = 0.5_real64*z**3
+                    z1 = z - 1.0_real64
+                    if (z1 > 0.0_real64) b = b - z1**3
+                else
+                    b = 3.0_real64*z - 3.0_real64
+                end if
+            end if
+        case (1)
+            if (z > 0.0_real64) then
+                if (z < 2.0_real64) then
+                    b = 1.5_real64*z**2
+                    z1 = z - 1.0_real64
+                    if (z1 > 0.0_real64) b = b - 3.0_real64*z1**2
+                    b = b*f
+                else
+                    b = 3.0_real64*f
+                end if
+            end if
+        case default
+            z1 = z - 1.0_real64
+            if (abs(z1) < 1.0_real64) then
+                b = 3.0_real64*z
+                if (z1 > 0.0_real64) b = b - 6.0_real64*z1
+                b = b*f*f
+            end if
+        end select
+    end function basis_factor
+
+    !> The scalar evaluation: checks and `ierror` as splde (:1166-1194: 101/102/103 return 0, 104 is
+    !! reported and the value is still computed), then the separable form of the reference's window
+    !! sum (:1197-1236): per dimension the (at most) four 1-D factors of the window
+    !! [ibmn, ibmx] (:1201-1209) are tabulated once, and the 4^ndim products are accumulated with the
+    !! first dimension running fastest.  Any ndim >= 1 (the reference documents 1..4, :1099).
+    function eval_point(me,ndim,x,nderiv,coef,xmin,xmax,nodes,ierror) result(f)
+        class(splpak_type),intent(inout) :: me
+        integer,intent(in) :: ndim
+        real(wp),intent(in) :: x(*)
+        integer,intent(in) :: nderiv(*)
+        real(wp),intent(in) :: coef(*)
+        real(wp),intent(in) :: xmin(*), xmax(*)
+        integer,intent(in) :: nodes(*)
+        integer,intent(out) :: ierror
+        real(wp) :: f
+        real(real64) :: tab(4,max(ndim,1)), dx, s, t, prod, acc
+        integer :: first(max(ndim,1)), width(max(ndim,1)), k(max(ndim,1)), stride(max(ndim,1))
+        integer :: idim, it, ibmn, ibmx, j, icol, ider
+        f = 0.0_wp
+        ierror = 0
+        me%mdim = ndim
+        if (ndim < 1) then
+            ierror = 101
+            call report(ierror,' splfe or splde - NDIM is less than 1')
+            return
+        end if
+        do idim = 1, ndim
+            if (nodes(idim) < 4) then
+                ierror = 102
+                call report(ierror,' splfe or splde - NODES(IDIM) is less than  4for some IDIM')
+                return
+            end if
+            if (xmax(idim) - xmin(idim) == 0.0_wp) then
+                ierror = 103
+                call report(ierror,' splfe or splde - XMIN(IDIM) = XMAX(IDIM) for some IDIM')
+                return
+            end if
+        end do
+        do idim = 1, ndim
+            if (nderiv(idim) < 0 .or. nderiv(idim) > 2) then
+                ierror = 104
+                call report(ierror,' splde - NDERIV(IDIM) IS less than 0 or greater than 2 for some IDIM')
+                exit                                        ! the reference reports and computes on (:1190-1194)
+            end if
+        end do
+        icol = 1
+        do idim = 1, ndim
+            stride(idim) = icol
+            icol = icol*nodes(idim)
+            dx = (real(xmax(idim),real64) - real(xmin(idim),real64))/real(nodes(idim)-1,real64)
+            s = 1.0_real64/dx
+            t = s*(real(x(idim),real64) - real(xmin(idim),real64))
+            it = int(max(min(t,2.0e9_real64),-2.0e9_real64))     ! truncation toward zero, saturating
+            ibmn = min(max(it-1,0),nodes(idim)-2)
+            ibmx = max(min(it+2,nodes(idim)-1),1)
+            first(idim) = ibmn
+            width(idim) = ibmx - ibmn + 1
+            ider = min(max(nderiv(idim),0),2)
+            do j = 1, width(idim)
+                tab(j,idim) = basis_factor(ibmn+j-1, nodes(idim), ider, real(x(idim),real64), &
+                                           real(xmin(idim),real64) + real(ibmn+j-1,real64)*dx, s)
+            end do
+        end do
+        acc = 0.0_real64
+        k = 1
+        do
+            prod = 1.0_real64
+            icol = 1
+            do idim = 1, ndim
+                prod = prod*tab(k(idim),idim)
+                icol = icol + (first(idim) + k(idim) - 1)*stride(idim)
+            end do
+            acc = acc + real(coef(icol),real64)*prod
+            idim = 1                                        ! odometer, first dimension fastest (:1228-1232)
+            do while (idim <= ndim)
+                k(idim) = k(idim) + 1
+                if (k(idim) <= width(idim)) exit
+                k(idim) = 1
+                idim = idim + 1
+            end do
+            if (idim > ndim) exit
+        end do
+        f = real(acc,wp)
+    end function eval_point
 
     !> Batch of values: x(ldx,nq) -> f(nq).  One kernel launch for all points.
     subroutine splfe_many(me,ndim,nq,x,ldx,coef,xmin,xmax,nodes,f,ierror)

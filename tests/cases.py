@@ -39,6 +39,8 @@ CASES = {
     "3d8_cc_clust":   dict(ndim=3, nodes=[8, 8, 8], m=8000, weighted=False, xtrap=1.0, variant="clustered"),
     "3d_aniso":       dict(ndim=3, nodes=[5, 9, 6], m=4000, weighted=True, xtrap=1.0, variant="box"),
     "3d12":           dict(ndim=3, nodes=[12, 12, 12], m=4000, weighted=True, xtrap=1.0, variant="dense"),
+    # SURVEY 8c's 3-D 16^3 (4096 columns) case: the largest 3-D grid the dense reference reaches (~2 h)
+    "3d16":           dict(ndim=3, nodes=[16, 16, 16], m=10000, weighted=True, xtrap=1.0, variant="dense", slow=True),
     "4d4":            dict(ndim=4, nodes=[4, 4, 4, 4], m=3000, weighted=True, xtrap=1.0, variant="dense"),
     "4d5_cc":         dict(ndim=4, nodes=[5, 5, 5, 5], m=4000, weighted=False, xtrap=1.0, variant="outside"),
     "4d6":            dict(ndim=4, nodes=[6, 6, 6, 6], m=5000, weighted=True, xtrap=1.0, variant="dense"),

@@ -141,3 +141,18 @@ def test_histogram_out_of_range_quirk(port):
     base = port.fit(2, x[:-1], y[:-1], None, [0.0, 0.0], [1.0, 1.0], [4, 4], 1.0)[2]
     diff = work[:16] - base[:16]
     assert diff[2] == 1.0 and np.count_nonzero(diff) == 1
+
+
+@pytest.mark.parametrize("name", ["2d8", "3d8", "4d4"])
+def test_real32_goldens_are_single_precision_images_of_the_real64_ones(name):
+    """tests/golden/*_r32.npz come from the reference built with -DREAL32 (src/splpak.F90:33-41) on the
+    inputs rounded to single precision: stored as float32, and within single-precision conditioning of
+    the real64 goldens (they are the oracle of the GPU tier's REAL32 tests)."""
+    g32, g64 = load_golden(name + "_r32"), load_golden(name)
+    assert g32["coef"].dtype == np.float32 and g32["values"].dtype == np.float32
+    assert int(g32["ierror"]) == 0
+    assert np.array_equal(g32["patterns"], g64["patterns"])
+    assert 1e-9 < relmax(g32["coef"], g64["coef"]) < 1e-3
+    assert relmax(g32["values"][0], g64["values"][0]) < 2e-3
+    if g64["hist"].size:
+        assert relmax(g32["hist"], g64["hist"]) < 1e-5
