@@ -280,6 +280,15 @@ def main():
     evals_per_s = world * nq / (ev_ms * 1e-3)
     ev_bytes = 8.0 * (nd + 1) * nq
 
+    # fabric bytes per launch of the dominant evaluation kernel (PMC passes, profiles/r02_eval_pmc.json)
+    eval_traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_eval_pmc.json")))
+        eval_traffic = {"kernel": "eval_binned_kernel<3,true>", "bytes_per_launch": pm["kernels"]["eval_binned_kernel<3, true>"]["hbm_bytes"],
+                        "queries_per_launch": pm["queries_per_launch"],
+                        "bytes_per_query_all_passes": pm["hbm_bytes_per_query_all_passes"], "algorithmic_bytes_per_query": 8.0 * (nd + 1)}
+    except Exception:
+        pass
     if rank == 0:
         line = {
             "metric": (f"fitted points/sec (splcw) + evals/sec (splfe), {nd}-D {m:.0e} pts {nod}^{nd} nodes"
@@ -310,11 +319,11 @@ def main():
             "evals_per_s": evals_per_s,
             "eval": {
                 "value": evals_per_s, "unit": "evals/s", "queries_per_gpu": nq, "ms_per_batch": ev_ms,
-                "path": "auto (LDS-binned: queries sorted by grid region, 3 passes + evaluation from LDS tiles)",
+                "path": "auto (LDS-binned: queries sorted by grid region -- count, place, evaluate from LDS tiles)",
                 "direct_path_evals_per_s": world * nq / (ev_direct_ms * 1e-3),
                 "roofline": {"bound": "hbm", "achieved": ev_bytes / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": ev_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": None},
+                             "traffic": eval_traffic},
             },
         }
         if kt_sum["syrk_ms"] > 0:

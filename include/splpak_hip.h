@@ -211,7 +211,7 @@ void splpak_shutdown(void);
  *   mode 0  automatic: batches of >= 2^20 queries on 3-D and 4-D grids of more than 32768 nodes
  *           take the binned path, everything else the direct one
  *   mode 1  direct: one thread per query, coefficients gathered from global memory
- *   mode 2  binned: queries are sorted by grid region, `chunk` queries at a time (0 = 2^26), and
+ *   mode 2  binned: queries are sorted by grid region, `chunk` queries at a time (0 = 2^24), and
  *           each region is evaluated from a copy of its coefficients in LDS; needs
  *           chunk*(8*ndim+4) bytes of device scratch, kept until splpak_shutdown
  * There is no counterpart in the reference (splde evaluates one point per call, :1089-1240). */

@@ -132,6 +132,87 @@ __host__ __device__ inline int window_table(const Grid &g, int d, double x, int 
     return ws;
 }
 
+// The same table for the VALUE (no derivative), written for the evaluation kernels, which spent most
+// of their instructions here (round 2 counters: ~550 of 650 VALU instructions per query).  The
+// piecewise definitions are applied with min/max instead of compare-and-select -- a cube of
+// min(z, 0) IS "z^3 if z < 0 else 0" -- which keeps the reference's strict inequalities and, on the
+// piece that applies, exactly basis_1d's operations in the same order: both tables return identical
+// bits.  `interior`: the caller knows that all four window functions are interior ("chapeau")
+// functions and all four lie inside [ibmn, ibmx] (2 <= ws <= nod-6 with the point inside the grid), so
+// the end-function form and the window clipping are skipped.
+__host__ __device__ inline double chapeau_value(double u)
+{
+#pragma clang fp contract(off)
+    const double z = fabs(u) - 2.0;                    // :253-270
+    const double zc = fmin(z, 0.0);
+    double b = -0.25 * (zc * zc * zc);
+    const double z1 = fmin(zc + 1.0, 0.0);
+    b += z1 * z1 * z1;
+    return b;
+}
+
+__host__ __device__ inline double endfn_value(double zarg)
+{
+#pragma clang fp contract(off)
+    // :345-379 with z = zarg: 0 for z <= 0, z^3/2 - (z-1)^3 [z > 1] on (0,2), 3z - 3 from 2 on
+    const double zp = fmax(zarg, 0.0);
+    double b = 0.5 * (zp * zp * zp);
+    const double z1 = fmax(zp - 1.0, 0.0);
+    b -= z1 * z1 * z1;
+    return (zarg < 2.0) ? b : 3.0 * zarg - 3.0;
+}
+
+// window start and whether the window is an interior one (see above); it = trunc(dxin (x - xmin))
+__host__ __device__ inline int window_start_value(const Grid &g, int d, double x, int &lo, int &hi, bool &interior)
+{
+#pragma clang fp contract(off)
+    const int nod = g.nodes[d];
+    const double t = g.dxin[d] * (x - g.xmin[d]);
+    int it = (t >= 2.0e9) ? 2000000000 : (t <= -2.0e9 ? -2000000000 : (int)t);
+    int a = it - 1;
+    if (a < 0) a = 0;
+    lo = a < nod - 2 ? a : nod - 2;
+    int h = it + 2;
+    if (h > nod - 1) h = nod - 1;
+    hi = h > 1 ? h : 1;
+    // it in [3, nod-5]: ws = it-1 in [2, nod-6], entries ws..ws+3 = it-1..it+2 <= nod-3 are chapeau
+    // functions and [lo, hi] = [ws, ws+3]
+    interior = it >= 3 && it <= nod - 5;
+    return a < nod - 4 ? a : nod - 4;
+}
+
+template <bool INTERIOR>
+__host__ __device__ inline void window_values(const Grid &g, int d, double x, int ws, int lo, int hi, double b[4])
+{
+#pragma clang fp contract(off)
+    const int nod = g.nodes[d];
+    const double s = g.dxin[d];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ib = ws + k;
+        const double xb = g.xmin[d] + (double)ib * g.dx[d];      // :246
+        const double bc = chapeau_value(s * (x - xb));
+        if (INTERIOR) {
+            b[k] = bc;
+        } else {
+            // entries 0,1 can only be left-end or interior functions, entries 2,3 interior or right-end
+            const double be = endfn_value(((k < 2) ? s * (xb - x) : s * (x - xb)) + 2.0);
+            const bool end = (k < 2) ? (ib <= 1) : (ib >= nod - 2);
+            const double v = end ? be : bc;
+            b[k] = (ib >= lo && ib <= hi) ? v : 0.0;
+        }
+    }
+}
+
+__host__ __device__ inline int window_table_value(const Grid &g, int d, double x, double b[4])
+{
+    int lo, hi;
+    bool interior;
+    const int ws = window_start_value(g, d, x, lo, hi, interior);
+    window_values<false>(g, d, x, ws, lo, hi, b);
+    return ws;
+}
+
 // nearest-node address of the sparse-area histogram (:894-902), including the
 // reference's quirk: an out-of-range coordinate only skips ITS dimension in the
 // Horner address; the point is still counted (:899).

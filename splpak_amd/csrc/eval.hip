@@ -13,51 +13,85 @@
 // path sorts large batches by grid region and gathers from LDS (see below).
 #include "basis.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace splpak {
 
 struct NDeriv { int v[MAXD]; };
 
-// Sum of the 4^D window products in the reference's order (dimension 1 fastest, :1228-1232).
-// load4(k1, k2, k3, c) delivers the 4 coefficients of the window row (k0 = 0..3).  Shared by the
-// direct and the binned kernels so that both produce bit-identical values.
+// Sum of the 4^D window products, factorised: the innermost dimension is contracted with its four
+// factors first, then the partial sums with the factors of the next dimension, and so on -- 64 + 16 + 4
+// fused multiply-adds in 3-D instead of the 64 * 3 multiplications of the plain triple product (the
+// reference forms every product basm = prod_d bas1_d and adds coef*basm, :1215-1236; the two orders
+// differ by rounding only).  load4(k1, k2, k3, c) delivers the 4 coefficients of the window row
+// (k0 = 0..3).  Shared by the direct and the binned kernels so that both produce bit-identical values.
 template <int D, typename L4>
 __device__ inline double window_sum(const double (&b)[D][4], L4 &&load4)
 {
-    double sum = 0.0;
-    auto row = [&](int k1, int k2, int k3, double scale) {
+    auto row = [&](int k1, int k2, int k3) {
         double c[4];
         load4(k1, k2, k3, c);
-        sum = fma(c[0], b[0][0] * scale, sum);
-        sum = fma(c[1], b[0][1] * scale, sum);
-        sum = fma(c[2], b[0][2] * scale, sum);
-        sum = fma(c[3], b[0][3] * scale, sum);
+        double t = c[0] * b[0][0];
+        t = fma(c[1], b[0][1], t);
+        t = fma(c[2], b[0][2], t);
+        t = fma(c[3], b[0][3], t);
+        return t;
     };
     if constexpr (D == 1) {
-        double c[4];
-        load4(0, 0, 0, c);
-#pragma unroll
-        for (int k0 = 0; k0 < 4; ++k0) sum = fma(c[k0], b[0][k0], sum);
+        return row(0, 0, 0);
     } else if constexpr (D == 2) {
+        double sum = 0.0;
 #pragma unroll
-        for (int k1 = 0; k1 < 4; ++k1) row(k1, 0, 0, b[1][k1]);
+        for (int k1 = 0; k1 < 4; ++k1) sum = fma(row(k1, 0, 0), b[1][k1], sum);
+        return sum;
     } else if constexpr (D == 3) {
+        double sum = 0.0;
 #pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2)
+        for (int k2 = 0; k2 < 4; ++k2) {
+            double r = 0.0;
 #pragma unroll
-            for (int k1 = 0; k1 < 4; ++k1) row(k1, k2, 0, b[1][k1] * b[2][k2]);
+            for (int k1 = 0; k1 < 4; ++k1) r = fma(row(k1, k2, 0), b[1][k1], r);
+            sum = fma(r, b[2][k2], sum);
+        }
+        return sum;
     } else {
-        for (int k3 = 0; k3 < 4; ++k3)
+        double sum = 0.0;
+        for (int k3 = 0; k3 < 4; ++k3) {
+            double q = 0.0;
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2)
+            for (int k2 = 0; k2 < 4; ++k2) {
+                double r = 0.0;
 #pragma unroll
-                for (int k1 = 0; k1 < 4; ++k1) row(k1, k2, k3, (b[1][k1] * b[2][k2]) * b[3][k3]);
+                for (int k1 = 0; k1 < 4; ++k1) r = fma(row(k1, k2, k3), b[1][k1], r);
+                q = fma(r, b[2][k2], q);
+            }
+            sum = fma(q, b[3][k3], sum);
+        }
+        return sum;
     }
-    return sum;
+}
+
+// the 4-entry factor table of dimension d: the branch-free value form when no derivative is asked for
+template <bool VAL>
+__device__ inline int eval_table(const Grid &g, int d, double x, int nder, double (&b)[4])
+{
+    if constexpr (VAL) {
+        int lo, hi;
+        bool interior;
+        const int ws = window_start_value(g, d, x, lo, hi, interior);
+        // wave-uniform choice: the short interior form when EVERY lane's window is an interior one
+        // (queries sorted by region: most waves), the general form for all lanes otherwise -- no
+        // wave ever executes both
+        if (__builtin_amdgcn_ballot_w64(!interior) == 0) window_values<true>(g, d, x, ws, lo, hi, b);
+        else window_values<false>(g, d, x, ws, lo, hi, b);
+        return ws;
+    } else {
+        return window_table(g, d, x, nder, b);
+    }
 }
 
 // ---- direct path: one thread per query, coefficient gathers from global memory (L2) -------------
-template <int D, typename T>
+template <int D, typename T, bool VAL>
 __global__ void __launch_bounds__(256)
 eval_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, NDeriv nd,
             const T *__restrict__ coef, T *__restrict__ out)
@@ -69,7 +103,7 @@ eval_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, NDeriv nd,
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const double x = (double)xq[i * ldxq + d];
-            const int ws = window_table(g, d, x, nd.v[d], b[d]);
+            const int ws = eval_table<VAL>(g, d, x, nd.v[d], b[d]);
             base += ws * g.colstride[d];
         }
         // The 4 coefficients of a window row are contiguous: two 16-byte loads instead of four
@@ -99,8 +133,9 @@ eval_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, NDeriv nd,
 // coefficients (box + 3 nodes per dimension, 4096 doubles = 32 KB) fit in LDS -- and evaluates
 // every region's queries from an LDS copy of its coefficients: the gathers become LDS reads, the
 // global traffic per query is its coordinates, a permutation index and the result.
-//   pass A  bin_count_kernel    region histogram of the chunk (LDS histogram per workgroup)
-//           bin_scan_kernel     offsets, cursors and workgroups per region
+//   pass A  bin_count_kernel    region histogram of the chunk + per-workgroup region counts
+//           bin_scan_kernel     offsets and workgroups per region
+//           bin_wgbase_kernel   where every pass-B workgroup's runs start (prefix over workgroups)
 //   pass B  bin_scatter_kernel  coordinates + original index copied into region order
 //   pass C  eval_binned_kernel  one workgroup per (region, 2048 queries)
 // The arithmetic per query is window_table + window_sum exactly as in the direct kernel, so both
@@ -111,7 +146,6 @@ template <> struct TileShape<3> { static constexpr int T[4] = {16, 16, 16, 1}; }
 template <> struct TileShape<4> { static constexpr int T[4] = {8, 8, 8, 8}; };
 constexpr int TILE_ELEMS = 4096;
 constexpr int BIN_MAX = 2048;          // regions per grid handled by the LDS histograms
-constexpr int BIN_QPT = 16;            // queries per thread in pass A
 constexpr int EVAL_QPW = 2048;         // queries per workgroup in pass C
 
 struct Regions { int nreg[MAXD]; int nbins; };
@@ -130,16 +164,24 @@ __device__ inline int region_of(const Grid &g, const Regions &rg, const double *
     return r;
 }
 
+template <int D> struct ScatterShape { static constexpr int QPT = D == 4 ? 4 : 8; };   // queries per thread in passes A and B
+
+// Pass A.  Workgroup w counts the SAME 256*QPT queries that workgroup w of pass B will place, and
+// leaves its per-region counts in row w of `cnt`; the column-wise prefix of that matrix
+// (bin_wgbase_kernel) then tells every pass-B workgroup where each of its runs starts.  No workgroup
+// ever waits on a global atomic (round 2: 2 050 workgroups taking turns on 125 cursor words cost 42 of
+// the 80 us of pass B), and the sorted order is a function of the input alone.
 template <int D>
 __global__ void __launch_bounds__(256)
-bin_count_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int ldxq, int *__restrict__ hist)
+bin_count_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int ldxq, int *__restrict__ cnt, int ldw)
 {
+    constexpr int QPT = ScatterShape<D>::QPT;
     __shared__ int lh[BIN_MAX];
     for (int b = threadIdx.x; b < rg.nbins; b += 256) lh[b] = 0;
     __syncthreads();
-    const int base = blockIdx.x * (256 * BIN_QPT);
-#pragma unroll 4
-    for (int j = 0; j < BIN_QPT; ++j) {
+    const int base = blockIdx.x * (256 * QPT);
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
         const int i = base + j * 256 + threadIdx.x;
         if (i < n) {
             double x[D];
@@ -149,8 +191,52 @@ bin_count_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int l
         }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < rg.nbins; b += 256)
-        if (lh[b]) atomicAdd(&hist[b], lh[b]);
+    for (int b = threadIdx.x; b < rg.nbins; b += 256) cnt[(long long)b * ldw + blockIdx.x] = lh[b];   // row b = region b
+}
+
+// hist[b] = sum_w cnt[b][w]: one workgroup per region, no atomics
+__global__ void __launch_bounds__(256)
+bin_total_kernel(int nwg, int ldw, const int *__restrict__ cnt, int *__restrict__ hist)
+{
+    __shared__ int part[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    int sum = 0;
+    for (int w = t; w < nwg; w += 256) sum += cnt[(long long)b * ldw + w];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) part[t] += part[t + o];
+        __syncthreads();
+    }
+    if (t == 0) hist[b] = part[0];
+}
+
+// cnt[b][w] <- off[b] + sum_{w' < w} cnt[b][w']: first sorted position of workgroup w's run of region b.
+// One workgroup per region.
+__global__ void __launch_bounds__(256)
+bin_wgbase_kernel(int nwg, int ldw, const int *__restrict__ off, int *__restrict__ cnt)
+{
+    __shared__ int part[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    int *__restrict__ row = cnt + (long long)b * ldw;
+    const int per = (nwg + 255) / 256;
+    const int w0 = t * per, w1 = (w0 + per < nwg) ? w0 + per : nwg;
+    int sum = 0;
+    for (int w = w0; w < w1; ++w) sum += row[w];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = off[b] + part[t] - sum;
+    for (int w = w0; w < w1; ++w) {
+        const int c = row[w];
+        row[w] = run;
+        run += c;
+    }
 }
 
 // ints: hist[nbins] | off[nbins+1] | cursor[nbins] | wgoff[nbins+1]
@@ -196,17 +282,17 @@ bin_scan_kernel(int nbins, const int *__restrict__ hist, int *__restrict__ off, 
 // memory walks every region's run with consecutive lanes on consecutive addresses (the
 // straightforward per-query scatter issued one 8-byte store request per coordinate and was
 // bound by the request rate, not by bytes).
-template <int D> struct ScatterShape { static constexpr int QPT = D == 4 ? 4 : 8; };   // queries per thread
 template <int D>
 __global__ void __launch_bounds__(256)
 bin_scatter_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int ldxq,
-                   int *__restrict__ cursor, double *__restrict__ xs, int *__restrict__ perm)
+                   const int *__restrict__ wgbase, int ldw, double *__restrict__ xs, long long ldp, int *__restrict__ perm)
 {
     constexpr int QPT = ScatterShape<D>::QPT, QPW = 256 * QPT;
     __shared__ double sx[QPW * D];
     __shared__ int sidx[QPW];
     __shared__ unsigned short srid[QPW];
-    __shared__ int lh[BIN_MAX], lbase[BIN_MAX];
+    extern __shared__ int lds_bins[];          // lh[nbins] | lbase[nbins]: sized by the launch, not by BIN_MAX
+    int *lh = lds_bins, *lbase = lds_bins + rg.nbins;
     __shared__ int sscan[256];
     for (int b = threadIdx.x; b < rg.nbins; b += 256) lh[b] = 0;
     __syncthreads();
@@ -243,7 +329,7 @@ bin_scatter_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int
     for (int b = b0; b < b0 + per && b < rg.nbins; ++b) {
         const int c = lh[b];
         lh[b] = q;
-        lbase[b] = (c ? atomicAdd(&cursor[b], c) : 0) - q;
+        lbase[b] = wgbase[(long long)b * ldw + blockIdx.x] - q;
         q += c;
     }
     const int total = sscan[255];
@@ -254,23 +340,25 @@ bin_scatter_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int
         const int i = base + j * 256 + threadIdx.x;
         const int lp = lh[rid[j]] + rank[j];
 #pragma unroll
-        for (int d = 0; d < D; ++d) sx[lp * D + d] = xr[j][d];
+        for (int d = 0; d < D; ++d) sx[d * QPW + lp] = xr[j][d];
         sidx[lp] = i;
         srid[lp] = (unsigned short)rid[j];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < total * D; e += 256) {
-        const int lp = e / D, d = e - lp * D;
+    // copy-out: the sorted image goes to D coordinate planes (xs[d*ldp + position]) and the permutation;
+    // consecutive lanes walk a region's run on consecutive addresses in every plane
+    for (int lp = threadIdx.x; lp < total; lp += 256) {
         const long long gpos = lp + lbase[srid[lp]];
-        xs[gpos * D + d] = sx[e];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xs[(long long)d * ldp + gpos] = sx[d * QPW + lp];
+        perm[gpos] = sidx[lp];
     }
-    for (int lp = threadIdx.x; lp < total; lp += 256) perm[lp + lbase[srid[lp]]] = sidx[lp];
 }
 
-template <int D>
+template <int D, bool VAL>
 __global__ void __launch_bounds__(256)
 eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coef,
-                   const double *__restrict__ xs, const int *__restrict__ perm,
+                   const double *__restrict__ xs, long long ldp, const int *__restrict__ perm,
                    const int *__restrict__ off, const int *__restrict__ wgoff, double *__restrict__ out)
 {
     __shared__ double tile[TILE_ELEMS];
@@ -310,13 +398,32 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coe
     const int qb = off[r] + part * EVAL_QPW;
     const int qe = min(off[r + 1], qb + EVAL_QPW);
     constexpr int t1 = TS::T[0], t2 = TS::T[0] * TS::T[1], t3 = TS::T[0] * TS::T[1] * TS::T[2];
-    for (int j = qb + threadIdx.x; j < qe; j += 256) {
+    // the coordinates (and the destination) of the NEXT round are in flight while the current one is
+    // evaluated: a round's global loads would otherwise be exposed once per round
+    int j = qb + threadIdx.x;
+    double xn[D];
+    int pn = 0;
+    if (j < qe) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) xn[d] = xs[(long long)d * ldp + j];
+        pn = perm[j];
+    }
+    while (j < qe) {
+        double x[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = xn[d];
+        const int p = pn;
+        const int jn = j + 256;
+        if (jn < qe) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) xn[d] = xs[(long long)d * ldp + jn];
+            pn = perm[jn];
+        }
         double b[D][4];
         int base = 0, m = 1;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const double x = xs[(long long)j * D + d];
-            const int ws = window_table(g, d, x, nd.v[d], b[d]);
+            const int ws = eval_table<VAL>(g, d, x[d], nd.v[d], b[d]);
             base += (ws - a[d]) * m;
             m *= TS::T[d];
         }
@@ -324,10 +431,11 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coe
             // four ds_read_b64 (2 LDS cycles each, 64 banks) instead of the two ds_read2_b64 the
             // compiler would merge them into (8 cycles each, 32 banks): volatile keeps them apart
             typedef const volatile __attribute__((address_space(3))) double *lds_cvd;
-            lds_cvd p = (lds_cvd)tile + (base + k1 * t1 + k2 * t2 + k3 * t3);
-            c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3];
+            lds_cvd q = (lds_cvd)tile + (base + k1 * t1 + k2 * t2 + k3 * t3);
+            c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[3];
         });
-        out[perm[j]] = sum;
+        out[p] = sum;
+        j = jn;
     }
 }
 
@@ -337,6 +445,7 @@ struct EvalScratch {
     double *xs = nullptr;
     int *perm = nullptr;
     int *ints = nullptr;          // hist | off | cursor | wgoff
+    int *cnt = nullptr;           // per-workgroup region counts / run bases
     long long cap = 0;            // queries per chunk the buffers hold
     int capd = 0;
     hipEvent_t last = nullptr;    // end of the previous use (another stream must wait for it)
@@ -353,6 +462,7 @@ void eval_scratch_shutdown()
     if (s.xs) (void)hipFree(s.xs);
     if (s.perm) (void)hipFree(s.perm);
     if (s.ints) (void)hipFree(s.ints);
+    if (s.cnt) (void)hipFree(s.cnt);
     if (s.last) (void)hipEventDestroy(s.last);
     s = EvalScratch();
 }
@@ -367,7 +477,12 @@ template <int D>
 static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, const double *xq, int ldxq,
                               const NDeriv &nd, const double *coef, double *out, hipStream_t st)
 {
-    long long chunk = g_eval_chunk > 0 ? g_eval_chunk : (1LL << 26);
+    // default chunk: 2^24 queries (measured best at 64^3: large enough that the ~8 000 evaluation
+    // workgroups of a chunk keep every CU full to the end; chunks small enough to stay in the Infinity
+    // Cache were not faster -- the passes are bound by instructions, not by HBM)
+    long long chunk = g_eval_chunk > 0 ? g_eval_chunk : (1LL << 24);
+    bool value_only = true;
+    for (int d = 0; d < D; ++d) value_only = value_only && nd.v[d] == 0;
     if (chunk > (1LL << 28)) chunk = 1LL << 28;
     if (chunk > nq) chunk = nq;
     EvalScratch &s = g_scratch;
@@ -378,6 +493,8 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
         hipError_t e = hipMalloc(&s.xs, sizeof(double) * (size_t)chunk * D);
         if (e == hipSuccess) e = hipMalloc(&s.perm, sizeof(int) * (size_t)chunk);
         if (e == hipSuccess) e = hipMalloc(&s.ints, sizeof(int) * (4 * BIN_MAX + 8));
+        // per-workgroup region counts of pass A -> run bases of pass B: [workgroups of a chunk][regions]
+        if (e == hipSuccess) e = hipMalloc(&s.cnt, sizeof(int) * (size_t)(chunk / (256 * ScatterShape<D>::QPT) + 2) * rg.nbins);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.last, hipEventDisableTiming);
         if (e != hipSuccess) { eval_scratch_shutdown(); return e; }
         s.cap = chunk;
@@ -387,19 +504,24 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
         (void)hipStreamWaitEvent(st, s.last, 0);
     }
     int *hist = s.ints, *off = hist + BIN_MAX, *cursor = off + BIN_MAX + 1, *wgoff = cursor + BIN_MAX;
+    const int ldw = (int)(s.cap / (256 * ScatterShape<D>::QPT) + 2);       // row length of the count matrix
     for (long long c0 = 0; c0 < nq; c0 += chunk) {
         const int n = (int)(nq - c0 < chunk ? nq - c0 : chunk);
         const double *xc = xq + c0 * ldxq;
-        const unsigned nb = (unsigned)((n + 256 * BIN_QPT - 1) / (256 * BIN_QPT));
-        hipError_t e = hipMemsetAsync(hist, 0, sizeof(int) * rg.nbins, st);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((bin_count_kernel<D>), dim3(nb), dim3(256), 0, st, g, rg, n, xc, ldxq, hist);
-        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, st, rg.nbins, (const int *)hist, off, cursor, wgoff);
         const unsigned nbs = (unsigned)((n + 256 * ScatterShape<D>::QPT - 1) / (256 * ScatterShape<D>::QPT));
-        hipLaunchKernelGGL((bin_scatter_kernel<D>), dim3(nbs), dim3(256), 0, st, g, rg, n, xc, ldxq, cursor, s.xs, s.perm);
+        hipLaunchKernelGGL((bin_count_kernel<D>), dim3(nbs), dim3(256), 0, st, g, rg, n, xc, ldxq, s.cnt, ldw);
+        hipLaunchKernelGGL(bin_total_kernel, dim3(rg.nbins), dim3(256), 0, st, (int)nbs, ldw, (const int *)s.cnt, hist);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, st, rg.nbins, (const int *)hist, off, cursor, wgoff);
+        hipLaunchKernelGGL(bin_wgbase_kernel, dim3(rg.nbins), dim3(256), 0, st, (int)nbs, ldw, (const int *)off, s.cnt);
+        hipLaunchKernelGGL((bin_scatter_kernel<D>), dim3(nbs), dim3(256), 2 * sizeof(int) * rg.nbins, st, g, rg, n, xc, ldxq,
+                           (const int *)s.cnt, ldw, s.xs, s.cap, s.perm);
         const unsigned nw = (unsigned)(n / EVAL_QPW + rg.nbins + 1);
-        hipLaunchKernelGGL((eval_binned_kernel<D>), dim3(nw), dim3(256), 0, st, g, rg, nd, coef,
-                           (const double *)s.xs, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
+        if (value_only)
+            hipLaunchKernelGGL((eval_binned_kernel<D, true>), dim3(nw), dim3(256), 0, st, g, rg, nd, coef,
+                               (const double *)s.xs, s.cap, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
+        else
+            hipLaunchKernelGGL((eval_binned_kernel<D, false>), dim3(nw), dim3(256), 0, st, g, rg, nd, coef,
+                               (const double *)s.xs, s.cap, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
     }
     (void)hipEventRecord(s.last, st);
     return hipGetLastError();
@@ -593,12 +715,18 @@ static hipError_t launch_eval_t(const Grid &g, long long nq, const T *xq, int ld
     long long blocks = (nq + threads - 1) / threads;
     if (blocks > 256LL * 32) blocks = 256LL * 32;   // grid-stride the rest
     dim3 gr((unsigned)blocks), bl(threads);
+    bool value_only = true;
+    for (int d = 0; d < g.ndim; ++d) value_only = value_only && nd.v[d] == 0;
+#define SPLPAK_EVAL(DD)                                                                                              \
+    if (value_only) hipLaunchKernelGGL((eval_kernel<DD, T, true>), gr, bl, 0, st, g, nq, xq, ldxq, nd, coef, out);   \
+    else hipLaunchKernelGGL((eval_kernel<DD, T, false>), gr, bl, 0, st, g, nq, xq, ldxq, nd, coef, out);
     switch (g.ndim) {
-    case 1: hipLaunchKernelGGL((eval_kernel<1, T>), gr, bl, 0, st, g, nq, xq, ldxq, nd, coef, out); break;
-    case 2: hipLaunchKernelGGL((eval_kernel<2, T>), gr, bl, 0, st, g, nq, xq, ldxq, nd, coef, out); break;
-    case 3: hipLaunchKernelGGL((eval_kernel<3, T>), gr, bl, 0, st, g, nq, xq, ldxq, nd, coef, out); break;
-    default: hipLaunchKernelGGL((eval_kernel<4, T>), gr, bl, 0, st, g, nq, xq, ldxq, nd, coef, out); break;
+    case 1: SPLPAK_EVAL(1) break;
+    case 2: SPLPAK_EVAL(2) break;
+    case 3: SPLPAK_EVAL(3) break;
+    default: SPLPAK_EVAL(4) break;
     }
+#undef SPLPAK_EVAL
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@ GPU tier : the three test programs -- re-creations of the reference's own tests
            pass on the MI355X.
 """
 import os
+import re
 import subprocess
 
 import pytest
@@ -15,7 +16,7 @@ from tests.conftest import ROOT
 
 FDIR = os.path.join(ROOT, "splpak_amd", "fortran")
 BUILD = os.path.join(FDIR, "build")
-PROGS = ["test_linear", "test_noisy", "test_api"]
+PROGS = ["test_linear", "test_noisy", "test_api", "test_info"]
 
 
 def _ensure_built():
@@ -51,3 +52,18 @@ def test_fortran_program_on_gpu(prog):
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"PASS {prog}" in r.stdout
+    if prog == "test_linear":
+        # the reference's own 100-call scalar loop (test/splpak_test_linear.f90:66-72) is a host computation
+        secs = float(re.search(r"scalar evaluate loop seconds =\s*(\S+)", r.stdout).group(1))
+        assert secs < 1e-3, secs
+    if prog == "test_info":
+        # `reserr` surfaced by last_fit_info against the oracle's value for the same inputs (case 2d16)
+        from oracle import binding
+        from tests.cases import CASES, make_inputs
+        if not binding.port_available():
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "port"])
+        inp = make_inputs(CASES["2d16"])
+        P = binding.Port()
+        _, e0, _ = P.fit(2, inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"], inp["nodes"], 1.0)
+        got = float(re.search(r"reserr =\s*(\S+)", r.stdout).group(1))
+        assert e0 == 0 and abs(got - P.last_reserr) <= 1e-9 * P.last_reserr, (got, P.last_reserr)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Mean hardware-counter value per launch and kernel from rocprofv3 --pmc CSVs (one or more passes).
+
+    tools/pmc_kernels.py out.json pass1.csv [pass2.csv ...]
+
+Kernel names are shortened to the function name.  FETCH_SIZE / WRITE_SIZE are reported in KB as the
+profiler gives them plus `hbm_bytes` = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of
+MI355X_MICROARCH.md (a wide coalesced streaming read is counted at half its bytes)."""
+import collections, csv, json, re, sys
+out, paths = sys.argv[1], sys.argv[2:]
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for p in paths:
+    for r in csv.DictReader(open(p)):
+        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("splpak::", "").replace("(anonymous namespace)::", "")
+        a = acc[name][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+res = {}
+for k, cs in sorted(acc.items()):
+    d = {c: s / n for c, (s, n) in cs.items()}
+    d["launches"] = max(n for _, n in cs.values())
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["hbm_bytes"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+        d["hbm_bytes_uncorrected"] = (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+    res[k] = d
+json.dump(res, open(out, "w"), indent=1)
+for k, d in res.items():
+    print(k, {c: (f"{v:.4g}" if isinstance(v, float) else v) for c, v in d.items()})
