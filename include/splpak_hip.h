@@ -159,6 +159,40 @@ const double *splpak_plan_hist_dev(const splpak_plan *plan);
 void    splpak_plan_enable_kernel_timing(splpak_plan *plan, int32_t on);
 void    splpak_plan_kernel_timing(const splpak_plan *plan, double *out7);
 
+/* ---------------------------------------------------------------------------
+ * Several GPUs of one node, driven from ONE process: what a Fortran caller reaches
+ * through `splpak_type%set_gpus(n)`.  The points are sharded over the GPUs, the band of the normal
+ * equations is DISTRIBUTED: its 256-column blocks are dealt to the GPUs in chunks of `chunk` blocks,
+ * every GPU stores and updates only its own block columns, the solved panel of every block step
+ * travels GPU-to-GPU with hipMemcpyPeerAsync over xGMI, and the triangular sweeps hand the active
+ * window from owner to owner.  Memory per GPU is 1/ngpus of the band (26.9 GB at 64^3; the 852 GB of
+ * the 4-D 32^4 grid of BASELINE config 5 fit a node of 8 x 288 GB only this way).  Results are those
+ * of the single-GPU fit (same kernels per tile; reductions in rank order: bitwise reproducible).
+ * `devices`: NULL = devices 0..ngpus-1; entries may repeat -- with SPLPAK_VIRTUAL_GPUS=1 in the
+ * environment every rank is placed on the current device, which runs the whole protocol on one GPU
+ * (the 1-GPU test tier does that).
+ * ------------------------------------------------------------------------- */
+typedef struct splpak_mplan splpak_mplan;
+int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk, int32_t ndim,
+                            const int32_t *nodes, const double *xmin, const double *xmax, double xtrap,
+                            int64_t max_ndata_per_gpu, splpak_mplan **mplan);
+void    splpak_mplan_destroy(splpak_mplan *mplan);
+/* device of a rank (for placing its shard) */
+int32_t splpak_mplan_device(const splpak_mplan *mplan, int32_t rank);
+/* xdata_dev[r] / ydata_dev[r] / wdata_dev[r] (wdata_dev may be NULL = unweighted) are device pointers
+ * on rank r's GPU holding ndata[r] points (0 allowed); coef_dev (ncol doubles) is on rank 0's GPU.
+ * Blocks until the fit is complete.  Status and `info` as splpak_plan_fit_dev. */
+int32_t splpak_mplan_fit_dev(splpak_mplan *mplan, const double *const *xdata_dev, int32_t l1xdat,
+                             const double *const *ydata_dev, const double *const *wdata_dev,
+                             const int64_t *ndata, double *coef_dev, double *info);
+/* one-shot host entry: as splpak_fit_f64 on `ngpus` GPUs (contiguous shards of the points); ngpus <= 1
+ * is splpak_fit_f64 itself.  SPLPAK_DIST_CHUNK sets the chunk (default 1). */
+int32_t splpak_fit_multi_f64(int32_t ngpus, int32_t ndim, const double *xdata, int32_t l1xdat,
+                             const double *ydata, const double *wdata, int64_t ndata,
+                             const double *xmin, const double *xmax, const int32_t *nodes,
+                             double xtrap, double *coef, int64_t ncf, int64_t nwrk,
+                             double *hist_out, double *info);
+
 /* Batched evaluation on resident data (asynchronous on `stream`; no validation
  * beyond the reference's 101..104, which is done on the host from the small
  * arguments). */

@@ -30,6 +30,7 @@ SYMBOLS = [
     "splpak_plan_hist_dev", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing",
     "splpak_eval_dev_f64", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
+    "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
     "splpak_debug_spd_band_solve_f64", "splpak_shutdown", "splpak_set_eval_mode",
     "splpak_last_error_message", "splpak_device_name",
 ]
@@ -94,6 +95,16 @@ def lib() -> C.CDLL:
     L.splpak_synth_queries_f64.argtypes = [i32, i64, i64, i64, vp, vp]
     L.splpak_debug_spd_band_solve_f64.restype = i32
     L.splpak_debug_spd_band_solve_f64.argtypes = [i32, i32, _dp, _dp, _dp]
+    L.splpak_mplan_create.restype = i32
+    L.splpak_mplan_create.argtypes = [i32, _ip, i32, i32, _ip, _dp, _dp, dbl, i64, C.POINTER(vp)]
+    L.splpak_mplan_destroy.restype = None
+    L.splpak_mplan_destroy.argtypes = [vp]
+    L.splpak_mplan_device.restype = i32
+    L.splpak_mplan_device.argtypes = [vp, i32]
+    L.splpak_mplan_fit_dev.restype = i32
+    L.splpak_mplan_fit_dev.argtypes = [vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp, _dp]
+    L.splpak_fit_multi_f64.restype = i32
+    L.splpak_fit_multi_f64.argtypes = [i32, i32, _dp, i32, _dp, _dp, i64, _dp, _dp, _ip, dbl, _dp, i64, i64, _dp, _dp]
     L.splpak_shutdown.restype = None
     L.splpak_shutdown.argtypes = []
     L.splpak_set_eval_mode.restype = i32
@@ -170,6 +181,70 @@ def fit(ndim, xdata, ydata, wdata, xmin, xmax, nodes, xtrap, ncf=None, nwrk=-1, 
                    _p(xmax, rp), _p(nodes, _ip), xt, _p(coef, rp), ncf, nwrk, _p(hist, rp),
                    _p(info, _dp)))
     return coef, rc, hist, info
+
+
+def fit_multi(ngpus, ndim, xdata, ydata, wdata, xmin, xmax, nodes, xtrap, want_hist=False):
+    """splcw / splcc on `ngpus` GPUs of this node (distributed band, one process).  -> (coef, ierror, hist|None, info)."""
+    xdata = np.ascontiguousarray(xdata, dtype=np.float64)
+    if xdata.ndim == 1:
+        xdata = xdata.reshape(-1, 1)
+    ydata = np.ascontiguousarray(ydata, dtype=np.float64)
+    if wdata is not None:
+        wdata = np.ascontiguousarray(wdata, dtype=np.float64)
+    xmin, xmax, nodes = _grid(ndim, xmin, xmax, nodes)
+    ncol = int(np.prod(np.maximum(nodes[:max(ndim, 1)].astype(np.int64), 1)))
+    coef = np.zeros(max(ncol, 1))
+    hist = np.zeros(max(ncol, 1)) if want_hist else None
+    info = np.zeros(10)
+    rc = _check(lib().splpak_fit_multi_f64(int(ngpus), ndim, _p(xdata, _dp), xdata.shape[1], _p(ydata, _dp), _p(wdata, _dp),
+                                           xdata.shape[0], _p(xmin, _dp), _p(xmax, _dp), _p(nodes, _ip), float(xtrap),
+                                           _p(coef, _dp), ncol, -1, _p(hist, _dp), _p(info, _dp)))
+    return coef, rc, hist, info
+
+
+class MultiPlan:
+    """A fit plan over several GPUs of this node (one process; torch tensors own the shards)."""
+
+    def __init__(self, ngpus, ndim, nodes, xmin, xmax, xtrap, max_ndata_per_gpu, devices=None, chunk=1):
+        self._L = lib()
+        self.ngpus = int(ngpus)
+        self.xmin, self.xmax, self.nodes = _grid(ndim, xmin, xmax, nodes)
+        dv = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        rc = self._L.splpak_mplan_create(self.ngpus, _p(dv, _ip), int(chunk), ndim, _p(self.nodes, _ip), _p(self.xmin, _dp),
+                                         _p(self.xmax, _dp), float(xtrap), int(max_ndata_per_gpu), C.byref(h))
+        if rc != 0:
+            if rc < 0:
+                _check(rc)
+            raise SplpakError(f"multi-GPU plan rejected with ierror {rc}")
+        self._h = h
+
+    def device(self, rank):
+        return int(self._L.splpak_mplan_device(self._h, int(rank)))
+
+    def fit(self, xs, ys, ws, coef):
+        """xs/ys/ws: lists (one entry per rank) of float64 device tensors on that rank's GPU (ws may be
+        None); coef: float64 tensor on rank 0's GPU.  Blocks.  -> (ierror, info)."""
+        R = self.ngpus
+        vp = C.c_void_p
+        ax = (vp * R)(*[vp(t.data_ptr()) for t in xs])
+        ay = (vp * R)(*[vp(t.data_ptr()) for t in ys])
+        aw = None if ws is None else (vp * R)(*[vp(t.data_ptr()) for t in ws])
+        nn = (C.c_int64 * R)(*[int(t.shape[0]) for t in xs])
+        info = np.zeros(10)
+        rc = self._L.splpak_mplan_fit_dev(self._h, ax, int(xs[0].shape[1]), ay, aw, nn, vp(coef.data_ptr()), _p(info, _dp))
+        return _check(rc), info
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.splpak_mplan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def evaluate(ndim, xq, nderiv, coef, xmin, xmax, nodes, real32=False):

@@ -779,7 +779,7 @@ backward_error_kernel(Grid g, const double *__restrict__ nst, const double *__re
 // ---------------------------------------------------------------------------
 template <int D>
 __global__ void __launch_bounds__(256)
-expand_kernel(Grid g, const double *__restrict__ nst, double *__restrict__ ab, long long lda)
+expand_kernel(Grid g, const double *__restrict__ nst, double *__restrict__ ab, long long lda, DistMap dm)
 {
     const long long total = (long long)g.ncol * g.hstencil;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -798,14 +798,16 @@ expand_kernel(Grid g, const double *__restrict__ nst, double *__restrict__ ab, l
             j += o * g.colstride[d];
         }
         if (!ok) continue;
-        ab[(long long)i + (long long)j * lda] = nst[t];
+        const int J = j / NBLK;                 // block column of the entry: stored here only if this rank owns it
+        if (!dm_owned(dm, J)) continue;
+        ab[dm_shift(dm, J) + (long long)i + (long long)j * lda] = nst[t];
     }
 }
 
-__global__ void pad_diag_kernel(double *ab, long long lda, int n, int npad)
+__global__ void pad_diag_kernel(double *ab, long long lda, int n, int npad, DistMap dm)
 {
     const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npad) ab[(long long)i + (long long)i * lda] = 1.0;
+    if (i < npad && dm_owned(dm, i / NBLK)) ab[dm_shift(dm, i / NBLK) + (long long)i + (long long)i * lda] = 1.0;
 }
 
 inline unsigned grid_for(long long n, int threads, long long maxblocks = 256LL * 16)
@@ -930,16 +932,16 @@ hipError_t launch_backward_error(const Grid &g, const double *nst, const double 
     return hipGetLastError();
 }
 
-hipError_t launch_expand(const Grid &g, const double *nst, const Band &b, hipStream_t st)
+hipError_t launch_expand(const Grid &g, const double *nst, const Band &b, const DistMap &dm, hipStream_t st)
 {
     hipError_t e = hipMemsetAsync(b.ab, 0, b.bytes, st);
     if (e != hipSuccess) return e;
     const long long total = (long long)g.ncol * g.hstencil;
     dim3 gr(grid_for(total, 256, 256LL * 64)), bl(256);
-    DISPATCH_D(g.ndim, hipLaunchKernelGGL(expand_kernel<D>, gr, bl, 0, st, g, nst, b.ab, b.lda));
+    DISPATCH_D(g.ndim, hipLaunchKernelGGL(expand_kernel<D>, gr, bl, 0, st, g, nst, b.ab, b.lda, dm));
     if (b.npad > b.n)
         hipLaunchKernelGGL(pad_diag_kernel, dim3((b.npad - b.n + 255) / 256), dim3(256), 0, st, b.ab,
-                           b.lda, b.n, b.npad);
+                           b.lda, b.n, b.npad, dm);
     return hipGetLastError();
 }
 

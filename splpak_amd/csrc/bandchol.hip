@@ -681,11 +681,13 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
 // One workgroup per block, one thread per column of the inverse.
 __global__ void __launch_bounds__(256)
 trtri_kernel(const double *__restrict__ ab, long long lda, double *__restrict__ dinv,
-             double *__restrict__ dinvt)
+             double *__restrict__ dinvt, DistMap dm, const int *__restrict__ blocks)
 {
-    const int k0 = blockIdx.x * NBLK;
+    // block column handled by this workgroup: the blockIdx-th OWNED one when the band is distributed
+    const int J = blocks ? blocks[blockIdx.x] : (int)blockIdx.x;
+    const int k0 = J * NBLK;
     const int c = threadIdx.x;
-    const double *__restrict__ L = ab + ((long long)k0 + (long long)k0 * lda);
+    const double *__restrict__ L = ab + dm_shift(dm, J) + ((long long)k0 + (long long)k0 * lda);
     double *__restrict__ T = dinv + (long long)blockIdx.x * NBLK * NBLK;
     double *__restrict__ Tt = dinvt + (long long)blockIdx.x * NBLK * NBLK;   // Tt[c*256 + r] = Linv(r,c)
 
@@ -1002,6 +1004,185 @@ axpy_absmax_kernel(int n, double *__restrict__ x, const double *__restrict__ dx,
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Distributed band: block columns dealt to the ranks (GPUs) in chunks of `c` (DistMap, kernels.hpp).
+// A rank stores only its own block columns, packed: block column J lives in local slot
+// Jl = ((J / c) / R) c + J mod c.  With the dense-view addressing A(i,j) = ab[i + j lda] (lda = ld - 1)
+// every block column is the same view shifted by dm_shift(J) = 256 ld (Jl - J) doubles, so the
+// single-GPU kernels work on a rank's storage when they are handed ab + dm_shift(J).
+//
+// Trailing update of the block columns a rank owns by a panel that arrived in a buffer of its own
+// (P, leading dimension ldp, first row = global row `row0`): same register-streaming form as
+// syrk64_kernel (one wave = one 64x64 piece of C, accumulators initialised with the C tile, operands
+// streamed in MFMA fragment shape).
+__global__ void __launch_bounds__(64, 1)
+syrk64d_kernel(double *__restrict__ abl, long long lda, DistMap dm, const double *__restrict__ P, long long ldp,
+               int row0, int jb, int je, int re, int nitems)
+{
+    constexpr int SD = 16;
+    int it = (int)blockIdx.x;
+    if (it >= nitems) return;
+    // item -> (J, tj, ti): owned block columns J in [jb, je), their four 64-wide tile columns, rows tj..re-1
+    const int J0 = row0 / NBLK;
+    int J = jb, tj = 0, ti = 0;
+    bool found = false;
+    for (; J < je && !found; ++J) {
+        if (!dm_owned(dm, J)) continue;
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+            const int tjj = 4 * (J - J0) + t;
+            const int cnt = re - tjj;
+            if (cnt <= 0) continue;
+            if (it < cnt) { tj = tjj; ti = tjj + it; found = true; break; }
+            it -= cnt;
+        }
+        if (found) break;
+    }
+    if (!found) return;
+    const bool diag = (ti == tj);
+    const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
+    const double *__restrict__ pJ = P + (long long)(tj * 64 + l15) + (long long)q * ldp;
+    const double *__restrict__ pI = P + (long long)(ti * 64 + l15) + (long long)q * ldp;
+    double *__restrict__ C = abl + dm_shift(dm, J) + (long long)(row0 + ti * 64) + (long long)(row0 + tj * 64) * lda;
+    d4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                acc[m][n][v] = __builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * lda]);
+    double qa[SD][4], qb[SD][4];
+    auto fetch = [&](int slot, int step) {
+        const long long off = (long long)(4 * step) * ldp;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            qa[slot][m] = -pJ[off + 16 * m];
+            qb[slot][m] = pI[off + 16 * m];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < SD; ++d) fetch(d, d);
+    constexpr int NSTEP = NBLK / 4;
+    for (int ks = 0; ks < NSTEP; ks += SD) {
+#pragma unroll
+        for (int d = 0; d < SD; ++d) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+            if (ks + d + SD < NSTEP) fetch(d, ks + d + SD);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int r = n * 16 + l15;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c = m * 16 + q + 4 * v;
+                if (!diag || r >= c) __builtin_nontemporal_store(acc[m][n][v], &C[r + (long long)c * lda]);
+            }
+        }
+}
+
+// dst[r + c nrows] = src[r + c lda]: the solved panel, packed for the transfer to the other ranks
+__global__ void __launch_bounds__(256)
+pack_panel_kernel(const double *__restrict__ src, long long lda, double *__restrict__ dst, int nrows)
+{
+    const int c = blockIdx.y;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < nrows; r += gridDim.x * 256)
+        dst[(long long)c * nrows + r] = src[r + (long long)c * lda];
+}
+
+// backward sweep of the distributed band, panel part:  part[split][c] = sum_r L[r, c] x[r]  over the rows of
+// this split (rows below the diagonal block of column block k; L = the local panel in place).
+// grid (4, nsplit): 64 columns per workgroup; lane = (column, 16-row segment) as in bwd_update_kernel.
+__global__ void __launch_bounds__(256)
+panel_tdot_kernel(const double *__restrict__ Lp, long long lda, const double *__restrict__ x, int nrows,
+                  int rows_per_split, double *__restrict__ part)
+{
+    __shared__ double sx[NBLK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = lane & 15, cs = lane >> 4;
+    const int rbeg = blockIdx.y * rows_per_split;
+    const int rend = (rbeg + rows_per_split < nrows) ? rbeg + rows_per_split : nrows;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r0 = rbeg; r0 < rend; r0 += NBLK) {       // nrows and rows_per_split are multiples of 256
+        __syncthreads();
+        sx[tid] = x[r0 + tid];
+        __syncthreads();
+        double xs[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xs[i] = sx[seg * 16 + i];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int j = blockIdx.x * 64 + wave * 16 + cc * 4 + cs;
+            const double *__restrict__ Lc = Lp + (long long)j * lda + r0 + seg * 16;
+            double t = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const d2_t l = *reinterpret_cast<const d2_t *>(Lc + 2 * u);
+                t += l[0] * xs[2 * u] + l[1] * xs[2 * u + 1];
+            }
+            s[cc] += t;
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        double t = s[cc];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        const int j = blockIdx.x * 64 + wave * 16 + cc * 4 + cs;
+        if (seg == 0) part[(long long)blockIdx.y * NBLK + j] = t;
+    }
+}
+
+// x_k = Linv_k^T (y_k - sum_split part[split])   (dinvt row-major = Linv^T); grid 16 x 256 threads
+__global__ void __launch_bounds__(256)
+bwd_block_kernel(const double *__restrict__ Mt, const double *__restrict__ yk, const double *__restrict__ part,
+                 int nsplit, double *__restrict__ xk)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 16 + wave * 4;
+    double vv[4], s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        double v = yk[lane + 64 * u];
+        for (int sp = 0; sp < nsplit; ++sp) v -= part[(long long)sp * NBLK + lane + 64 * u];
+        vv[u] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s[i] = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[i] += Mt[(r0 + i) * NBLK + lane + 64 * u] * vv[u];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xk[r0 + i] = s[i];
+    }
+}
+
+// dst[i] += src[i]   /   dst[i] = owned(block of i) ? dst[i] : 0
+__global__ void __launch_bounds__(256)
+vec_add_kernel(long long n, double *__restrict__ dst, const double *__restrict__ src)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+__global__ void __launch_bounds__(256)
+mask_owned_kernel(int n, DistMap dm, double *__restrict__ x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !dm_owned(dm, i / NBLK)) x[i] = 0.0;
+}
+
 // absmax2[0] = max |a[i]|, absmax2[1] = max |b[i]|
 __global__ void __launch_bounds__(256)
 absmax2_kernel(int n, const double *__restrict__ a, const double *__restrict__ b,
@@ -1307,7 +1488,8 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     if (std::getenv("SPLPAK_DEBUG"))
         std::fprintf(stderr, "[splpak] band_cholesky: host enqueue of %d steps took %.1f ms\n", b.nblk,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
-    hipLaunchKernelGGL(trtri_kernel, dim3(b.nblk), dim3(256), 0, st, b.ab, b.lda, b.dinv, b.dinvt);
+    hipLaunchKernelGGL(trtri_kernel, dim3(b.nblk), dim3(256), 0, st, (const double *)b.ab, b.lda, b.dinv, b.dinvt,
+                       DistMap{1, 0, 1, b.lda + 1}, (const int *)nullptr);
     if (b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1)
         hipLaunchKernelGGL(sweepmat_kernel, dim3(2 * (b.nblk - 1), 16), dim3(256), 0, st, (const double *)b.ab, b.lda,
                            (const double *)b.dinv, (const double *)b.dinvt, b.mfwd, b.mbwd, b.nblk - 1);
@@ -1401,6 +1583,101 @@ hipError_t launch_axpy_absmax(int n, double *x, const double *dx, double *absmax
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(axpy_absmax_kernel, dim3(blocks), dim3(256), 0, st, n, x, dx,
                        reinterpret_cast<unsigned long long *>(absmax2));
+    return hipGetLastError();
+}
+
+// ---- launchers of the distributed-band pieces (dist.hip drives them) ----------------------------------
+hipError_t launch_potrf_block(double *abJ, long long lda, int k0, int *info, double *minpiv, double *inv16, hipStream_t st)
+{
+    hipLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, st, abJ, lda, k0, info, minpiv, inv16);
+    return hipGetLastError();
+}
+
+hipError_t launch_trsm_panel(const double *Lkk, double *X, long long lda, const double *inv16, int nrows, hipStream_t st)
+{
+    if (nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(trsm_kernel, dim3(nrows / 16), dim3(64), 0, st, Lkk, X, lda, inv16, nrows);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_panel(const double *src, long long lda, double *dst, int nrows, hipStream_t st)
+{
+    if (nrows <= 0) return hipSuccess;
+    int gx = (nrows + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(pack_panel_kernel, dim3(gx, NBLK), dim3(256), 0, st, src, lda, dst, nrows);
+    return hipGetLastError();
+}
+
+long long syrk64d_items(const DistMap &dm, int row0, int jb, int je, int re)
+{
+    long long items = 0;
+    const int J0 = row0 / NBLK;
+    for (int J = jb; J < je; ++J) {
+        if (!dm_owned(dm, J)) continue;
+        for (int t = 0; t < 4; ++t) {
+            const int cnt = re - (4 * (J - J0) + t);
+            if (cnt > 0) items += cnt;
+        }
+    }
+    return items;
+}
+
+hipError_t launch_syrk64d(double *abl, long long lda, const DistMap &dm, const double *P, long long ldp, int row0,
+                          int jb, int je, int re, hipStream_t st)
+{
+    const long long items = syrk64d_items(dm, row0, jb, je, re);
+    if (items <= 0) return hipSuccess;
+    hipLaunchKernelGGL(syrk64d_kernel, dim3((unsigned)items), dim3(64), 0, st, abl, lda, dm, P, ldp, row0, jb, je, re, (int)items);
+    return hipGetLastError();
+}
+
+hipError_t launch_trtri_owned(const double *abl, long long lda, const DistMap &dm, const int *blocks_dev, int nown,
+                              double *dinv, double *dinvt, hipStream_t st)
+{
+    if (nown <= 0) return hipSuccess;
+    hipLaunchKernelGGL(trtri_kernel, dim3(nown), dim3(256), 0, st, abl, lda, dinv, dinvt, dm, blocks_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_blockmv(const double *M, const double *v, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st, M, v, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fwd_update(const double *Lpanel, long long lda, const double *yk, double *vbelow, int nrows, hipStream_t st)
+{
+    if (nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fwd_update_kernel, dim3(nrows / 64), dim3(512), 0, st, Lpanel, lda, yk, vbelow, nrows);
+    return hipGetLastError();
+}
+
+hipError_t launch_bwd_column(const double *Lpanel, long long lda, const double *xbelow, int nrows, const double *dinvt_k,
+                             const double *yk, double *part, double *xk, hipStream_t st)
+{
+    int nsplit = 0;
+    if (nrows > 0) {
+        const int rows_per_split = 4 * NBLK;
+        nsplit = (nrows + rows_per_split - 1) / rows_per_split;
+        hipLaunchKernelGGL(panel_tdot_kernel, dim3(4, nsplit), dim3(256), 0, st, Lpanel, lda, xbelow, nrows, rows_per_split, part);
+    }
+    hipLaunchKernelGGL(bwd_block_kernel, dim3(16), dim3(256), 0, st, dinvt_k, yk, (const double *)part, nsplit, xk);
+    return hipGetLastError();
+}
+
+hipError_t launch_vec_add(long long n, double *dst, const double *src, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vec_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, dst, src);
+    return hipGetLastError();
+}
+
+hipError_t launch_mask_owned(int n, const DistMap &dm, double *x, hipStream_t st)
+{
+    hipLaunchKernelGGL(mask_owned_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, dm, x);
     return hipGetLastError();
 }
 

@@ -70,6 +70,25 @@ hipError_t launch_to_reference_order(const Grid &g, const double *xvec, double *
 
 // ---- bandchol.hip
 constexpr int NBLK = 256;     // block size of the band factorisation
+
+// Distribution of the block columns of the band over R ranks (GPUs): chunks of c consecutive block
+// columns are dealt round-robin; a rank stores its own block columns packed.  R = 1: everything local.
+struct DistMap {
+    int R, r, c;
+    long long ld;             // column stride of the band storage (lda + 1)
+};
+__host__ __device__ inline int dm_owner(const DistMap &m, int J) { return (J / m.c) % m.R; }
+__host__ __device__ inline bool dm_owned(const DistMap &m, int J) { return dm_owner(m, J) == m.r; }
+__host__ __device__ inline int dm_slot(const DistMap &m, int J) { return ((J / m.c) / m.R) * m.c + J % m.c; }
+// A(i,j) of block column J = (ab + dm_shift(J))[i + j lda]
+__host__ __device__ inline long long dm_shift(const DistMap &m, int J) { return 256LL * m.ld * (dm_slot(m, J) - J); }
+// number of block columns a rank stores when nblk are dealt
+inline int dm_local_blocks(const DistMap &m, int nblk)
+{
+    int n = 0;
+    for (int J = 0; J < nblk; ++J) n += dm_owned(m, J) ? 1 : 0;
+    return n;
+}
 struct Band {
     double *ab;       // dense-view base: A(i,j) = ab[i + j*lda], j <= i <= j + halfbw
     double *dinv;     // [nblk][NBLK*NBLK] inverses of the diagonal blocks of L (row-major)
@@ -87,8 +106,10 @@ struct Band {
                                     // use, released by band_pipeline_destroy -- owned by whoever owns the Band
 };
 size_t band_bytes(int n, int halfbw, Band *desc);
-// zero the band, put 1 on the padded diagonal, scatter the half-stencil into it
-hipError_t launch_expand(const Grid &g, const double *nst, const Band &b, hipStream_t st);
+struct DistMap;
+// zero the band, put 1 on the padded diagonal, scatter the half-stencil into it (the block columns
+// DistMap gives to this rank)
+hipError_t launch_expand(const Grid &g, const double *nst, const Band &b, const DistMap &dm, hipStream_t st);
 
 struct CholStats {            // optional per-kernel accounting (HIP events)
     bool enabled = false;
@@ -104,6 +125,22 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
 void band_pipeline_destroy(void *pipe);
 // x <- (L L^T)^{-1} x; x and tmp of length npad (padding entries of x must be 0)
 hipError_t band_solve(const Band &b, double *x, double *tmp, hipStream_t st);
+
+// pieces of the distributed band factorisation / sweeps (driven by dist.hip)
+hipError_t launch_potrf_block(double *abJ, long long lda, int k0, int *info, double *minpiv, double *inv16, hipStream_t st);
+hipError_t launch_trsm_panel(const double *Lkk, double *X, long long lda, const double *inv16, int nrows, hipStream_t st);
+hipError_t launch_pack_panel(const double *src, long long lda, double *dst, int nrows, hipStream_t st);
+long long syrk64d_items(const DistMap &dm, int row0, int jb, int je, int re);
+hipError_t launch_syrk64d(double *abl, long long lda, const DistMap &dm, const double *P, long long ldp, int row0,
+                          int jb, int je, int re, hipStream_t st);
+hipError_t launch_trtri_owned(const double *abl, long long lda, const DistMap &dm, const int *blocks_dev, int nown,
+                              double *dinv, double *dinvt, hipStream_t st);
+hipError_t launch_blockmv(const double *M, const double *v, double *out, hipStream_t st);
+hipError_t launch_fwd_update(const double *Lpanel, long long lda, const double *yk, double *vbelow, int nrows, hipStream_t st);
+hipError_t launch_bwd_column(const double *Lpanel, long long lda, const double *xbelow, int nrows, const double *dinvt_k,
+                             const double *yk, double *part, double *xk, hipStream_t st);
+hipError_t launch_vec_add(long long n, double *dst, const double *src, hipStream_t st);
+hipError_t launch_mask_owned(int n, const DistMap &dm, double *x, hipStream_t st);
 
 // small vector helpers (vecops in bandchol.hip)
 hipError_t launch_axpy_absmax(int n, double *x, const double *dx, double *absmax2, hipStream_t st);

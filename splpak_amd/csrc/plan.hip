@@ -15,8 +15,7 @@
 // through the caller's hook (RCCL via torch.distributed); 3 is applied by rank 0
 // before the reduction so all ranks hold bit-identical normal equations; 4-5 are
 // replicated.
-#include "kernels.hpp"
-#include "../../include/splpak_hip.h"
+#include "plan.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -42,8 +41,8 @@ bool hip_ok(hipError_t e, const char *what)
 
 // reference-order validation shared by fit and evaluation (:716-750, :1166-1210).
 // returns 0 or 101/102/103
-static int build_grid(int ndim, const int *nodes, const double *xmin, const double *xmax, Grid &g,
-                      long long *ncol_out, bool reorder = false)
+int build_grid(int ndim, const int *nodes, const double *xmin, const double *xmax, Grid &g,
+               long long *ncol_out, bool reorder)
 {
     std::memset(&g, 0, sizeof(g));
     if (ndim < 1) return 101;
@@ -106,35 +105,6 @@ static int build_grid(int ndim, const int *nodes, const double *xmin, const doub
 
 using namespace splpak;
 
-struct splpak_plan {
-    Grid g{};
-    double xtrap = 0;
-    long long max_ndata = 0;
-    SortScratch s{};
-    Band band{};
-    double *comm = nullptr;
-    bool own_comm = false;
-    long long comm_len = 0;
-    // views into comm
-    double *nst = nullptr, *rhs = nullptr, *scalG = nullptr, *hist = nullptr, *scalH = nullptr,
-           *rho = nullptr;
-    long long lenG = 0, lenH = 0, lenR = 0;
-    double *xvec = nullptr, *tmp = nullptr, *small = nullptr;   // small: [absmax(2) | minpiv(1) | backward error(1) | pad]
-    double *gscratch = nullptr;   // per-cell Gram blocks: the band storage itself when it is large enough (it is only
-                                  // filled after the gather), a buffer of its own otherwise
-    double *rcell = nullptr;      // [ncell][nb] per-cell shares of the refinement residual
-    double *tbuf = nullptr;       // [ncol][ndim(ndim+1)/2] constraint-row dot products of the refinement residual
-    int *info = nullptr;
-    splpak_allreduce_fn ar = nullptr;
-    void *ar_user = nullptr;
-    int rank = 0, world = 1;
-    int max_refine = 4;           // nominal number of refinement steps; a solve that is still contracting goes on (max_refine_hard)
-    int max_refine_hard = 16;
-    double tol = 1e-12;
-    CholStats stats;
-    std::vector<void *> owned;
-};
-
 static long long comm_len_of(const Grid &g)
 {
     const long long npad = ((g.ncol + NBLK - 1) / NBLK) * (long long)NBLK;
@@ -162,7 +132,8 @@ static bool dev_alloc(splpak_plan *p, T **ptr, size_t count)
     return true;
 }
 
-static int device_ready()
+namespace splpak {
+int device_ready()
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -173,6 +144,7 @@ static int device_ready()
     }
     return 0;
 }
+}  // namespace splpak
 
 extern "C" {
 
@@ -187,6 +159,15 @@ int64_t splpak_plan_comm_len(int32_t ndim, const int32_t *nodes)
 int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmin,
                            const double *xmax, double xtrap, int64_t max_ndata,
                            void *comm_buf_dev, int64_t comm_len, splpak_plan **plan)
+{
+    return plan_create_dist(ndim, nodes, xmin, xmax, xtrap, max_ndata, comm_buf_dev, comm_len, 1, 0, 1, plan);
+}
+
+}  // extern "C"
+
+int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, const double *xmax, double xtrap,
+                             long long max_ndata, void *comm_buf_dev, long long comm_len, int R, int r, int c,
+                             splpak_plan **plan)
 {
     if (!plan || !nodes || !xmin || !xmax) { set_error("null argument"); return SPLPAK_E_BADARG; }
     *plan = nullptr;
@@ -222,16 +203,30 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
     ok = ok && dev_alloc(p, &p->s.idx, (size_t)max_ndata);
     ok = ok && dev_alloc(p, &p->rcell, (size_t)g.ncell * g.nb);
     ok = ok && dev_alloc(p, &p->tbuf, (size_t)g.ncol * (g.ndim * (g.ndim + 1) / 2));
-    // band
+    // band: all of it (R = 1) or the block columns dealt to rank r of R
     band_bytes(g.ncol, g.halfbw, &p->band);
+    (void)hipGetDevice(&p->device);
+    p->dm = DistMap{R < 1 ? 1 : R, r, c < 1 ? 1 : c, p->band.lda + 1};
+    for (int J = 0; J < p->band.nblk; ++J)
+        if (dm_owned(p->dm, J)) p->own_blocks_host.push_back(J);
+    p->nown = (int)p->own_blocks_host.size();
+    if (p->dm.R > 1) p->band.bytes = (size_t)(p->nown > 0 ? p->nown : 1) * NBLK * (size_t)p->dm.ld * sizeof(double) + 4096;
     ok = ok && dev_alloc(p, &p->band.ab, p->band.bytes / sizeof(double));
     if ((size_t)gram_scratch_doubles(g) * sizeof(double) <= p->band.bytes) p->gscratch = p->band.ab;
     else ok = ok && dev_alloc(p, &p->gscratch, (size_t)gram_scratch_doubles(g));
-    ok = ok && dev_alloc(p, &p->band.dinv, (size_t)p->band.nblk * NBLK * NBLK);
-    ok = ok && dev_alloc(p, &p->band.dinvt, (size_t)p->band.nblk * NBLK * NBLK);
-    ok = ok && dev_alloc(p, &p->band.inv64, (size_t)p->band.nblk * 4 * 64 * 64);
-    ok = ok && dev_alloc(p, &p->band.mfwd, (size_t)p->band.nblk * NBLK * NBLK);
-    ok = ok && dev_alloc(p, &p->band.mbwd, (size_t)p->band.nblk * NBLK * NBLK);
+    const size_t nloc = (size_t)(p->nown > 0 ? p->nown : 1);
+    ok = ok && dev_alloc(p, &p->band.dinv, nloc * NBLK * NBLK);
+    ok = ok && dev_alloc(p, &p->band.dinvt, nloc * NBLK * NBLK);
+    ok = ok && dev_alloc(p, &p->band.inv64, nloc * 4 * 64 * 64);
+    if (p->dm.R == 1) {
+        ok = ok && dev_alloc(p, &p->band.mfwd, nloc * NBLK * NBLK);
+        ok = ok && dev_alloc(p, &p->band.mbwd, nloc * NBLK * NBLK);
+    } else {
+        ok = ok && dev_alloc(p, &p->own_blocks, nloc);
+        if (ok && p->nown > 0)
+            ok = hip_ok(hipMemcpy(p->own_blocks, p->own_blocks_host.data(), sizeof(int) * (size_t)p->nown, hipMemcpyHostToDevice),
+                        "hipMemcpy of the block list");
+    }
     // communication buffer
     p->comm_len = comm_len_of(g);
     if (comm_buf_dev) {
@@ -265,6 +260,8 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
     *plan = p;
     return 0;
 }
+
+extern "C" {
 
 void splpak_plan_destroy(splpak_plan *p)
 {
@@ -388,8 +385,8 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     const double inf = std::numeric_limits<double>::infinity();
     SPLPAK_HIP_TRY(hipMemsetAsync(p->info, 0, 2 * sizeof(int), st), SPLPAK_E_NODEVICE);
     SPLPAK_HIP_TRY(hipMemcpyAsync(p->small + 2, &inf, sizeof(double), hipMemcpyHostToDevice, st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(launch_expand(g, p->nst, b, st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(band_cholesky(b, p->info, p->small + 2, st, &p->stats), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(launch_expand(g, p->nst, b, p->dm, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(p->factor_fn ? p->factor_fn(p, p->info, p->small + 2, st, p->fn_user) : band_cholesky(b, p->info, p->small + 2, st, &p->stats), SPLPAK_E_NODEVICE);
     int hinfo = 0;
     double minpiv = 0.0;
     SPLPAK_HIP_TRY(hipMemcpyAsync(&hinfo, p->info, sizeof(int), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
@@ -411,7 +408,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     // ---- solve + refinement --------------------------------------------
     SPLPAK_HIP_TRY(hipMemsetAsync(p->xvec, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
     SPLPAK_HIP_TRY(hipMemcpyAsync(p->xvec, p->rhs, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(band_solve(b, p->xvec, p->tmp, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(p->solve_fn ? p->solve_fn(p, p->xvec, p->tmp, st, p->fn_user) : band_solve(b, p->xvec, p->tmp, st), SPLPAK_E_NODEVICE);
     int steps = 0;
     double last_rel = 0.0, prev_rel = inf, ratio = 0.0;
     // converged: the (estimated) remaining error is below tol, or the corrections sit at the rounding
@@ -425,7 +422,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->hist, p->scalH, p->xtrap, smooth && p->rank == 0,
                                        p->tbuf, p->rho, nullptr, st), SPLPAK_E_NODEVICE);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
-        SPLPAK_HIP_TRY(band_solve(b, p->rho, p->tmp, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(p->solve_fn ? p->solve_fn(p, p->rho, p->tmp, st, p->fn_user) : band_solve(b, p->rho, p->tmp, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(launch_axpy_absmax(g.ncol, p->xvec, p->rho, p->small, st), SPLPAK_E_NODEVICE);
         double am[2];
         SPLPAK_HIP_TRY(hipMemcpyAsync(am, p->small, 2 * sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);

@@ -1,0 +1,57 @@
+// The fit plan (internal): shared by plan.hip (single-GPU driver, C ABI) and dist.hip (several GPUs).
+#pragma once
+#include "kernels.hpp"
+#include "../../include/splpak_hip.h"
+#include <vector>
+
+struct splpak_plan {
+    splpak::Grid g{};
+    double xtrap = 0;
+    long long max_ndata = 0;
+    splpak::SortScratch s{};
+    splpak::Band band{};
+    double *comm = nullptr;
+    bool own_comm = false;
+    long long comm_len = 0;
+    // views into comm
+    double *nst = nullptr, *rhs = nullptr, *scalG = nullptr, *hist = nullptr, *scalH = nullptr,
+           *rho = nullptr;
+    long long lenG = 0, lenH = 0, lenR = 0;
+    double *xvec = nullptr, *tmp = nullptr, *small = nullptr;   // small: [absmax(2) | minpiv(1) | backward error(1) | pad]
+    double *gscratch = nullptr;   // per-cell Gram blocks: the band storage itself when it is large enough (it is only
+                                  // filled after the gather), a buffer of its own otherwise
+    double *rcell = nullptr;      // [ncell][nb] per-cell shares of the refinement residual
+    double *tbuf = nullptr;       // [ncol][ndim(ndim+1)/2] constraint-row dot products of the refinement residual
+    int *info = nullptr;
+    splpak_allreduce_fn ar = nullptr;
+    void *ar_user = nullptr;
+    int rank = 0, world = 1;
+    int max_refine = 4;           // nominal number of refinement steps; a solve that is still contracting goes on (max_refine_hard)
+    int max_refine_hard = 16;
+    double tol = 1e-12;
+    splpak::CholStats stats;
+    std::vector<void *> owned;
+    // distributed band (dist.hip): this plan holds the block columns DistMap deals to rank dm.r
+    splpak::DistMap dm{1, 0, 1, 0};
+    int nown = 0;                 // block columns stored here
+    int *own_blocks = nullptr;    // [nown] their global indices, ascending (device)
+    std::vector<int> own_blocks_host;
+    int device = 0;
+    // factorisation / solve of the normal equations: NULL = the single-GPU band Cholesky of bandchol.hip;
+    // dist.hip installs the distributed versions (same contract as band_cholesky / band_solve)
+    hipError_t (*factor_fn)(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStream_t st, void *user) = nullptr;
+    hipError_t (*solve_fn)(splpak_plan *p, double *x, double *tmp, hipStream_t st, void *user) = nullptr;
+    void *fn_user = nullptr;
+};
+
+
+namespace splpak {
+// reference-order validation shared by fit and evaluation (:716-750, :1166-1210): 0 or 101/102/103
+int build_grid(int ndim, const int *nodes, const double *xmin, const double *xmax, Grid &g, long long *ncol_out,
+               bool reorder = false);
+int device_ready();
+// plan for rank r of R (chunks of c block columns); R = 1 is the ordinary single-GPU plan
+int plan_create_dist(int ndim, const int *nodes, const double *xmin, const double *xmax, double xtrap,
+                     long long max_ndata, void *comm_buf_dev, long long comm_len, int R, int r, int c,
+                     splpak_plan **plan);
+}  // namespace splpak

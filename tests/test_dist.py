@@ -127,3 +127,54 @@ def test_sharded_fit_two_ranks_one_gpu(name):
     # rows were counted globally
     spec_rows = res[0][3][0]
     assert spec_rows == res[1][3][0]
+
+
+# ---------------------------------------------------------------------------
+# distributed band (one process, several GPUs): rehearsed with virtual GPUs on the one device
+# ---------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,ngpus,chunk", [("3d12", 2, 1), ("3d12", 3, 2), ("2d64_c2grid", 4, 1), ("4d6", 2, 1),
+                                              ("3d8_cc_clust", 4, 1), ("2d16_zero_w", 3, 1), ("c1_1d16", 2, 1)])
+def test_distributed_band_fit_virtual_gpus(name, ngpus, chunk, monkeypatch):
+    """splpak_fit_multi_f64 with every rank on the one GPU of the test box (SPLPAK_VIRTUAL_GPUS): point
+    shards, rank-ordered reductions, block columns dealt to the ranks, panel hand-over, look-ahead and
+    the owner-to-owner sweeps all run; the result must hold the reference golden at 1e-10 and agree
+    with the single-GPU fit."""
+    from splpak_amd import capi
+    from tests.cases import CASES, make_inputs
+    monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
+    monkeypatch.setenv("SPLPAK_DIST_CHUNK", str(chunk))
+    inp = make_inputs(CASES[name])
+    gold = load_golden(name)
+    args = (inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"], inp["nodes"], inp["xtrap"])
+    c1, e1, h1, i1 = capi.fit(*args, want_hist=True)
+    cm, em, hm, im = capi.fit_multi(ngpus, *args, want_hist=True)
+    assert e1 == em == 0
+    print(f"{name} x{ngpus} (chunk {chunk}): rel={relmax(cm, gold['coef']):.2e} vs single={relmax(cm, c1):.2e} "
+          f"steps={im[2]:.0f} optimality={im[9]:.1e}")
+    assert relmax(cm, gold["coef"]) < 1e-10
+    assert relmax(cm, c1) < 1e-12
+    assert im[0] == i1[0] and im[1] == i1[1]                 # rows counted over all shards
+    assert im[9] < 1e-9
+    if inp["xtrap"] != 0.0:
+        assert relmax(hm, gold["hist"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_distributed_band_24cubed_and_errors(monkeypatch):
+    """24^3 grid (54 block steps, band 8 blocks wide) on 4 virtual GPUs: spline-space data reproduced to
+    1e-10; a rank-deficient problem returns 107 on every rank (no rank is left waiting)."""
+    from splpak_amd import capi
+    from splpak_amd.synth import synth_points, synth_queries
+    monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
+    nd, nod, m = 3, 24, 200000
+    x, _, _ = synth_points(nd, m)
+    f = lambda p: 1.0 + 2.0 * p[:, 0] - 3.0 * p[:, 1] + 0.5 * p[:, 2]
+    c, ierr, _, info = capi.fit_multi(4, nd, x, f(x), None, [0.0] * nd, [1.0] * nd, [nod] * nd, 0.0)
+    assert ierr == 0
+    q = synth_queries(nd, 2000, m) * 1.2 - 0.1
+    v, _ = capi.evaluate(nd, q, None, c, [0.0] * nd, [1.0] * nd, [nod] * nd)
+    assert np.max(np.abs(v - f(q))) < 1e-10 and info[9] < 1e-9
+    xc = np.random.default_rng(0).random((400, 2)) * 0.2     # all data in one corner, no smoothing rows
+    assert capi.fit_multi(3, 2, xc, xc.sum(axis=1), None, [0.0, 0.0], [1.0, 1.0], [8, 8], 0.0)[1] == 107
+    assert capi.fit_multi(2, 0, xc, xc.sum(axis=1), None, [0.0, 0.0], [1.0, 1.0], [8, 8], 0.0)[1] == 101
