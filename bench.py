@@ -157,6 +157,53 @@ def bench_c2(capi, dev, stream, steps):
             "refine_steps": int(info[2]), "optimality_residual": float(info[9])}
 
 
+def bench_dist_band(capi, ngpus, nd, nod, m_total, virtual, steps):
+    """The fit with the band factor DISTRIBUTED over `ngpus` GPUs, driven from this one process
+    (splpak_mplan_*: block columns dealt to the GPUs, panels handed over by peer copies).  Strong
+    scaling: the point count is fixed.  virtual=True places every rank on this GPU (a rehearsal of the
+    protocol, not a speed-up)."""
+    import torch
+    nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
+    if virtual:
+        os.environ["SPLPAK_VIRTUAL_GPUS"] = "1"
+    try:
+        per = (m_total + ngpus - 1) // ngpus
+        mp = capi.MultiPlan(ngpus, nd, nodes, lo, hi, 1.0, per)
+        xs, ys, ws = [], [], []
+        cur = torch.cuda.current_device()
+        for r in range(ngpus):
+            n = max(0, min(per, m_total - r * per))
+            d = torch.device("cuda", mp.device(r))
+            torch.cuda.set_device(d)
+            x = torch.empty((n, nd), dtype=torch.float64, device=d)
+            y = torch.empty(n, dtype=torch.float64, device=d)
+            w = torch.empty(n, dtype=torch.float64, device=d)
+            capi.synth_points_dev(nd, r * per, n, x, y, w, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            xs.append(x); ys.append(y); ws.append(w)
+        torch.cuda.set_device(cur)
+        coef = torch.zeros(nod ** nd, dtype=torch.float64, device=torch.device("cuda", mp.device(0)))
+        ierr, info = mp.fit(xs, ys, ws, coef)                      # warm-up
+        assert ierr == 0, f"distributed fit failed with ierror {ierr}"
+        n = max(1, min(steps, 3))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ierr, info = mp.fit(xs, ys, ws, coef)
+        dt = (time.perf_counter() - t0) / n
+        mp.close()
+        assert ierr == 0 and info[9] < 1e-9, f"distributed fit: ierror {ierr}, optimality residual {info[9]:.2e}"
+        return {"workload": f"{nd}-D splcw fit, {m_total} points in all (strong scaling), {nod}^{nd} nodes, band factor distributed over "
+                            f"{ngpus} {'virtual GPUs (all ranks on this device: protocol rehearsal)' if virtual else 'GPUs, one process, peer copies over xGMI'}",
+                "value": m_total / dt, "unit": "points/s", "ms_per_fit": 1e3 * dt, "n_gpus": ngpus, "virtual": bool(virtual),
+                "phase_seconds": {"assembly": float(info[5]), "factor": float(info[6]), "solve_refine": float(info[7])},
+                "refine_steps": int(info[2]), "optimality_residual": float(info[9])}
+    except Exception as exc:      # the headline line must survive a failure of this leg
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        if virtual:
+            os.environ.pop("SPLPAK_VIRTUAL_GPUS", None)
+
+
 def bench_incl_h2d(capi, x, y, w, lo, hi, nodes):
     """The host-pointer entry (what the Fortran module binds): pageable host arrays in, coefficients
     out, PCIe transfers included.  Never `value`."""
@@ -289,6 +336,17 @@ def main():
                         "bytes_per_query_all_passes": pm["hbm_bytes_per_query_all_passes"], "algorithmic_bytes_per_query": 8.0 * (nd + 1)}
     except Exception:
         pass
+    dist_leg = None
+    if world > 1 and not args.no_side_legs:
+        # strong scaling with a DISTRIBUTED factorisation: rank 0's process drives all `world` GPUs of the node
+        # (native peer copies, no Python in the loop); the other ranks free their plans and wait
+        if rank != 0:
+            plan.close()
+            torch.cuda.empty_cache()
+        barrier()
+        if rank == 0:
+            dist_leg = bench_dist_band(capi, world, nd, nod, m, False, args.steps)
+        barrier()
     if rank == 0:
         line = {
             "metric": (f"fitted points/sec (splcw) + evals/sec (splfe), {nd}-D {m:.0e} pts {nod}^{nd} nodes"
@@ -348,8 +406,12 @@ def main():
                 "factorisation_tflops": kt_sum["total_flop"] / max(kt_sum["factor_ms"], 1e-9) / 1e9,
             }
         if world == 1 and not args.no_side_legs:
+            # rehearsal of the distributed-band path on this one GPU (2 virtual ranks, reduced size)
+            line["dist_band"] = bench_dist_band(capi, 2, nd, min(nod, 32), 1_000_000, True, args.steps)
             line["c2"] = bench_c2(capi, dev, stream, args.steps)
             line["fit_incl_h2d"] = bench_incl_h2d(capi, x, y, w, lo, hi, nodes)
+        if dist_leg is not None:
+            line["dist_band"] = dist_leg
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nd)
         print(json.dumps(line), flush=True)

@@ -47,6 +47,7 @@ module splpak_module
         private
         integer :: mdim = 0    !! dimension of the last call (the reference keeps scratch here, :95-111)
         real(real64) :: info(10) = 0.0_real64   !! diagnostics of the last fit (include/splpak_hip.h, `info`)
+        integer :: ngpus = 1   !! GPUs of this node the fit is spread over (set_gpus)
     contains
         private
         generic,public   :: initialize    => splcc, splcw        !! fit
@@ -55,6 +56,7 @@ module splpak_module
         procedure,public :: evaluate_derivatives => splpak_derivs_many !! value + gradient (+ Hessian) of a batch (additive)
         procedure,public :: destroy       => destroy_splpak
         procedure,public :: last_fit_info => splpak_last_fit_info   !! reserr, row counts, ... of the last fit (additive)
+        procedure,public :: set_gpus      => splpak_set_gpus        !! spread the following fits over n GPUs of this node (additive)
         procedure,private :: splcc
         procedure,private :: splcw
         procedure,private :: splfe
@@ -102,6 +104,16 @@ module splpak_module
             integer(c_int64_t),value :: nq
             type(c_ptr),value :: xq, coef, xmin, xmax, nodes, out
         end function c_eval_derivs
+#ifndef REAL32
+        integer(c_int32_t) function c_fit_multi(ngpus,ndim,xdata,l1xdat,ydata,wdata,ndata,xmin,xmax,nodes,xtrap,&
+                                                coef,ncf,nwrk,hist,info) bind(C,name='splpak_fit_multi_f64')
+            import :: c_int32_t, c_int64_t, c_ptr, wp
+            integer(c_int32_t),value :: ngpus, ndim, l1xdat
+            integer(c_int64_t),value :: ndata, ncf, nwrk
+            type(c_ptr),value :: xdata, ydata, wdata, xmin, xmax, nodes, coef, hist, info
+            real(wp),value :: xtrap
+        end function c_fit_multi
+#endif
         subroutine c_shutdown() bind(C,name='splpak_shutdown')
         end subroutine c_shutdown
         integer(c_int32_t) function c_last_error(buf,buflen) bind(C,name='splpak_last_error_message')
@@ -127,6 +139,15 @@ module splpak_module
             call c_shutdown()
         end if
     end subroutine destroy_splpak
+
+    !> The following `initialize` calls of this object use `n` GPUs of the node: the points are sharded
+    !! and the band of the normal equations is distributed over them (include/splpak_hip.h,
+    !! splpak_fit_multi_f64); n <= 1 is the single-GPU fit.  Same arguments, same results.
+    subroutine splpak_set_gpus(me,n)
+        class(splpak_type),intent(inout) :: me
+        integer,intent(in) :: n
+        me%ngpus = max(n,1)
+    end subroutine splpak_set_gpus
 
     !> Diagnostics of the last `initialize` of this object.  `reserr` is the residual norm
     !! ||rows*coef - rhs||_2 over data and constraint rows that the reference computes in suprls
@@ -250,9 +271,19 @@ module splpak_module
             ncol = ncol*int(max(nodes(idim),1),c_int64_t)
         end do
         if (ndim >= 1 .and. xtrap /= 0.0_wp .and. int(nwrk,c_int64_t) >= ncol) hist = c_loc(work)
+#ifndef REAL32
+        if (me%ngpus > 1) then
+            rc = c_fit_multi(int(me%ngpus,c_int32_t), int(ndim,c_int32_t), xdata, int(l1xdat,c_int32_t), ydata, wdata, &
+                             int(ndata,c_int64_t), xmin, xmax, c_loc(nodes), xtrap, c_loc(coef), &
+                             int(ncf,c_int64_t), int(nwrk,c_int64_t), hist, c_loc(me%info))
+        else
+#endif
         rc = c_fit(int(ndim,c_int32_t), xdata, int(l1xdat,c_int32_t), ydata, wdata, &
                    int(ndata,c_int64_t), xmin, xmax, c_loc(nodes), xtrap, c_loc(coef), &
                    int(ncf,c_int64_t), int(nwrk,c_int64_t), hist, c_loc(me%info))
+#ifndef REAL32
+        end if
+#endif
         ierror = int(rc)
         if (rc > 0) then
             call report_fit(ierror)

@@ -10,7 +10,8 @@ program test_info
     integer,parameter :: m = 10000, nq = 500
     integer :: nodes(2), ierror, i, nrows, ncons, nsteps, nbad
     real(wp) :: xdata(2,m), ydata(m), wdata(m), xmin(2), xmax(2), coef(256), work(256*257)
-    real(wp) :: xs(2,nq), fs(nq), f, reserr, omega, u(4)
+    real(wp) :: xs(2,nq), fs(nq), f, reserr, omega, u(4), coef2(256)
+    character(len=16) :: envval
     integer(8) :: s
     type(splpak_type) :: solver
 
@@ -51,6 +52,19 @@ program test_info
         f = solver%evaluate(2,xs(:,i),[1,2],coef,xmin,xmax,nodes,ierror)
         if (abs(f - fs(i)) > 1.0e-12_wp*max(3375.0_wp,abs(f))) call fail('scalar vs batched derivative')
     end do
+    ! the same fit spread over 2 GPUs (SPLPAK_VIRTUAL_GPUS=1 in the environment: 2 ranks on this GPU)
+    call get_environment_variable('SPLPAK_VIRTUAL_GPUS', envval, status=i)
+    if (i == 0) then
+        coef2 = coef
+        call solver%set_gpus(2)
+        call solver%initialize(2,xdata,2,ydata,wdata,m,xmin,xmax,nodes,1.0_wp,coef,256,work,256*257,ierror)
+        if (ierror /= 0) error stop 'multi-GPU fit failed'
+        if (maxval(abs(coef - coef2)) > 1.0e-12_wp*maxval(abs(coef2))) call fail('2-GPU fit differs from 1-GPU fit')
+        call solver%last_fit_info(ndata_rows=nrows)
+        if (nrows /= m) call fail('data row count over the shards')
+        write(*,'(A,ES12.3)') ' 2-GPU vs 1-GPU coefficients: ', maxval(abs(coef - coef2))/maxval(abs(coef2))
+        call solver%set_gpus(1)
+    end if
     call solver%destroy()
     if (nbad /= 0) error stop 'test_info FAILED'
     write(*,*) 'PASS test_info'

@@ -48,7 +48,8 @@ def test_fortran_fails_loudly_without_gpu():
 @pytest.mark.parametrize("prog", PROGS)
 def test_fortran_program_on_gpu(prog):
     _ensure_built()
-    r = subprocess.run([os.path.join(BUILD, prog)], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, SPLPAK_VIRTUAL_GPUS="1")      # test_info also runs its fit on 2 (virtual) GPUs
+    r = subprocess.run([os.path.join(BUILD, prog)], capture_output=True, text=True, timeout=300, env=env)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"PASS {prog}" in r.stdout
@@ -67,3 +68,4 @@ def test_fortran_program_on_gpu(prog):
         _, e0, _ = P.fit(2, inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"], inp["nodes"], 1.0)
         got = float(re.search(r"reserr =\s*(\S+)", r.stdout).group(1))
         assert e0 == 0 and abs(got - P.last_reserr) <= 1e-9 * P.last_reserr, (got, P.last_reserr)
+        assert "2-GPU vs 1-GPU coefficients" in r.stdout
