@@ -263,13 +263,13 @@ __global__ void __launch_bounds__(GramCfg<D>::NT)
 gram_block_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
                   const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
                   double *__restrict__ blk, double *__restrict__ rblk, double *__restrict__ hblk,
-                  double *__restrict__ hist)
+                  double *__restrict__ hist, int cell0)
 {
     using C = GramCfg<D>;
     constexpr int NB = C::NB, TR = C::TR, TC = C::TC, NT = C::NT, PCH = C::PCH;
     constexpr int CW = C::NTX * TC;            // columns handled by this workgroup
     constexpr long long TRI = (long long)NB * (NB + 1) / 2;
-    const int cell = blockIdx.x;
+    const int cell = cell0 + blockIdx.x;       // the scratch image holds the cells of one slab, from cell0 on
     const int cpass = blockIdx.y;
     const long long beg = offset[cell], end = offset[cell + 1];
     if (beg == end) return;                    // the gather skips empty cells
@@ -318,8 +318,26 @@ gram_block_kernel(Grid g, const int *__restrict__ offset, const double *__restri
         __syncthreads();
     }
 
-    if (tile_on) {
-        double *__restrict__ out = blk + (long long)cell * TRI;
+    double *__restrict__ out = blk + (long long)(cell - cell0) * TRI;
+    if constexpr (TRI <= (long long)PCH * NB) {
+        // the packed triangle is assembled in LDS (the point image is no longer needed) and leaves with
+        // consecutive lanes on consecutive addresses (the 4x4 register tiles written directly put 8 bytes
+        // every 32; same kernel time at 64^3 -- the kernel is bound by its per-cell phases, not by the
+        // stores -- but a quarter of the write requests)
+        if (tile_on) {
+#pragma unroll
+            for (int i = 0; i < TR; ++i) {
+                const int r = r0 + i;
+#pragma unroll
+                for (int j = 0; j < TC; ++j) {
+                    const int c = c0 + j;
+                    if (c <= r) bw[r * (r + 1) / 2 + c] = acc[i][j];
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < (int)TRI; e += NT) out[e] = bw[e];
+    } else if (tile_on) {
 #pragma unroll
         for (int i = 0; i < TR; ++i) {
             const int r = r0 + i;
@@ -331,8 +349,8 @@ gram_block_kernel(Grid g, const int *__restrict__ offset, const double *__restri
         }
     }
     if (vec_on) {
-        rblk[(long long)cell * NB + tid] = racc;
-        if (hist_on) hblk[(long long)cell * NB + tid] = hacc;
+        rblk[(long long)(cell - cell0) * NB + tid] = racc;
+        if (hist_on) hblk[(long long)(cell - cell0) * NB + tid] = hacc;
     }
 }
 
@@ -375,15 +393,19 @@ template <int D>
 __global__ void __launch_bounds__(256)
 stencil_gather_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ blk,
                       const double *__restrict__ rblk, const double *__restrict__ hblk,
-                      double *__restrict__ nst, double *__restrict__ rhs, double *__restrict__ hist)
+                      double *__restrict__ nst, double *__restrict__ rhs, double *__restrict__ hist,
+                      int cell0, int cell1, int node0, int node1)
 {
     constexpr int NB = 1 << (2 * D);
     constexpr long long TRI = (long long)NB * (NB + 1) / 2;
     constexpr int HS = (D == 1) ? 4 : (D == 2) ? 25 : (D == 3) ? 172 : 1201;
     __shared__ double sacc[4][HS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int node = blockIdx.x * 4 + wave;
-    if (node >= g.ncol) return;                // whole waves leave; no workgroup barrier below
+    // the cells [cell0, cell1) of the current slab (whole hyper-rows of the slowest dimension) touch the
+    // nodes [node0, node1); with one slab that is everything.  Sums of successive slabs add up in nst
+    // (zero on entry), in slab order: still one owner and a fixed order per entry.
+    const int node = node0 + blockIdx.x * 4 + wave;
+    if (node >= node1) return;                 // whole waves leave; no workgroup barrier below
     double *acc = sacc[wave];
     for (int e = lane; e < HS; e += 64) acc[e] = 0.0;
     int in[D];
@@ -394,8 +416,9 @@ stencil_gather_kernel(Grid g, const int *__restrict__ offset, const double *__re
     for (int e = 0; e < cr.total; ++e) {
         int cell, r;
         cr.get(g, in, e, cell, r);
+        if (cell < cell0 || cell >= cell1) continue;
         if (offset[cell] == offset[cell + 1]) continue;
-        const double *__restrict__ row = blk + (long long)cell * TRI + (long long)r * (r + 1) / 2;
+        const double *__restrict__ row = blk + (long long)(cell - cell0) * TRI + (long long)r * (r + 1) / 2;
         for (int c = lane; c <= r; c += 64) {
             int code = 0, m7 = 1;
 #pragma unroll
@@ -406,16 +429,16 @@ stencil_gather_kernel(Grid g, const int *__restrict__ offset, const double *__re
             acc[code] += row[c];
         }
         if (lane == 0) {
-            racc += rblk[(long long)cell * NB + r];
-            if (hblk) hacc += hblk[(long long)cell * NB + r];
+            racc += rblk[(long long)(cell - cell0) * NB + r];
+            if (hblk) hacc += hblk[(long long)(cell - cell0) * NB + r];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     double *__restrict__ out = nst + (long long)node * g.hstencil;
-    for (int e = lane; e < HS; e += 64) out[e] = acc[e];
+    for (int e = lane; e < HS; e += 64) out[e] += acc[e];
     if (lane == 0) {
-        rhs[node] = racc;
+        rhs[node] += racc;
         if (hblk) {
             int refnode = 0;                   // the histogram is kept in the caller's dimension order
 #pragma unroll
@@ -563,13 +586,30 @@ __device__ inline double constraint_entry(const Grid &g, const int *nn, const in
     return rowwt * basm;                                          // :1011
 }
 
+// Pre-pass: which nodes are data sparse, and their constraint weight -- once per fit (the histogram is
+// final), so that the row gathers below look a neighbour up with one byte instead of re-deriving it
+template <int D>
+__global__ void __launch_bounds__(256)
+sparse_mark_kernel(Grid g, const double *__restrict__ hist, const double *__restrict__ scal, double xtrap,
+                   double *__restrict__ dcw, unsigned char *__restrict__ spf)
+{
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= g.ncol) return;
+    int in[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) in[d] = (node / g.colstride[d]) % g.nodes[d];
+    const SparseNode sn = sparse_node<D>(g, in, hist, scal[SC_TOTLWT], xtrap);
+    dcw[node] = sn.dcwght;
+    spf[node] = sn.sparse ? 1 : 0;
+}
+
 // One wave per stencil row i: nst[i][code(j - i)] += sum over the sparse nodes n within one node of
 // both i and j, and over n's rows, of row[i] * row[j] -- neighbours and rows in a fixed order, the
 // row's owner adds with plain read-modify-writes.  Also counts the rows (scal_out[SC_NROWS_CONS]).
 template <int D>
 __global__ void __launch_bounds__(256)
-constraint_rows_kernel(Grid g, const double *__restrict__ hist, const double *__restrict__ scal,
-                       double xtrap, double *__restrict__ nst, double *__restrict__ scal_out)
+constraint_rows_kernel(Grid g, const double *__restrict__ dcw, const unsigned char *__restrict__ spf,
+                       double *__restrict__ nst, double *__restrict__ scal_out)
 {
     constexpr int NE = (D == 1) ? 3 : (D == 2) ? 9 : (D == 3) ? 27 : 81;
     constexpr int HS = (D == 1) ? 4 : (D == 2) ? 25 : (D == 3) ? 172 : 1201;
@@ -578,14 +618,28 @@ constraint_rows_kernel(Grid g, const double *__restrict__ hist, const double *__
     const int node = blockIdx.x * 4 + wave;
     if (node >= g.ncol) return;
     double *acc = sacc[wave];
-    for (int e = lane; e < HS; e += 64) acc[e] = 0.0;
     int in[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) in[d] = (node / g.colstride[d]) % g.nodes[d];
-    const double totlwt = scal[SC_TOTLWT];
+    // lanes look the 3^D neighbours up in parallel; most rows have no sparse neighbour and leave here
+    bool mine = false;
+    for (int ne = lane; ne < NE; ne += 64) {
+        int t = ne, col = 0;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int nd_ = in[d] + t % 3 - 1;
+            t /= 3;
+            ok = ok && nd_ >= 0 && nd_ <= g.nodes[d] - 1;
+            col += nd_ * g.colstride[d];
+        }
+        mine = mine || (ok && spf[col] != 0);
+    }
+    if (__builtin_amdgcn_ballot_w64(mine) == 0) return;
+    for (int e = lane; e < HS; e += 64) acc[e] = 0.0;
     bool any = false;
     for (int ne = 0; ne < NE; ++ne) {            // neighbour n = i + offn, offn_d in [-1,1], dim 0 fastest
-        int nn[D], offi[D], t = ne;
+        int nn[D], offi[D], t = ne, ncol_n = 0;
         bool ok = true;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -594,10 +648,13 @@ constraint_rows_kernel(Grid g, const double *__restrict__ hist, const double *__
             nn[d] = in[d] + o;
             offi[d] = -o;                        // i = n + offi
             ok = ok && nn[d] >= 0 && nn[d] <= g.nodes[d] - 1;
+            ncol_n += nn[d] * g.colstride[d];
         }
         if (!ok) continue;
-        const SparseNode sn = sparse_node<D>(g, nn, hist, totlwt, xtrap);
-        if (!sn.sparse) continue;
+        if (spf[ncol_n] == 0) continue;
+        SparseNode sn;
+        sn.sparse = true;
+        sn.dcwght = dcw[ncol_n];
         any = true;
         if (ne == NE / 2 && lane == 0) atomicAdd(&scal_out[SC_NROWS_CONS], (double)(D * (D + 1) / 2));   // integer-valued
         for (int idm = 0; idm < D; ++idm)
@@ -636,9 +693,8 @@ constraint_rows_kernel(Grid g, const double *__restrict__ hist, const double *__
 // residual mode, step 1: t[n][pair] = row(n, pair) . x for every sparse node (0 otherwise); one wave per node
 template <int D>
 __global__ void __launch_bounds__(256)
-constraint_dots_kernel(Grid g, const double *__restrict__ hist, const double *__restrict__ scal,
-                       double xtrap, const double *__restrict__ xvec, double *__restrict__ tbuf,
-                       double *__restrict__ ssq)
+constraint_dots_kernel(Grid g, const double *__restrict__ dcw, const unsigned char *__restrict__ spf,
+                       const double *__restrict__ xvec, double *__restrict__ tbuf, double *__restrict__ ssq)
 {
     constexpr int NE = (D == 1) ? 3 : (D == 2) ? 9 : (D == 3) ? 27 : 81;
     constexpr int NP = D * (D + 1) / 2;
@@ -648,7 +704,9 @@ constraint_dots_kernel(Grid g, const double *__restrict__ hist, const double *__
     int nn[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) nn[d] = (node / g.colstride[d]) % g.nodes[d];
-    const SparseNode sn = sparse_node<D>(g, nn, hist, scal[SC_TOTLWT], xtrap);
+    SparseNode sn;
+    sn.sparse = spf[node] != 0;
+    sn.dcwght = dcw[node];
     double *__restrict__ out = tbuf + (long long)node * NP;
     if (!sn.sparse) {
         if (lane < NP) out[lane] = 0.0;
@@ -686,7 +744,7 @@ constraint_dots_kernel(Grid g, const double *__restrict__ hist, const double *__
 template <int D>
 __global__ void __launch_bounds__(256)
 rho_gather_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ rcell,
-                  const double *__restrict__ hist, const double *__restrict__ scal, double xtrap,
+                  const double *__restrict__ dcw, const unsigned char *__restrict__ spf,
                   const double *__restrict__ tbuf, double *__restrict__ rho)
 {
     constexpr int NB = 1 << (2 * D);
@@ -705,7 +763,6 @@ rho_gather_kernel(Grid g, const int *__restrict__ offset, const double *__restri
         if (offset[cell] != offset[cell + 1]) acc += rcell[(long long)cell * NB + r];
     }
     if (tbuf) {
-        const double totlwt = scal[SC_TOTLWT];
         for (int ne = 0; ne < NE; ++ne) {
             int nn[D], offi[D], t = ne, ncol_n = 0;
             bool ok = true;
@@ -719,8 +776,10 @@ rho_gather_kernel(Grid g, const int *__restrict__ offset, const double *__restri
                 ncol_n += nn[d] * g.colstride[d];
             }
             if (!ok) continue;
-            const SparseNode sn = sparse_node<D>(g, nn, hist, totlwt, xtrap);
-            if (!sn.sparse) continue;
+            if (spf[ncol_n] == 0) continue;
+            SparseNode sn;
+            sn.sparse = true;
+            sn.dcwght = dcw[ncol_n];
             int pair = 0;
             for (int idm = 0; idm < D; ++idm)
                 for (int jdm = idm; jdm < D; ++jdm, ++pair) {
@@ -874,36 +933,63 @@ hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ld
     return hipGetLastError();
 }
 
-hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, bool smooth, double *nst,
-                       double *rhs, double *hist, double *scalH, hipStream_t st)
+long long gram_scratch_min_doubles(const Grid &g)
+{   // one hyper-row of cells along the slowest dimension
+    return (long long)g.cellstride[g.ndim - 1] * (gram_tri(g.nb) + 2LL * g.nb);
+}
+
+hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, long long scratch_doubles, bool smooth,
+                       double *nst, double *rhs, double *hist, double *scalH, hipStream_t st)
 {
-    const long long tri = gram_tri(g.nb);
-    double *blk = scratch;
-    double *rblk = blk + (long long)g.ncell * tri;
-    double *hblk = smooth ? rblk + (long long)g.ncell * g.nb : nullptr;
-    DISPATCH_D(g.ndim, {
-        using C = GramCfg<D>;
-        dim3 gr((unsigned)g.ncell, (unsigned)(C::NB / (C::NTX * C::TC)));
-        hipLaunchKernelGGL(gram_block_kernel<D>, gr, dim3(C::NT), 0, st, g, (const int *)s.offset, (const double *)s.xs,
-                           (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist);
-        hipLaunchKernelGGL(stencil_gather_kernel<D>, dim3((unsigned)((g.ncol + 3) / 4)), dim3(256), 0, st, g,
-                           (const int *)s.offset, (const double *)blk, (const double *)rblk, (const double *)hblk,
-                           nst, rhs, hist);
-    });
+    // The per-cell blocks are produced and gathered slab by slab: as many whole hyper-rows of cells (along
+    // the slowest dimension) as the scratch holds -- all of them at 64^3 (3.9 GB), two or three slabs of
+    // the 189 GB that the 29^4 cells of the 4-D 32^4 grid would need at once.
+    const long long per_cell = gram_tri(g.nb) + 2LL * g.nb;
+    const int hrow = g.cellstride[g.ndim - 1];              // cells per hyper-row
+    const int nhrow = g.cells[g.ndim - 1];
+    long long fit_rows = scratch_doubles / (per_cell * hrow);
+    if (fit_rows < 1) return hipErrorInvalidValue;
+    if (fit_rows > nhrow) fit_rows = nhrow;
+    const int nstride = g.colstride[g.ndim - 1];            // nodes per hyper-row of nodes
+    for (int h0 = 0; h0 < nhrow; h0 += (int)fit_rows) {
+        const int h1 = (h0 + fit_rows < nhrow) ? h0 + (int)fit_rows : nhrow;
+        const int cell0 = h0 * hrow, cell1 = h1 * hrow, ncells = cell1 - cell0;
+        const int node0 = h0 * nstride, node1 = (h1 + 3) * nstride;     // window starts h0..h1-1 touch nodes h0..h1+2
+        double *blk = scratch;
+        double *rblk = blk + (long long)ncells * gram_tri(g.nb);
+        double *hblk = smooth ? rblk + (long long)ncells * g.nb : nullptr;
+        DISPATCH_D(g.ndim, {
+            using C = GramCfg<D>;
+            dim3 gr((unsigned)ncells, (unsigned)(C::NB / (C::NTX * C::TC)));
+            hipLaunchKernelGGL(gram_block_kernel<D>, gr, dim3(C::NT), 0, st, g, (const int *)s.offset, (const double *)s.xs,
+                               (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist, cell0);
+            hipLaunchKernelGGL(stencil_gather_kernel<D>, dim3((unsigned)((node1 - node0 + 3) / 4)), dim3(256), 0, st, g,
+                               (const int *)s.offset, (const double *)blk, (const double *)rblk, (const double *)hblk,
+                               nst, rhs, hist, cell0, cell1, node0, node1);
+        });
+    }
     if (smooth) hipLaunchKernelGGL(hist_total_kernel, dim3(1), dim3(1024), 0, st, (const double *)hist, g.ncol, scalH);
     return hipGetLastError();
 }
 
-hipError_t launch_constraint_rows(const Grid &g, const double *hist, const double *scal, double xtrap,
-                                  double *nst, double *scal_out, hipStream_t st)
+hipError_t launch_sparse_mark(const Grid &g, const double *hist, const double *scal, double xtrap, double *dcw,
+                              unsigned char *spf, hipStream_t st)
+{
+    DISPATCH_D(g.ndim, hipLaunchKernelGGL(sparse_mark_kernel<D>, dim3((unsigned)((g.ncol + 255) / 256)), dim3(256), 0, st,
+                                          g, hist, scal, xtrap, dcw, spf));
+    return hipGetLastError();
+}
+
+hipError_t launch_constraint_rows(const Grid &g, const double *dcw, const unsigned char *spf, double *nst,
+                                  double *scal_out, hipStream_t st)
 {
     dim3 gr((unsigned)((g.ncol + 3) / 4)), bl(256);
-    DISPATCH_D(g.ndim, hipLaunchKernelGGL(constraint_rows_kernel<D>, gr, bl, 0, st, g, hist, scal, xtrap, nst, scal_out));
+    DISPATCH_D(g.ndim, hipLaunchKernelGGL(constraint_rows_kernel<D>, gr, bl, 0, st, g, dcw, spf, nst, scal_out));
     return hipGetLastError();
 }
 
 hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rcell,
-                           const double *hist, const double *scal, double xtrap, bool constraints,
+                           const double *dcw, const unsigned char *spf, bool constraints,
                            double *tbuf, double *rho, double *ssq, hipStream_t st)
 {
     dim3 gn((unsigned)((g.ncol + 3) / 4)), bl(256);
@@ -913,9 +999,9 @@ hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xv
                            (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
                            s.cap, xvec, rcell, ssq);
         if (constraints)
-            hipLaunchKernelGGL(constraint_dots_kernel<D>, gn, bl, 0, st, g, hist, scal, xtrap, xvec, tbuf, ssq);
+            hipLaunchKernelGGL(constraint_dots_kernel<D>, gn, bl, 0, st, g, dcw, spf, xvec, tbuf, ssq);
         hipLaunchKernelGGL(rho_gather_kernel<D>, dim3((unsigned)((g.ncol + 255) / 256)), bl, 0, st, g,
-                           (const int *)s.offset, (const double *)rcell, hist, scal, xtrap,
+                           (const int *)s.offset, (const double *)rcell, dcw, spf,
                            constraints ? (const double *)tbuf : (const double *)nullptr, rho);
     });
     return hipGetLastError();

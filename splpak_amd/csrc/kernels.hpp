@@ -46,20 +46,25 @@ struct SortScratch {
 // cell ordered by original index
 hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ldx, const double *y,
                              const double *w, const SortScratch &s, double *scal, hipStream_t st);
-// doubles of scratch launch_gram needs (per-cell Gram blocks, right-hand sides, histogram shares)
+// doubles of scratch launch_gram uses when it can hold every cell's blocks at once (per-cell Gram blocks,
+// right-hand sides, histogram shares), and the least it can work with (one hyper-row of cells)
 long long gram_scratch_doubles(const Grid &g);
+long long gram_scratch_min_doubles(const Grid &g);
 // per-cell Gram blocks -> (owner gathers) half-stencil normal equations nst[ncol][hstencil], rhs[ncol] and,
 // when smooth, the nearest-node histogram hist[ncol] (caller's order; must be zero on entry) + its total
-hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, bool smooth, double *nst,
-                       double *rhs, double *hist, double *scalH, hipStream_t st);
+hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, long long scratch_doubles, bool smooth,
+                       double *nst, double *rhs, double *hist, double *scalH, hipStream_t st);
 // derivative-constraint rows of the data-sparse nodes (:921-1046): nst += C^T C, rows counted into
 // scal_out[SC_NROWS_CONS]
-hipError_t launch_constraint_rows(const Grid &g, const double *hist, const double *scal, double xtrap,
-                                  double *nst, double *scal_out, hipStream_t st);
+// dcw[node] / spf[node]: constraint weight xtrap (expect - have) and "data sparse" flag of every node (:923-960)
+hipError_t launch_sparse_mark(const Grid &g, const double *hist, const double *scal, double xtrap, double *dcw,
+                              unsigned char *spf, hipStream_t st);
+hipError_t launch_constraint_rows(const Grid &g, const double *dcw, const unsigned char *spf, double *nst,
+                                  double *scal_out, hipStream_t st);
 // refinement residual rho = A^T W (W y - W A x) [- C^T C x when `constraints`]; rcell: [ncell][nb] scratch,
 // tbuf: [ncol][ndim(ndim+1)/2] scratch; ssq != NULL: also accumulate the sum of squared row residuals
 hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rcell,
-                           const double *hist, const double *scal, double xtrap, bool constraints,
+                           const double *dcw, const unsigned char *spf, bool constraints,
                            double *tbuf, double *rho, double *ssq, hipStream_t st);
 // out[0] = max_i |rho_i| / ((|N||x|)_i + |rhs_i|): componentwise backward error with respect to the rows
 hipError_t launch_backward_error(const Grid &g, const double *nst, const double *xvec, const double *rho,

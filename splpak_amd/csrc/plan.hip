@@ -203,6 +203,8 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     ok = ok && dev_alloc(p, &p->s.idx, (size_t)max_ndata);
     ok = ok && dev_alloc(p, &p->rcell, (size_t)g.ncell * g.nb);
     ok = ok && dev_alloc(p, &p->tbuf, (size_t)g.ncol * (g.ndim * (g.ndim + 1) / 2));
+    ok = ok && dev_alloc(p, &p->dcw, (size_t)g.ncol);
+    ok = ok && dev_alloc(p, &p->spf, (size_t)g.ncol);
     // band: all of it (R = 1) or the block columns dealt to rank r of R
     band_bytes(g.ncol, g.halfbw, &p->band);
     (void)hipGetDevice(&p->device);
@@ -212,8 +214,23 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     p->nown = (int)p->own_blocks_host.size();
     if (p->dm.R > 1) p->band.bytes = (size_t)(p->nown > 0 ? p->nown : 1) * NBLK * (size_t)p->dm.ld * sizeof(double) + 4096;
     ok = ok && dev_alloc(p, &p->band.ab, p->band.bytes / sizeof(double));
-    if ((size_t)gram_scratch_doubles(g) * sizeof(double) <= p->band.bytes) p->gscratch = p->band.ab;
-    else ok = ok && dev_alloc(p, &p->gscratch, (size_t)gram_scratch_doubles(g));
+    {
+        // scratch of the per-cell Gram blocks: everything at once if <= 8 GB (or if the band storage, which is
+        // idle until the gather is done, holds it); otherwise slabs of what there is (launch_gram)
+        const long long full = gram_scratch_doubles(g), least = gram_scratch_min_doubles(g);
+        long long want = full;
+        const char *cap = std::getenv("SPLPAK_GRAM_SCRATCH_MB");
+        const long long budget = cap ? atoll(cap) * (1LL << 17) : (1LL << 30);      // doubles (default 8 GB)
+        if (want > budget) want = budget > least ? budget : least;
+        const long long band_doubles = (long long)(p->band.bytes / sizeof(double));
+        if (band_doubles >= want && !cap) {
+            p->gscratch = p->band.ab;
+            p->gscratch_doubles = band_doubles < full ? band_doubles : full;
+        } else {
+            ok = ok && dev_alloc(p, &p->gscratch, (size_t)want);
+            p->gscratch_doubles = want;
+        }
+    }
     const size_t nloc = (size_t)(p->nown > 0 ? p->nown : 1);
     ok = ok && dev_alloc(p, &p->band.dinv, nloc * NBLK * NBLK);
     ok = ok && dev_alloc(p, &p->band.dinvt, nloc * NBLK * NBLK);
@@ -342,7 +359,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     // ---- assembly -------------------------------------------------------
     SPLPAK_HIP_TRY(hipMemsetAsync(p->comm, 0, sizeof(double) * (size_t)(p->lenG + p->lenH), st), SPLPAK_E_NODEVICE);
     SPLPAK_HIP_TRY(launch_bin_points(g, ndata, x, l1xdat, y, w, p->s, p->scalH, st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(launch_gram(g, p->s, p->gscratch, smooth, p->nst, p->rhs, p->hist, p->scalH, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(launch_gram(g, p->s, p->gscratch, p->gscratch_doubles, smooth, p->nst, p->rhs, p->hist, p->scalH, st), SPLPAK_E_NODEVICE);
     double hs[2 * SC_COUNT];
     if (p->world > 1) {
         const double one = 1.0;
@@ -357,8 +374,10 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
             return SPLPAK_E_COMM;
         }
     }
-    if (smooth && p->rank == 0)
-        SPLPAK_HIP_TRY(launch_constraint_rows(g, p->hist, p->scalH, p->xtrap, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
+    if (smooth && p->rank == 0) {
+        SPLPAK_HIP_TRY(launch_sparse_mark(g, p->hist, p->scalH, p->xtrap, p->dcw, p->spf, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_constraint_rows(g, p->dcw, p->spf, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
+    }
     if (int r = do_allreduce(p, p->nst, p->lenG, st)) return r;
 
     SPLPAK_HIP_TRY(hipMemcpyAsync(hs, p->scalG, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
@@ -419,7 +438,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     bool converged = p->max_refine == 0, diverged = false;
     for (int it = 0; it < p->max_refine_hard && !converged; ++it) {
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->hist, p->scalH, p->xtrap, smooth && p->rank == 0,
+        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, smooth && p->rank == 0,
                                        p->tbuf, p->rho, nullptr, st), SPLPAK_E_NODEVICE);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
         SPLPAK_HIP_TRY(p->solve_fn ? p->solve_fn(p, p->rho, p->tmp, st, p->fn_user) : band_solve(b, p->rho, p->tmp, st), SPLPAK_E_NODEVICE);
@@ -464,7 +483,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     if (info) {
         double *scalR = p->rho + b.npad;
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->hist, p->scalH, p->xtrap, smooth && p->rank == 0,
+        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, smooth && p->rank == 0,
                                        p->tbuf, p->rho, scalR, st), SPLPAK_E_NODEVICE);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
         SPLPAK_HIP_TRY(launch_backward_error(g, p->nst, p->xvec, p->rho, p->rhs, p->small + 3, st), SPLPAK_E_NODEVICE);

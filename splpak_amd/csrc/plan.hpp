@@ -20,6 +20,9 @@ struct splpak_plan {
     double *xvec = nullptr, *tmp = nullptr, *small = nullptr;   // small: [absmax(2) | minpiv(1) | backward error(1) | pad]
     double *gscratch = nullptr;   // per-cell Gram blocks: the band storage itself when it is large enough (it is only
                                   // filled after the gather), a buffer of its own otherwise
+    long long gscratch_doubles = 0;
+    double *dcw = nullptr;        // [ncol] constraint weight of every node, spf: [ncol] "data sparse" flags (:923-960)
+    unsigned char *spf = nullptr;
     double *rcell = nullptr;      // [ncell][nb] per-cell shares of the refinement residual
     double *tbuf = nullptr;       // [ncol][ndim(ndim+1)/2] constraint-row dot products of the refinement residual
     int *info = nullptr;

@@ -178,3 +178,42 @@ def test_distributed_band_24cubed_and_errors(monkeypatch):
     xc = np.random.default_rng(0).random((400, 2)) * 0.2     # all data in one corner, no smoothing rows
     assert capi.fit_multi(3, 2, xc, xc.sum(axis=1), None, [0.0, 0.0], [1.0, 1.0], [8, 8], 0.0)[1] == 107
     assert capi.fit_multi(2, 0, xc, xc.sum(axis=1), None, [0.0, 0.0], [1.0, 1.0], [8, 8], 0.0)[1] == 101
+
+
+@pytest.mark.gpu
+def test_distributed_band_4d_12_property(monkeypatch):
+    """BASELINE config 5's shape at a size one test can afford: 4-D 12^4 grid (20 736 columns, band 23
+    blocks wide, 81 block steps) through the distributed path on 4 virtual GPUs.  Data sampled from a
+    spline of the grid with random coefficients (xtrap = 0: the fit is a projection) must give those
+    coefficients back to 1e-10 -- the dense reference cannot run this grid in test time."""
+    import torch
+    from splpak_amd import capi
+    monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
+    nd, nod, m, R = 4, 12, 400000, 4
+    nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    ctrue = torch.randn(nod ** nd, dtype=torch.float64, device=dev, generator=gen)
+    per = m // R
+    xs, ys = [], []
+    for r in range(R):
+        x = torch.empty((per, nd), dtype=torch.float64, device=dev)
+        capi.synth_points_dev(nd, r * per, per, x, None, None, st)
+        y = torch.empty(per, dtype=torch.float64, device=dev)
+        capi.evaluate_dev(nd, x, None, ctrue, lo, hi, nodes, y, st)
+        xs.append(x)
+        ys.append(y)
+    torch.cuda.synchronize()
+    mp = capi.MultiPlan(R, nd, nodes, lo, hi, 0.0, per, chunk=2)
+    try:
+        coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
+        ierr, info = mp.fit(xs, ys, None, coef)
+        err = float((coef - ctrue).abs().max() / ctrue.abs().max())
+        print(f"4-D 12^4 x{R} virtual GPUs: coefficient error {err:.2e}, steps {info[2]:.0f}, optimality {info[9]:.1e}, "
+              f"phases {info[5]:.3f} / {info[6]:.3f} / {info[7]:.3f} s")
+        assert ierr == 0 and info[0] == m
+        assert err < 1e-10 and info[9] < 1e-9
+    finally:
+        mp.close()

@@ -516,6 +516,24 @@ def test_c3_full_size_properties():
         plan.close()
 
 
+@pytest.mark.parametrize("name,mb", [("3d12", 3), ("4d6", 8), ("2d32", 1), ("c1_1d16", 1)])
+def test_gram_blocks_in_slabs_match_golden(name, mb, monkeypatch):
+    """The per-cell Gram blocks are produced and gathered in slabs when the scratch cannot hold all of
+    them (189 GB at the 4-D 32^4 grid): force a scratch of a few MB so that these grids take several
+    slabs; the fit must hold the golden exactly as with one slab."""
+    capi.lib().splpak_shutdown()                     # drop the cached plan of the one-shot entry
+    monkeypatch.setenv("SPLPAK_GRAM_SCRATCH_MB", str(mb))
+    gold = load_golden(name)
+    inp = make_inputs(CASES[name])
+    try:
+        coef, ierr, hist, info = capi.fit(inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"],
+                                          inp["xmax"], inp["nodes"], inp["xtrap"], want_hist=True)
+    finally:
+        capi.lib().splpak_shutdown()
+    assert ierr == 0 and relmax(coef, gold["coef"]) < COEF_TOL
+    assert relmax(hist, gold["hist"]) < 1e-12 and info[9] < 1e-9
+
+
 def test_slowly_contracting_refinement_is_not_a_silent_success():
     """A solve whose refinement has not converged must not return ierror 0: with the
     nominal step count forced to 1 and an unreachable tolerance the loop continues while it
