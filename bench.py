@@ -204,6 +204,34 @@ def bench_dist_band(capi, ngpus, nd, nod, m_total, virtual, steps):
             os.environ.pop("SPLPAK_VIRTUAL_GPUS", None)
 
 
+def bench_c5_eval(capi, dev, stream):
+    """BASELINE config 5, evaluation half at full size: 4-D 32^4 coefficients (8 MB), 1e8 queries of the
+    seeded stream, splfe and two splde derivative patterns; real64 resident data.  (The fit half of
+    config 5 needs the distributed band: 852 GB.)"""
+    import torch
+    nd, nod, nq = 4, 32, 100_000_000
+    nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    coef = torch.randn(nod ** nd, dtype=torch.float64, device=dev, generator=gen)
+    xq = torch.empty((nq, nd), dtype=torch.float64, device=dev)
+    out = torch.empty(nq, dtype=torch.float64, device=dev)
+    capi.synth_queries_dev(nd, 10_000_000, 0, nq, xq, stream)
+    res = {}
+    for label, pat in (("splfe", None), ("splde_1000", [1, 0, 0, 0]), ("splde_0201", [0, 2, 0, 1])):
+        capi.evaluate_dev(nd, xq, pat, coef, lo, hi, nodes, out, stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        capi.evaluate_dev(nd, xq, pat, coef, lo, hi, nodes, out, stream)
+        torch.cuda.synchronize()
+        res[label] = nq / (time.perf_counter() - t0)
+    del xq, out
+    return {"workload": "C5 (evaluation half): 4-D, 32^4 nodes, 1e8 queries, real64, resident data", "unit": "evals/s",
+            "value": res["splfe"], **{k + "_evals_per_s": v for k, v in res.items()},
+            "roofline": {"bound": "hbm", "achieved": 40.0 * res["splfe"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": 40.0 * res["splfe"] / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+
+
 def bench_incl_h2d(capi, x, y, w, lo, hi, nodes):
     """The host-pointer entry (what the Fortran module binds): pageable host arrays in, coefficients
     out, PCIe transfers included.  Never `value`."""
@@ -387,7 +415,7 @@ def main():
         if kt_sum["syrk_ms"] > 0:
             ach = kt_sum["syrk_flop"] / (kt_sum["syrk_ms"] * 1e-3) / 1e12
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_syrk_pmc.json")
+            pmc = os.path.join(ROOT, "profiles", "r02_fit_pmc.json")
             if os.path.exists(pmc):
                 try:
                     traffic = json.load(open(pmc)).get("bulk_hbm_bytes_per_launch")
@@ -409,6 +437,9 @@ def main():
             # rehearsal of the distributed-band path on this one GPU (2 virtual ranks, reduced size)
             line["dist_band"] = bench_dist_band(capi, 2, nd, min(nod, 32), 1_000_000, True, args.steps)
             line["c2"] = bench_c2(capi, dev, stream, args.steps)
+            del xq, out
+            torch.cuda.empty_cache()
+            line["c5_eval"] = bench_c5_eval(capi, dev, stream)
             line["fit_incl_h2d"] = bench_incl_h2d(capi, x, y, w, lo, hi, nodes)
         if dist_leg is not None:
             line["dist_band"] = dist_leg

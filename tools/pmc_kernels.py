@@ -11,7 +11,8 @@ out, paths = sys.argv[1], sys.argv[2:]
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for p in paths:
     for r in csv.DictReader(open(p)):
-        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("splpak::", "").replace("(anonymous namespace)::", "")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("splpak::", "")
+        name = re.sub(r"\(.*", "", name)
         a = acc[name][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 res = {}
