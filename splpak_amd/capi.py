@@ -53,6 +53,14 @@ def lib() -> C.CDLL:
         raise SplpakError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); the splpak HIP path has no CPU fallback")
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  Two HIP runtimes in one process do not share
+    # the device (whichever comes second finds "no GPUs"), so if torch is installed it is imported FIRST:
+    # libsplpak_hip.so then binds to the runtime that is already loaded.  Without torch (Fortran callers,
+    # plain ctypes users) the system runtime under /opt/rocm is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.splpak_fit_f64.restype = i32

@@ -439,6 +439,12 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coe
     }
 }
 
+// pass C of the fused value / gradient / Hessian evaluation (defined with eval_derivs_kernel below)
+template <int D, int ORDER>
+__global__ void eval_derivs_binned_kernel(Grid g, Regions rg, const double *__restrict__ coef, const double *__restrict__ xs,
+                                          long long ldp, const int *__restrict__ perm, const int *__restrict__ off,
+                                          const int *__restrict__ wgoff, double *__restrict__ out, int ldout);
+
 // scratch of the binned path: per thread, grown on demand, released by splpak_shutdown
 namespace {
 struct EvalScratch {
@@ -473,9 +479,11 @@ void set_eval_mode(int mode, long long chunk)
     g_eval_chunk = chunk;
 }
 
+// order == 0: one nderiv pattern (nd) -> out[nq]; order 1 / 2: value + gradient (+ Hessian) -> out[nq][ldout]
 template <int D>
 static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, const double *xq, int ldxq,
-                              const NDeriv &nd, const double *coef, double *out, hipStream_t st)
+                              const NDeriv &nd, const double *coef, double *out, hipStream_t st,
+                              int order = 0, int ldout = 1)
 {
     // default chunk: 2^24 queries (measured best at 64^3: large enough that the ~8 000 evaluation
     // workgroups of a chunk keep every CU full to the end; chunks small enough to stay in the Infinity
@@ -516,7 +524,13 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
         hipLaunchKernelGGL((bin_scatter_kernel<D>), dim3(nbs), dim3(256), 2 * sizeof(int) * rg.nbins, st, g, rg, n, xc, ldxq,
                            (const int *)s.cnt, ldw, s.xs, s.cap, s.perm);
         const unsigned nw = (unsigned)(n / EVAL_QPW + rg.nbins + 1);
-        if (value_only)
+        if (order == 1)
+            hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 1>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs, s.cap,
+                               (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
+        else if (order == 2)
+            hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 2>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs, s.cap,
+                               (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
+        else if (value_only)
             hipLaunchKernelGGL((eval_binned_kernel<D, true>), dim3(nw), dim3(256), 0, st, g, rg, nd, coef,
                                (const double *)s.xs, s.cap, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
         else
@@ -548,6 +562,82 @@ static bool make_regions(const Grid &g, Regions &rg)
 //   [ f, df/dx_1 .. df/dx_D, (ORDER 2:) d2f/dx_1dx_1, d2f/dx_1dx_2, .., d2f/dx_1dx_D, d2f/dx_2dx_2, .. ]
 // Each entry is the reference's sum  sum_window coef * prod_d bas1(nderiv_d; x_d)  for its nderiv
 // pattern; the 1-D factors come from the same window_table as everywhere else.
+// acc[*] for one query from its factor tables b[a][d][k] (a = derivative order) and a loader of window
+// rows: load4(k, c) delivers the 4 coefficients (k_0 = 0..3) of the row with window indices k[1..D-1].
+// Shared by the direct and the binned kernel: identical bits.
+template <int D, int ORDER, typename L4>
+__device__ inline void derivs_accumulate(const double (&b)[ORDER + 1][D][4], L4 &&load4,
+                                         double (&acc)[1 + D + (ORDER == 2 ? D * (D + 1) / 2 : 0)])
+{
+    constexpr int NOUT = 1 + D + (ORDER == 2 ? D * (D + 1) / 2 : 0);
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
+    // window rows (k_0 = 0..3 contiguous): contract dimension 1 with its value / first / second
+    // derivative factors first, then combine with the factors of the other dimensions
+    constexpr int NROW = D == 1 ? 1 : (D == 2 ? 4 : (D == 3 ? 16 : 64));
+    for (int e = 0; e < NROW; ++e) {
+        int k[D];
+        k[0] = 0;
+#pragma unroll
+        for (int d = 1; d < D; ++d) k[d] = (e >> (2 * (d - 1))) & 3;
+        double c[4];
+        load4(k, c);
+        double r[ORDER + 1];                  // r[a] = sum_k0 c[k0] * (a-th derivative factor of dim 1)
+#pragma unroll
+        for (int a = 0; a <= ORDER; ++a) {
+            double t = 0.0;
+#pragma unroll
+            for (int k0 = 0; k0 < 4; ++k0) t = fma(c[k0], b[a][0][k0], t);
+            r[a] = t;
+        }
+        double v0[D], v1[D], pex[D];          // dims >= 1: pex[d] = prod_{f >= 1, f != d} v0[f]
+        double full = 1.0;                    // prod_{f >= 1} v0[f]
+        v0[0] = v1[0] = pex[0] = 1.0;
+#pragma unroll
+        for (int d = 1; d < D; ++d) {
+            v0[d] = b[0][d][k[d]];
+            v1[d] = b[1][d][k[d]];
+            full *= v0[d];
+        }
+#pragma unroll
+        for (int d = 1; d < D; ++d) {
+            double pd = 1.0;
+#pragma unroll
+            for (int f = 1; f < D; ++f)
+                if (f != d) pd *= v0[f];
+            pex[d] = pd;
+        }
+        acc[0] = fma(r[0], full, acc[0]);
+        acc[1] = fma(r[1], full, acc[1]);
+#pragma unroll
+        for (int d = 1; d < D; ++d) acc[1 + d] = fma(r[0], v1[d] * pex[d], acc[1 + d]);
+        if constexpr (ORDER == 2) {
+            int j = 1 + D;
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int f = d; f < D; ++f) {
+                    double term;
+                    if (d == 0 && f == 0) {
+                        term = r[2] * full;
+                    } else if (d == 0) {
+                        term = r[1] * (v1[f] * pex[f]);
+                    } else if (f == d) {
+                        term = r[0] * (b[2][d][k[d]] * pex[d]);
+                    } else {
+                        double pdf = 1.0;
+#pragma unroll
+                        for (int h = 1; h < D; ++h)
+                            if (h != d && h != f) pdf *= v0[h];
+                        term = r[0] * (v1[d] * v1[f] * pdf);
+                    }
+                    acc[j] += term;
+                    ++j;
+                }
+        }
+    }
+}
+
 template <int D, int ORDER, typename T>
 __global__ void __launch_bounds__(256)
 eval_derivs_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, const T *__restrict__ coef,
@@ -567,20 +657,10 @@ eval_derivs_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, con
             base += ws * g.colstride[d];
         }
         double acc[NOUT];
+        derivs_accumulate<D, ORDER>(b, [&](const int (&k)[D], double (&c)[4]) {
+            int off = 0;
 #pragma unroll
-        for (int j = 0; j < NOUT; ++j) acc[j] = 0.0;
-        // window rows (k_0 = 0..3 contiguous): contract dimension 1 with its value / first / second
-        // derivative factors first, then combine with the factors of the other dimensions
-        constexpr int NROW = D == 1 ? 1 : (D == 2 ? 4 : (D == 3 ? 16 : 64));
-        for (int e = 0; e < NROW; ++e) {
-            int k[D], off = 0;
-            k[0] = 0;
-#pragma unroll
-            for (int d = 1; d < D; ++d) {
-                k[d] = (e >> (2 * (d - 1))) & 3;
-                off += k[d] * g.colstride[d];
-            }
-            double c[4];
+            for (int d = 1; d < D; ++d) off += k[d] * g.colstride[d];
             if constexpr (sizeof(T) == 8) {
                 typedef double d2v __attribute__((ext_vector_type(2), aligned(8)));
                 const d2v lo2 = *reinterpret_cast<const d2v *>(coef + base + off);
@@ -590,62 +670,84 @@ eval_derivs_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, con
 #pragma unroll
                 for (int k0 = 0; k0 < 4; ++k0) c[k0] = (double)coef[base + off + k0];
             }
-            double r[ORDER + 1];                  // r[a] = sum_k0 c[k0] * (a-th derivative factor of dim 1)
-#pragma unroll
-            for (int a = 0; a <= ORDER; ++a) {
-                double t = 0.0;
-#pragma unroll
-                for (int k0 = 0; k0 < 4; ++k0) t = fma(c[k0], b[a][0][k0], t);
-                r[a] = t;
-            }
-            double v0[D], v1[D], pex[D];          // dims >= 1: pex[d] = prod_{f >= 1, f != d} v0[f]
-            double full = 1.0;                    // prod_{f >= 1} v0[f]
-            v0[0] = v1[0] = pex[0] = 1.0;
-#pragma unroll
-            for (int d = 1; d < D; ++d) {
-                v0[d] = b[0][d][k[d]];
-                v1[d] = b[1][d][k[d]];
-                full *= v0[d];
-            }
-#pragma unroll
-            for (int d = 1; d < D; ++d) {
-                double pd = 1.0;
-#pragma unroll
-                for (int f = 1; f < D; ++f)
-                    if (f != d) pd *= v0[f];
-                pex[d] = pd;
-            }
-            acc[0] = fma(r[0], full, acc[0]);
-            acc[1] = fma(r[1], full, acc[1]);
-#pragma unroll
-            for (int d = 1; d < D; ++d) acc[1 + d] = fma(r[0], v1[d] * pex[d], acc[1 + d]);
-            if constexpr (ORDER == 2) {
-                int j = 1 + D;
-#pragma unroll
-                for (int d = 0; d < D; ++d)
-#pragma unroll
-                    for (int f = d; f < D; ++f) {
-                        double term;
-                        if (d == 0 && f == 0) {
-                            term = r[2] * full;
-                        } else if (d == 0) {
-                            term = r[1] * (v1[f] * pex[f]);
-                        } else if (f == d) {
-                            term = r[0] * (b[2][d][k[d]] * pex[d]);
-                        } else {
-                            double pdf = 1.0;
-#pragma unroll
-                            for (int h = 1; h < D; ++h)
-                                if (h != d && h != f) pdf *= v0[h];
-                            term = r[0] * (v1[d] * v1[f] * pdf);
-                        }
-                        acc[j] += term;
-                        ++j;
-                    }
-            }
-        }
+        }, acc);
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) out[i * ldout + j] = (T)acc[j];
+    }
+}
+
+// binned form (pass C of the region sort, see eval_binned_kernel): the window rows come from the LDS tile
+template <int D, int ORDER>
+__global__ void __launch_bounds__(256)
+eval_derivs_binned_kernel(Grid g, Regions rg, const double *__restrict__ coef, const double *__restrict__ xs,
+                          long long ldp, const int *__restrict__ perm, const int *__restrict__ off,
+                          const int *__restrict__ wgoff, double *__restrict__ out, int ldout)
+{
+    constexpr int NOUT = 1 + D + (ORDER == 2 ? D * (D + 1) / 2 : 0);
+    __shared__ double tile[TILE_ELEMS];
+    using TS = TileShape<D>;
+    const int wg = blockIdx.x;
+    if (wg >= wgoff[rg.nbins]) return;
+    int lo = 0, hi = rg.nbins;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (wgoff[mid] <= wg) lo = mid; else hi = mid;
+    }
+    const int r = lo, part = wg - wgoff[r];
+    int a[D];
+    {
+        int rr = r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            a[d] = (rr % rg.nreg[d]) * (TS::T[d] - 3);
+            rr /= rg.nreg[d];
+        }
+    }
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += 256) {
+        int rem = e, idx = 0;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int l = rem % TS::T[d];
+            rem /= TS::T[d];
+            const int node = a[d] + l;
+            ok = ok && node < g.nodes[d];
+            idx += node * g.colstride[d];
+        }
+        tile[e] = ok ? coef[idx] : 0.0;
+    }
+    __syncthreads();
+    const int qb = off[r] + part * EVAL_QPW;
+    const int qe = min(off[r + 1], qb + EVAL_QPW);
+    int tstr[D];
+    {
+        int m = 1;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { tstr[d] = m; m *= TS::T[d]; }
+    }
+    for (int j = qb + threadIdx.x; j < qe; j += 256) {
+        double b[ORDER + 1][D][4];
+        int base = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const double x = xs[(long long)d * ldp + j];
+            int ws = 0;
+#pragma unroll
+            for (int aa = 0; aa <= ORDER; ++aa) ws = window_table(g, d, x, aa, b[aa][d]);
+            base += (ws - a[d]) * tstr[d];
+        }
+        double acc[NOUT];
+        derivs_accumulate<D, ORDER>(b, [&](const int (&k)[D], double (&c)[4]) {
+            int o = base;
+#pragma unroll
+            for (int d = 1; d < D; ++d) o += k[d] * tstr[d];
+            typedef const volatile __attribute__((address_space(3))) double *lds_cvd;
+            lds_cvd q = (lds_cvd)tile + o;
+            c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[3];
+        }, acc);
+        const long long p = perm[j];
+#pragma unroll
+        for (int jj = 0; jj < NOUT; ++jj) out[p * ldout + jj] = acc[jj];
     }
 }
 
@@ -654,6 +756,23 @@ static hipError_t launch_eval_derivs_t(const Grid &g, long long nq, const T *xq,
                                        const T *coef, T *out, int ldout, hipStream_t st)
 {
     if (nq <= 0) return hipSuccess;
+    if constexpr (sizeof(T) == 8) {
+        // same rule as the single-pattern evaluation: large batches on 3-D / 4-D grids go through the region sort
+        Regions rg;
+        bool can = false;
+        if (g.ndim == 2) can = make_regions<2>(g, rg);
+        if (g.ndim == 3) can = make_regions<3>(g, rg);
+        if (g.ndim == 4) can = make_regions<4>(g, rg);
+        const bool want = g_eval_mode == 2 || (g_eval_mode == 0 && g.ndim >= 3 && nq >= (1LL << 20) && g.ncol > 32768);
+        if (can && want) {
+            NDeriv nd0{};
+            hipError_t e = g.ndim == 2   ? eval_binned<2>(g, rg, nq, xq, ldxq, nd0, coef, out, st, order, ldout)
+                           : g.ndim == 3 ? eval_binned<3>(g, rg, nq, xq, ldxq, nd0, coef, out, st, order, ldout)
+                                         : eval_binned<4>(g, rg, nq, xq, ldxq, nd0, coef, out, st, order, ldout);
+            if (e != hipErrorOutOfMemory) return e;
+            (void)hipGetLastError();
+        }
+    }
     long long blocks = (nq + 255) / 256;
     if (blocks > 256LL * 32) blocks = 256LL * 32;
     dim3 gr((unsigned)blocks), bl(256);

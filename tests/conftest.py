@@ -9,6 +9,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before the HIP library is loaded: one HIP runtime per process (see splpak_amd/capi.py)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -174,6 +174,38 @@ def test_eval_binned_path_is_bit_identical_to_direct(port, nodes):
         capi.set_eval_mode(7)
 
 
+@pytest.mark.parametrize("nodes", [(20, 17, 30), (12, 9, 8, 14), (70, 40)])
+def test_eval_derivs_binned_path_is_bit_identical_to_direct(nodes):
+    """Value + gradient + Hessian through the region sort (LDS tiles) must return the bits of the direct
+    kernel: queries outside the grid, padded rows, a ragged last chunk, both orders."""
+    import torch
+    nd = len(nodes)
+    rng = np.random.default_rng(nd * 77 + nodes[0])
+    dev = torch.device("cuda", 0)
+    coef = torch.tensor(rng.standard_normal(int(np.prod(nodes))), device=dev)
+    lo = -1.0 + rng.random(nd)
+    hi = lo + 1.0 + 3.0 * rng.random(nd)
+    nq = 30011
+    q = np.full((nq, nd + 1), 1e300)
+    q[:, :nd] = lo + (hi - lo) * (-0.2 + 1.4 * rng.random((nq, nd)))
+    q[:50, :nd] = lo + (hi - lo) * rng.integers(0, 2, (50, nd))
+    qd = torch.tensor(q, device=dev)
+    try:
+        for order in (1, 2):
+            nout = capi.derivs_nout(nd, order)
+            od = torch.full((nq, nout + 1), -7.0, dtype=torch.float64, device=dev)
+            ob = torch.full((nq, nout + 1), -7.0, dtype=torch.float64, device=dev)
+            capi.set_eval_mode(capi.EVAL_DIRECT)
+            assert capi.evaluate_derivs_dev(nd, qd, order, coef, lo, hi, nodes, od) == 0
+            capi.set_eval_mode(capi.EVAL_BINNED, 4099)
+            assert capi.evaluate_derivs_dev(nd, qd, order, coef, lo, hi, nodes, ob) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(od, ob), (nodes, order)
+            assert bool((ob[:, nout] == -7.0).all())          # the padding column is not touched
+    finally:
+        capi.set_eval_mode(capi.EVAL_AUTO)
+
+
 @pytest.mark.parametrize("name", ["c1_1d16", "2d16", "3d8", "3d_aniso", "4d6"])
 def test_eval_derivs_matches_splde_patterns(port, name):
     """Fused value / gradient / Hessian evaluation: every output column equals splde with the
