@@ -140,6 +140,9 @@ class Port(_Base):
         L.oracle_splde_many.argtypes = [C.c_int, C.c_long, _dp, C.c_int, _ip, _dp, _dp, _dp, _ip, _dp]
         L.oracle_last_reserr.restype = C.c_double
         L.oracle_last_reserr.argtypes = []
+        L.oracle_splcw_banded.restype = C.c_int
+        L.oracle_splcw_banded.argtypes = [C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _ip, C.c_double, _dp,
+                                          C.c_int, C.c_int, _dp]
         L.oracle_bascmp.restype = C.c_double
         L.oracle_bascmp.argtypes = [C.c_int, _dp, _ip, _ip, _dp, _dp, _ip, _ip]
 
@@ -166,6 +169,20 @@ class Port(_Base):
                                      _ptr(work, _dp), nwrk, 1 if quiet else 0)
         self.last_reserr = float(self.lib.oracle_last_reserr())
         return coef, ierr, work
+
+    def fit_banded(self, ndim, xdata, ydata, wdata, xmin, xmax, nodes, xtrap, nthreads=0):
+        """The reference's rows solved as banded normal equations + Cholesky + refinement on all host
+        cores (oracle/splpak_banded.c): the "best CPU" comparator.  Returns (coef, ierror, info[10])."""
+        xdata, ydata, wdata, xmin, xmax, nodes = self._prep(ndim, xdata, ydata, wdata, xmin, xmax, nodes)
+        ncol = int(np.prod(nodes[:max(ndim, 1)].astype(np.int64)))
+        coef = np.zeros(max(ncol, 1), dtype=np.float64)
+        info = np.zeros(10)
+        if wdata is None:
+            wdata = np.array([-1.0])
+        ierr = self.lib.oracle_splcw_banded(ndim, _ptr(xdata, _dp), xdata.shape[1], _ptr(ydata, _dp), _ptr(wdata, _dp),
+                                            xdata.shape[0], _ptr(xmin, _dp), _ptr(xmax, _dp), _ptr(nodes, _ip),
+                                            float(xtrap), _ptr(coef, _dp), ncol, int(nthreads), _ptr(info, _dp))
+        return coef, ierr, info
 
     def evaluate(self, ndim, xq, nderiv, coef, xmin, xmax, nodes):
         xq = np.ascontiguousarray(xq, dtype=np.float64)

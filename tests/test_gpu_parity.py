@@ -566,6 +566,25 @@ def test_gram_blocks_in_slabs_match_golden(name, mb, monkeypatch):
     assert relmax(hist, gold["hist"]) < 1e-12 and info[9] < 1e-9
 
 
+@pytest.mark.parametrize("nod,m", [(24, 100000), (32, 150000)])
+def test_fit_matches_banded_cpu_beyond_the_dense_oracle(port, nod, m):
+    """Grids the dense reference algorithm cannot reach in test time (24^3 = 13 824, 32^3 = 32 768 columns),
+    WITH weights and derivative-constraint rows: the GPU fit against the independent CPU solve of the
+    reference's rows (oracle/splpak_banded.c, itself pinned to the reference goldens)."""
+    from splpak_amd.synth import synth_points
+    nd = 3
+    x, y, w = synth_points(nd, m)
+    lo, hi, nodes = [0.0] * nd, [1.0] * nd, [nod] * nd
+    c0, e0, i0 = port.fit_banded(nd, x, y, w, lo, hi, nodes, 1.0)
+    c1, e1, _, i1 = capi.fit(nd, x, y, w, lo, hi, nodes, 1.0)
+    assert e0 == e1 == 0
+    print(f"{nod}^3: GPU vs banded CPU rel={relmax(c1, c0):.2e}; rows {i1[0]:.0f}+{i1[1]:.0f}; reserr GPU {i1[8]:.6e} CPU {i0[8]:.6e}; "
+          f"CPU {i0[5] + i0[6] + i0[7]:.1f} s on {i0[9]:.0f} threads")
+    assert relmax(c1, c0) < COEF_TOL
+    assert i1[0] == i0[0] and i1[1] == i0[1]
+    assert abs(i1[8] - i0[8]) <= 1e-9 * i0[8]
+
+
 def test_slowly_contracting_refinement_is_not_a_silent_success():
     """A solve whose refinement has not converged must not return ierror 0: with the
     nominal step count forced to 1 and an unreachable tolerance the loop continues while it

@@ -156,3 +156,19 @@ def test_real32_goldens_are_single_precision_images_of_the_real64_ones(name):
     assert relmax(g32["values"][0], g64["values"][0]) < 2e-3
     if g64["hist"].size:
         assert relmax(g32["hist"], g64["hist"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", FAST + ["2d32", "3d12", "2d64_c2grid", "3d16"])
+def test_banded_cpu_solver_matches_reference_golden(port, name):
+    """oracle/splpak_banded.c (the reference's rows -> banded normal equations -> Cholesky -> refinement,
+    all host cores) is pinned to the same reference goldens as the port: it is the "best CPU" comparator
+    of bench.py and the independent answer for grids beyond the dense algorithm's reach."""
+    spec = CASES[name]
+    gold = load_golden(name)
+    inp = make_inputs(spec)
+    coef, ierr, info = port.fit_banded(inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"],
+                                       inp["xmax"], inp["nodes"], inp["xtrap"])
+    assert ierr == 0
+    assert relmax(coef, gold["coef"]) < COEF_TOL
+    nd_rows = inp["xdata"].shape[0] if inp["wdata"] is None else int(np.count_nonzero(inp["wdata"]))
+    assert info[0] == nd_rows
