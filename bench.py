@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the C2 and host-pointer (PCIe-inclusive) legs")
+    ap.add_argument("--dist-child", type=str, default="", help=argparse.SUPPRESS)   # internal: "ngpus,nod,m,virtual"
     return ap.parse_args()
 
 
@@ -249,6 +250,29 @@ def bench_c5_eval(capi, dev, stream):
                          "frac": 40.0 * res["splfe"] / 1e9 / HBM_PEAK_GBS, "traffic": None}}
 
 
+def dist_band_in_child(ngpus, nd, nod, m_total, virtual, steps, timeout):
+    """Run bench_dist_band in a CHILD process with a time limit: the distributed-band leg drives several GPUs
+    from one process, and nothing it does -- a failure, a hang on an untested interconnect -- may take the
+    headline line with it.  (A child is started, nothing is exec'ed over this process.)"""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
+              "TORCHELASTIC_RUN_ID", "ROLE_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--ndim", str(nd), "--steps", str(steps),
+           "--dist-child", f"{ngpus},{nod},{m_total},{int(bool(virtual))}"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": f"distributed-band child exited with {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"distributed-band child exceeded {timeout} s"}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def bench_incl_h2d(capi, x, y, w, lo, hi, nodes):
     """The host-pointer entry (what the Fortran module binds): pageable host arrays in, coefficients
     out, PCIe transfers included.  Never `value`."""
@@ -265,6 +289,11 @@ def bench_incl_h2d(capi, x, y, w, lo, hi, nodes):
 
 def main():
     args = parse()
+    if args.dist_child:
+        from splpak_amd import capi
+        ng, nod_c, m_c, virt = (int(v) for v in args.dist_child.split(","))
+        print(json.dumps(bench_dist_band(capi, ng, args.ndim, nod_c, m_c, bool(virt), args.steps)), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -390,7 +419,7 @@ def main():
             torch.cuda.empty_cache()
         barrier()
         if rank == 0:
-            dist_leg = bench_dist_band(capi, world, nd, nod, m, False, args.steps)
+            dist_leg = dist_band_in_child(world, nd, nod, m, False, args.steps, 300)
         barrier()
     if rank == 0:
         line = {
@@ -451,8 +480,9 @@ def main():
                 "factorisation_tflops": kt_sum["total_flop"] / max(kt_sum["factor_ms"], 1e-9) / 1e9,
             }
         if world == 1 and not args.no_side_legs:
+            plan.close()                      # the side legs have the GPU to themselves
             # rehearsal of the distributed-band path on this one GPU (2 virtual ranks, reduced size)
-            line["dist_band"] = bench_dist_band(capi, 2, nd, min(nod, 32), 1_000_000, True, args.steps)
+            line["dist_band"] = dist_band_in_child(2, nd, min(nod, 32), 1_000_000, True, args.steps, 180)
             line["c2"] = bench_c2(capi, dev, stream, args.steps)
             del xq, out
             torch.cuda.empty_cache()

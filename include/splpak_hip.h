@@ -61,7 +61,7 @@ extern "C" {
  *       max_i |rho_i| / ((|N| |x|)_i + |A^T W^2 y|_i), N = A^T W^2 A + C^T C; 0 at the minimiser the reference
  *       computes, ~1e-14 when the fit is converged, ~cond(N) eps for plain normal equations.
  * The band-Cholesky solution is refined against the rows until the estimated remaining error
- * |dx|/|x| is below 1e-12 (2-3 steps at 64^3); a solve that is still contracting after the nominal
+ * |dx|/|x| is below 1e-11 (2 steps at 64^3: corrections 9e-5, 1e-8, then an estimated 2e-12); a solve that is still contracting after the nominal
  * number of steps continues (up to 16), and one that then still misses 1e-10, or whose corrections
  * stop contracting while above 1e-8, is reported as 107 ("suprls failure") with an explanatory
  * splpak_last_error_message -- never as a silent success. */
@@ -129,7 +129,7 @@ void    splpak_plan_set_allreduce(splpak_plan *plan, splpak_allreduce_fn fn, voi
                                   int32_t rank, int32_t world);
 /* tuning / test knobs: nominal refinement steps (default 4; 0 = none; a solve that still contracts goes on
  * up to max(steps, 16)) and the tolerance on the (estimated) remaining relative error |dx|/|x| after a
- * step (default 1e-12; the parity bar is 1e-10) */
+ * step (default 1e-11; the parity bar is 1e-10) */
 void    splpak_plan_set_refine(splpak_plan *plan, int32_t max_steps, double tol);
 
 /* The fit on resident data.  xdata_dev/ydata_dev/wdata_dev (wdata_dev may be

@@ -31,7 +31,7 @@ struct splpak_plan {
     int rank = 0, world = 1;
     int max_refine = 4;           // nominal number of refinement steps; a solve that is still contracting goes on (max_refine_hard)
     int max_refine_hard = 16;
-    double tol = 1e-12;
+    double tol = 1e-11;           // on the ESTIMATED remaining error; the parity bar is 1e-10
     splpak::CholStats stats;
     std::vector<void *> owned;
     // distributed band (dist.hip): this plan holds the block columns DistMap deals to rank dm.r
