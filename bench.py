@@ -363,6 +363,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert ierr == 0, f"fit failed with ierror {ierr}"
+    stages = plan.stage_timing()
     # parity gate at the size that is timed: the MEASURED optimality residual of the returned coefficients
     # (gradient of the least-squares functional, relative to |A^T W^2 y|) must be at rounding level
     assert info[9] < 1e-9, f"optimality residual {info[9]:.2e} of the timed fit exceeds 1e-9"
@@ -458,6 +459,26 @@ def main():
                              "traffic": eval_traffic},
             },
         }
+        if stages["bin_ms"] > 0:
+            # the HBM-bound stages around the factorisation: algorithmic bytes (8*(d+1+[weighted]) per point
+            # and streaming pass) over the HIP-event time of the stage in the last timed fit
+            bpp = 8.0 * (nd + 2)
+            hst = (7 ** nd + 1) // 2                                  # stored stencil entries per row
+            halfbw = 3 * sum(nod ** k for k in range(nd))
+            ldband = (min(-(-halfbw // 256), max(-(-ncol // 256) - 1, 0)) + 1) * 256 + 17   # column stride of the band storage
+            def hbm(nbytes, ms):
+                gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                return {"ms": ms, "algorithmic_GB": nbytes / 1e9, "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+            line["assembly"] = {
+                "binning (keys, scan, scatter, in-cell order)": hbm(m * (2 * bpp + bpp + 4.0), stages["bin_ms"]),
+                "gram blocks + stencil gather": hbm(m * bpp + 8.0 * ncol * hst, stages["gram_ms"]),
+                "constraint rows": {"ms": stages["constraints_ms"]},
+                "band memset + expansion": hbm(8.0 * ncol * hst + 8.0 * ncol * ldband, stages["expand_ms"]),
+                "refinement residual pass": hbm(m * bpp, stages["residual_pass_ms"]),
+                "one solve (two band sweeps)": hbm(2 * 8.0 * ncol * ldband, stages["solve_ms"]),
+                "note": "the Gram stage moves 3.9 GB of per-cell blocks through HBM on top of its algorithmic bytes (PMC: profiles/r02_fit_pmc.json)"
+                        if nd == 3 and nod == 64 else "",
+            }
         if kt_sum["syrk_ms"] > 0:
             ach = kt_sum["syrk_flop"] / (kt_sum["syrk_ms"] * 1e-3) / 1e12
             traffic = None

@@ -158,6 +158,10 @@ const double *splpak_plan_hist_dev(const splpak_plan *plan);
  * Timing is only collected when enabled. */
 void    splpak_plan_enable_kernel_timing(splpak_plan *plan, int32_t on);
 void    splpak_plan_kernel_timing(const splpak_plan *plan, double *out7);
+/* milliseconds of the stages of the last fit around the factorisation (HIP events on the fit's stream, collected
+ * with kernel timing enabled): out[0] binning (keys, scan, scatter, in-cell ordering), [1] Gram blocks + gather,
+ * [2] constraint rows, [3] band memset + expansion, [4] one refinement-residual pass, [5] one solve (two sweeps) */
+void    splpak_plan_stage_timing(const splpak_plan *plan, double *out6);
 
 /* ---------------------------------------------------------------------------
  * Several GPUs of one node, driven from ONE process: what a Fortran caller reaches

@@ -27,7 +27,7 @@ SYMBOLS = [
     "splpak_fit_f64", "splpak_fit_f32", "splpak_eval_f64", "splpak_eval_f32",
     "splpak_plan_comm_len", "splpak_plan_create", "splpak_plan_destroy",
     "splpak_plan_set_allreduce", "splpak_plan_set_refine", "splpak_plan_fit_dev",
-    "splpak_plan_hist_dev", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing",
+    "splpak_plan_hist_dev", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing", "splpak_plan_stage_timing",
     "splpak_eval_dev_f64", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
     "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
@@ -89,6 +89,8 @@ def lib() -> C.CDLL:
     L.splpak_plan_enable_kernel_timing.argtypes = [vp, i32]
     L.splpak_plan_kernel_timing.restype = None
     L.splpak_plan_kernel_timing.argtypes = [vp, _dp]
+    L.splpak_plan_stage_timing.restype = None
+    L.splpak_plan_stage_timing.argtypes = [vp, _dp]
     L.splpak_eval_dev_f64.restype = i32
     L.splpak_eval_dev_f64.argtypes = [i32, i64, vp, i32, _ip, vp, _dp, _dp, _ip, vp, vp]
     L.splpak_eval_derivs_f64.restype = i32
@@ -376,6 +378,11 @@ class Plan:
         self._L.splpak_plan_kernel_timing(self._h, _p(out, _dp))
         return dict(syrk_launches=out[0], syrk_ms=out[1], syrk_flop=out[2], factor_ms=out[3], total_flop=out[4],
                     bulk_launches=out[5], bulk_flop=out[6])
+
+    def stage_timing(self):
+        out = np.zeros(6)
+        self._L.splpak_plan_stage_timing(self._h, _p(out, _dp))
+        return dict(bin_ms=out[0], gram_ms=out[1], constraints_ms=out[2], expand_ms=out[3], residual_pass_ms=out[4], solve_ms=out[5])
 
     def fit(self, xdata, ydata, wdata, coef, stream=0):
         """All arguments are torch float64 device tensors; xdata is (ndata, l1xdat) row-major

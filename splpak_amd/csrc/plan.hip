@@ -284,6 +284,7 @@ void splpak_plan_destroy(splpak_plan *p)
 {
     if (!p) return;
     band_pipeline_destroy(p->band.pipe);
+    for (hipEvent_t e : p->evStage) if (e) (void)hipEventDestroy(e);
     for (void *q : p->owned) (void)hipFree(q);
     delete p;
 }
@@ -323,6 +324,12 @@ void splpak_plan_kernel_timing(const splpak_plan *p, double *out4)
     out4[4] = p->stats.total_flop;
 }
 
+void splpak_plan_stage_timing(const splpak_plan *p, double *out6)
+{
+    if (!p || !out6) return;
+    for (int i = 0; i < 6; ++i) out6[i] = p->stage_ms[i];
+}
+
 const double *splpak_plan_hist_dev(const splpak_plan *p) { return p ? p->hist : nullptr; }
 
 static int do_allreduce(splpak_plan *p, double *buf, long long count, hipStream_t st)
@@ -357,9 +364,17 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     if (info) for (int i = 0; i < 10; ++i) info[i] = 0.0;
 
     // ---- assembly -------------------------------------------------------
+    const bool stamps = p->stats.enabled;
+    if (stamps)
+        for (hipEvent_t &e : p->evStage)
+            if (!e) SPLPAK_HIP_TRY(hipEventCreate(&e), SPLPAK_E_NODEVICE);
+    auto stamp = [&](int i) { if (stamps) (void)hipEventRecord(p->evStage[i], st); };
     SPLPAK_HIP_TRY(hipMemsetAsync(p->comm, 0, sizeof(double) * (size_t)(p->lenG + p->lenH), st), SPLPAK_E_NODEVICE);
+    stamp(0);
     SPLPAK_HIP_TRY(launch_bin_points(g, ndata, x, l1xdat, y, w, p->s, p->scalH, st), SPLPAK_E_NODEVICE);
+    stamp(1);
     SPLPAK_HIP_TRY(launch_gram(g, p->s, p->gscratch, p->gscratch_doubles, smooth, p->nst, p->rhs, p->hist, p->scalH, st), SPLPAK_E_NODEVICE);
+    stamp(2);
     double hs[2 * SC_COUNT];
     if (p->world > 1) {
         const double one = 1.0;
@@ -378,6 +393,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         SPLPAK_HIP_TRY(launch_sparse_mark(g, p->hist, p->scalH, p->xtrap, p->dcw, p->spf, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(launch_constraint_rows(g, p->dcw, p->spf, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
     }
+    stamp(3);
     if (int r = do_allreduce(p, p->nst, p->lenG, st)) return r;
 
     SPLPAK_HIP_TRY(hipMemcpyAsync(hs, p->scalG, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
@@ -404,7 +420,9 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     const double inf = std::numeric_limits<double>::infinity();
     SPLPAK_HIP_TRY(hipMemsetAsync(p->info, 0, 2 * sizeof(int), st), SPLPAK_E_NODEVICE);
     SPLPAK_HIP_TRY(hipMemcpyAsync(p->small + 2, &inf, sizeof(double), hipMemcpyHostToDevice, st), SPLPAK_E_NODEVICE);
+    stamp(4);
     SPLPAK_HIP_TRY(launch_expand(g, p->nst, b, p->dm, st), SPLPAK_E_NODEVICE);
+    stamp(5);
     SPLPAK_HIP_TRY(p->factor_fn ? p->factor_fn(p, p->info, p->small + 2, st, p->fn_user) : band_cholesky(b, p->info, p->small + 2, st, &p->stats), SPLPAK_E_NODEVICE);
     int hinfo = 0;
     double minpiv = 0.0;
@@ -427,7 +445,9 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     // ---- solve + refinement --------------------------------------------
     SPLPAK_HIP_TRY(hipMemsetAsync(p->xvec, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
     SPLPAK_HIP_TRY(hipMemcpyAsync(p->xvec, p->rhs, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
+    stamp(6);
     SPLPAK_HIP_TRY(p->solve_fn ? p->solve_fn(p, p->xvec, p->tmp, st, p->fn_user) : band_solve(b, p->xvec, p->tmp, st), SPLPAK_E_NODEVICE);
+    stamp(7);
     int steps = 0;
     double last_rel = 0.0, prev_rel = inf, ratio = 0.0;
     // converged: the (estimated) remaining error is below tol, or the corrections sit at the rounding
@@ -483,8 +503,18 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     if (info) {
         double *scalR = p->rho + b.npad;
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
+        hipEvent_t r0 = nullptr, r1 = nullptr;
+        if (stamps && hipEventCreate(&r0) == hipSuccess && hipEventCreate(&r1) == hipSuccess) (void)hipEventRecord(r0, st);
         SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, smooth && p->rank == 0,
                                        p->tbuf, p->rho, scalR, st), SPLPAK_E_NODEVICE);
+        if (r0 && r1) {
+            (void)hipEventRecord(r1, st);
+            (void)hipEventSynchronize(r1);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r0, r1) == hipSuccess) p->stage_ms[4] = ms;
+        }
+        if (r0) (void)hipEventDestroy(r0);
+        if (r1) (void)hipEventDestroy(r1);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
         SPLPAK_HIP_TRY(launch_backward_error(g, p->nst, p->xvec, p->rho, p->rhs, p->small + 3, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(hipMemcpyAsync(&ssq, scalR, sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
@@ -492,6 +522,16 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     }
     SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
     auto t3 = clk::now();
+    if (stamps) {
+        // all stages are complete (the stream was synchronised above); residual pass: timed separately below
+        const int pairs[5][2] = {{0, 1}, {1, 2}, {2, 3}, {4, 5}, {6, 7}};
+        const int slot[5] = {0, 1, 2, 3, 5};
+        for (int i = 0; i < 5; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p->evStage[pairs[i][0]], p->evStage[pairs[i][1]]) == hipSuccess) p->stage_ms[slot[i]] = ms;
+            else (void)hipGetLastError();
+        }
+    }
     if (info) {
         info[2] = steps;
         info[3] = last_rel;

@@ -33,6 +33,9 @@ struct splpak_plan {
     int max_refine_hard = 16;
     double tol = 1e-11;           // on the ESTIMATED remaining error; the parity bar is 1e-10
     splpak::CholStats stats;
+    // stage timing of the assembly and of one residual pass (HIP events on the fit's stream, kernel timing only)
+    hipEvent_t evStage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double stage_ms[6] = {0, 0, 0, 0, 0, 0};    // bin, gram blocks + gather, constraint rows, expand (+ band memset), residual pass, solve
     std::vector<void *> owned;
     // distributed band (dist.hip): this plan holds the block columns DistMap deals to rank dm.r
     splpak::DistMap dm{1, 0, 1, 0};
