@@ -172,6 +172,7 @@ void    splpak_plan_stage_timing(const splpak_plan *plan, double *out6);
  * window from owner to owner.  Memory per GPU is 1/ngpus of the band (26.9 GB at 64^3; the 852 GB of
  * the 4-D 32^4 grid of BASELINE config 5 fit a node of 8 x 288 GB only this way).  Results are those
  * of the single-GPU fit (same kernels per tile; reductions in rank order: bitwise reproducible).
+ * `chunk` < 1 chooses it automatically: about one chunk per GPU inside the band window, at most 8 blocks.
  * `devices`: NULL = devices 0..ngpus-1; entries may repeat -- with SPLPAK_VIRTUAL_GPUS=1 in the
  * environment every rank is placed on the current device, which runs the whole protocol on one GPU
  * (the 1-GPU test tier does that).
@@ -190,7 +191,7 @@ int32_t splpak_mplan_fit_dev(splpak_mplan *mplan, const double *const *xdata_dev
                              const double *const *ydata_dev, const double *const *wdata_dev,
                              const int64_t *ndata, double *coef_dev, double *info);
 /* one-shot host entry: as splpak_fit_f64 on `ngpus` GPUs (contiguous shards of the points); ngpus <= 1
- * is splpak_fit_f64 itself.  SPLPAK_DIST_CHUNK sets the chunk (default 1). */
+ * is splpak_fit_f64 itself.  SPLPAK_DIST_CHUNK sets the chunk (default 0 = automatic). */
 int32_t splpak_fit_multi_f64(int32_t ngpus, int32_t ndim, const double *xdata, int32_t l1xdat,
                              const double *ydata, const double *wdata, int64_t ndata,
                              const double *xmin, const double *xmax, const int32_t *nodes,

@@ -215,7 +215,7 @@ def fit_multi(ngpus, ndim, xdata, ydata, wdata, xmin, xmax, nodes, xtrap, want_h
 class MultiPlan:
     """A fit plan over several GPUs of this node (one process; torch tensors own the shards)."""
 
-    def __init__(self, ngpus, ndim, nodes, xmin, xmax, xtrap, max_ndata_per_gpu, devices=None, chunk=1):
+    def __init__(self, ngpus, ndim, nodes, xmin, xmax, xtrap, max_ndata_per_gpu, devices=None, chunk=0):
         self._L = lib()
         self.ngpus = int(ngpus)
         self.xmin, self.xmax, self.nodes = _grid(ndim, xmin, xmax, nodes)

@@ -428,7 +428,23 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
     const bool virt = std::getenv("SPLPAK_VIRTUAL_GPUS") != nullptr;
     splpak_mplan *mp = new splpak_mplan();
     mp->R = ngpus;
-    mp->chunk = chunk < 1 ? 1 : chunk;
+    if (chunk < 1) {
+        // automatic: about one chunk per rank inside the band window, at most 8 blocks.  Consecutive block
+        // columns on the same GPU keep the panel chain (column update -> potrf -> panel solve) local for
+        // chunk-1 of every chunk steps -- the 25.7 MB panel then crosses xGMI on the critical path only once
+        // per chunk -- while the window (bw blocks) still spreads over all the ranks.
+        Grid g0;
+        long long nc = 0;
+        Band b0{};
+        chunk = 1;
+        if (build_grid(ndim, nodes, xmin, xmax, g0, &nc, std::getenv("SPLPAK_NO_REORDER") == nullptr) == 0) {
+            band_bytes(g0.ncol, g0.halfbw, &b0);
+            chunk = b0.bw / ngpus;
+            if (chunk > 8) chunk = 8;
+            if (chunk < 1) chunk = 1;
+        }
+    }
+    mp->chunk = chunk;
     mp->bar.n = ngpus;
     int rc = 0;
     for (int r = 0; r < ngpus && rc == 0; ++r) {
@@ -570,7 +586,7 @@ int32_t splpak_fit_multi_f64(int32_t ngpus, int32_t ndim, const double *xdata, i
     const long long per = (ndata + ngpus - 1) / ngpus;
     splpak_mplan *mp = nullptr;
     const char *ck = std::getenv("SPLPAK_DIST_CHUNK");
-    int rc = splpak_mplan_create(ngpus, nullptr, ck ? atoi(ck) : 1, ndim, nodes, xmin, xmax, xtrap, per, &mp);
+    int rc = splpak_mplan_create(ngpus, nullptr, ck ? atoi(ck) : 0, ndim, nodes, xmin, xmax, xtrap, per, &mp);
     if (rc != 0) return rc;
     int cur = 0;
     (void)hipGetDevice(&cur);

@@ -12,7 +12,7 @@ from splpak_amd import capi
 nod = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 rs = [int(a) for a in sys.argv[3:]] or [2, 4]
-chunk = int(os.environ.get("SPLPAK_DIST_CHUNK", "1"))
+chunk = int(os.environ.get("SPLPAK_DIST_CHUNK", "0"))
 nd = 3
 nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
 ndev = torch.cuda.device_count()
