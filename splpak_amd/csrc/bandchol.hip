@@ -249,6 +249,250 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
 }
 
 // ---------------------------------------------------------------------------
+// Cholesky of one 256x256 diagonal block, strip form (round 2).  The kernel above sends the whole
+// trailing part of the block through global memory (L2) once per 16-column panel: 16 passes, ~2.7 MB per
+// block, which is where its time goes (47 % "in-block update", mostly waiting for C tiles).  Here the
+// block is processed in four 64-column STRIPS that live in LDS (rows below the strip's first column x 64
+// columns, 139 KB): the sixteen 16-column steps -- leaf factorisation by wave 0, row solves, update of the
+// rest of the strip -- never leave the CU, and the part of the block right of the strip is updated ONCE
+// per strip with K = 64 from the LDS-resident strip: 4 passes, ~0.6 MB of global traffic per block.  Same
+// arithmetic per element as the panel form (the sums over the 16-column panels are taken in the same
+// order), rolled loops (cold instruction cache, see above).  It has a CU's LDS to itself, which is what
+// the reserved CU of the look-ahead pipeline gives it anyway.
+constexpr int SPW = 64;                // strip width
+constexpr int SLD = NBLK + 16;         // LDS column stride of the strip image S[c*SLD + r]
+
+#ifdef SPLPAK_POTRF_STAMPS        // tools/potrf_probe.hip: cycles of wave 0 per phase, summed over the kernel
+__device__ unsigned long long g_strip_cycles[8];
+#define STRIP_T0() unsigned long long st_last = __builtin_amdgcn_s_memtime()
+#define STRIP_ACC(i) do { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); if (tid == 0) g_strip_cycles[i] += st_now - st_last; st_last = st_now; } while (0)
+#else
+#define STRIP_T0() do { } while (0)
+#define STRIP_ACC(i) do { } while (0)
+#endif
+__global__ void __launch_bounds__(256)
+potrf_strip_kernel(double *__restrict__ ab, long long lda, int k0, int *__restrict__ info,
+                   double *__restrict__ minpiv, double *__restrict__ inv16)
+{
+    __shared__ double Ls[IB * (IB + 1)];
+    __shared__ double Lrd[IB];               // reciprocals of the leaf's diagonal
+    __shared__ double S[SPW * SLD];
+    double *A = ab + (long long)k0 + (long long)k0 * lda;    // A(r,c) = A[r + c*lda], r >= c
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    __builtin_amdgcn_s_setprio(3);
+    STRIP_T0();
+
+    for (int c0 = 0; c0 < NBLK; c0 += SPW) {
+        // ---- strip -> LDS (whole rectangle rows >= c0; the part above the diagonal is never used):
+        // one row per thread, 16 columns in flight at a time
+        if (c0 + tid < NBLK) {
+            const double *__restrict__ rowp = A + (c0 + tid) + (long long)c0 * lda;
+#pragma unroll 1
+            for (int cb = 0; cb < SPW; cb += 16) {
+                double v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = rowp[(long long)(cb + i) * lda];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S[(cb + i) * SLD + c0 + tid] = v[i];
+            }
+        }
+        __syncthreads();
+        STRIP_ACC(0);
+        for (int pc = 0; pc < SPW; pc += IB) {     // 16-column steps inside the strip
+            const int d0 = c0 + pc;                // first row / column of the leaf (block relative)
+            const int base = d0 + IB;              // first row below the leaf
+            const int mrem = NBLK - base;
+            // (i) leaf: wave 0, one row per lane, columns broadcast with v_readlane
+            if (wave == 0) {
+                const int r = l15;
+                double a[IB];
+#pragma unroll
+                for (int c = 0; c < IB; ++c) a[c] = (c <= r) ? S[(pc + c) * SLD + d0 + r] : 0.0;
+                double dmin = a[0];
+                bool bad = false;
+                double rdiag = 0.0;
+#pragma unroll
+                for (int j = 0; j < IB; ++j) {
+                    const double d = readlane_f64(a[j], j);
+                    bad = bad || !(d > 0.0);
+                    dmin = fmin(dmin, d);
+                    // 1/sqrt(d) from the hardware estimate + two Newton steps, sqrt(d) = d * rs corrected once:
+                    // the sqrt and the division of the textbook form are ~55 instructions on the critical
+                    // path of every column, this is ~14 (results within an ulp of the correctly rounded ones)
+                    double rs = __builtin_amdgcn_rsq(d);
+                    rs = rs * fma(-0.5 * d * rs, rs, 1.5);
+                    rs = rs * fma(-0.5 * d * rs, rs, 1.5);
+                    double sd = d * rs;
+                    sd = fma(fma(-sd, sd, d), 0.5 * rs, sd);
+                    if (r == j) rdiag = rs;
+                    a[j] = (r == j) ? sd : a[j] * rs;
+#pragma unroll
+                    for (int c = j + 1; c < IB; ++c) a[c] -= a[j] * readlane_f64(a[j], c);
+                }
+                if (lane < IB) {
+                    Lrd[r] = rdiag;
+#pragma unroll
+                    for (int c = 0; c < IB; ++c) {
+                        Ls[r * (IB + 1) + c] = a[c];
+                        if (c <= r) S[(pc + c) * SLD + d0 + r] = a[c];
+                    }
+                }
+                if (lane == 0) {
+                    if (bad) atomicCAS(info, 0, k0 + d0 + 1);
+                    if (dmin < *minpiv || !(dmin == dmin)) *minpiv = dmin;
+                }
+            }
+            __syncthreads();
+            STRIP_ACC(1);
+            // (ii) rows below the leaf: x = a L^{-T}, one row per thread, in place in the strip
+            if (tid < mrem) {
+                const int row = base + tid;
+                double x[IB];
+#pragma unroll
+                for (int c = 0; c < IB; ++c) x[c] = S[(pc + c) * SLD + row];
+#pragma unroll
+                for (int c = 0; c < IB; ++c) {
+#pragma unroll
+                    for (int k = 0; k < c; ++k) x[c] -= x[k] * Ls[c * (IB + 1) + k];
+                    x[c] *= Lrd[c];
+                }
+#pragma unroll
+                for (int c = 0; c < IB; ++c) S[(pc + c) * SLD + row] = x[c];
+            }
+            __syncthreads();
+            STRIP_ACC(2);
+            // (iii) the rest of the strip (columns pc+16 .. 63, rows from each tile column's diagonal down):
+            // 16x16 tiles in LDS, one MFMA chain of K = 16 each
+            {
+                const int ntc = (SPW - pc - IB) / 16;          // tile columns left in the strip
+                const int ntr = mrem / 16;                      // tile rows below the leaf
+                // tile (tc, tr), tr >= tc: strip column pc+16+16 tc, block row base + 16 tr
+                int ntl = 0;
+                for (int tc = 0; tc < ntc; ++tc) ntl += ntr - tc;
+                for (int t = wave; t < ntl; t += 4) {
+                    int tc = 0, rem = t;
+                    while (rem >= ntr - tc) { rem -= ntr - tc; ++tc; }
+                    const int tr = tc + rem;
+                    const int scol = pc + IB + 16 * tc;         // strip column of the tile's first column
+                    const int crow = base + 16 * tc;            // block row that corresponds to that column
+                    const int rrow = base + 16 * tr;
+                    d4_t acc;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[v] = S[(scol + q + 4 * v) * SLD + rrow + l15];
+#pragma unroll
+                    for (int s4 = 0; s4 < IB / 4; ++s4) {
+                        const double av = -S[(pc + 4 * s4 + q) * SLD + crow + l15];
+                        const double bv = S[(pc + 4 * s4 + q) * SLD + rrow + l15];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) S[(scol + q + 4 * v) * SLD + rrow + l15] = acc[v];
+                }
+            }
+            __syncthreads();
+            STRIP_ACC(3);
+        }
+        // ---- the finished strip (64 columns of L) back to global: lower part only, one row per thread
+        if (c0 + tid < NBLK) {
+            double *__restrict__ rowp = A + (c0 + tid) + (long long)c0 * lda;
+            const int cmax = tid < SPW - 1 ? tid : SPW - 1;     // row c0+tid holds columns c0 .. c0+min(tid, 63)
+#pragma unroll 4
+            for (int c = 0; c <= cmax; ++c) rowp[(long long)c * lda] = S[c * SLD + c0 + tid];
+        }
+        STRIP_ACC(4);
+        // ---- the block right of the strip: C -= S S^T with K = 64, C tiles in global memory, lower part
+        {
+            const int base = c0 + SPW;
+            const int nt = (NBLK - base) / 16;
+            const int ntiles = nt * (nt + 1) / 2;
+            const unsigned voff = (unsigned)(l15 + (long long)q * lda) * 8u;
+            auto load_round = [&](int t0, d4_t (&cc)[PTB], int (&roff)[PTB], int (&coff)[PTB]) {
+                int ct = 0, rem = t0;               // tile t -> (ct, ct + rem), column-major over the lower triangle
+                while (ct < nt && rem >= nt - ct) { rem -= nt - ct; ++ct; }
+#pragma unroll
+                for (int u = 0; u < PTB; ++u) {
+                    roff[u] = -1;
+                    coff[u] = 0;
+                    if (t0 + u < ntiles) {
+                        roff[u] = base + 16 * (ct + rem);
+                        coff[u] = base + 16 * ct;
+                        const char *tile = reinterpret_cast<const char *>(A + roff[u] + (long long)coff[u] * lda);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            cc[u][v] = *reinterpret_cast<const double *>(tile + (long long)(4 * v) * lda * 8 + voff);
+                    }
+                    if (++rem >= nt - ct) { rem = 0; ++ct; }
+                }
+            };
+            auto compute_round = [&](d4_t (&cc)[PTB], int (&roff)[PTB], int (&coff)[PTB]) {
+#pragma unroll
+                for (int u = 0; u < PTB; ++u) {
+                    if (roff[u] < 0) continue;
+                    d4_t acc = cc[u];
+#pragma unroll
+                    for (int s4 = 0; s4 < SPW / 4; ++s4) {        // all 32 operand reads of the tile in flight
+                        const double av = -S[(4 * s4 + q) * SLD + coff[u] + l15];
+                        const double bv = S[(4 * s4 + q) * SLD + roff[u] + l15];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    }
+                    char *tile = reinterpret_cast<char *>(A + roff[u] + (long long)coff[u] * lda);
+                    if (roff[u] != coff[u]) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            *reinterpret_cast<double *>(tile + (long long)(4 * v) * lda * 8 + voff) = acc[v];
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (l15 >= q + 4 * v)
+                                *reinterpret_cast<double *>(tile + (long long)(4 * v) * lda * 8 + voff) = acc[v];
+                    }
+                }
+            };
+            // the C tiles of the next round are in flight while the current one is computed
+            d4_t ccA[PTB], ccB[PTB];
+            int roA[PTB], coA[PTB], roB[PTB], coB[PTB];
+            int tA = wave * PTB;
+            if (tA < ntiles) load_round(tA, ccA, roA, coA);
+            while (tA < ntiles) {
+                const int tB = tA + 4 * PTB;
+                if (tB < ntiles) load_round(tB, ccB, roB, coB);
+                compute_round(ccA, roA, coA);
+                if (tB >= ntiles) break;
+                tA = tB + 4 * PTB;
+                if (tA < ntiles) load_round(tA, ccA, roA, coA);
+                compute_round(ccB, roB, coB);
+            }
+        }
+        __syncthreads();        // everybody is done with the strip (and its stores are issued) before it is replaced
+        __threadfence_block();
+        STRIP_ACC(5);
+    }
+    // the next strip's loads read what this workgroup stored: make the stores visible to the whole workgroup
+    __syncthreads();
+    // inverses of the sixteen 16x16 diagonal leaves, as in potrf_block_kernel
+    {
+        const int leaf = wave * 4 + q, r = l15;
+        const int d0 = leaf * IB;
+        double a[IB];
+#pragma unroll
+        for (int c = 0; c < IB; ++c) a[c] = (c <= r) ? A[(d0 + r) + (long long)(d0 + c) * lda] : 0.0;
+        double xi[IB];
+#pragma unroll
+        for (int rr = 0; rr < IB; ++rr) {
+            double sacc = (rr == r) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < rr; ++k) sacc -= __shfl(a[k], rr, 16) * xi[k];
+            xi[rr] = sacc / __shfl(a[rr], rr, 16);
+        }
+        double *out = inv16 + leaf * (IB * IB) + r * IB;
+#pragma unroll
+        for (int rr = 0; rr < IB; ++rr) out[rr] = (rr >= r) ? xi[rr] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // X = A * L^{-T} for rows below the diagonal block, on the f64 matrix cores.
 //
 // One wave owns 16 rows for the whole solve and walks the 256 columns in 16-column blocks:
@@ -457,6 +701,9 @@ syrk_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt, in
 // two co-resident workgroups is gone.  Two waves per SIMD (<= 256 VGPRs) overlap one
 // wave's C read-modify-write with the other's main loop.
 constexpr int SYRK_ABL = 4;        // product configuration of syrk64_kernel (see ABL)
+#ifndef SYRK_SD
+#define SYRK_SD 4
+#endif
 // SD = k-steps of look-ahead in the operand queue; WPS = waves per SIMD the register budget
 // allows; ABL = ablation switches for tools/syrk_bench (0 = the product kernel)
 __device__ inline unsigned my_cu_id()
@@ -555,6 +802,14 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
     // subtracted (negated A operand), so the tile is read at the very beginning -- together with
     // the first operands, one exposed latency -- and the epilogue is stores only.
     constexpr bool CINIT = (ABL & 4) != 0;
+    // ABL&512 (the small launches of the panel chain, which have a SIMD per wave): accumulators start as -C and
+    // collect +P P^T, the epilogue stores their negatives (bit for bit C - P P^T), and the refills are pinned SD
+    // k-steps ahead of their use with scheduling barriers.  With the operand negated at load time the compiler
+    // waits for every refill right behind its issue (s_waitcnt vmcnt(2) after the loads, then the v_xor), which a
+    // second wave on the SIMD hides in the bulk launch (measured there: 0.695 ms this way, 0.730 ms pinned with two
+    // waves and SD 4, 0.838 ms un-negated without the barriers because the loads are sunk to their uses) but a
+    // lone wave pays as one memory round trip per k-step.
+    constexpr bool NEGEND = CINIT && (ABL & 512) != 0;
     double *__restrict__ C = ab + (long long)(row0 + ti * 64) + (long long)(row0 + tj * 64) * lda;
     d4_t acc[4][4];
 #pragma unroll
@@ -563,8 +818,10 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
         for (int n = 0; n < 4; ++n) {
             if (CINIT) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    acc[m][n][v] = __builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * lda]);
+                for (int v = 0; v < 4; ++v) {
+                    const double c0v = __builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * lda]);
+                    acc[m][n][v] = NEGEND ? -c0v : c0v;
+                }
             } else {
                 acc[m][n] = (d4_t){0.0, 0.0, 0.0, 0.0};
             }
@@ -575,7 +832,7 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
         const long long off = (long long)(4 * step) * lda;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            qa[slot][m] = CINIT ? -pJ[off + 16 * m] : pJ[off + 16 * m];
+            qa[slot][m] = (CINIT && !NEGEND) ? -pJ[off + 16 * m] : pJ[off + 16 * m];
             qb[slot][m] = pI[off + 16 * m];
         }
     };
@@ -613,7 +870,11 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+            // NEGEND: the refill of slot d is issued HERE, SD k-steps ahead of its use, and stays here (without the
+            // scheduling barriers the compiler sinks the side-effect free loads down to the MFMA that consumes them)
+            if (NEGEND) __builtin_amdgcn_sched_barrier(0);
             if ((ABL & 1) == 0 && ks + d + SD < NSTEP) fetch(d, ks + d + SD);   // ABL&1: no operand refills
+            if (NEGEND) __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (ABL & 2) {                                 // ABL&2: no C read-modify-write
@@ -636,7 +897,7 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int c = m * 16 + q + 4 * v;
-                    if (!diag || r >= c) __builtin_nontemporal_store(acc[m][n][v], &C[r + (long long)c * lda]);
+                    if (!diag || r >= c) __builtin_nontemporal_store(NEGEND ? -acc[m][n][v] : acc[m][n][v], &C[r + (long long)c * lda]);
                 }
             }
         if ((ABL & 128) && threadIdx.x == 0 && g_syrk_clock_probe) {     // shader cycles and 100 MHz ticks of this wave
@@ -1016,11 +1277,11 @@ axpy_absmax_kernel(int n, double *__restrict__ x, const double *__restrict__ dx,
 // (P, leading dimension ldp, first row = global row `row0`): same register-streaming form as
 // syrk64_kernel (one wave = one 64x64 piece of C, accumulators initialised with the C tile, operands
 // streamed in MFMA fragment shape).
-__global__ void __launch_bounds__(64, 1)
+__global__ void __launch_bounds__(64, 2)
 syrk64d_kernel(double *__restrict__ abl, long long lda, DistMap dm, const double *__restrict__ P, long long ldp,
                int row0, int jb, int je, int re, int nitems)
 {
-    constexpr int SD = 16;
+    constexpr int SD = SYRK_SD;
     int it = (int)blockIdx.x;
     if (it >= nitems) return;
     // item -> (J, tj, ti): owned block columns J in [jb, je), their four 64-wide tile columns, rows tj..re-1
@@ -1051,20 +1312,21 @@ syrk64d_kernel(double *__restrict__ abl, long long lda, DistMap dm, const double
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                acc[m][n][v] = __builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * lda]);
+            for (int v = 0; v < 4; ++v)       // -C + P P^T, stored negated (see syrk64_kernel)
+                acc[m][n][v] = -__builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * lda]);
     double qa[SD][4], qb[SD][4];
     auto fetch = [&](int slot, int step) {
         const long long off = (long long)(4 * step) * ldp;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            qa[slot][m] = -pJ[off + 16 * m];
+            qa[slot][m] = pJ[off + 16 * m];
             qb[slot][m] = pI[off + 16 * m];
         }
     };
 #pragma unroll
     for (int d = 0; d < SD; ++d) fetch(d, d);
     constexpr int NSTEP = NBLK / 4;
+#pragma unroll 1
     for (int ks = 0; ks < NSTEP; ks += SD) {
 #pragma unroll
         for (int d = 0; d < SD; ++d) {
@@ -1073,7 +1335,9 @@ syrk64d_kernel(double *__restrict__ abl, long long lda, DistMap dm, const double
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);          // the refill stays SD k-steps ahead of its use (see syrk64_kernel)
             if (ks + d + SD < NSTEP) fetch(d, ks + d + SD);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
@@ -1084,7 +1348,73 @@ syrk64d_kernel(double *__restrict__ abl, long long lda, DistMap dm, const double
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int c = m * 16 + q + 4 * v;
-                if (!diag || r >= c) __builtin_nontemporal_store(acc[m][n][v], &C[r + (long long)c * lda]);
+                if (!diag || r >= c) __builtin_nontemporal_store(-acc[m][n][v], &C[r + (long long)c * lda]);
+            }
+        }
+}
+
+#ifndef SYRK32_SD
+#define SYRK32_SD 8
+#endif
+// The update of ONE 256x256 diagonal block by the panel (the "topA" launch on the chain of the look-ahead
+// pipeline) in 32x32 pieces: 36 waves of a quarter of the work each instead of 10 waves of 64x64 -- the
+// launch is on the critical path of chain-bound (narrow-band) factorisations, where it ran 47-85 us for
+// 21 MFlop.  Same operand streaming as syrk64_kernel, 2x2 accumulator tiles.
+__global__ void __launch_bounds__(64)
+syrk32_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int nt)
+{
+    constexpr int SD = SYRK32_SD;            // 8 k-steps (4 MFMAs each) in flight: one wave per SIMD has to cover a memory round trip
+    int it = (int)blockIdx.x, tj = 0;
+    while (it >= nt - tj) { it -= nt - tj; ++tj; }
+    const int ti = tj + it;
+    if (tj >= nt) return;
+    const bool diag = (ti == tj);
+    const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
+    const double *__restrict__ pJ = ab + (long long)(row0 + tj * 32 + l15) + (long long)(k0 + q) * lda;
+    const double *__restrict__ pI = ab + (long long)(row0 + ti * 32 + l15) + (long long)(k0 + q) * lda;
+    double *__restrict__ C = ab + (long long)(row0 + ti * 32) + (long long)(row0 + tj * 32) * lda;
+    d4_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[m][n][v] = -C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * lda];
+    double qa[SD][2], qb[SD][2];
+    auto fetch = [&](int slot, int step) {
+        const long long off = (long long)(4 * step) * lda;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            qa[slot][m] = pJ[off + 16 * m];
+            qb[slot][m] = pI[off + 16 * m];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < SD; ++d) fetch(d, d);
+    constexpr int NSTEP = NBLK / 4;
+#pragma unroll 1
+    for (int ks = 0; ks < NSTEP; ks += SD) {
+#pragma unroll
+        for (int d = 0; d < SD; ++d) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + d + SD < NSTEP) fetch(d, ks + d + SD);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int r = n * 16 + l15;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c = m * 16 + q + 4 * v;
+                if (!diag || r >= c) C[r + (long long)c * lda] = -acc[m][n][v];
             }
         }
 }
@@ -1401,7 +1731,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
             hipExtLaunchKernelGGL((syrk64_kernel<16, 1, SYRK_ABL>), dim3((unsigned)items + margin), dim3(64), 0, s, a, c, 0,
                                   b.ab, b.lda, k0, k0 + NBLK, cb, ce, rb, re, (int)items, margin, pl.reserved, queue);
         else
-            hipLaunchKernelGGL((syrk64_kernel<16, 1, SYRK_ABL | 8>), dim3((unsigned)items + margin), dim3(64), 0, s, b.ab,
+            hipLaunchKernelGGL((syrk64_kernel<SYRK_SD, 2, SYRK_ABL | 8 | 512>), dim3((unsigned)items + margin), dim3(64), 0, s, b.ab,
                                b.lda, k0, k0 + NBLK, cb, ce, rb, re, (int)items, margin, pl.reserved, queue);
         if (timed) {
             evs.push_back(a);
@@ -1415,6 +1745,8 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
             stats->bulk_flop += 2.0 * (double)items * 64 * 64 * NBLK;
         }
     };
+    const bool potrf_v1 = std::getenv("SPLPAK_POTRF_V1") != nullptr;     // the panel form (round 1), for comparison
+    const bool top32 = std::getenv("SPLPAK_TOPA64") == nullptr;          // topA in 32x32 pieces (36 waves) unless asked otherwise
     auto potrf = [&](int k) {        // potrf(k) (+ the 16x16 leaf inverses) pinned to the reserved CU
         const int k0 = k * NBLK;
         if (sR != sP) {
@@ -1422,8 +1754,12 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
             (void)hipStreamWaitEvent(sR, pl.evR[0], 0);
         }
         // the kernel's completion is evI[k] (stop event of the dispatch): no separate record packets
-        hipExtLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, sR, nullptr, pl.evI[k], 0, b.ab, b.lda, k0,
-                              info_dev, minpiv_dev, b.inv64 + (long long)k * 4 * 64 * 64);
+        if (potrf_v1)
+            hipExtLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, sR, nullptr, pl.evI[k], 0, b.ab, b.lda, k0,
+                                  info_dev, minpiv_dev, b.inv64 + (long long)k * 4 * 64 * 64);
+        else
+            hipExtLaunchKernelGGL(potrf_strip_kernel, dim3(1), dim3(256), 0, sR, nullptr, pl.evI[k], 0, b.ab, b.lda, k0,
+                                  info_dev, minpiv_dev, b.inv64 + (long long)k * 4 * 64 * 64);
         if (sR != sP) (void)hipStreamWaitEvent(sP, pl.evI[k], 0);
     };
     // panel solve of rows [r0, r1) below the diagonal block k
@@ -1466,7 +1802,9 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
             (void)hipStreamWaitEvent(sP, pl.evU[k - 1], 0);
             (void)hipStreamWaitEvent(sC, pl.evU[k - 1], 0);
         }
-        syrk(sP, k, 0, 4, 0, 4);                        // topA: block (k+1,k+1)
+        if (top32)                                      // topA: block (k+1,k+1), in 36 32x32 pieces
+            hipLaunchKernelGGL(syrk32_kernel, dim3(36), dim3(64), 0, sP, b.ab, b.lda, k * NBLK, k * NBLK + NBLK, 8);
+        else syrk(sP, k, 0, 4, 0, 4);
         potrf(k + 1);
         (void)hipStreamWaitEvent(sC, pl.evP[k], 0);
         syrk(sC, k, 0, 4, 4, n64 < 8 ? n64 : 8);        // topB: block (k+2,k+1)
@@ -1488,6 +1826,8 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     if (std::getenv("SPLPAK_DEBUG"))
         std::fprintf(stderr, "[splpak] band_cholesky: host enqueue of %d steps took %.1f ms\n", b.nblk,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
+    // (computing these block by block on a side stream beside a narrow-band chain was tried: the 256-thread
+    // inversions slow the chain's own workgroups by as much as the two launches cost here - no gain at 2-D 64^2 / 32^3)
     hipLaunchKernelGGL(trtri_kernel, dim3(b.nblk), dim3(256), 0, st, (const double *)b.ab, b.lda, b.dinv, b.dinvt,
                        DistMap{1, 0, 1, b.lda + 1}, (const int *)nullptr);
     if (b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1)
@@ -1589,7 +1929,8 @@ hipError_t launch_axpy_absmax(int n, double *x, const double *dx, double *absmax
 // ---- launchers of the distributed-band pieces (dist.hip drives them) ----------------------------------
 hipError_t launch_potrf_block(double *abJ, long long lda, int k0, int *info, double *minpiv, double *inv16, hipStream_t st)
 {
-    hipLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, st, abJ, lda, k0, info, minpiv, inv16);
+    if (std::getenv("SPLPAK_POTRF_V1")) hipLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(256), 0, st, abJ, lda, k0, info, minpiv, inv16);
+    else hipLaunchKernelGGL(potrf_strip_kernel, dim3(1), dim3(256), 0, st, abJ, lda, k0, info, minpiv, inv16);
     return hipGetLastError();
 }
 

@@ -40,5 +40,25 @@ int main()
             }
         }
     }
+    // strip form: cycles of wave 0 per phase, summed over the kernel (s_memtime ticks of 10 ns)
+    for (int rep = 0; rep < 4; ++rep) {
+        (void)hipMemcpy(ab, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+        (void)hipMemset(info, 0, 4);
+        double big = 1e300; (void)hipMemcpy(minp, &big, 8, hipMemcpyHostToDevice);
+        unsigned long long zero[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_strip_cycles), zero, sizeof(zero));
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(potrf_strip_kernel, dim3(1), dim3(256), 0, 0, ab, lda, 0, info, minp, inv);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long st[8];
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_strip_cycles), sizeof(st));
+        int hinfo; (void)hipMemcpy(&hinfo, info, 4, hipMemcpyDeviceToHost);
+        printf("strip rep %d: %.1f us, info %d:", rep, 1e3 * ms, hinfo);
+        const char *nm[6] = {"strip load", "leaf", "row solve", "in-strip update", "strip store", "trailing K=64"};
+        for (int i = 0; i < 6; ++i) printf("  %s %.1f us;", nm[i], (double)st[i] * 0.01);
+        printf("\n");
+    }
     return 0;
 }
