@@ -25,7 +25,7 @@
 //                       128x128 form, kept for tools/syrk_bench.hip only.
 // The steps are pipelined over four HIP streams with one block column of look-ahead.
 // Solves (band_solve) use explicit inverses of the 256x256 diagonal blocks of L
-// (trtri_kernel) and the coupling blocks of sweepmat_kernel, computed once after the
+// (trinv_kernel) and the coupling blocks of sweepmat_kernel, computed once after the
 // factorisation, so that every step of the forward / backward sweep is ONE short launch.
 #include "kernels.hpp"
 #include <chrono>
@@ -507,7 +507,6 @@ potrf_strip_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
 // takes the place of one retiring trailing-update wave (252 registers, two per SIMD) beside the
 // other one.  Only L / Inv elements (L2 resident, shared by all waves) and the wave's own rows
 // are loaded.
-constexpr int TCB = 32;            // register block of trtri_kernel
 // The L operands of block row cb+1 and its right-hand side are fetched while block row cb is
 // being computed (lb[] is refilled slot by slot as soon as the MFMA that read the slot has been
 // issued): one exposed L2 round trip per block row instead of one per two k blocks took the
@@ -515,22 +514,22 @@ constexpr int TCB = 32;            // register block of trtri_kernel
 // (257 registers: no longer fits beside a trailing-update wave, 380 us), unguarded refills
 // (exactly counted waits, but 76 % more loads through the L1 that the update waves stream
 // their operands through: 127 us).
-__global__ void __launch_bounds__(64)
-trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long lda,
-            const double *__restrict__ inv16, int nrows)
+// EYE: the right-hand side is the identity (rows r0.. of it, never read from memory), X has its own leading
+// dimension ldx and is also stored transposed into Xt: X = L^{-T}, i.e. the inverse of the diagonal block
+// (trinv_kernel below).
+template <bool EYE>
+__device__ __forceinline__ void trsm_rows(const double *__restrict__ L, double *__restrict__ Xbase, long long lda,
+                                          long long ldx, const double *__restrict__ inv16, double *__restrict__ Xt,
+                                          int r0, double *__restrict__ xs)
 {
-    __shared__ double xs[(NBLK - 16) * 16];               // xs[col*16 + row] = -X(row, col), columns 0..239
     const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
-    const int r0 = blockIdx.x * 16;
-    if (r0 >= nrows) return;
-    __builtin_amdgcn_s_setprio(3);
-    double *__restrict__ Xr = Xbase + r0 + l15;          // Xr[c*lda] = X(row, c)
+    double *__restrict__ Xr = Xbase + r0 + l15;          // Xr[c*ldx] = X(row, c)
     constexpr int NCB = NBLK / 16;
 
     double lb[NCB - 1][4];        // lb[kb][s] = L(16 cb + l15, 16 kb + 4 s + q), block row cb (then cb+1)
     d4_t Tn;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) Tn[v] = Xr[(long long)(q + 4 * v) * lda];
+    for (int v = 0; v < 4; ++v) Tn[v] = EYE ? (r0 + l15 == q + 4 * v ? 1.0 : 0.0) : Xr[(long long)(q + 4 * v) * ldx];
 #pragma unroll 1
     for (int cb = 0; cb < NCB; ++cb) {          // stays rolled: the code must stay small (cold I-cache)
         d4_t T = Tn;
@@ -541,7 +540,8 @@ trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long 
         for (int s = 0; s < 4; ++s) iv[s] = Inv[l15 + 16 * (4 * s + q)];
         if (more) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) Tn[v] = Xr[(long long)(16 * (cb + 1) + q + 4 * v) * lda];
+            for (int v = 0; v < 4; ++v)
+                Tn[v] = EYE ? (r0 + l15 == 16 * (cb + 1) + q + 4 * v ? 1.0 : 0.0) : Xr[(long long)(16 * (cb + 1) + q + 4 * v) * ldx];
         }
         const double *__restrict__ Ln = L + (16 * (cb + 1) + l15) + (long long)q * lda;   // block row cb+1
 #pragma unroll
@@ -564,12 +564,43 @@ trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long 
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int c = 16 * cb + q + 4 * v;
-            Xr[(long long)c * lda] = X[v];
+            Xr[(long long)c * ldx] = X[v];
+            if (EYE) Xt[(long long)(r0 + l15) * ldx + c] = X[v];
             if (more) xs[c * 16 + l15] = -X[v];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+__global__ void __launch_bounds__(64)
+trsm_kernel(const double *__restrict__ L, double *__restrict__ Xbase, long long lda,
+            const double *__restrict__ inv16, int nrows)
+{
+    __shared__ double xs[(NBLK - 16) * 16];               // xs[col*16 + row] = -X(row, col), columns 0..239
+    const int r0 = blockIdx.x * 16;
+    if (r0 >= nrows) return;
+    __builtin_amdgcn_s_setprio(3);
+    trsm_rows<false>(L, Xbase, lda, lda, inv16, nullptr, r0, xs);
+}
+
+// Inverses of the 256x256 diagonal blocks of L as the panel solve of the identity, X = I L^{-T}: wave (y, x)
+// produces rows 16x.. of X for the y-th block, so that  dinvt[r*256 + c] = X(r, c) = Linv(c, r)  (row-major
+// L^{-T}) and dinv = its transpose (row-major Linv; the zero triangles are stored, the sweeps read full rows).
+// Replaces a thread-per-column substitution that took 0.5 ms per block (a fixed cost of every fit, 1.6 ms at
+// 64^3); this one runs on the matrix cores against the leaf inverses potrf leaves behind.
+__global__ void __launch_bounds__(64)
+trinv_kernel(const double *__restrict__ ab, long long lda, const double *__restrict__ inv16, double *__restrict__ dinv,
+             double *__restrict__ dinvt, DistMap dm, const int *__restrict__ blocks)
+{
+    __shared__ double xs[(NBLK - 16) * 16];
+    // block column handled by this workgroup: the blockIdx.y-th OWNED one when the band is distributed
+    const int J = blocks ? blocks[blockIdx.y] : (int)blockIdx.y;
+    const long long k0 = (long long)J * NBLK;
+    const double *__restrict__ L = ab + dm_shift(dm, J) + (k0 + k0 * lda);
+    // column-major X with leading dimension 256 is row-major Linv: X(r, c) at [r + 256 c] = Linv(c, r)
+    trsm_rows<true>(L, dinv + (long long)blockIdx.y * NBLK * NBLK, lda, NBLK, inv16 + (long long)blockIdx.y * 4 * 64 * 64,
+                    dinvt + (long long)blockIdx.y * NBLK * NBLK, blockIdx.x * 16, xs);
 }
 
 // ---------------------------------------------------------------------------
@@ -861,6 +892,28 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+    } else if (ABL & 1024) {
+        // KTOT = several panels per pass: the unrolled 64-step body of one panel, repeated (code size of K = 256)
+        constexpr int NH = KTOT / NBLK, HS = NBLK / 4;
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+            for (int ks = 0; ks < HS; ks += SD) {
+#pragma unroll
+                for (int d = 0; d < SD; ++d) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+                    if (ks + d + SD < HS) fetch(d, h * HS + ks + d + SD);
+                    else {                                   // the first steps of the next panel (clamped: re-reads in the last one)
+                        const int nx = h * HS + ks + d + SD;
+                        fetch(d, nx < NSTEP ? nx : NSTEP - 1);
+                    }
+                }
+            }
+        }
     } else
     for (int ks = 0; ks < NSTEP; ks += SD) {
 #pragma unroll
@@ -935,50 +988,6 @@ syrk64_kernel(double *__restrict__ ab, long long lda, int k0, int row0, int cb, 
     cload(3, cold[1]);
     cstore(2, cold[0]);
     cstore(3, cold[1]);
-}
-
-// ---------------------------------------------------------------------------
-// Inverse of every 256x256 diagonal block of L, row-major: T[r*256 + c] = Linv(r,c).
-// One workgroup per block, one thread per column of the inverse.
-__global__ void __launch_bounds__(256)
-trtri_kernel(const double *__restrict__ ab, long long lda, double *__restrict__ dinv,
-             double *__restrict__ dinvt, DistMap dm, const int *__restrict__ blocks)
-{
-    // block column handled by this workgroup: the blockIdx-th OWNED one when the band is distributed
-    const int J = blocks ? blocks[blockIdx.x] : (int)blockIdx.x;
-    const int k0 = J * NBLK;
-    const int c = threadIdx.x;
-    const double *__restrict__ L = ab + dm_shift(dm, J) + ((long long)k0 + (long long)k0 * lda);
-    double *__restrict__ T = dinv + (long long)blockIdx.x * NBLK * NBLK;
-    double *__restrict__ Tt = dinvt + (long long)blockIdx.x * NBLK * NBLK;   // Tt[c*256 + r] = Linv(r,c)
-
-    for (int rb = 0; rb < NBLK / TCB; ++rb) {
-        double acc[TCB];
-#pragma unroll
-        for (int r = 0; r < TCB; ++r) acc[r] = (rb * TCB + r == c) ? 1.0 : 0.0;
-        for (int kb = 0; kb < rb; ++kb) {
-            double xk[TCB];
-#pragma unroll
-            for (int k = 0; k < TCB; ++k) xk[k] = T[(kb * TCB + k) * NBLK + c];
-#pragma unroll
-            for (int k = 0; k < TCB; ++k) {
-                const double *__restrict__ Lc = L + (rb * TCB) + (long long)(kb * TCB + k) * lda;
-#pragma unroll
-                for (int r = 0; r < TCB; ++r) acc[r] -= xk[k] * Lc[r];
-            }
-        }
-        const double *__restrict__ Ld = L + (rb * TCB) + (long long)(rb * TCB) * lda;
-#pragma unroll
-        for (int r = 0; r < TCB; ++r) {
-#pragma unroll
-            for (int k = 0; k < r; ++k) acc[r] -= acc[k] * Ld[r + (long long)k * lda];
-            acc[r] /= Ld[r + (long long)r * lda];
-        }
-#pragma unroll
-        for (int r = 0; r < TCB; ++r) T[(rb * TCB + r) * NBLK + c] = acc[r];
-#pragma unroll
-        for (int r = 0; r < TCB; ++r) Tt[c * NBLK + rb * TCB + r] = acc[r];
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1828,8 +1837,8 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
     // (computing these block by block on a side stream beside a narrow-band chain was tried: the 256-thread
     // inversions slow the chain's own workgroups by as much as the two launches cost here - no gain at 2-D 64^2 / 32^3)
-    hipLaunchKernelGGL(trtri_kernel, dim3(b.nblk), dim3(256), 0, st, (const double *)b.ab, b.lda, b.dinv, b.dinvt,
-                       DistMap{1, 0, 1, b.lda + 1}, (const int *)nullptr);
+    hipLaunchKernelGGL(trinv_kernel, dim3(NBLK / 16, b.nblk), dim3(64), 0, st, (const double *)b.ab, b.lda,
+                       (const double *)b.inv64, b.dinv, b.dinvt, DistMap{1, 0, 1, b.lda + 1}, (const int *)nullptr);
     if (b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1)
         hipLaunchKernelGGL(sweepmat_kernel, dim3(2 * (b.nblk - 1), 16), dim3(256), 0, st, (const double *)b.ab, b.lda,
                            (const double *)b.dinv, (const double *)b.dinvt, b.mfwd, b.mbwd, b.nblk - 1);
@@ -1974,10 +1983,10 @@ hipError_t launch_syrk64d(double *abl, long long lda, const DistMap &dm, const d
 }
 
 hipError_t launch_trtri_owned(const double *abl, long long lda, const DistMap &dm, const int *blocks_dev, int nown,
-                              double *dinv, double *dinvt, hipStream_t st)
+                              const double *inv16, double *dinv, double *dinvt, hipStream_t st)
 {
     if (nown <= 0) return hipSuccess;
-    hipLaunchKernelGGL(trtri_kernel, dim3(nown), dim3(256), 0, st, abl, lda, dinv, dinvt, dm, blocks_dev);
+    hipLaunchKernelGGL(trinv_kernel, dim3(NBLK / 16, nown), dim3(64), 0, st, abl, lda, inv16, dinv, dinvt, dm, blocks_dev);
     return hipGetLastError();
 }
 

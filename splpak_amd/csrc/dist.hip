@@ -300,7 +300,7 @@ hipError_t dist_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStr
     DTRY(hipStreamWaitEvent(st, me->evTmp, 0));
     if (nblk >= 2) DTRY(hipStreamWaitEvent(st, me->evBulk[nblk - 2], 0));
     DTRY(hipStreamSynchronize(me->sCopy));          // peer copies INTO this rank are complete
-    DTRY(launch_trtri_owned(b.ab, b.lda, dm, p->own_blocks, p->nown, b.dinv, b.dinvt, st));
+    DTRY(launch_trtri_owned(b.ab, b.lda, dm, p->own_blocks, p->nown, b.inv64, b.dinv, b.dinvt, st));
     // the send buffers may still be read by slower ranks: nobody leaves before everybody has every panel
     DTRY(hipStreamSynchronize(st));
     if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;

@@ -139,7 +139,7 @@ long long syrk64d_items(const DistMap &dm, int row0, int jb, int je, int re);
 hipError_t launch_syrk64d(double *abl, long long lda, const DistMap &dm, const double *P, long long ldp, int row0,
                           int jb, int je, int re, hipStream_t st);
 hipError_t launch_trtri_owned(const double *abl, long long lda, const DistMap &dm, const int *blocks_dev, int nown,
-                              double *dinv, double *dinvt, hipStream_t st);
+                              const double *inv16, double *dinv, double *dinvt, hipStream_t st);
 hipError_t launch_blockmv(const double *M, const double *v, double *out, hipStream_t st);
 hipError_t launch_fwd_update(const double *Lpanel, long long lda, const double *yk, double *vbelow, int nrows, hipStream_t st);
 hipError_t launch_bwd_column(const double *Lpanel, long long lda, const double *xbelow, int nrows, const double *dinvt_k,

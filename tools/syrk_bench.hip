@@ -63,7 +63,8 @@ int main()
         {"s64 SD16 C-init (product, unrolled)", flop64, {}}, {"s64 SD16 C-init rolled K=256", flop64, {}},
         {"s64 SD16 C-init rolled K=512", 2 * flop64, {}}, {"s64 SD8 C-init rolled K=512", 2 * flop64, {}},
         {"s64 SD16 C-init rolled K=1024", 4 * flop64, {}}, {"s64 SD8 C-init rolled K=256", flop64, {}},
-        {"s64 SD16 C-init 4-wave WG", flop64, {}}};
+        {"s64 SD16 C-init 4-wave WG", flop64, {}}, {"s64 SD16 C-init unrolled K=512", 2 * flop64, {}},
+        {"s64 SD16 C-init K=512 as 2 unrolled halves", 2 * flop64, {}}, {"s64 SD16 C-init K=1024 as 4 unrolled quarters", 4 * flop64, {}}};
     for (int r = 0; r < rounds; ++r) {
         v[0].t.push_back(run64<16, 1, 4>(ab, lda, n64));
         v[1].t.push_back(run64<16, 1, 4 | 64>(ab, lda, n64));
@@ -72,29 +73,34 @@ int main()
         v[4].t.push_back(run64<16, 1, 4 | 64, 1024>(ab, lda, n64));
         v[5].t.push_back(run64<8, 1, 4 | 64>(ab, lda, n64));
         v[6].t.push_back(run64x4<16, 4>(ab, lda, n64));
+        v[7].t.push_back(run64<16, 1, 4, 512>(ab, lda, n64));
+        v[8].t.push_back(run64<16, 1, 4 | 1024, 512>(ab, lda, n64));
+        v[9].t.push_back(run64<16, 1, 4 | 1024, 1024>(ab, lda, n64));
     }
     // steady state on a plain created stream: back-to-back launches (includes the launch-to-launch gap)
     {
         hipStream_t st;
         (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         long long items = 0; for (int c = 4; c < n64; ++c) items += n64 - c;
-        for (int variant = 0; variant < 3; ++variant) {
+        for (int variant = 0; variant < 4; ++variant) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-            const int reps = variant == 2 ? 10 : 20;
+            const int reps = variant >= 2 ? 10 : 20;
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < reps; ++r) {
                 if (variant == 0)
                     hipLaunchKernelGGL((syrk64_kernel<16, 1, 4>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
                 else if (variant == 1)
                     hipLaunchKernelGGL((syrk64_kernel<16, 1, 4 | 64>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
-                else
+                else if (variant == 2)
                     hipLaunchKernelGGL((syrk64_kernel<16, 1, 4 | 64, 512>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, 512, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+                else
+                    hipLaunchKernelGGL((syrk64_kernel<16, 1, 4 | 1024, 512>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, 512, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
             }
             (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-            const double fl = (variant == 2 ? 2.0 : 1.0) * flop64;
+            const double fl = (variant >= 2 ? 2.0 : 1.0) * flop64;
             printf("back-to-back %-28s: %.3f ms per launch (%.1f TF incl. gaps)\n",
-                   variant == 0 ? "product K=256 unrolled" : variant == 1 ? "rolled K=256" : "rolled K=512", ms / reps, fl / (ms / reps) / 1e9);
+                   variant == 0 ? "product K=256 unrolled" : variant == 1 ? "rolled K=256" : variant == 2 ? "rolled K=512" : "K=512 in 2 unrolled halves", ms / reps, fl / (ms / reps) / 1e9);
         }
     }
     {
@@ -167,7 +173,7 @@ int main()
         hipStream_t st;
         (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         long long items = 0; for (int c = 4; c < n64; ++c) items += n64 - c;
-        for (int variant = 0; variant < 3; ++variant) {
+        for (int variant = 0; variant < 4; ++variant) {
             const int reps = 30;
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, st);
