@@ -1578,9 +1578,14 @@ struct Pipeline {
     bool used = false;
     std::vector<hipEvent_t> evA;  // start events of the timed bulk launches (kernel timing only)
     hipEvent_t f0 = nullptr, f1 = nullptr;
+    bool res_tried = false;       // the CU-masked stream is created on the first factorisation that pins potrf
 };
 void pipeline_release(Pipeline &p);
-Pipeline &pipeline(void *&slot, int nblk)
+// wide = the four-stream form (column and bulk streams, optionally the CU-masked one); a narrow-band chain only
+// uses `panel` beside the caller's stream.  Every stream is a hardware queue, and the device advances only a
+// few queues that sit on dependency barriers at the same time (measured: the second of two concurrently
+// enqueued three-stream pipelines did not start before the first had drained), so nothing is created unused.
+Pipeline &pipeline(void *&slot, int nblk, bool wide, bool want_res)
 {
     if (!slot) slot = new Pipeline();
     Pipeline &p = *static_cast<Pipeline *>(slot);
@@ -1591,33 +1596,8 @@ Pipeline &pipeline(void *&slot, int nblk)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // hi = numerically lowest = highest priority
         (void)hipStreamCreateWithPriority(&p.panel, hipStreamNonBlocking, hi);
-        (void)hipStreamCreateWithPriority(&p.col, hipStreamNonBlocking, hi);
-        // the bulk runs on a private non-blocking stream: the caller's stream may be the legacy
-        // NULL stream, which would serialise against the (blocking) CU-masked stream below
-        (void)hipStreamCreateWithFlags(&p.upd, hipStreamNonBlocking);
-        // One CU is left to the diagonal-block factorisation: v_mfma_f64 runs on the same f64
-        // pipes as f64 VALU code, so the latency-bound potrf workgroup ran 3x slower beside
-        // trailing-update waves.  potrf is pinned to that CU through a CU-masked stream; the
-        // trailing-update waves are NOT masked (masked queues cost them ~8 %): a wave that finds
-        // itself on the reserved CU steps aside (syrk64_kernel).  The CU's id is read back once.
         p.reserved = ~0u;
-        if (!std::getenv("SPLPAK_NO_PANEL_CU")) {
-            hipDeviceProp_t prop;
-            (void)hipGetDeviceProperties(&prop, dev);
-            const int ncu = prop.multiProcessorCount;
-            std::vector<uint32_t> only((size_t)(ncu + 31) / 32, 0u);
-            only[0] = 1u;
-            unsigned *d = nullptr, h = ~0u;
-            if (hipExtStreamCreateWithCUMask(&p.res, (uint32_t)only.size(), only.data()) == hipSuccess &&
-                hipMalloc(&d, sizeof(unsigned)) == hipSuccess) {
-                hipLaunchKernelGGL(whoami_kernel, dim3(1), dim3(64), 0, p.res, d);
-                if (hipStreamSynchronize(p.res) == hipSuccess &&
-                    hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess)
-                    p.reserved = h;
-            }
-            if (d) (void)hipFree(d);
-            if (p.reserved == ~0u) { (void)hipGetLastError(); p.res = nullptr; }
-        }
+        p.res_tried = false;
         p.dev = dev;
         p.evP.clear();
         p.evU.clear();
@@ -1646,6 +1626,42 @@ Pipeline &pipeline(void *&slot, int nblk)
         p.evI.push_back(e);
         (void)hipEventCreate(&e);
         p.evT.push_back(e);
+    }
+    if (wide && !p.col) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        (void)hipStreamCreateWithPriority(&p.col, hipStreamNonBlocking, hi);
+        // the bulk runs on a private non-blocking stream: the caller's stream may be the legacy
+        // NULL stream, which would serialise against the (blocking) CU-masked stream below
+        (void)hipStreamCreateWithFlags(&p.upd, hipStreamNonBlocking);
+    }
+    if (want_res && !p.res_tried) {
+        p.res_tried = true;
+        // One CU is left to the diagonal-block factorisation: v_mfma_f64 runs on the same f64
+        // pipes as f64 VALU code, so the latency-bound potrf workgroup ran 3x slower beside
+        // trailing-update waves.  potrf is pinned to that CU through a CU-masked stream; the
+        // trailing-update waves are NOT masked (masked queues cost them ~8 %): a wave that finds
+        // itself on the reserved CU steps aside (syrk64_kernel).  The CU's id is read back once.
+        // (Only created for bands wide enough to use it: every stream is a hardware queue, and the
+        // two pipelines of a two-ended factorisation plus the caller's streams already fill the
+        // queue slots the device runs concurrently.)
+        if (!std::getenv("SPLPAK_NO_PANEL_CU")) {
+            hipDeviceProp_t prop;
+            (void)hipGetDeviceProperties(&prop, dev);
+            const int ncu = prop.multiProcessorCount;
+            std::vector<uint32_t> only((size_t)(ncu + 31) / 32, 0u);
+            only[0] = 1u;
+            unsigned *d = nullptr, h = ~0u;
+            if (hipExtStreamCreateWithCUMask(&p.res, (uint32_t)only.size(), only.data()) == hipSuccess &&
+                hipMalloc(&d, sizeof(unsigned)) == hipSuccess) {
+                hipLaunchKernelGGL(whoami_kernel, dim3(1), dim3(64), 0, p.res, d);
+                if (hipStreamSynchronize(p.res) == hipSuccess &&
+                    hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess)
+                    p.reserved = h;
+            }
+            if (d) (void)hipFree(d);
+            if (p.reserved == ~0u) { (void)hipGetLastError(); p.res = nullptr; }
+        }
     }
     return p;
 }
@@ -1683,16 +1699,30 @@ void band_pipeline_destroy(void *slot)
 //   panel stream : [update of block column k+1 by panel k] -> potrf(k+1) -> trsm(k+1)
 //   update stream: bulk trailing update by panel k (block columns >= k+2)
 // so the latency-bound panel work runs beside the MFMA-bound bulk update.
+// Block columns [kbeg, kend) are eliminated (default: all of them): afterwards the columns from kend on carry
+// every update of the eliminated ones but are not factored -- a later call continues there, or the caller adds
+// another Schur complement first (the two-ended factorisation of twoend.hip).  nfinish = number of leading block
+// columns whose inverses / sweep coupling blocks are produced at the end (default: all; 0 = none yet).
 hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipStream_t st,
-                         CholStats *stats)
+                         CholStats *stats, int kbeg, int kend, int nfinish)
 {
+    if (kend < 0 || kend > b.nblk) kend = b.nblk;
+    if (nfinish < 0 || nfinish > b.nblk) nfinish = b.nblk;
+    if (kbeg < 0 || kbeg >= kend) return hipErrorInvalidValue;
+    const bool partial = kend < b.nblk;
+    {   // narrow bands: the two-stream form below (SPLPAK_NO_NARROW keeps the four-stream pipeline, for comparison)
+        if (b.bw < narrow_band_limit() && !std::getenv("SPLPAK_NO_NARROW")) {
+            if (stats) *stats = CholStats{stats->enabled};
+            return band_cholesky_narrow(b, info_dev, minpiv_dev, st, kbeg, kend, nfinish);
+        }
+    }
     const bool timing = stats && stats->enabled;
     const auto t_enq = std::chrono::steady_clock::now();
-    Pipeline &pl = pipeline(b.pipe, b.nblk);
-    hipStream_t sP = pl.panel, sC = pl.col, sU = pl.upd;
     // potrf is pinned to the reserved CU (own stream, two event hops per step) when the trailing update is
     // heavy enough to starve it; with a narrow band the step is bound by the chain itself and the hops cost more
     const int pin_bw = std::getenv("SPLPAK_PIN_BW") ? atoi(std::getenv("SPLPAK_PIN_BW")) : 24;
+    Pipeline &pl = pipeline(b.pipe, b.nblk, true, b.bw >= pin_bw);
+    hipStream_t sP = pl.panel, sC = pl.col, sU = pl.upd;
     hipStream_t sR = (pl.res && b.bw >= pin_bw) ? pl.res : pl.panel;
     if (!sP || !sC || !sU || std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = sC = sU = sR = st;   // no streams / diagnostics: no overlap
     // the item queues and events belong to the pipeline, not to the caller's stream: a factorisation
@@ -1799,37 +1829,47 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     (void)hipStreamWaitEvent(sC, pl.evU[b.nblk], 0);
     if (sR != sP) (void)hipStreamWaitEvent(sR, pl.evU[b.nblk], 0);
     (void)hipStreamWaitEvent(sU, pl.evU[b.nblk], 0);
-    potrf(0);
-    trsm(sP, 0, 0, tb_of(0) * NBLK, pl.evT[0]);
-    (void)hipEventRecord(pl.evP[0], sP);
-    for (int k = 0; k < b.nblk; ++k) {
+    potrf(kbeg);
+    trsm(sP, kbeg, 0, tb_of(kbeg) * NBLK, pl.evT[kbeg]);
+    (void)hipEventRecord(pl.evP[kbeg], sP);
+    for (int k = kbeg; k < kend; ++k) {
         const int tb = tb_of(k);
         if (tb <= 0) continue;
+        const bool next = k + 1 < kend;                 // block column k+1 is factored in this call
         const int n64 = tb * NBLK / 64;                 // trailing rows / columns in 64-row units
         const int nrows1 = tb_of(k + 1) * NBLK;         // rows below the diagonal block of panel k+1
-        if (k > 0) {
+        if (k > kbeg) {
             (void)hipStreamWaitEvent(sP, pl.evU[k - 1], 0);
             (void)hipStreamWaitEvent(sC, pl.evU[k - 1], 0);
         }
         if (top32)                                      // topA: block (k+1,k+1), in 36 32x32 pieces
             hipLaunchKernelGGL(syrk32_kernel, dim3(36), dim3(64), 0, sP, b.ab, b.lda, k * NBLK, k * NBLK + NBLK, 8);
         else syrk(sP, k, 0, 4, 0, 4);
-        potrf(k + 1);
+        if (next) potrf(k + 1);
         (void)hipStreamWaitEvent(sC, pl.evP[k], 0);
         syrk(sC, k, 0, 4, 4, n64 < 8 ? n64 : 8);        // topB: block (k+2,k+1)
         (void)hipEventRecord(pl.evC[k], sC);
         syrk(sC, k, 0, 4, 8, n64);                      // colU: blocks (>=k+3, k+1)
-        (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
-        trsm(sP, k + 1, 0, nrows1 < NBLK ? nrows1 : NBLK, pl.evT[k + 1]);
-        (void)hipStreamWaitEvent(sC, pl.evI[k + 1], 0);
-        trsm(sC, k + 1, NBLK, nrows1);
-        (void)hipStreamWaitEvent(sC, pl.evT[k + 1], 0);
-        (void)hipEventRecord(pl.evP[k + 1], sC);
+        if (next) {
+            (void)hipStreamWaitEvent(sP, pl.evC[k], 0);
+            trsm(sP, k + 1, 0, nrows1 < NBLK ? nrows1 : NBLK, pl.evT[k + 1]);
+            (void)hipStreamWaitEvent(sC, pl.evI[k + 1], 0);
+            trsm(sC, k + 1, NBLK, nrows1);
+            (void)hipStreamWaitEvent(sC, pl.evT[k + 1], 0);
+            (void)hipEventRecord(pl.evP[k + 1], sC);
+        }
         (void)hipStreamWaitEvent(sU, pl.evP[k], 0);
         syrk(sU, k, 4, n64, 0, n64, true);              // bulk: block columns >= k+2
         if (!bulk_stop_event) (void)hipEventRecord(pl.evU[k], sU);
     }
-    (void)hipStreamWaitEvent(sU, pl.evP[b.nblk - 1], 0);
+    if (partial) {                                 // the last step's chain and column pieces are not followed by a panel
+        (void)hipEventRecord(pl.evT[kend], sP);
+        (void)hipEventRecord(pl.evP[kend], sC);
+        (void)hipStreamWaitEvent(sU, pl.evT[kend], 0);
+        (void)hipStreamWaitEvent(sU, pl.evP[kend], 0);
+    } else {
+        (void)hipStreamWaitEvent(sU, pl.evP[b.nblk - 1], 0);
+    }
     (void)hipEventRecord(pl.evC[b.nblk], sU);      // join: the caller's stream continues after the pipeline
     (void)hipStreamWaitEvent(st, pl.evC[b.nblk], 0);
     if (std::getenv("SPLPAK_DEBUG"))
@@ -1837,11 +1877,16 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
     // (computing these block by block on a side stream beside a narrow-band chain was tried: the 256-thread
     // inversions slow the chain's own workgroups by as much as the two launches cost here - no gain at 2-D 64^2 / 32^3)
-    hipLaunchKernelGGL(trinv_kernel, dim3(NBLK / 16, b.nblk), dim3(64), 0, st, (const double *)b.ab, b.lda,
-                       (const double *)b.inv64, b.dinv, b.dinvt, DistMap{1, 0, 1, b.lda + 1}, (const int *)nullptr);
-    if (b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1)
-        hipLaunchKernelGGL(sweepmat_kernel, dim3(2 * (b.nblk - 1), 16), dim3(256), 0, st, (const double *)b.ab, b.lda,
-                           (const double *)b.dinv, (const double *)b.dinvt, b.mfwd, b.mbwd, b.nblk - 1);
+    if (nfinish > 0) {
+        hipLaunchKernelGGL(trinv_kernel, dim3(NBLK / 16, nfinish), dim3(64), 0, st, (const double *)b.ab, b.lda,
+                           (const double *)b.inv64, b.dinv, b.dinvt, DistMap{1, 0, 1, b.lda + 1}, (const int *)nullptr);
+        // pair k couples blocks k and k+1; with nfinish < nblk the last pair has only its backward block valid
+        // (N = Linv_k^T L_{k+1,k}^T needs block k alone), which is the one a sweep that is GIVEN block nfinish uses
+        const int npairs = nfinish < b.nblk ? nfinish : b.nblk - 1;
+        if (b.mfwd && b.mbwd && b.bw > 0 && npairs > 0)
+            hipLaunchKernelGGL(sweepmat_kernel, dim3(2 * npairs, 16), dim3(256), 0, st, (const double *)b.ab, b.lda,
+                               (const double *)b.dinv, (const double *)b.dinvt, b.mfwd, b.mbwd, npairs);
+    }
     if (pl.done) {
         (void)hipEventRecord(pl.done, st);
         pl.used = true;
@@ -1861,32 +1906,166 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     return err;
 }
 
-hipError_t band_solve(const Band &b, double *x, double *tmp, hipStream_t st)
+// The same factorisation for NARROW bands (chain-bound: the trailing update of a step is a fraction of the
+// potrf -> panel solve -> diagonal update chain), on two streams instead of four:
+//   chain (own high-priority stream): topA(k) -> potrf(k+1) -> panel solve of block (k+2, k+1)
+//   rest  (the caller's stream)     : ONE launch for every other tile panel k updates, then the panel solve of
+//                                     the rows below block row k+2
+// One launch instead of three for the updates: with the chip idle all of its items run at once (one item time,
+// ~60 us), where topB / colU / bulk each cost that much one after the other.  Two streams instead of four:
+// two such factorisations run side by side (twoend.hip) within the four hardware queues that make progress
+// concurrently.  Same range arguments as band_cholesky.
+hipError_t band_cholesky_narrow(const Band &b, int *info_dev, double *minpiv_dev, hipStream_t st, int kbeg, int kend,
+                                int nfinish)
 {
-    // forward: x -> tmp (y), the not-yet-solved part of x is updated in place;
-    // backward: tmp -> x
-    if (b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1) {
-        // one launch per block step (coupling blocks M_k, N_k from sweepmat_kernel)
-        const long long nb2 = (long long)NBLK * NBLK;
-        hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st, (const double *)b.dinv, (const double *)x, tmp);
-        for (int k = 0; k + 1 < b.nblk; ++k) {
+    if (kend < 0 || kend > b.nblk) kend = b.nblk;
+    if (nfinish < 0 || nfinish > b.nblk) nfinish = b.nblk;
+    if (kbeg < 0 || kbeg >= kend) return hipErrorInvalidValue;
+    Pipeline &pl = pipeline(b.pipe, b.nblk, false, false);
+    hipStream_t sP = pl.panel;
+    if (!sP || std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = st;
+    if (pl.used && pl.done) (void)hipStreamWaitEvent(st, pl.done, 0);
+    auto tb_of = [&](int k) { int t = b.nblk - 1 - k; return t > b.bw ? b.bw : t; };
+    auto potrf = [&](int k) {
+        hipExtLaunchKernelGGL(potrf_strip_kernel, dim3(1), dim3(256), 0, sP, nullptr, pl.evI[k], 0, b.ab, b.lda, k * NBLK,
+                              info_dev, minpiv_dev, b.inv64 + (long long)k * 4 * 64 * 64);
+    };
+    auto trsm = [&](hipStream_t s, int k, int r0, int r1, hipEvent_t done) {
+        if (r1 <= r0) {
+            if (done) (void)hipEventRecord(done, s);
+            return;
+        }
+        const int k0 = k * NBLK;
+        hipExtLaunchKernelGGL(trsm_kernel, dim3((r1 - r0) / 16), dim3(64), 0, s, nullptr, done, 0,
+                              (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda),
+                              b.ab + (long long)(k0 + NBLK + r0) + (long long)k0 * b.lda, b.lda,
+                              (const double *)(b.inv64 + (long long)k * 4 * 64 * 64), r1 - r0);
+    };
+    (void)hipEventRecord(pl.evU[b.nblk], st);              // the chain starts after everything queued on the caller's stream
+    if (sP != st) (void)hipStreamWaitEvent(sP, pl.evU[b.nblk], 0);
+    potrf(kbeg);
+    trsm(sP, kbeg, 0, tb_of(kbeg) * NBLK, pl.evT[kbeg]);    // the first panel is solved whole on the chain
+    (void)hipEventRecord(pl.evP[kbeg], sP);
+    for (int k = kbeg; k < kend; ++k) {
+        const int tb = tb_of(k);
+        if (tb <= 0) continue;
+        const bool next = k + 1 < kend;
+        const int n64 = tb * NBLK / 64;
+        const int nrows1 = tb_of(k + 1) * NBLK;
+        // chain: block (k+1,k+1) has the updates of the steps before k (evU[k-1], waited for ahead of the last panel solve)
+        hipLaunchKernelGGL(syrk32_kernel, dim3(36), dim3(64), 0, sP, b.ab, b.lda, k * NBLK, k * NBLK + NBLK, 8);
+        if (next) potrf(k + 1);
+        // rest: every tile of the trailing window except block (k+1,k+1): columns [0, n64) x rows [max(col, 4), n64)
+        if (sP != st) (void)hipStreamWaitEvent(st, pl.evP[k], 0);
+        long long items = 0;
+        for (int c = 0; c < n64; ++c) items += n64 - (c > 4 ? c : 4);
+        if (items > 0)
+            hipExtLaunchKernelGGL((syrk64_kernel<SYRK_SD, 2, SYRK_ABL | 8 | 512>), dim3((unsigned)items), dim3(64), 0, st, nullptr,
+                                  pl.evU[k], 0, b.ab, b.lda, k * NBLK, k * NBLK + NBLK, 0, n64, 4, n64, (int)items, 0, ~0u,
+                                  (int *)nullptr);
+        else (void)hipEventRecord(pl.evU[k], st);
+        if (sP != st) (void)hipStreamWaitEvent(sP, pl.evU[k], 0);
+        if (next) {
+            trsm(sP, k + 1, 0, nrows1 < NBLK ? nrows1 : NBLK, pl.evT[k + 1]);
+            if (sP != st) (void)hipStreamWaitEvent(st, pl.evI[k + 1], 0);
+            trsm(st, k + 1, NBLK, nrows1, nullptr);
+            if (sP != st) (void)hipStreamWaitEvent(st, pl.evT[k + 1], 0);
+            (void)hipEventRecord(pl.evP[k + 1], st);
+        }
+    }
+    if (sP != st) {                                         // join (the last step's diagonal update, when no panel followed)
+        (void)hipEventRecord(pl.evR[0], sP);
+        (void)hipStreamWaitEvent(st, pl.evR[0], 0);
+    }
+    if (nfinish > 0) {
+        hipLaunchKernelGGL(trinv_kernel, dim3(NBLK / 16, nfinish), dim3(64), 0, st, (const double *)b.ab, b.lda,
+                           (const double *)b.inv64, b.dinv, b.dinvt, DistMap{1, 0, 1, b.lda + 1}, (const int *)nullptr);
+        const int npairs = nfinish < b.nblk ? nfinish : b.nblk - 1;
+        if (b.mfwd && b.mbwd && b.bw > 0 && npairs > 0)
+            hipLaunchKernelGGL(sweepmat_kernel, dim3(2 * npairs, 16), dim3(256), 0, st, (const double *)b.ab, b.lda,
+                               (const double *)b.dinv, (const double *)b.dinvt, b.mfwd, b.mbwd, npairs);
+    }
+    if (pl.done) {
+        (void)hipEventRecord(pl.done, st);
+        pl.used = true;
+    }
+    return hipGetLastError();
+}
+
+hipError_t band_forward(const Band &b, double *x, double *tmp, int kb, int ke, hipStream_t st)
+{
+    if (ke > b.nblk) ke = b.nblk;
+    if (kb < 0 || kb >= ke) return hipSuccess;
+    const long long nb2 = (long long)NBLK * NBLK;
+    auto tb_of = [&](int k) { int t = b.nblk - 1 - k; return t > b.bw ? b.bw : t; };
+    const bool fused = b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1;
+    if (fused) {
+        // one launch per block step (coupling blocks M_k from sweepmat_kernel)
+        hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st, (const double *)(b.dinv + kb * nb2),
+                           (const double *)(x + (long long)kb * NBLK), tmp + (long long)kb * NBLK);
+        for (int k = kb; k + 1 < ke; ++k) {
             const int k0 = k * NBLK;
-            int tb = b.nblk - 1 - k;
-            if (tb > b.bw) tb = b.bw;
-            const int nrows2 = (tb - 1) * NBLK;
+            const int nrows2 = (tb_of(k) - 1) * NBLK;
             hipLaunchKernelGGL(fwd_step_kernel, dim3(16 + nrows2 / 64), dim3(512), 0, st,
                                (const double *)(b.dinv + (k + 1) * nb2), (const double *)(b.mfwd + k * nb2),
                                (const double *)(b.ab + (long long)(k0 + 2 * NBLK) + (long long)k0 * b.lda), b.lda,
                                (const double *)(tmp + k0), (const double *)(x + k0 + NBLK), tmp + k0 + NBLK,
                                x + k0 + 2 * NBLK);
         }
-        const int last = (b.nblk - 1) * NBLK;
-        hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st, (const double *)(b.dinvt + (b.nblk - 1) * nb2),
-                           (const double *)(tmp + last), x + last);
-        for (int k = b.nblk - 1; k >= 1; --k) {
+        // the panel of the last solved block has not been applied to the rows below it (a fused step does that
+        // together with the solve of the next block)
+        const int k = ke - 1, k0 = k * NBLK, nrows = tb_of(k) * NBLK;
+        if (ke < b.nblk && nrows > 0)
+            hipLaunchKernelGGL(fwd_update_kernel, dim3(nrows / 64), dim3(512), 0, st,
+                               (const double *)(b.ab + (long long)(k0 + NBLK) + (long long)k0 * b.lda), b.lda,
+                               (const double *)(tmp + k0), x + k0 + NBLK, nrows);
+        return hipGetLastError();
+    }
+    for (int k = kb; k < ke; ++k) {
+        const int k0 = k * NBLK;
+        const int nrows = tb_of(k) * NBLK;
+        hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st,
+                           (const double *)(b.dinv + (long long)k * NBLK * NBLK), (const double *)(x + k0), tmp + k0);
+        if (nrows > 0)
+            hipLaunchKernelGGL(fwd_update_kernel, dim3(nrows / 64), dim3(512), 0, st,
+                               (const double *)(b.ab + (long long)(k0 + NBLK) + (long long)k0 * b.lda), b.lda,
+                               (const double *)(tmp + k0), x + k0 + NBLK, nrows);
+    }
+    return hipGetLastError();
+}
+
+hipError_t band_backward(const Band &b, double *x, double *tmp, int kgiven, hipStream_t st, int kstop, bool resume)
+{
+    const long long nb2 = (long long)NBLK * NBLK;
+    const bool fused = b.mfwd && b.mbwd && b.bw > 0 && b.nblk > 1;
+    if (kgiven > b.nblk) kgiven = b.nblk;
+    if (kstop < 0) kstop = 0;
+    // a solved block pushes its contributions L[block k rows, j]^T x_k into the right-hand sides to its left
+    auto push = [&](int k) {
+        const int k0 = k * NBLK;
+        const int tb = k > b.bw ? b.bw : k;
+        const int ncols = tb * NBLK, jbeg = k0 - ncols;
+        if (ncols > 0)
+            hipLaunchKernelGGL(bwd_update_kernel, dim3(ncols / 64), dim3(256), 0, st,
+                               (const double *)(b.ab + (long long)k0 + (long long)jbeg * b.lda), b.lda,
+                               (const double *)(x + k0), tmp + jbeg, ncols);
+    };
+    if (fused) {
+        // step k solves block k-1 (coupled to x_k through N_{k-1}) and pushes x_k to the left of block k-1
+        int kstart = kgiven;
+        if (!resume) {
+            if (kgiven >= b.nblk) {
+                const int last = (b.nblk - 1) * NBLK;
+                hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st, (const double *)(b.dinvt + (b.nblk - 1) * nb2),
+                                   (const double *)(tmp + last), x + last);
+                kstart = b.nblk - 1;
+            } else {
+                for (int k = b.nblk - 1; k > kgiven; --k) push(k);     // the lowest given block is pushed by its step
+            }
+        }
+        for (int k = kstart; k >= 1 && k - 1 >= kstop; --k) {
             const int k0 = k * NBLK;
-            int tb = k;
-            if (tb > b.bw) tb = b.bw;
+            const int tb = k > b.bw ? b.bw : k;
             const int ncols2 = (tb - 1) * NBLK;
             const int jbeg = k0 - tb * NBLK;
             hipLaunchKernelGGL(bwd_step_kernel, dim3(16 + ncols2 / 64), dim3(256), 0, st,
@@ -1896,32 +2075,23 @@ hipError_t band_solve(const Band &b, double *x, double *tmp, hipStream_t st)
         }
         return hipGetLastError();
     }
-    for (int k = 0; k < b.nblk; ++k) {
+    for (int k = resume ? kgiven - 1 : b.nblk - 1; k >= kstop; --k) {
         const int k0 = k * NBLK;
-        int tb = b.nblk - 1 - k;
-        if (tb > b.bw) tb = b.bw;
-        const int nrows = tb * NBLK;
-        hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st,
-                           (const double *)(b.dinv + (long long)k * NBLK * NBLK), (const double *)(x + k0), tmp + k0);
-        if (nrows > 0)
-            hipLaunchKernelGGL(fwd_update_kernel, dim3(nrows / 64), dim3(512), 0, st,
-                               (const double *)(b.ab + (long long)(k0 + NBLK) + (long long)k0 * b.lda), b.lda,
-                               (const double *)(tmp + k0), x + k0 + NBLK, nrows);
-    }
-    for (int k = b.nblk - 1; k >= 0; --k) {
-        const int k0 = k * NBLK;
-        int tb = k;
-        if (tb > b.bw) tb = b.bw;
-        const int ncols = tb * NBLK;
-        const int jbeg = k0 - ncols;
-        hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st,
-                           (const double *)(b.dinvt + (long long)k * NBLK * NBLK), (const double *)(tmp + k0), x + k0);
-        if (ncols > 0)
-            hipLaunchKernelGGL(bwd_update_kernel, dim3(ncols / 64), dim3(256), 0, st,
-                               (const double *)(b.ab + (long long)k0 + (long long)jbeg * b.lda), b.lda,
-                               (const double *)(x + k0), tmp + jbeg, ncols);
+        if (k < kgiven)
+            hipLaunchKernelGGL(blockmv_kernel, dim3(16), dim3(256), 0, st,
+                               (const double *)(b.dinvt + (long long)k * NBLK * NBLK), (const double *)(tmp + k0), x + k0);
+        push(k);
     }
     return hipGetLastError();
+}
+
+hipError_t band_solve(const Band &b, double *x, double *tmp, hipStream_t st)
+{
+    // forward: x -> tmp (y), the not-yet-solved part of x is updated in place;
+    // backward: tmp -> x
+    hipError_t e = band_forward(b, x, tmp, 0, b.nblk, st);
+    if (e != hipSuccess) return e;
+    return band_backward(b, x, tmp, b.nblk, st, 0, false);
 }
 
 hipError_t launch_axpy_absmax(int n, double *x, const double *dx, double *absmax2, hipStream_t st)

@@ -1,5 +1,6 @@
 // Host-side launchers of the HIP kernels (implemented in the .hip files).
 #pragma once
+#include <cstdlib>
 #include "common.hpp"
 #include <vector>
 
@@ -124,12 +125,36 @@ struct CholStats {            // optional per-kernel accounting (HIP events)
 };
 // in-place L L^T; *info_dev (device int) is set to 1 + column of the first
 // non-positive pivot (0 = success); min pivot is tracked in minpiv_dev
+// Only block columns [kbeg, kend) are eliminated (kend < 0: to the end), leaving the rest updated but unfactored;
+// inverses / sweep coupling blocks are produced for the first nfinish block columns (< 0: all).
 hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipStream_t st,
-                         CholStats *stats);
+                         CholStats *stats, int kbeg = 0, int kend = -1, int nfinish = -1);
+// Block half-bandwidth below which a factorisation is chain-bound and takes the narrow form (and, with enough
+// block columns, both ends at once: twoend.hip).  Measured crossover on MI355X: 44^3 nodes (24 blocks) 112 ms
+// two-ended against 131 ms, 48^3 (28 blocks) equal, 56^3 (38 blocks) 393 against 370 ms.  SPLPAK_PIN_BW (the
+// threshold for pinning potrf in the four-stream pipeline) lowers it too, so that SPLPAK_PIN_BW=1 still forces
+// that pipeline onto small grids.
+inline int narrow_band_limit()
+{
+    if (const char *e = std::getenv("SPLPAK_NARROW_BW")) return atoi(e);
+    if (const char *e = std::getenv("SPLPAK_PIN_BW")) return atoi(e);
+    return 28;
+}
+// the same for narrow (chain-bound) bands: one extra stream, one update launch per step (see bandchol.hip)
+hipError_t band_cholesky_narrow(const Band &b, int *info_dev, double *minpiv_dev, hipStream_t st, int kbeg = 0,
+                                int kend = -1, int nfinish = -1);
 // release a Band's pipeline (streams / events / queues); NULL is fine
 void band_pipeline_destroy(void *pipe);
 // x <- (L L^T)^{-1} x; x and tmp of length npad (padding entries of x must be 0)
 hipError_t band_solve(const Band &b, double *x, double *tmp, hipStream_t st);
+// The two sweeps of band_solve, by block ranges (twoend.hip).  Forward over blocks [kb, ke): y -> tmp, every row
+// below a solved block (also those from ke on) is updated in x.  Backward: blocks >= kgiven already hold their
+// solution in x (kgiven >= nblk: none); the blocks [kstop, kgiven) are solved from tmp into x.  resume = the
+// blocks >= kgiven were solved by an earlier call that stopped at kstop = kgiven (their contributions to the
+// right-hand sides are in place, except what the step that solves block kgiven - 1 applies itself).
+hipError_t band_forward(const Band &b, double *x, double *tmp, int kb, int ke, hipStream_t st);
+hipError_t band_backward(const Band &b, double *x, double *tmp, int kgiven, hipStream_t st, int kstop = 0,
+                         bool resume = false);
 
 // pieces of the distributed band factorisation / sweeps (driven by dist.hip)
 hipError_t launch_potrf_block(double *abJ, long long lda, int k0, int *info, double *minpiv, double *inv16, hipStream_t st);

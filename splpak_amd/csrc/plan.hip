@@ -274,6 +274,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     p->hist = p->scalG + SC_COUNT;
     p->scalH = p->hist + g.ncol;
     p->rho = p->scalH + SC_COUNT;
+    twoend_attach(p);
     *plan = p;
     return 0;
 }
@@ -283,6 +284,7 @@ extern "C" {
 void splpak_plan_destroy(splpak_plan *p)
 {
     if (!p) return;
+    if (p->fn_destroy) p->fn_destroy(p->fn_user);
     band_pipeline_destroy(p->band.pipe);
     for (hipEvent_t e : p->evStage) if (e) (void)hipEventDestroy(e);
     for (void *q : p->owned) (void)hipFree(q);
@@ -421,7 +423,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     SPLPAK_HIP_TRY(hipMemsetAsync(p->info, 0, 2 * sizeof(int), st), SPLPAK_E_NODEVICE);
     SPLPAK_HIP_TRY(hipMemcpyAsync(p->small + 2, &inf, sizeof(double), hipMemcpyHostToDevice, st), SPLPAK_E_NODEVICE);
     stamp(4);
-    SPLPAK_HIP_TRY(launch_expand(g, p->nst, b, p->dm, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(p->expand_fn ? p->expand_fn(p, st, p->fn_user) : launch_expand(g, p->nst, b, p->dm, st), SPLPAK_E_NODEVICE);
     stamp(5);
     SPLPAK_HIP_TRY(p->factor_fn ? p->factor_fn(p, p->info, p->small + 2, st, p->fn_user) : band_cholesky(b, p->info, p->small + 2, st, &p->stats), SPLPAK_E_NODEVICE);
     int hinfo = 0;
@@ -883,6 +885,12 @@ int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double 
 {
     if (n < 1 || halfbw < 0 || !a_lower || !bvec || !x) { set_error("bad argument"); return SPLPAK_E_BADARG; }
     if (int r = device_ready()) return r;
+    if (std::getenv("SPLPAK_DEBUG_TWOEND")) {          // the two-ended factorisation (twoend.hip) on the same input
+        int hinfo = 0;
+        const int rc = twoend_debug_solve(n, halfbw, a_lower, bvec, x, &hinfo);
+        if (rc == 0) return hinfo != 0 ? 107 : 0;
+        if (rc != 1) { set_error("two-ended band solve failed"); return rc; }
+    }
     splpak_plan holder;
     Band b;
     band_bytes(n, halfbw, &b);

@@ -47,7 +47,10 @@ struct splpak_plan {
     // dist.hip installs the distributed versions (same contract as band_cholesky / band_solve)
     hipError_t (*factor_fn)(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStream_t st, void *user) = nullptr;
     hipError_t (*solve_fn)(splpak_plan *p, double *x, double *tmp, hipStream_t st, void *user) = nullptr;
+    // half stencil -> band storage, when the factorisation keeps its own (twoend.hip); NULL = launch_expand
+    hipError_t (*expand_fn)(splpak_plan *p, hipStream_t st, void *user) = nullptr;
     void *fn_user = nullptr;
+    void (*fn_destroy)(void *user) = nullptr;      // releases fn_user with the plan (NULL: not the plan's to release)
 };
 
 
@@ -60,4 +63,7 @@ int device_ready();
 int plan_create_dist(int ndim, const int *nodes, const double *xmin, const double *xmax, double xtrap,
                      long long max_ndata, void *comm_buf_dev, long long comm_len, int R, int r, int c,
                      splpak_plan **plan);
+// narrow bands on one GPU: install the two-ended factorisation (twoend.hip) when it shortens the chain
+void twoend_attach(splpak_plan *p);
+int twoend_debug_solve(int n, int halfbw, const double *a_lower, const double *bvec, double *x_out, int *hinfo_out);
 }  // namespace splpak

@@ -10,6 +10,9 @@ nd = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 nod = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
 dev = torch.device("cuda", 0)
+if os.environ.get("C2_OWN_STREAM"):            # a created (non-NULL) stream instead of the legacy default stream
+    _own = torch.cuda.Stream()
+    torch.cuda.set_stream(_own)
 st = torch.cuda.current_stream().cuda_stream
 x = torch.empty((m, nd), dtype=torch.float64, device=dev)
 y = torch.empty(m, dtype=torch.float64, device=dev)
