@@ -149,30 +149,40 @@ def spawn_ranks(n):
     return max(p.wait() for p in procs)
 
 
-def bench_c2(capi, dev, stream, steps):
-    """BASELINE config 2 (2-D, 1e6 scattered points, 64x64 nodes, equal weights = splcc), resident data."""
+def bench_small(capi, dev, stream, steps, nd, nod, m, weighted, label):
+    """A chain-bound (narrow-band) grid with resident data: BASELINE config 2 or the 32^3 grid VERDICT r01 names."""
     import torch
-    nd, nodes, m = 2, [64, 64], 1_000_000
+    nodes = [nod] * nd
     x = torch.empty((m, nd), dtype=torch.float64, device=dev)
     y = torch.empty(m, dtype=torch.float64, device=dev)
-    capi.synth_points_dev(nd, 0, m, x, y, None, stream)
-    coef = torch.zeros(64 * 64, dtype=torch.float64, device=dev)
+    w = torch.empty(m, dtype=torch.float64, device=dev) if weighted else None
+    capi.synth_points_dev(nd, 0, m, x, y, w, stream)
+    coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
     plan = capi.Plan(nd, nodes, [0.0] * nd, [1.0] * nd, 1.0, m)
     for _ in range(3):
-        ierr, info = plan.fit(x, y, None, coef, stream)
-        assert ierr == 0, f"C2 fit failed with ierror {ierr}"
+        ierr, info = plan.fit(x, y, w, coef, stream)
+        assert ierr == 0, f"{label} fit failed with ierror {ierr}"
     torch.cuda.synchronize()
     n = max(steps, 10)
     t0 = time.perf_counter()
+    phase = np.zeros(3)
     for _ in range(n):
-        ierr, info = plan.fit(x, y, None, coef, stream)
+        ierr, info = plan.fit(x, y, w, coef, stream)
+        phase += info[5:8]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     plan.close()
-    assert ierr == 0 and info[9] < 1e-9, f"C2: ierror {ierr}, optimality residual {info[9]:.2e}"
-    return {"workload": "C2: 2-D splcc fit, 1e6 scattered points (same stream), 64x64 nodes, xtrap=1, real64, resident data",
-            "value": m / dt, "unit": "points/s", "ms_per_fit": 1e3 * dt, "fits_timed": n,
+    assert ierr == 0 and info[9] < 1e-9, f"{label}: ierror {ierr}, optimality residual {info[9]:.2e}"
+    return {"workload": label, "value": m / dt, "unit": "points/s", "ms_per_fit": 1e3 * dt, "fits_timed": n,
+            "phase_ms": {"assembly": 1e3 * phase[0] / n, "factor": 1e3 * phase[1] / n, "solve_refine": 1e3 * phase[2] / n},
+            "factorisation": "two-ended band Cholesky (both ends eliminated concurrently, csrc/twoend.hip)",
             "refine_steps": int(info[2]), "optimality_residual": float(info[9])}
+
+
+def bench_c2(capi, dev, stream, steps):
+    """BASELINE config 2 (2-D, 1e6 scattered points, 64x64 nodes, equal weights = splcc), resident data."""
+    return bench_small(capi, dev, stream, steps, 2, 64, 1_000_000, False,
+                       "C2: 2-D splcc fit, 1e6 scattered points (same stream), 64x64 nodes, xtrap=1, real64, resident data")
 
 
 def bench_dist_band(capi, ngpus, nd, nod, m_total, virtual, steps):
@@ -505,6 +515,8 @@ def main():
             # rehearsal of the distributed-band path on this one GPU (2 virtual ranks, reduced size)
             line["dist_band"] = dist_band_in_child(2, nd, min(nod, 32), 1_000_000, True, args.steps, 180)
             line["c2"] = bench_c2(capi, dev, stream, args.steps)
+            line["grid32"] = bench_small(capi, dev, stream, args.steps, 3, 32, 1_000_000, True,
+                                         "3-D splcw fit, 1e6 weighted scattered points, 32x32x32 nodes, xtrap=1, real64, resident data")
             del xq, out
             torch.cuda.empty_cache()
             line["c5_eval"] = bench_c5_eval(capi, dev, stream)

@@ -300,11 +300,31 @@ potrf_strip_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
         }
         __syncthreads();
         STRIP_ACC(0);
+        // one 16x16 tile of the in-strip update by the panel at strip column ppc (first row below its leaf: pbase):
+        // tile column tc (strip column ppc+16+16 tc), tile row tr >= tc; an MFMA chain of K = 16 on LDS operands
+        auto tile_update = [&](int ppc, int pbase, int tc, int tr) {
+            const int scol = ppc + IB + 16 * tc;        // strip column of the tile's first column
+            const int crow = pbase + 16 * tc;           // block row that corresponds to that column
+            const int rrow = pbase + 16 * tr;
+            d4_t acc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = S[(scol + q + 4 * v) * SLD + rrow + l15];
+#pragma unroll
+            for (int s4 = 0; s4 < IB / 4; ++s4) {
+                const double av = -S[(ppc + 4 * s4 + q) * SLD + crow + l15];
+                const double bv = S[(ppc + 4 * s4 + q) * SLD + rrow + l15];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) S[(scol + q + 4 * v) * SLD + rrow + l15] = acc[v];
+        };
         for (int pc = 0; pc < SPW; pc += IB) {     // 16-column steps inside the strip
             const int d0 = c0 + pc;                // first row / column of the leaf (block relative)
             const int base = d0 + IB;              // first row below the leaf
             const int mrem = NBLK - base;
-            // (i) leaf: wave 0, one row per lane, columns broadcast with v_readlane
+            // (i) leaf: wave 0, one row per lane, columns broadcast with v_readlane.  Beside it waves 1..3 apply
+            // the PREVIOUS panel to the strip columns right of this panel (look-ahead: only this panel's own
+            // columns were updated before the leaf could start)
             if (wave == 0) {
                 const int r = l15;
                 double a[IB];
@@ -343,6 +363,16 @@ potrf_strip_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
                     if (bad) atomicCAS(info, 0, k0 + d0 + 1);
                     if (dmin < *minpiv || !(dmin == dmin)) *minpiv = dmin;
                 }
+            } else if (pc > 0) {
+                const int ppc = pc - IB, pbase = d0;           // the previous panel; the first row below its leaf is this leaf's
+                const int ntc = (SPW - ppc - IB) / 16, ntr = (NBLK - pbase) / 16;
+                int ntl = 0;                                    // tiles of the tile columns 1 .. ntc-1
+                for (int tc = 1; tc < ntc; ++tc) ntl += ntr - tc;
+                for (int t = wave - 1; t < ntl; t += 3) {
+                    int tc = 1, rem = t;
+                    while (rem >= ntr - tc) { rem -= ntr - tc; ++tc; }
+                    tile_update(ppc, pbase, tc, tc + rem);
+                }
             }
             __syncthreads();
             STRIP_ACC(1);
@@ -363,35 +393,13 @@ potrf_strip_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
             }
             __syncthreads();
             STRIP_ACC(2);
-            // (iii) the rest of the strip (columns pc+16 .. 63, rows from each tile column's diagonal down):
-            // 16x16 tiles in LDS, one MFMA chain of K = 16 each
-            {
-                const int ntc = (SPW - pc - IB) / 16;          // tile columns left in the strip
-                const int ntr = mrem / 16;                      // tile rows below the leaf
-                // tile (tc, tr), tr >= tc: strip column pc+16+16 tc, block row base + 16 tr
-                int ntl = 0;
-                for (int tc = 0; tc < ntc; ++tc) ntl += ntr - tc;
-                for (int t = wave; t < ntl; t += 4) {
-                    int tc = 0, rem = t;
-                    while (rem >= ntr - tc) { rem -= ntr - tc; ++tc; }
-                    const int tr = tc + rem;
-                    const int scol = pc + IB + 16 * tc;         // strip column of the tile's first column
-                    const int crow = base + 16 * tc;            // block row that corresponds to that column
-                    const int rrow = base + 16 * tr;
-                    d4_t acc;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[v] = S[(scol + q + 4 * v) * SLD + rrow + l15];
-#pragma unroll
-                    for (int s4 = 0; s4 < IB / 4; ++s4) {
-                        const double av = -S[(pc + 4 * s4 + q) * SLD + crow + l15];
-                        const double bv = S[(pc + 4 * s4 + q) * SLD + rrow + l15];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) S[(scol + q + 4 * v) * SLD + rrow + l15] = acc[v];
-                }
+            // (iii) the next panel's 16 columns (tile column 0) now, by all waves; the columns beyond them wait
+            // for the next leaf (above).  Every tile still receives its panels in the same order as before.
+            if (pc + IB < SPW) {
+                const int ntr = mrem / 16;
+                for (int t = wave; t < ntr; t += 4) tile_update(pc, base, 0, t);
+                __syncthreads();
             }
-            __syncthreads();
             STRIP_ACC(3);
         }
         // ---- the finished strip (64 columns of L) back to global: lower part only, one row per thread
@@ -745,7 +753,7 @@ __device__ inline unsigned my_cu_id()
     return ((xcc & 0xfu) << 16) | (hw & 0xff00u);
 }
 
-__global__ void whoami_kernel(unsigned *out) { if (threadIdx.x == 0) out[0] = my_cu_id(); }
+__global__ void whoami_kernel(unsigned *out) { if (threadIdx.x == 0 && out) out[0] = my_cu_id(); }
 
 // queue[0]: next item, queue[1]: waves that stepped aside.  A wave that finds itself on the
 // CU reserved for the panel factorisation (`reserved`, ~0u = none) steps aside without taking
