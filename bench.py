@@ -429,8 +429,18 @@ def main():
             plan.close()
             torch.cuda.empty_cache()
         barrier()
+        # the other ranks wait on the rendezvous store, not in a collective: an RCCL barrier would keep a kernel
+        # spinning on every GPU the child is about to drive
+        from datetime import timedelta
+        store = dist.distributed_c10d._get_default_store()
         if rank == 0:
-            dist_leg = dist_band_in_child(world, nd, nod, m, False, args.steps, 300)
+            try:
+                dist_leg = dist_band_in_child(world, nd, nod, m, bool(os.environ.get("SPLPAK_BENCH_SINGLE_DEVICE")),
+                                              args.steps, 300)
+            finally:
+                store.set("splpak_dist_leg_done", "1")
+        else:
+            store.wait(["splpak_dist_leg_done"], timedelta(seconds=600))
         barrier()
     if rank == 0:
         line = {

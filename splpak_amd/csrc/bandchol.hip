@@ -338,12 +338,15 @@ potrf_strip_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
                     const double d = readlane_f64(a[j], j);
                     bad = bad || !(d > 0.0);
                     dmin = fmin(dmin, d);
-                    // 1/sqrt(d) from the hardware estimate + two Newton steps, sqrt(d) = d * rs corrected once:
-                    // the sqrt and the division of the textbook form are ~55 instructions on the critical
-                    // path of every column, this is ~14 (results within an ulp of the correctly rounded ones)
+                    // 1/sqrt(d) from the hardware estimate + ONE third-order (Halley) step, sqrt(d) = d * rs corrected
+                    // once: the sqrt and the division of the textbook form are ~55 instructions on the critical
+                    // path of every column, two Newton steps 8 dependent ones, this is 4 (e = 1 - d rs^2 is ~2^-26
+                    // after v_rsq_f64, the step leaves e^3: results within an ulp of the correctly rounded ones)
                     double rs = __builtin_amdgcn_rsq(d);
-                    rs = rs * fma(-0.5 * d * rs, rs, 1.5);
-                    rs = rs * fma(-0.5 * d * rs, rs, 1.5);
+                    {
+                        const double e = fma(-d * rs, rs, 1.0);
+                        rs = fma(rs * e, fma(0.375, e, 0.5), rs);
+                    }
                     double sd = d * rs;
                     sd = fma(fma(-sd, sd, d), 0.5 * rs, sd);
                     if (r == j) rdiag = rs;
