@@ -62,7 +62,7 @@ extern "C" {
  *       computes, ~1e-14 when the fit is converged, ~cond(N) eps for plain normal equations.
  * The band-Cholesky solution is refined against the rows until the estimated remaining error
  * |dx|/|x| is below 1e-11 (2 steps at 64^3: corrections 9e-5, 1e-8, then an estimated 2e-12); a solve that is still contracting after the nominal
- * number of steps continues (up to 16), and one that then still misses 1e-10, or whose corrections
+ * number of steps continues (up to 30), and one that then still misses 1e-10, or whose corrections
  * stop contracting while above 1e-8, is reported as 107 ("suprls failure") with an explanatory
  * splpak_last_error_message -- never as a silent success. */
 int32_t splpak_fit_f64(int32_t ndim, const double *xdata, int32_t l1xdat,

@@ -305,7 +305,7 @@ void splpak_plan_set_refine(splpak_plan *p, int32_t max_steps, double tol)
 {
     if (!p) return;
     p->max_refine = max_steps < 0 ? 0 : max_steps;
-    p->max_refine_hard = p->max_refine == 0 ? 0 : (p->max_refine > 16 ? p->max_refine : 16);
+    p->max_refine_hard = p->max_refine == 0 ? 0 : (p->max_refine > 30 ? p->max_refine : 30);
     p->tol = tol;
 }
 
@@ -478,12 +478,15 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
             // linear convergence: after this step the error is ~ dx * ratio / (1 - ratio); stop as soon
             // as that estimate is below the tolerance instead of paying for one more solve
             ratio = last_rel / prev_rel;
-            if (ratio < 0.5 && last_rel * ratio / (1.0 - ratio) <= p->tol) { converged = true; break; }
-            if (ratio > 0.5) {                                // stagnation: fine at the rounding floor,
+            if (ratio < 0.9 && last_rel * ratio / (1.0 - ratio) <= p->tol) { converged = true; break; }
+            if (ratio >= 0.9) {                               // stagnation: fine at the rounding floor,
                 diverged = last_rel > 1e-8;                   // a failure if the corrections are still large
                 converged = !diverged;
                 break;
             }
+            // 0.5 .. 0.9: an ill-conditioned grid whose corrections still shrink -- go on (up to max_refine_hard):
+            // stopping here left 1-D grids of 2 000-3 000 nodes 1e-7 .. 1e-10 away from the converged solution
+            // (randomized sweep, tools/fuzz_parity.py big)
         }
         prev_rel = last_rel;
         if (it + 1 >= p->max_refine && it + 1 < p->max_refine_hard && std::getenv("SPLPAK_DEBUG"))

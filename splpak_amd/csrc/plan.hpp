@@ -30,7 +30,7 @@ struct splpak_plan {
     void *ar_user = nullptr;
     int rank = 0, world = 1;
     int max_refine = 4;           // nominal number of refinement steps; a solve that is still contracting goes on (max_refine_hard)
-    int max_refine_hard = 16;
+    int max_refine_hard = 30;
     double tol = 1e-11;           // on the ESTIMATED remaining error; the parity bar is 1e-10
     splpak::CholStats stats;
     // stage timing of the assembly and of one residual pass (HIP events on the fit's stream, kernel timing only)
