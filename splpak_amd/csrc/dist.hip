@@ -462,6 +462,7 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
         rc = plan_create_dist(ndim, nodes, xmin, xmax, xtrap, max_ndata_per_gpu, nullptr, 0, ngpus, r, mp->chunk, &m->p);
         if (rc != 0) break;
         splpak_plan *p = m->p;
+        twoend_detach(p);                 // (a one-rank plan may have chosen the two-ended single-GPU factorisation)
         p->ar = ar_callback;
         p->ar_user = m;
         p->rank = r;

@@ -65,5 +65,6 @@ int plan_create_dist(int ndim, const int *nodes, const double *xmin, const doubl
                      splpak_plan **plan);
 // narrow bands on one GPU: install the two-ended factorisation (twoend.hip) when it shortens the chain
 void twoend_attach(splpak_plan *p);
+void twoend_detach(splpak_plan *p);
 int twoend_debug_solve(int n, int halfbw, const double *a_lower, const double *bvec, double *x_out, int *hinfo_out);
 }  // namespace splpak

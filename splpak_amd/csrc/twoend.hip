@@ -300,6 +300,19 @@ void twoend_attach(splpak_plan *p)
     p->fn_destroy = te_destroy;
 }
 
+// another factorisation takes over the plan (the distributed band of dist.hip, also with one rank): release the
+// two-ended state and its hooks
+void twoend_detach(splpak_plan *p)
+{
+    if (p->fn_destroy != te_destroy) return;
+    te_destroy(p->fn_user);
+    p->expand_fn = nullptr;
+    p->factor_fn = nullptr;
+    p->solve_fn = nullptr;
+    p->fn_user = nullptr;
+    p->fn_destroy = nullptr;
+}
+
 // Dense-input debugging entry (splpak_debug_spd_band_solve_f64 with two ends): factor and solve an SPD band
 // matrix given as a dense lower triangle on the host.  1 = the matrix has too few blocks for two ends.
 int twoend_debug_solve(int n, int halfbw, const double *a_lower, const double *bvec, double *x_out, int *hinfo_out)

@@ -134,7 +134,8 @@ def test_sharded_fit_two_ranks_one_gpu(name):
 # ---------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,ngpus,chunk", [("3d12", 2, 1), ("3d12", 3, 2), ("2d64_c2grid", 4, 1), ("4d6", 2, 1),
-                                              ("3d8_cc_clust", 4, 1), ("2d16_zero_w", 3, 1), ("c1_1d16", 2, 1)])
+                                              ("3d8_cc_clust", 4, 1), ("2d16_zero_w", 3, 1), ("c1_1d16", 2, 1),
+                                              ("2d64_c2grid", 1, 1), ("3d12", 1, 2)])     # one rank: the distributed code on a plan that would otherwise be two-ended
 def test_distributed_band_fit_virtual_gpus(name, ngpus, chunk, monkeypatch):
     """splpak_fit_multi_f64 with every rank on the one GPU of the test box (SPLPAK_VIRTUAL_GPUS): point
     shards, rank-ordered reductions, block columns dealt to the ranks, panel hand-over, look-ahead and
