@@ -262,6 +262,76 @@ potrf_block_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
 constexpr int SPW = 64;                // strip width
 constexpr int SLD = NBLK + 16;         // LDS column stride of the strip image S[c*SLD + r]
 
+// The part of the diagonal block right of a finished 64-column strip: C -= S S^T with K = 64, C tiles in global
+// memory (lower part), operands from the LDS strip image S.  32x32 pieces per wave (2x2 MFMA tiles: four independent
+// accumulator chains, one LDS operand read per MFMA); the next piece's C values are in flight while the current one
+// is computed.  (16x16 pieces with one dependent chain of 16 MFMAs each took 44 us per block, 5x their MFMA time.)
+// Not inlined: its register allocation and scheduling stay apart from the latency-critical leaf / row-solve code.
+typedef const __attribute__((address_space(3))) double *lds_cptr;      // LDS pointer that survives a function boundary as ds_read
+__device__ __noinline__ void strip_trailing_update(double *__restrict__ A, long long lda, lds_cptr S,
+                                                    int c0, int wave, int l15, int q)
+{
+    const int base = c0 + SPW;
+    const int nt = (NBLK - base) / 32;
+    const int ntiles = nt * (nt + 1) / 2;
+    auto decode = [&](int t, int &roff, int &coff) {        // tile t -> column-major over the lower triangle
+        int ct = 0, rem = t;
+        while (rem >= nt - ct) { rem -= nt - ct; ++ct; }
+        coff = base + 32 * ct;
+        roff = base + 32 * (ct + rem);
+    };
+    auto cload = [&](int roff, int coff, d4_t (&cc)[2][2]) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    cc[mi][ni][v] = A[(roff + 16 * ni + l15) + (long long)(coff + 16 * mi + q + 4 * v) * lda];
+    };
+    d4_t cur[2][2], nxt[2][2];
+    int t = wave, roff = 0, coff = 0;
+    if (t < ntiles) {
+        decode(t, roff, coff);
+        cload(roff, coff, cur);
+    }
+    while (t < ntiles) {
+        const int tn = t + 4;
+        int rn = 0, cn = 0;
+        if (tn < ntiles) {
+            decode(tn, rn, cn);
+            cload(rn, cn, nxt);
+        }
+#pragma unroll 4
+        for (int s4 = 0; s4 < SPW / 4; ++s4) {
+            lds_cptr Sk = S + (4 * s4 + q) * SLD + l15;
+            const double a0 = -Sk[coff], a1 = -Sk[coff + 16];
+            const double b0 = Sk[roff], b1 = Sk[roff + 16];
+            cur[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, cur[0][0], 0, 0, 0);
+            cur[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, cur[0][1], 0, 0, 0);
+            cur[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, cur[1][0], 0, 0, 0);
+            cur[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, cur[1][1], 0, 0, 0);
+        }
+        const bool diag = roff == coff;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int rr = 16 * ni + l15, cc = 16 * mi + q + 4 * v;      // inside the 32x32 piece
+                    if (!diag || rr >= cc) A[(roff + rr) + (long long)(coff + cc) * lda] = cur[mi][ni][v];
+                }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) cur[mi][ni] = nxt[mi][ni];
+        t = tn;
+        roff = rn;
+        coff = cn;
+    }
+}
+
 #ifdef SPLPAK_POTRF_STAMPS        // tools/potrf_probe.hip: cycles of wave 0 per phase, summed over the kernel
 __device__ unsigned long long g_strip_cycles[8];
 #define STRIP_T0() unsigned long long st_last = __builtin_amdgcn_s_memtime()
@@ -385,6 +455,9 @@ potrf_strip_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
                 double x[IB];
 #pragma unroll
                 for (int c = 0; c < IB; ++c) x[c] = S[(pc + c) * SLD + row];
+                // (bound by the 136 broadcasts of leaf elements, not by the FMAs: the same time whether they are
+                // LDS broadcast reads as here, or v_readlane from a register copy of the leaf, column by column or
+                // right-looking -- measured; without the arithmetic the phase is 10x shorter)
 #pragma unroll
                 for (int c = 0; c < IB; ++c) {
 #pragma unroll
@@ -413,69 +486,8 @@ potrf_strip_kernel(double *__restrict__ ab, long long lda, int k0, int *__restri
             for (int c = 0; c <= cmax; ++c) rowp[(long long)c * lda] = S[c * SLD + c0 + tid];
         }
         STRIP_ACC(4);
-        // ---- the block right of the strip: C -= S S^T with K = 64, C tiles in global memory, lower part
-        {
-            const int base = c0 + SPW;
-            const int nt = (NBLK - base) / 16;
-            const int ntiles = nt * (nt + 1) / 2;
-            const unsigned voff = (unsigned)(l15 + (long long)q * lda) * 8u;
-            auto load_round = [&](int t0, d4_t (&cc)[PTB], int (&roff)[PTB], int (&coff)[PTB]) {
-                int ct = 0, rem = t0;               // tile t -> (ct, ct + rem), column-major over the lower triangle
-                while (ct < nt && rem >= nt - ct) { rem -= nt - ct; ++ct; }
-#pragma unroll
-                for (int u = 0; u < PTB; ++u) {
-                    roff[u] = -1;
-                    coff[u] = 0;
-                    if (t0 + u < ntiles) {
-                        roff[u] = base + 16 * (ct + rem);
-                        coff[u] = base + 16 * ct;
-                        const char *tile = reinterpret_cast<const char *>(A + roff[u] + (long long)coff[u] * lda);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            cc[u][v] = *reinterpret_cast<const double *>(tile + (long long)(4 * v) * lda * 8 + voff);
-                    }
-                    if (++rem >= nt - ct) { rem = 0; ++ct; }
-                }
-            };
-            auto compute_round = [&](d4_t (&cc)[PTB], int (&roff)[PTB], int (&coff)[PTB]) {
-#pragma unroll
-                for (int u = 0; u < PTB; ++u) {
-                    if (roff[u] < 0) continue;
-                    d4_t acc = cc[u];
-#pragma unroll
-                    for (int s4 = 0; s4 < SPW / 4; ++s4) {        // all 32 operand reads of the tile in flight
-                        const double av = -S[(4 * s4 + q) * SLD + coff[u] + l15];
-                        const double bv = S[(4 * s4 + q) * SLD + roff[u] + l15];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                    }
-                    char *tile = reinterpret_cast<char *>(A + roff[u] + (long long)coff[u] * lda);
-                    if (roff[u] != coff[u]) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            *reinterpret_cast<double *>(tile + (long long)(4 * v) * lda * 8 + voff) = acc[v];
-                    } else {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            if (l15 >= q + 4 * v)
-                                *reinterpret_cast<double *>(tile + (long long)(4 * v) * lda * 8 + voff) = acc[v];
-                    }
-                }
-            };
-            // the C tiles of the next round are in flight while the current one is computed
-            d4_t ccA[PTB], ccB[PTB];
-            int roA[PTB], coA[PTB], roB[PTB], coB[PTB];
-            int tA = wave * PTB;
-            if (tA < ntiles) load_round(tA, ccA, roA, coA);
-            while (tA < ntiles) {
-                const int tB = tA + 4 * PTB;
-                if (tB < ntiles) load_round(tB, ccB, roB, coB);
-                compute_round(ccA, roA, coA);
-                if (tB >= ntiles) break;
-                tA = tB + 4 * PTB;
-                if (tA < ntiles) load_round(tA, ccA, roA, coA);
-                compute_round(ccB, roB, coB);
-            }
-        }
+        // ---- the block right of the strip: C -= S S^T with K = 64 (strip_trailing_update above)
+        strip_trailing_update(A, lda, (lds_cptr)S, c0, wave, l15, q);
         __syncthreads();        // everybody is done with the strip (and its stores are issued) before it is replaced
         __threadfence_block();
         STRIP_ACC(5);

@@ -31,4 +31,8 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"{nd}-D {nod}^{nd} m={m}: {dt*1e3:.3f} ms per fit; phases {info[5]*1e3:.3f} / {info[6]*1e3:.3f} / {info[7]*1e3:.3f} ms; steps {info[2]:.0f} ierr {ierr}")
+if os.environ.get("C2_STAGES"):
+    plan.enable_kernel_timing(True)
+    plan.fit(x, y, ww, coef, st)
+    print("  stages (ms):", {k: round(v, 3) for k, v in plan.stage_timing().items()})
 plan.close()
