@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsplpak_hip.so")
+LIB_PATH = os.environ.get("SPLPAK_LIB") or os.path.join(_HERE, "libsplpak_hip.so")      # SPLPAK_LIB: another build of the same library (A/B measurements)
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
