@@ -355,8 +355,9 @@ bin_scatter_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int
     }
 }
 
+constexpr int EVAL_WG = 1024;          // threads per workgroup in pass C (value path): 16 waves share one 32 KB tile (A/B: 256 -> 512 threads +3 %, 1024 +5 %)
 template <int D, bool VAL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(EVAL_WG)
 eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coef,
                    const double *__restrict__ xs, long long ldp, const int *__restrict__ perm,
                    const int *__restrict__ off, const int *__restrict__ wgoff, double *__restrict__ out)
@@ -381,7 +382,7 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coe
             rr /= rg.nreg[d];
         }
     }
-    for (int e = threadIdx.x; e < TILE_ELEMS; e += 256) {
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += EVAL_WG) {
         int rem = e, idx = 0;
         bool ok = true;
 #pragma unroll
@@ -413,7 +414,7 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coe
 #pragma unroll
         for (int d = 0; d < D; ++d) x[d] = xn[d];
         const int p = pn;
-        const int jn = j + 256;
+        const int jn = j + EVAL_WG;
         if (jn < qe) {
 #pragma unroll
             for (int d = 0; d < D; ++d) xn[d] = xs[(long long)d * ldp + jn];
@@ -531,10 +532,10 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
             hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 2>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs, s.cap,
                                (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
         else if (value_only)
-            hipLaunchKernelGGL((eval_binned_kernel<D, true>), dim3(nw), dim3(256), 0, st, g, rg, nd, coef,
+            hipLaunchKernelGGL((eval_binned_kernel<D, true>), dim3(nw), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
                                (const double *)s.xs, s.cap, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
         else
-            hipLaunchKernelGGL((eval_binned_kernel<D, false>), dim3(nw), dim3(256), 0, st, g, rg, nd, coef,
+            hipLaunchKernelGGL((eval_binned_kernel<D, false>), dim3(nw), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
                                (const double *)s.xs, s.cap, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
     }
     (void)hipEventRecord(s.last, st);
