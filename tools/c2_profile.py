@@ -21,11 +21,11 @@ capi.synth_points_dev(nd, 0, m, x, y, w, st)
 coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
 plan = capi.Plan(nd, [nod] * nd, [0.0] * nd, [1.0] * nd, 1.0, m)
 ww = None if nd == 2 else w
-for _ in range(3):
+for _ in range(int(os.environ.get("C2_WARM", 3))):
     plan.fit(x, y, ww, coef, st)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n = 10
+n = int(os.environ.get("C2_REPS", 10))
 for _ in range(n):
     ierr, info = plan.fit(x, y, ww, coef, st)
 torch.cuda.synchronize()
