@@ -509,7 +509,7 @@ def main():
                 except Exception:
                     traffic = None
             line["roofline"] = {
-                "kernel": "syrk64_kernel<16,1,4> (bulk trailing update C -= P P^T of the band Cholesky, v_mfma_f64_16x16x4_f64; one launch per block step)",
+                "kernel": "syrk64_kernel<16,1,4,256> (bulk trailing update C -= P P^T of the band Cholesky, v_mfma_f64_16x16x4_f64; one launch per block step)",
                 "bound": "mfma", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "timed_launches": kt_sum["syrk_launches"], "launches": kt_sum["bulk_launches"],
