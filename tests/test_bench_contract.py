@@ -1,0 +1,56 @@
+"""The bench line the driver parses: the committed output of `python bench.py` on MI355X (profiles/r02_c3_bench.json)
+must carry the contract's keys, BASELINE.json's metric, a roofline object for the dominant kernel whose numbers are
+consistent with each other, and a CPU baseline -- checked on the CPU tier so that a change to bench.py that drops a
+key is caught before the GPU run."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    txt = open(os.path.join(ROOT, "profiles", "r02_c3_bench.json")).read().strip().splitlines()
+    lines = [ln for ln in txt if ln.startswith("{")]
+    assert len(lines) == 1, "bench.py prints ONE JSON line"
+    return json.loads(lines[0])
+
+
+def test_contract_keys_and_metric():
+    d = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    norm = lambda s: s.replace("³", "^3").replace(" ", "")
+    assert norm(d["metric"]) == norm(base["metric"])
+    assert d["unit"] == "points/s" and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = points of all ranks / time of the timed steps
+    pts = d["config"]["points_total"]
+    assert abs(d["value"] - pts / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["config"]["optimality_residual"] < 1e-9
+
+
+def test_roofline_object_is_consistent():
+    r = _line()["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # achieved = algorithmic flops per launch / average launch duration (HIP events inside the timed region)
+    assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert 0.3 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+
+
+def test_cpu_baseline_and_side_objects():
+    d = _line()
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+    assert d["eval"]["roofline"]["bound"] == "hbm" and 0 < d["eval"]["roofline"]["frac"] < 1
+    for k in ("c2", "grid32", "dist_band", "fit_incl_h2d", "c5_eval", "assembly"):
+        assert k in d, k
+    assert d["c2"]["optimality_residual"] < 1e-9 and d["grid32"]["optimality_residual"] < 1e-9
