@@ -436,11 +436,11 @@ def main():
         if rank == 0:
             try:
                 dist_leg = dist_band_in_child(world, nd, nod, m, bool(os.environ.get("SPLPAK_BENCH_SINGLE_DEVICE")),
-                                              args.steps, 300)
+                                              args.steps, 150)
             finally:
                 store.set("splpak_dist_leg_done", "1")
         else:
-            store.wait(["splpak_dist_leg_done"], timedelta(seconds=600))
+            store.wait(["splpak_dist_leg_done"], timedelta(seconds=400))
         barrier()
     if rank == 0:
         line = {
