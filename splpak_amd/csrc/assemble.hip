@@ -249,17 +249,17 @@ __device__ inline int local_col(const Grid &g, int colbase, int c)
 
 template <int D>
 struct GramCfg;
-template <> struct GramCfg<1> { static constexpr int NB = 4,   TR = 1, TC = 1, NTY = 4,  NTX = 4,  NT = 64,   PCH = 64; };
-template <> struct GramCfg<2> { static constexpr int NB = 16,  TR = 1, TC = 1, NTY = 16, NTX = 16, NT = 256,  PCH = 128; };
-template <> struct GramCfg<3> { static constexpr int NB = 64,  TR = 4, TC = 4, NTY = 16, NTX = 16, NT = 256,  PCH = 64; };
-template <> struct GramCfg<4> { static constexpr int NB = 256, TR = 4, TC = 4, NTY = 64, NTX = 16, NT = 1024, PCH = 16; };
+template <> struct GramCfg<1> { static constexpr int NB = 4,   TR = 1, TC = 1, NTY = 4,  NTX = 4,  NT = 64,   PCH = 64,  WPE = 1; };
+template <> struct GramCfg<2> { static constexpr int NB = 16,  TR = 1, TC = 1, NTY = 16, NTX = 16, NT = 256,  PCH = 128, WPE = 1; };
+template <> struct GramCfg<3> { static constexpr int NB = 64,  TR = 4, TC = 4, NTY = 16, NTX = 16, NT = 256,  PCH = 64,  WPE = 4; };
+template <> struct GramCfg<4> { static constexpr int NB = 256, TR = 4, TC = 4, NTY = 64, NTX = 16, NT = 1024, PCH = 16,  WPE = 1; };
 
 // scratch image of the per-cell blocks: [ncell][TRI] packed lower triangles (row-major: entry (r,c),
 // c <= r, at r(r+1)/2 + c), then [ncell][NB] right-hand sides, then [ncell][NB] histogram shares
 __host__ __device__ inline long long gram_tri(int nb) { return (long long)nb * (nb + 1) / 2; }
 
 template <int D>
-__global__ void __launch_bounds__(GramCfg<D>::NT)
+__global__ void __launch_bounds__(GramCfg<D>::NT, GramCfg<D>::WPE)
 gram_block_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
                   const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
                   double *__restrict__ blk, double *__restrict__ rblk, double *__restrict__ hblk,
@@ -274,8 +274,11 @@ gram_block_kernel(Grid g, const int *__restrict__ offset, const double *__restri
     const long long beg = offset[cell], end = offset[cell + 1];
     if (beg == end) return;                    // the gather skips empty cells
 
+    // (the point image doubles as the staging area of the packed triangle on the way out: at least TRI entries when
+    // one column pass covers the block)
+    constexpr int BWN = (C::NTX * TC >= NB && TRI > (long long)PCH * NB) ? (int)TRI : PCH * NB;
     __shared__ double tab[PCH * D * 4];
-    __shared__ double bw[PCH * NB];
+    __shared__ double bw[BWN];
     __shared__ double wy[PCH];
     __shared__ double wt[PCH];
     __shared__ int hslot[PCH];
@@ -319,7 +322,7 @@ gram_block_kernel(Grid g, const int *__restrict__ offset, const double *__restri
     }
 
     double *__restrict__ out = blk + (long long)(cell - cell0) * TRI;
-    if constexpr (TRI <= (long long)PCH * NB) {
+    if constexpr (TRI <= (long long)BWN) {
         // the packed triangle is assembled in LDS (the point image is no longer needed) and leaves with
         // consecutive lanes on consecutive addresses (the 4x4 register tiles written directly put 8 bytes
         // every 32; same kernel time at 64^3 -- the kernel is bound by its per-cell phases, not by the
