@@ -1966,6 +1966,33 @@ hipError_t band_cholesky_narrow(const Band &b, int *info_dev, double *minpiv_dev
     };
     (void)hipEventRecord(pl.evU[b.nblk], st);              // the chain starts after everything queued on the caller's stream
     if (sP != st) (void)hipStreamWaitEvent(sP, pl.evU[b.nblk], 0);
+    if (b.bw <= 1) {
+        // block tridiagonal (2-D grids up to 84 nodes in the fast dimension, every 1-D grid): the trailing window of a
+        // step IS block (k+1,k+1), so the chain is all there is -- three plain launches per step in stream order,
+        // no events and no hops to the other stream on the critical path
+        auto potrf_plain = [&](int k) {
+            hipLaunchKernelGGL(potrf_strip_kernel, dim3(1), dim3(256), 0, sP, b.ab, b.lda, k * NBLK, info_dev, minpiv_dev,
+                               b.inv64 + (long long)k * 4 * 64 * 64);
+        };
+        auto trsm_plain = [&](int k) {
+            const int k0 = k * NBLK, rows = tb_of(k) * NBLK;
+            if (rows > 0)
+                hipLaunchKernelGGL(trsm_kernel, dim3(rows / 16), dim3(64), 0, sP,
+                                   (const double *)(b.ab + (long long)k0 + (long long)k0 * b.lda),
+                                   b.ab + (long long)(k0 + NBLK) + (long long)k0 * b.lda, b.lda,
+                                   (const double *)(b.inv64 + (long long)k * 4 * 64 * 64), rows);
+        };
+        potrf_plain(kbeg);
+        trsm_plain(kbeg);
+        for (int k = kbeg; k < kend; ++k) {
+            if (tb_of(k) <= 0) continue;
+            hipLaunchKernelGGL(syrk32_kernel, dim3(36), dim3(64), 0, sP, b.ab, b.lda, k * NBLK, k * NBLK + NBLK, 8);
+            if (k + 1 < kend) {
+                potrf_plain(k + 1);
+                trsm_plain(k + 1);
+            }
+        }
+    } else {
     potrf(kbeg);
     trsm(sP, kbeg, 0, tb_of(kbeg) * NBLK, pl.evT[kbeg]);    // the first panel is solved whole on the chain
     (void)hipEventRecord(pl.evP[kbeg], sP);
@@ -1995,6 +2022,7 @@ hipError_t band_cholesky_narrow(const Band &b, int *info_dev, double *minpiv_dev
             if (sP != st) (void)hipStreamWaitEvent(st, pl.evT[k + 1], 0);
             (void)hipEventRecord(pl.evP[k + 1], st);
         }
+    }
     }
     if (sP != st) {                                         // join (the last step's diagonal update, when no panel followed)
         (void)hipEventRecord(pl.evR[0], sP);
