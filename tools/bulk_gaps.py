@@ -7,7 +7,7 @@ for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
 def short(nm):
-    if "syrk64_kernel<16, 1, 4" in nm: return "bulk"
+    if "syrk64_kernel<16, 1, 4" in nm or "syrk64_kernel<16, 1, 2052" in nm: return "bulk"
     if "syrk64_kernel<16, 1, 12" in nm: return "colpiece"
     for k in ("trsm", "potrf", "trtri", "sweepmat", "fwd_step", "bwd_step", "gram", "residual", "expand"):
         if k in nm: return k
