@@ -1666,8 +1666,7 @@ Pipeline &pipeline(void *&slot, int nblk, bool wide, bool want_res)
         // trailing-update waves are NOT masked (masked queues cost them ~8 %): a wave that finds
         // itself on the reserved CU steps aside (syrk64_kernel).  The CU's id is read back once.
         // (Only created for bands wide enough to use it: every stream is a hardware queue, and the
-        // two pipelines of a two-ended factorisation plus the caller's streams already fill the
-        // queue slots the device runs concurrently.)
+        // fewer of them a two-ended factorisation holds, the better its two chains overlap.)
         if (!std::getenv("SPLPAK_NO_PANEL_CU")) {
             hipDeviceProp_t prop;
             (void)hipGetDeviceProperties(&prop, dev);
@@ -1936,8 +1935,8 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
 //                                     the rows below block row k+2
 // One launch instead of three for the updates: with the chip idle all of its items run at once (one item time,
 // ~60 us), where topB / colU / bulk each cost that much one after the other.  Two streams instead of four:
-// two such factorisations run side by side (twoend.hip) within the four hardware queues that make progress
-// concurrently.  Same range arguments as band_cholesky.
+// two such factorisations run side by side (twoend.hip) on four hardware queues in all, which is what it took
+// for both chains to run at full speed (see pipeline()).  Same range arguments as band_cholesky.
 hipError_t band_cholesky_narrow(const Band &b, int *info_dev, double *minpiv_dev, hipStream_t st, int kbeg, int kend,
                                 int nfinish)
 {
