@@ -242,6 +242,17 @@ int32_t splpak_synth_queries_f64(int32_t ndim, int64_t ndata_before, int64_t fir
 int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double *a_lower,
                                         const double *b, double *x);
 
+/* Diagnostics (host only, no device needed): builds the nested-dissection elimination tree the fit uses for
+ * large 3-D / 4-D grids (csrc/ndtree.hpp; separators 3 nodes thick because the normal equations of the
+ * window rule src/splpak.F90:821-827 couple nodes up to 3 apart) and reports its size.  split_min <= 0: the
+ * library default; check != 0: verify the tree's invariants (slow on big grids).  out16:
+ *   [0] fronts  [1] depth  [2] bytes of factor panels  [3] bytes of the two Schur arenas  [4] bytes of all Schur
+ *   buffers of one fit  [5] flop of the blocked factorisation (padded)  [6] flop without padding  [7] largest
+ *   separator  [8] largest border  [9] 256x256 diagonal blocks  [10] local vector length  [11] own rows (padded)
+ *   [12] border rows (padded)  [13] bytes of the diagonal-block inverses.
+ * Returns 0, 101/102/103 (grid checks) or a negative SPLPAK_E_* code. */
+int32_t splpak_debug_nd_tree(int32_t ndim, const int32_t *nodes, int32_t split_min, int32_t check, double *out16);
+
 /* Releases the calling thread's internal HIP streams, events, queues and evaluation scratch
  * (created lazily and kept for reuse).  Optional; plans stay valid. */
 void splpak_shutdown(void);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "splpak_eval_dev_f64", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
     "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
-    "splpak_debug_spd_band_solve_f64", "splpak_shutdown", "splpak_set_eval_mode",
+    "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_shutdown", "splpak_set_eval_mode",
     "splpak_last_error_message", "splpak_device_name",
 ]
 
@@ -105,6 +105,8 @@ def lib() -> C.CDLL:
     L.splpak_synth_queries_f64.argtypes = [i32, i64, i64, i64, vp, vp]
     L.splpak_debug_spd_band_solve_f64.restype = i32
     L.splpak_debug_spd_band_solve_f64.argtypes = [i32, i32, _dp, _dp, _dp]
+    L.splpak_debug_nd_tree.restype = i32
+    L.splpak_debug_nd_tree.argtypes = [i32, _ip, i32, i32, _dp]
     L.splpak_mplan_create.restype = i32
     L.splpak_mplan_create.argtypes = [i32, _ip, i32, i32, _ip, _dp, _dp, dbl, i64, C.POINTER(vp)]
     L.splpak_mplan_destroy.restype = None
@@ -427,6 +429,21 @@ def synth_points_dev(ndim, first_point, ndata, xdata, ydata, wdata, stream=0):
 def synth_queries_dev(ndim, ndata_before, first_query, nq, xq, stream=0):
     return _check(lib().splpak_synth_queries_f64(ndim, int(ndata_before), int(first_query), int(nq),
                                                  xq.data_ptr(), C.c_void_p(stream)))
+
+
+ND_TREE_FIELDS = ("fronts", "depth", "factor_bytes", "arena_bytes", "schur_bytes_per_fit", "flop", "flop_exact",
+                  "max_separator", "max_border", "diag_blocks", "vec_len", "own_rows", "border_rows", "inverse_bytes")
+
+
+def debug_nd_tree(nodes, split_min=0, check=True):
+    """Host-only: size of the nested-dissection elimination tree the fit uses for large 3-D / 4-D grids
+    (csrc/ndtree.hpp), optionally with its invariants verified.  -> dict (ND_TREE_FIELDS)."""
+    nodes = np.ascontiguousarray(np.atleast_1d(nodes), dtype=np.int32)
+    out = np.zeros(16)
+    rc = _check(lib().splpak_debug_nd_tree(len(nodes), _p(nodes, _ip), int(split_min), 1 if check else 0, _p(out, _dp)))
+    if rc != 0:
+        raise SplpakError(f"grid rejected: {rc}")
+    return dict(zip(ND_TREE_FIELDS, out.tolist()))
 
 
 def debug_spd_band_solve(a_lower, halfbw, b):

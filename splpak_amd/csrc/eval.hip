@@ -454,6 +454,7 @@ struct EvalScratch {
     int *ints = nullptr;          // hist | off | cursor | wgoff
     int *cnt = nullptr;           // per-workgroup region counts / run bases
     long long cap = 0;            // queries per chunk the buffers hold
+    long long cnt_ints = 0;       // ints allocated for cnt (count matrix: workgroups of a chunk x regions of the grid)
     int capd = 0;
     hipEvent_t last = nullptr;    // end of the previous use (another stream must wait for it)
     int dev = -1;
@@ -497,23 +498,28 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
     EvalScratch &s = g_scratch;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (s.dev != dev || s.cap < chunk || s.capd < D) {
+    // row length of the count matrix for THIS chunk and dimension count, and what it needs for THIS grid's regions:
+    // the scratch is regrown when a later grid has more regions than the one it was sized for (round-2 advice:
+    // a 40^3 spline followed by a 64^3 one wrote past the allocation)
+    const int ldw = (int)(chunk / (256 * ScatterShape<D>::QPT) + 2);
+    const long long cnt_need = (long long)ldw * rg.nbins;
+    if (s.dev != dev || s.cap < chunk || s.capd < D || s.cnt_ints < cnt_need) {
         eval_scratch_shutdown();
         hipError_t e = hipMalloc(&s.xs, sizeof(double) * (size_t)chunk * D);
         if (e == hipSuccess) e = hipMalloc(&s.perm, sizeof(int) * (size_t)chunk);
         if (e == hipSuccess) e = hipMalloc(&s.ints, sizeof(int) * (4 * BIN_MAX + 8));
         // per-workgroup region counts of pass A -> run bases of pass B: [workgroups of a chunk][regions]
-        if (e == hipSuccess) e = hipMalloc(&s.cnt, sizeof(int) * (size_t)(chunk / (256 * ScatterShape<D>::QPT) + 2) * rg.nbins);
+        if (e == hipSuccess) e = hipMalloc(&s.cnt, sizeof(int) * (size_t)cnt_need);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.last, hipEventDisableTiming);
         if (e != hipSuccess) { eval_scratch_shutdown(); return e; }
         s.cap = chunk;
+        s.cnt_ints = cnt_need;
         s.capd = D;
         s.dev = dev;
     } else {
         (void)hipStreamWaitEvent(st, s.last, 0);
     }
     int *hist = s.ints, *off = hist + BIN_MAX, *cursor = off + BIN_MAX + 1, *wgoff = cursor + BIN_MAX;
-    const int ldw = (int)(s.cap / (256 * ScatterShape<D>::QPT) + 2);       // row length of the count matrix
     for (long long c0 = 0; c0 < nq; c0 += chunk) {
         const int n = (int)(nq - c0 < chunk ? nq - c0 : chunk);
         const double *xc = xq + c0 * ldxq;

@@ -1,0 +1,916 @@
+// Nested-dissection multifrontal Cholesky of the normal equations on gfx950.
+//
+// Replaces, for large 3-D / 4-D grids, the band factorisation of bandchol.hip -- and through it the dense
+// row-streaming Householder triangularisation + back-substitution of suprls (src/splpak.F90:1375-1695, called
+// from splcw :849, :1025, :1052) -- by a factorisation in the nested-dissection order of ndtree.hpp: 1.2e13
+// flop and 14 GB of factor at 64^3 nodes instead of 4.1e13 / 26.9 GB, 2.7e14 flop at 24^4 instead of 6.2e14.
+// The refinement against the rows (plan.hip) is unchanged, so the result is the same minimiser.
+//
+// Every front is a dense column-major PANEL (rows: own | border, columns: own, padded to 256 with identity)
+// and, while it is being eliminated, a dense Schur buffer S (border x border):
+//
+//     for the 256-column blocks k of the panel:   potrf(k) -> panel solve of all rows below -> update of the
+//         panel columns right of k (chain stream) ;  S -= L21_k L21_k^T (second stream, beside the chain of k+1)
+//     then S is added into the parent's panel / Schur buffer through the monotone child -> parent row map.
+//
+// Fronts of one tree depth are processed TOGETHER: every launch is a batch over job tables built once per plan
+// (potrf: a workgroup per front; panel solve: a wave per 16 rows; updates: a wave per 64x64x256 item on the f64
+// matrix cores, the register-streaming form of bandchol.hip's trailing update).  The two children of a parent
+// add their Schur complements in two launches (slot 0, then slot 1), so every sum has a fixed order: the
+// factor is bitwise reproducible from run to run.
+//
+// Solves walk the tree with per-front local vectors: forward bottom-up (gather the right-hand side, add the
+// children's border updates, y_k = Linv_k v_k and v_below -= L_below,k y_k per block), backward top-down (border
+// values from the parent, x_k = Linv_k^T (y_k - L_below,k^T x_below)), with explicit inverses of the 256x256
+// diagonal blocks as in bandchol.hip.
+#include "plan.hpp"
+#include "ndtree.hpp"
+#include "chol_device.hpp"
+#include <hip/hip_ext.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+
+namespace splpak {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// job tables (device PODs)
+struct PotrfJob { double *A; double *inv16; long long ld; int k0; int pad; };
+struct TrsmJob { const double *L; double *X; const double *inv16; long long ld; int nrows; int wg0; };
+// C(ti, tj) -= P_ti P_tj^T for the 64-row tiles tj in [0, nc), ti in [tj, nr); K = 256 columns of P
+struct SyrkJob { const double *P; double *C; long long ldp, ldc; int nc, nr; int item0; int pad; };
+struct TrinvJob { const double *L; const double *inv16; double *dinv; double *dinvt; long long ld; };
+// child's Schur buffer -> parent's panel (columns < wpp) / Schur buffer
+struct AddJob { const double *S; const int *pm; double *P; double *Sp; long long lds, ldp, ldsp; int h, nt, wpp, tile0; };
+struct MvJob { const double *M; const double *v; double *out; };
+struct FwdJob { const double *L; const double *y; double *v; long long ld; int nrows; int wg0; };
+struct DotJob { const double *L; const double *x; double *part; long long ld; int nrows; int nsplit; int rps; int wg0; };
+struct BwdJob { const double *Mt; const double *y; const double *part; double *x; int nsplit; int pad; };
+struct MapJob { double *child; double *par; const int *pm; int h; int pad; };
+struct FrontDev { long long panel_off, ld, bofs; int own0, w, wp, h; };
+
+constexpr int DOT_RPS = 1024;          // rows per split of the backward sweep's column dots
+
+// job of the flat workgroup / item index `b`: first[j] <= b < first[j + 1] (first = the wg0 / item0 / tile0 field)
+template <typename J, typename F>
+__device__ __forceinline__ int find_job(const J *__restrict__ jobs, int njobs, int b, F &&first)
+{
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first(jobs[mid]) <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// item -> (tj, ti) of a trapezoid of 64-row tiles stored column by column: column tj holds ti = tj .. nr-1
+__device__ __forceinline__ void trapezoid_decode(int it, int nr, int &tj, int &ti)
+{
+    const double b = 2.0 * nr + 1.0;
+    int c = (int)((b - sqrt(b * b - 8.0 * (double)it)) * 0.5);
+    if (c < 0) c = 0;
+    while (c > 0 && (long long)c * nr - (long long)c * (c - 1) / 2 > it) --c;
+    while ((long long)(c + 1) * nr - (long long)(c + 1) * c / 2 <= it) ++c;
+    tj = c;
+    ti = c + it - (int)((long long)c * nr - (long long)c * (c - 1) / 2);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+nd_potrf_kernel(const PotrfJob *__restrict__ jobs, int *__restrict__ info, double *__restrict__ minpiv)
+{
+    const PotrfJob j = jobs[blockIdx.x];
+    potrf_strip_body(j.A, j.ld, j.k0, info, minpiv, j.inv16);
+}
+
+__global__ void __launch_bounds__(64)
+nd_trsm_kernel(const TrsmJob *__restrict__ jobs, int njobs)
+{
+    __shared__ double xs[(NBLK - 16) * 16];
+    const int b = blockIdx.x;
+    const int ji = find_job(jobs, njobs, b, [](const TrsmJob &t) { return t.wg0; });
+    const TrsmJob j = jobs[ji];
+    const int r0 = (b - j.wg0) * 16;
+    if (r0 >= j.nrows) return;
+    __builtin_amdgcn_s_setprio(3);
+    trsm_rows<false>(j.L, j.X, j.ld, j.ld, j.inv16, nullptr, r0, xs);
+}
+
+__global__ void __launch_bounds__(64)
+nd_trinv_kernel(const TrinvJob *__restrict__ jobs)
+{
+    __shared__ double xs[(NBLK - 16) * 16];
+    const TrinvJob j = jobs[blockIdx.y];
+    trsm_rows<true>(j.L, j.dinv, j.ld, NBLK, j.inv16, j.dinvt, blockIdx.x * 16, xs);
+}
+
+// The trailing update of the multifrontal factorisation: one wave = one 64x64 item of C -= P_i P_j^T with
+// K = 256, in the register-streaming form of bandchol.hip's syrk64_kernel (operands loaded in MFMA fragment
+// shape SD k-steps ahead into a register queue, 16 independent v_mfma_f64_16x16x4_f64 accumulators that start
+// as the C tile; no LDS, no barriers).  P and C have their own base pointers and leading dimensions: P is a
+// block column of a front's panel, C the panel right of it or the front's Schur buffer.  This kernel carries
+// ~97 % of the flops of a large fit and is the roofline kernel of bench.py.
+template <int SD, int WPS>
+__global__ void __launch_bounds__(64, WPS)
+nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs)
+{
+    const int b = blockIdx.x;
+    const int ji = find_job(jobs, njobs, b, [](const SyrkJob &t) { return t.item0; });
+    const SyrkJob j = jobs[ji];
+    int tj, ti;
+    trapezoid_decode(b - j.item0, j.nr, tj, ti);
+    if (tj >= j.nc || ti >= j.nr) return;
+    const bool diag = ti == tj;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
+    const double *__restrict__ pJ = j.P + (long long)(tj * 64 + l15) + (long long)q * j.ldp;
+    const double *__restrict__ pI = j.P + (long long)(ti * 64 + l15) + (long long)q * j.ldp;
+    double *__restrict__ C = j.C + (long long)(ti * 64) + (long long)(tj * 64) * j.ldc;
+    const long long ldp = j.ldp, ldc = j.ldc;
+    d4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                acc[m][n][v] = __builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * ldc]);
+    double qa[SD][4], qb[SD][4];
+    auto fetch = [&](int slot, int step) {
+        const long long off = (long long)(4 * step) * ldp;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            qa[slot][m] = -pJ[off + 16 * m];
+            qb[slot][m] = pI[off + 16 * m];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < SD; ++d) fetch(d, d);
+    constexpr int NSTEP = NBLK / 4;
+    static_assert(NSTEP % SD == 0, "queue depth must divide the k-steps");
+    for (int ks = 0; ks < NSTEP; ks += SD) {
+#pragma unroll
+        for (int d = 0; d < SD; ++d) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+            if (ks + d + SD < NSTEP) fetch(d, ks + d + SD);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int r = n * 16 + l15;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c = m * 16 + q + 4 * v;
+                if (!diag || r >= c) __builtin_nontemporal_store(acc[m][n][v], &C[r + (long long)c * ldc]);
+            }
+        }
+}
+
+// half stencil -> panels: entry (i, j) of N, j <= i in the natural order, belongs to the front that owns the
+// earlier eliminated of the two nodes, at the row of the other one (own row, or border row found by bisection
+// of the front's ascending border positions)
+template <int D>
+__global__ void __launch_bounds__(256)
+nd_assemble_kernel(Grid g, const double *__restrict__ nst, const int *__restrict__ pos, const int *__restrict__ front_of,
+                   const FrontDev *__restrict__ fd, const int *__restrict__ bpos, double *__restrict__ factor)
+{
+    const long long total = (long long)g.ncol * g.hstencil;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int i = (int)(t / g.hstencil);
+        int code = (int)(t % g.hstencil);
+        int j = i;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int o = (code % 7) - 3;
+            code /= 7;
+            const int id = (i / g.colstride[d]) % g.nodes[d];
+            const int jd = id + o;
+            if (jd < 0 || jd > g.nodes[d] - 1) ok = false;
+            j += o * g.colstride[d];
+        }
+        if (!ok) continue;
+        const int pi = pos[i], pj = pos[j];
+        const int c = pi < pj ? i : j;
+        const int pc = pi < pj ? pi : pj, pr = pi < pj ? pj : pi;
+        const FrontDev f = fd[front_of[c]];
+        const int col = pc - f.own0;
+        int row;
+        if (pr < f.own0 + f.w) row = pr - f.own0;
+        else {
+            const int *__restrict__ bp = bpos + f.bofs;
+            int lo = 0, hi = f.h - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (bp[mid] < pr) lo = mid + 1;
+                else hi = mid;
+            }
+            row = f.wp + lo;
+        }
+        factor[f.panel_off + row + (long long)col * f.ld] = nst[t];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+nd_pad_diag_kernel(const long long *__restrict__ where, int n, double *__restrict__ factor)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) factor[where[i]] = 1.0;
+}
+
+// Schur buffer of a child -> its parent: workgroup = one 64x64 tile of the child's lower triangle
+__global__ void __launch_bounds__(256)
+nd_extend_add_kernel(const AddJob *__restrict__ jobs, int njobs)
+{
+    __shared__ int pr[64], pc[64];
+    const int b = blockIdx.x;
+    const int ji = find_job(jobs, njobs, b, [](const AddJob &t) { return t.tile0; });
+    const AddJob j = jobs[ji];
+    int tj, ti;
+    trapezoid_decode(b - j.tile0, j.nt, tj, ti);
+    if (tj >= j.nt || ti >= j.nt) return;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int r = ti * 64 + tid;
+        pr[tid] = r < j.h ? j.pm[r] : -1;
+    } else if (tid < 128) {
+        const int c = tj * 64 + tid - 64;
+        pc[tid - 64] = c < j.h ? j.pm[c] : -1;
+    }
+    __syncthreads();
+    const int r = tid & 63;
+    const int prow = pr[r];
+    if (prow < 0) return;
+    const double *__restrict__ S = j.S + (long long)(ti * 64 + r) + (long long)(tj * 64) * j.lds;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const int c = (tid >> 6) + 4 * u;
+        const int pcol = pc[c];
+        if (pcol < 0 || (ti == tj && r < c)) continue;
+        const double v = S[(long long)c * j.lds];
+        double *dst = pcol < j.wpp ? j.P + prow + (long long)pcol * j.ldp
+                                   : j.Sp + (prow - j.wpp) + (long long)(pcol - j.wpp) * j.ldsp;
+        *dst += v;
+    }
+}
+
+// ---- solves ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+nd_gather_kernel(long long n, const int *__restrict__ rowsrc, const double *__restrict__ b, double *__restrict__ V)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int s = rowsrc[i];
+        V[i] = s >= 0 ? b[s] : 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+nd_scatter_kernel(long long n, const int *__restrict__ rowsrc, const double *__restrict__ V, double *__restrict__ x)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int s = rowsrc[i];
+        if (s >= 0) x[s] = V[i];
+    }
+}
+
+// forward: parent rows += the child's border updates; backward: the child's border values = parent rows
+template <bool TAKE>
+__global__ void __launch_bounds__(256)
+nd_map_kernel(const MapJob *__restrict__ jobs)
+{
+    const MapJob j = jobs[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j.h; i += gridDim.x * blockDim.x) {
+        const int r = j.pm[i];
+        if (TAKE) j.child[i] = j.par[r];
+        else j.par[r] += j.child[i];
+    }
+}
+
+// out = M v for row-major 256x256 blocks; grid (16, jobs) x 256 threads: a wave dots 4 rows
+__global__ void __launch_bounds__(256)
+nd_mv_kernel(const MvJob *__restrict__ jobs)
+{
+    const MvJob j = jobs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 16 + wave * 4;
+    double vv[4], s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vv[u] = j.v[lane + 64 * u];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s[i] = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[i] += j.M[(r0 + i) * NBLK + lane + 64 * u] * vv[u];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) j.out[r0 + i] = s[i];
+    }
+}
+
+// v[rows below] -= L[rows, block] y: workgroup = 64 rows x 256 columns, 512 threads = 32 row pairs x 16 column groups
+__global__ void __launch_bounds__(512)
+nd_fwd_kernel(const FwdJob *__restrict__ jobs, int njobs)
+{
+    __shared__ double sy[NBLK];
+    __shared__ double part[16][64];
+    const int b = blockIdx.x;
+    const int ji = find_job(jobs, njobs, b, [](const FwdJob &t) { return t.wg0; });
+    const FwdJob j = jobs[ji];
+    const int wg = b - j.wg0;
+    if (wg * 64 >= j.nrows) return;
+    const int tid = threadIdx.x;
+    if (tid < NBLK) sy[tid] = j.y[tid];
+    __syncthreads();
+    const int rp = tid & 31, cg = tid >> 5;
+    const int r = wg * 64 + 2 * rp;
+    const double *__restrict__ Lr = j.L + r + (long long)(cg * 16) * j.ld;
+    d2_t l[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) l[c] = *reinterpret_cast<const d2_t *>(Lr + (long long)c * j.ld);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const double yv = sy[cg * 16 + c];
+        s0 += l[c][0] * yv;
+        s1 += l[c][1] * yv;
+    }
+    part[cg][2 * rp] = s0;
+    part[cg][2 * rp + 1] = s1;
+    __syncthreads();
+    if (tid < 64) {
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += part[g][tid];
+        j.v[wg * 64 + tid] -= s;
+    }
+}
+
+// part[split][c] = sum over the rows of the split of L[r, c] x[r]; workgroup = (16 columns, split), a wave takes 4 columns
+__global__ void __launch_bounds__(256)
+nd_dot_kernel(const DotJob *__restrict__ jobs, int njobs)
+{
+    const int b = blockIdx.x;
+    const int ji = find_job(jobs, njobs, b, [](const DotJob &t) { return t.wg0; });
+    const DotJob j = jobs[ji];
+    const int lw = b - j.wg0;
+    const int cg = lw & 15, split = lw >> 4;
+    if (split >= j.nsplit) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = cg * 16 + wave * 4;
+    const int rbeg = split * j.rps;
+    const int rend = rbeg + j.rps < j.nrows ? rbeg + j.rps : j.nrows;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const double *__restrict__ Lc = j.L + lane + (long long)c0 * j.ld;
+    for (int r = rbeg; r < rend; r += 64) {
+        const double xr = j.x[r + lane];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += Lc[r + (long long)c * j.ld] * xr;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = wave_sum(acc[c]);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) j.part[(long long)split * NBLK + c0 + c] = acc[c];
+    }
+}
+
+// x_k = Linv_k^T (y_k - sum_split part[split]); grid (16, jobs) x 256 threads
+__global__ void __launch_bounds__(256)
+nd_bwd_kernel(const BwdJob *__restrict__ jobs)
+{
+    const BwdJob j = jobs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 16 + wave * 4;
+    double vv[4], s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        double v = j.y[lane + 64 * u];
+        for (int sp = 0; sp < j.nsplit; ++sp) v -= j.part[(long long)sp * NBLK + lane + 64 * u];
+        vv[u] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s[i] = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[i] += j.Mt[(r0 + i) * NBLK + lane + 64 * u] * vv[u];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) j.x[r0 + i] = s[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+struct Launch { int first = 0, count = 0; unsigned grid = 0; double flop = 0; };
+
+template <typename J>
+struct JobTable {
+    std::vector<J> host;
+    J *dev = nullptr;
+};
+
+struct NdState {
+    NdTree t;
+    int device = 0;
+    // arenas
+    double *factor = nullptr, *sar[2] = {nullptr, nullptr}, *dinv = nullptr, *dinvt = nullptr, *inv16 = nullptr;
+    double *V = nullptr, *Y = nullptr, *part = nullptr;
+    long long part_cap = 0;                        // doubles of the backward sweep's partial sums (one launch at a time)
+    int *pos = nullptr, *front_of = nullptr, *bpos = nullptr, *pmap = nullptr, *rowsrc = nullptr;
+    long long *padwhere = nullptr;
+    int npad = 0;
+    FrontDev *fdev = nullptr;
+    std::vector<long long> s_depth_doubles;         // Schur doubles of every depth (a prefix of its arena)
+    // job tables; launches indexed [depth][step]
+    JobTable<PotrfJob> potrf;
+    JobTable<TrsmJob> trsm;
+    JobTable<SyrkJob> upd, schur;
+    JobTable<TrinvJob> trinv;
+    JobTable<AddJob> add;
+    JobTable<MvJob> mv;
+    JobTable<FwdJob> fwd;
+    JobTable<DotJob> dot;
+    JobTable<BwdJob> bwd;
+    JobTable<MapJob> map;
+    std::vector<std::vector<Launch>> l_potrf, l_trsm, l_upd, l_schur, l_mv, l_fwd, l_dot, l_bwd;
+    std::vector<Launch> l_add[2], l_mapslot[2], l_mapall;     // per depth (of the children)
+    // streams / events
+    hipStream_t sP = nullptr, sU = nullptr, sZ = nullptr;
+    std::vector<hipEvent_t> evT;                   // panel of step k solved (per step of the current depth)
+    std::vector<hipEvent_t> evE, evZ;              // depth consumed / depth zeroed
+    hipEvent_t ev0 = nullptr, evJ = nullptr, evU = nullptr, evZlast = nullptr, evDone = nullptr;
+    bool zlast_valid = false, used = false;
+    bool s_clean = false;                          // the Schur buffers of the two deepest levels are zero
+    std::vector<hipEvent_t> evA, evB;              // start / stop of the timed update launches
+    hipEvent_t f0 = nullptr, f1 = nullptr;
+    std::vector<void *> owned;
+};
+
+template <typename T>
+bool nd_alloc(NdState *s, T **ptr, size_t count)
+{
+    void *q = nullptr;
+    if (count == 0) count = 1;
+    if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) {
+        (void)hipGetLastError();
+        char buf[160];
+        snprintf(buf, sizeof buf, "nested dissection: hipMalloc of %.3f GB failed", (double)(count * sizeof(T)) / 1e9);
+        set_error(buf);
+        return false;
+    }
+    s->owned.push_back(q);
+    *ptr = static_cast<T *>(q);
+    return true;
+}
+
+template <typename T>
+bool nd_upload(NdState *s, T **dev, const std::vector<T> &host)
+{
+    if (!nd_alloc(s, dev, host.size())) return false;
+    if (host.empty()) return true;
+    return hip_ok(hipMemcpy(*dev, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice), "nested dissection: table upload");
+}
+
+void nd_destroy(void *user)
+{
+    NdState *s = static_cast<NdState *>(user);
+    if (!s) return;
+    (void)hipDeviceSynchronize();
+    for (hipStream_t *q : {&s->sP, &s->sU, &s->sZ}) if (*q) (void)hipStreamDestroy(*q);
+    for (auto *v : {&s->evT, &s->evE, &s->evZ, &s->evA, &s->evB})
+        for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->f0, s->f1}) if (e) (void)hipEventDestroy(e);
+    for (void *q : s->owned) (void)hipFree(q);
+    delete s;
+}
+
+long long trapezoid_items(long long nc, long long nr) { return nc * nr - nc * (nc - 1) / 2; }
+
+// builds every job table from the tree and the arena pointers
+bool nd_build_jobs(NdState *s)
+{
+    NdTree &t = s->t;
+    const int nd = t.maxdepth + 1;
+    int maxsteps = 0;
+    for (const NdFront &f : t.fr) maxsteps = std::max(maxsteps, f.nsteps);
+    for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_upd, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) L->assign((size_t)nd, {});
+    for (int sl = 0; sl < 2; ++sl) { s->l_add[sl].assign((size_t)nd, Launch()); s->l_mapslot[sl].assign((size_t)nd, Launch()); }
+    s->l_mapall.assign((size_t)nd, Launch());
+    long long part_max = 0;
+    for (int d = 0; d < nd; ++d) {
+        const std::vector<int> &ids = t.by_depth[(size_t)d];
+        int steps = 0;
+        for (int id : ids) steps = std::max(steps, t.fr[(size_t)id].nsteps);
+        for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_upd, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) (*L)[(size_t)d].assign((size_t)steps, Launch());
+        for (int k = 0; k < steps; ++k) {
+            Launch lp, lt, lu, ls, lm, lf, ld, lb;
+            lp.first = (int)s->potrf.host.size();
+            lt.first = (int)s->trsm.host.size();
+            lu.first = (int)s->upd.host.size();
+            ls.first = (int)s->schur.host.size();
+            lm.first = (int)s->mv.host.size();
+            lf.first = (int)s->fwd.host.size();
+            ld.first = (int)s->dot.host.size();
+            lb.first = (int)s->bwd.host.size();
+            long long twg = 0, ui = 0, si = 0, fwg = 0, dwg = 0, partofs = 0;
+            for (int id : ids) {
+                const NdFront &f = t.fr[(size_t)id];
+                if (k >= f.nsteps) continue;
+                double *panel = s->factor + f.panel_off;
+                double *diag = panel + (long long)k * 256 + (long long)k * 256 * f.ld;
+                double *below = diag + 256;
+                const int nrows = f.fp - (k + 1) * 256;
+                double *i16 = s->inv16 + (long long)(f.blk0 + k) * 4096;
+                s->potrf.host.push_back(PotrfJob{diag, i16, f.ld, f.own0 + k * 256, 0});
+                ++lp.count;
+                if (nrows > 0) {
+                    s->trsm.host.push_back(TrsmJob{diag, below, i16, f.ld, nrows, (int)twg});
+                    twg += nrows / 16;
+                    ++lt.count;
+                }
+                const int nc = (f.wp - (k + 1) * 256) / 64, nr = nrows / 64;
+                if (nc > 0) {
+                    // panel columns right of block k: rows and columns relative to row (k+1)*256
+                    s->upd.host.push_back(SyrkJob{below, below + (long long)256 * f.ld, f.ld, f.ld, nc, nr, (int)ui, 0});
+                    ui += trapezoid_items(nc, nr);
+                    ++lu.count;
+                }
+                const int ns = f.hp / 64;
+                if (ns > 0) {
+                    s->schur.host.push_back(SyrkJob{panel + f.wp + (long long)k * 256 * f.ld, s->sar[f.depth & 1] + f.s_off, f.ld,
+                                                    f.lds, ns, ns, (int)si, 0});
+                    si += trapezoid_items(ns, ns);
+                    ++ls.count;
+                }
+                // solves
+                double *Vf = s->V + f.vofs, *Yf = s->Y + f.vofs;
+                s->mv.host.push_back(MvJob{s->dinv + (long long)(f.blk0 + k) * 65536, Vf + k * 256, Yf + k * 256});
+                ++lm.count;
+                int nsplit = 0;
+                double *partp = s->part + partofs;
+                if (nrows > 0) {
+                    s->fwd.host.push_back(FwdJob{below, Yf + k * 256, Vf + (k + 1) * 256, f.ld, nrows, (int)fwg});
+                    fwg += nrows / 64;
+                    ++lf.count;
+                    nsplit = (nrows + DOT_RPS - 1) / DOT_RPS;
+                    s->dot.host.push_back(DotJob{below, Vf + (k + 1) * 256, partp, f.ld, nrows, nsplit, DOT_RPS, (int)dwg});
+                    dwg += 16 * nsplit;
+                    partofs += (long long)nsplit * 256;
+                    ++ld.count;
+                }
+                s->bwd.host.push_back(BwdJob{s->dinvt + (long long)(f.blk0 + k) * 65536, Yf + k * 256, partp, Vf + k * 256, nsplit, 0});
+                ++lb.count;
+            }
+            if (twg > 0x7fffffffLL || ui > 0x7fffffffLL || si > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+            part_max = std::max(part_max, partofs);
+            lp.grid = (unsigned)lp.count;
+            lt.grid = (unsigned)twg;
+            lu.grid = (unsigned)ui;
+            lu.flop = 2.0 * 64 * 64 * 256 * (double)ui;
+            ls.grid = (unsigned)si;
+            ls.flop = 2.0 * 64 * 64 * 256 * (double)si;
+            lm.grid = (unsigned)lm.count;
+            lf.grid = (unsigned)fwg;
+            ld.grid = (unsigned)dwg;
+            lb.grid = (unsigned)lb.count;
+            // sentinels for the job search (first field of the element after the last job)
+            if (lt.count) s->trsm.host.push_back(TrsmJob{nullptr, nullptr, nullptr, 0, 0, (int)twg});
+            if (lu.count) s->upd.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)ui, 0});
+            if (ls.count) s->schur.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)si, 0});
+            if (lf.count) s->fwd.host.push_back(FwdJob{nullptr, nullptr, nullptr, 0, 0, (int)fwg});
+            if (ld.count) s->dot.host.push_back(DotJob{nullptr, nullptr, nullptr, 0, 0, 0, 0, (int)dwg});
+            s->l_potrf[(size_t)d][(size_t)k] = lp;
+            s->l_trsm[(size_t)d][(size_t)k] = lt;
+            s->l_upd[(size_t)d][(size_t)k] = lu;
+            s->l_schur[(size_t)d][(size_t)k] = ls;
+            s->l_mv[(size_t)d][(size_t)k] = lm;
+            s->l_fwd[(size_t)d][(size_t)k] = lf;
+            s->l_dot[(size_t)d][(size_t)k] = ld;
+            s->l_bwd[(size_t)d][(size_t)k] = lb;
+        }
+        // children at depth d -> parents at depth d - 1
+        if (d >= 1) {
+            for (int sl = 0; sl < 2; ++sl) {
+                Launch la, lmj;
+                la.first = (int)s->add.host.size();
+                lmj.first = (int)s->map.host.size();
+                long long tiles = 0;
+                for (int id : ids) {
+                    const NdFront &f = t.fr[(size_t)id];
+                    if (f.slot != sl || f.h == 0) continue;
+                    const NdFront &p = t.fr[(size_t)f.parent];
+                    const int nt = f.hp / 64;
+                    s->add.host.push_back(AddJob{s->sar[f.depth & 1] + f.s_off, s->pmap + f.bofs, s->factor + p.panel_off,
+                                                 p.hp > 0 ? s->sar[p.depth & 1] + p.s_off : nullptr, f.lds, p.ld, p.lds, f.h, nt, p.wp,
+                                                 (int)tiles});
+                    tiles += trapezoid_items(nt, nt);
+                    ++la.count;
+                    s->map.host.push_back(MapJob{s->V + f.vofs + f.wp, s->V + p.vofs, s->pmap + f.bofs, f.h, 0});
+                    ++lmj.count;
+                }
+                if (tiles > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+                la.grid = (unsigned)tiles;
+                lmj.grid = (unsigned)lmj.count;
+                if (la.count) s->add.host.push_back(AddJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, (int)tiles});
+                s->l_add[sl][(size_t)d] = la;
+                s->l_mapslot[sl][(size_t)d] = lmj;
+            }
+            // backward: both slots at once = the two consecutive runs of map jobs
+            Launch all;
+            all.first = s->l_mapslot[0][(size_t)d].first;
+            all.count = s->l_mapslot[0][(size_t)d].count + s->l_mapslot[1][(size_t)d].count;
+            all.grid = (unsigned)all.count;
+            s->l_mapall[(size_t)d] = all;
+        }
+    }
+    for (const NdFront &f : t.fr)
+        for (int k = 0; k < f.nsteps; ++k) {
+            const double *diag = s->factor + f.panel_off + (long long)k * 256 + (long long)k * 256 * f.ld;
+            s->trinv.host.push_back(TrinvJob{diag, s->inv16 + (long long)(f.blk0 + k) * 4096, s->dinv + (long long)(f.blk0 + k) * 65536,
+                                             s->dinvt + (long long)(f.blk0 + k) * 65536, f.ld});
+        }
+    (void)maxsteps;
+    return part_max <= s->part_cap;
+}
+
+void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipStream_t st, CholStats *stats, bool timing)
+{
+    if (l.count == 0 || l.grid == 0) return;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (timing) {
+        const size_t i = (size_t)stats->syrk_launches;
+        while (s->evA.size() <= i) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            s->evA.push_back(e);
+            (void)hipEventCreate(&e);
+            s->evB.push_back(e);
+        }
+        a = s->evA[i];
+        b = s->evB[i];
+        stats->syrk_launches += 1;
+        stats->syrk_flop += l.flop;
+    }
+    if (stats) {
+        stats->total_flop += l.flop;
+        stats->bulk_launches += 1;
+        stats->bulk_flop += l.flop;
+    }
+    hipExtLaunchKernelGGL((nd_syrk_kernel<16, 1>), dim3(l.grid), dim3(64), 0, st, a, b, 0, (const SyrkJob *)(tab.dev + l.first), l.count);
+}
+
+hipError_t nd_assemble(splpak_plan *p, hipStream_t st, void *user)
+{
+    NdState *s = static_cast<NdState *>(user);
+    const Grid &g = p->g;
+    hipError_t e = hipMemsetAsync(s->factor, 0, sizeof(double) * (size_t)s->t.factor_doubles, st);
+    if (e != hipSuccess) return e;
+    const long long total = (long long)g.ncol * g.hstencil;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256LL * 64) blocks = 256LL * 64;
+    switch (g.ndim) {
+    case 1: hipLaunchKernelGGL(nd_assemble_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor); break;
+    case 2: hipLaunchKernelGGL(nd_assemble_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor); break;
+    case 3: hipLaunchKernelGGL(nd_assemble_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor); break;
+    default: hipLaunchKernelGGL(nd_assemble_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor); break;
+    }
+    if (s->npad > 0)
+        hipLaunchKernelGGL(nd_pad_diag_kernel, dim3((unsigned)((s->npad + 255) / 256)), dim3(256), 0, st, (const long long *)s->padwhere, s->npad, s->factor);
+    return hipGetLastError();
+}
+
+hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStream_t st, void *user)
+{
+    NdState *s = static_cast<NdState *>(user);
+    NdTree &t = s->t;
+    CholStats *stats = &p->stats;
+    const bool timing = stats->enabled;
+    const bool enabled = stats->enabled;
+    *stats = CholStats{};
+    stats->enabled = enabled;
+    const int nd = t.maxdepth + 1;
+    hipStream_t sP = s->sP, sU = s->sU, sZ = s->sZ;
+    if (std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = sU = sZ = st;
+    if (timing) {
+        if (!s->f0) { (void)hipEventCreate(&s->f0); (void)hipEventCreate(&s->f1); }
+        (void)hipEventRecord(s->f0, st);
+    }
+    if (s->used && s->evDone) (void)hipStreamWaitEvent(st, s->evDone, 0);
+    if (s->zlast_valid) (void)hipStreamWaitEvent(st, s->evZlast, 0);
+    if (!s->s_clean) {          // first fit, or the previous one was abandoned: zero both arenas
+        for (int a = 0; a < 2; ++a)
+            if (t.s_doubles[a] > 0) (void)hipMemsetAsync(s->sar[a], 0, sizeof(double) * (size_t)t.s_doubles[a], st);
+    }
+    s->s_clean = false;
+    (void)hipEventRecord(s->ev0, st);
+    if (sP != st) (void)hipStreamWaitEvent(sP, s->ev0, 0);
+    if (sU != st) (void)hipStreamWaitEvent(sU, s->ev0, 0);
+    if (sZ != st) (void)hipStreamWaitEvent(sZ, s->ev0, 0);
+    auto deepest_with_parity = [&](int par) { int d = t.maxdepth; if ((d & 1) != par) --d; return d; };
+    std::vector<char> zeroed_now((size_t)nd + 2, 0);
+    for (int d = t.maxdepth; d >= 0; --d) {
+        const int steps = (int)s->l_potrf[(size_t)d].size();
+        while ((int)s->evT.size() < steps) {
+            hipEvent_t e;
+            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            s->evT.push_back(e);
+        }
+        for (int k = 0; k < steps; ++k) {
+            const Launch &lp = s->l_potrf[(size_t)d][(size_t)k], &lt = s->l_trsm[(size_t)d][(size_t)k];
+            const Launch &lu = s->l_upd[(size_t)d][(size_t)k], &ls = s->l_schur[(size_t)d][(size_t)k];
+            hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sP, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
+            if (lt.count)
+                hipLaunchKernelGGL(nd_trsm_kernel, dim3(lt.grid), dim3(64), 0, sP, (const TrsmJob *)(s->trsm.dev + lt.first), lt.count);
+            if (ls.count && sU != sP) {
+                (void)hipEventRecord(s->evT[(size_t)k], sP);
+                (void)hipStreamWaitEvent(sU, s->evT[(size_t)k], 0);
+            }
+            launch_syrk(s, s->upd, lu, sP, stats, timing);
+            launch_syrk(s, s->schur, ls, sU, stats, timing);
+        }
+        if (sU != sP) {                                 // the depth's Schur updates are complete before they are handed on
+            (void)hipEventRecord(s->evU, sU);
+            (void)hipStreamWaitEvent(sP, s->evU, 0);
+        }
+        if (d >= 1) {
+            if (zeroed_now[(size_t)(d - 1)] && sZ != sP) (void)hipStreamWaitEvent(sP, s->evZ[(size_t)(d - 1)], 0);
+            for (int sl = 0; sl < 2; ++sl) {
+                const Launch &la = s->l_add[sl][(size_t)d];
+                if (la.count)
+                    hipLaunchKernelGGL(nd_extend_add_kernel, dim3(la.grid), dim3(256), 0, sP, (const AddJob *)(s->add.dev + la.first), la.count);
+            }
+            // depth d is consumed: its arena half is free -- zero what uses it next (depth d - 2, or the deepest depth
+            // of that parity for the NEXT fit), beside the work of depth d - 1
+            (void)hipEventRecord(s->evE[(size_t)d], sP);
+            const int target = d - 2 >= 1 ? d - 2 : deepest_with_parity(d & 1);
+            if (target >= 1 && s->s_depth_doubles[(size_t)target] > 0) {
+                if (sZ != sP) (void)hipStreamWaitEvent(sZ, s->evE[(size_t)d], 0);
+                (void)hipMemsetAsync(s->sar[target & 1], 0, sizeof(double) * (size_t)s->s_depth_doubles[(size_t)target], sZ);
+                (void)hipEventRecord(s->evZ[(size_t)target], sZ);
+                if (target == d - 2) zeroed_now[(size_t)target] = 1;
+            }
+        }
+    }
+    // inverses of all diagonal blocks (the solves' operands)
+    hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)t.nblocks), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev);
+    (void)hipEventRecord(s->evJ, sP);
+    if (sP != st) (void)hipStreamWaitEvent(st, s->evJ, 0);
+    if (sZ != st) {
+        (void)hipEventRecord(s->evZlast, sZ);
+        s->zlast_valid = true;
+    }
+    s->s_clean = true;
+    (void)hipEventRecord(s->evDone, st);
+    s->used = true;
+    hipError_t err = hipGetLastError();
+    if (timing) {
+        (void)hipEventRecord(s->f1, st);
+        (void)hipEventSynchronize(s->f1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, s->f0, s->f1);
+        stats->factor_ms = ms;
+        for (size_t i = 0; i < (size_t)stats->syrk_launches; ++i) {
+            if (hipEventElapsedTime(&ms, s->evA[i], s->evB[i]) == hipSuccess) stats->syrk_ms += ms;
+            else (void)hipGetLastError();
+        }
+    }
+    if (err != hipSuccess) s->s_clean = false;
+    return err;
+}
+
+hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void *user)
+{
+    (void)tmp;
+    NdState *s = static_cast<NdState *>(user);
+    NdTree &t = s->t;
+    const long long n = t.vec_doubles;
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(nd_gather_kernel, dim3(gb), dim3(256), 0, st, n, (const int *)s->rowsrc, (const double *)x, s->V);
+    // forward, bottom-up
+    for (int d = t.maxdepth; d >= 0; --d) {
+        if (d < t.maxdepth)
+            for (int sl = 0; sl < 2; ++sl) {
+                const Launch &lm = s->l_mapslot[sl][(size_t)(d + 1)];
+                if (lm.count) hipLaunchKernelGGL(nd_map_kernel<false>, dim3(8, lm.grid), dim3(256), 0, st, (const MapJob *)(s->map.dev + lm.first));
+            }
+        const int steps = (int)s->l_mv[(size_t)d].size();
+        for (int k = 0; k < steps; ++k) {
+            const Launch &lm = s->l_mv[(size_t)d][(size_t)k], &lf = s->l_fwd[(size_t)d][(size_t)k];
+            hipLaunchKernelGGL(nd_mv_kernel, dim3(16, lm.grid), dim3(256), 0, st, (const MvJob *)(s->mv.dev + lm.first));
+            if (lf.count) hipLaunchKernelGGL(nd_fwd_kernel, dim3(lf.grid), dim3(512), 0, st, (const FwdJob *)(s->fwd.dev + lf.first), lf.count);
+        }
+    }
+    // backward, top-down
+    for (int d = 0; d <= t.maxdepth; ++d) {
+        if (d >= 1) {
+            const Launch &lm = s->l_mapall[(size_t)d];
+            if (lm.count) hipLaunchKernelGGL(nd_map_kernel<true>, dim3(8, lm.grid), dim3(256), 0, st, (const MapJob *)(s->map.dev + lm.first));
+        }
+        const int steps = (int)s->l_mv[(size_t)d].size();
+        for (int k = steps - 1; k >= 0; --k) {
+            const Launch &ld = s->l_dot[(size_t)d][(size_t)k], &lb = s->l_bwd[(size_t)d][(size_t)k];
+            if (ld.count) hipLaunchKernelGGL(nd_dot_kernel, dim3(ld.grid), dim3(256), 0, st, (const DotJob *)(s->dot.dev + ld.first), ld.count);
+            hipLaunchKernelGGL(nd_bwd_kernel, dim3(16, lb.grid), dim3(256), 0, st, (const BwdJob *)(s->bwd.dev + lb.first));
+        }
+    }
+    hipLaunchKernelGGL(nd_scatter_kernel, dim3(gb), dim3(256), 0, st, n, (const int *)s->rowsrc, (const double *)s->V, x);
+    (void)p;
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// SPLPAK_ND: 0 = never, 1 = always; otherwise 3-D / 4-D grids whose band is wide enough for the four-stream
+// band pipeline (below that the two-ended narrow form of twoend.hip is used)
+bool nd_wanted(const Grid &g, const Band &band)
+{
+    if (const char *e = std::getenv("SPLPAK_ND")) return atoi(e) != 0;
+    return g.ndim >= 3 && band.bw >= narrow_band_limit();
+}
+
+// Installs the nested-dissection factorisation on a single-GPU plan: builds the tree, allocates the arenas,
+// uploads the tables.  Returns 0, or an SPLPAK_E_* code (the plan is then unusable).  *factor_arena /
+// *factor_doubles: the factor storage, idle until the half stencil is assembled (the Gram scratch may live there).
+int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
+{
+    NdState *s = new NdState();
+    (void)hipGetDevice(&s->device);
+    p->fn_user = s;
+    p->fn_destroy = nd_destroy;
+    if (!nd_build(p->g, s->t, nd_default_split_min())) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
+    NdTree &t = s->t;
+    const int nd = t.maxdepth + 1;
+    s->s_depth_doubles.assign((size_t)nd, 0);
+    for (const NdFront &f : t.fr) s->s_depth_doubles[(size_t)f.depth] = std::max(s->s_depth_doubles[(size_t)f.depth], f.s_off + f.lds * (long long)f.hp);
+    bool ok = nd_alloc(s, &s->factor, (size_t)t.factor_doubles + 64) && nd_alloc(s, &s->sar[0], (size_t)t.s_doubles[0] + 64) &&
+              nd_alloc(s, &s->sar[1], (size_t)t.s_doubles[1] + 64) && nd_alloc(s, &s->dinv, (size_t)t.nblocks * 65536) &&
+              nd_alloc(s, &s->dinvt, (size_t)t.nblocks * 65536) && nd_alloc(s, &s->inv16, (size_t)t.nblocks * 4096) &&
+              nd_alloc(s, &s->V, (size_t)t.vec_doubles) && nd_alloc(s, &s->Y, (size_t)t.vec_doubles) &&
+              nd_alloc(s, &s->part, (size_t)(s->part_cap = t.vec_doubles / 4 + 256LL * (long long)t.fr.size() + 4096));
+    if (!ok) return SPLPAK_E_NOMEM;
+    // tables
+    std::vector<int> rowsrc((size_t)t.vec_doubles, -1);
+    std::vector<long long> padwhere;
+    std::vector<FrontDev> fdev;
+    for (const NdFront &f : t.fr) {
+        for (int r = 0; r < f.w; ++r) rowsrc[(size_t)(f.vofs + r)] = t.ownvar[(size_t)(f.rofs + r)];
+        for (int r = f.w; r < f.wp; ++r) padwhere.push_back(f.panel_off + r + (long long)r * f.ld);
+        fdev.push_back(FrontDev{f.panel_off, f.ld, f.bofs, f.own0, f.w, f.wp, f.h});
+    }
+    s->npad = (int)padwhere.size();
+    ok = nd_upload(s, &s->pos, t.pos) && nd_upload(s, &s->front_of, t.front_of) && nd_upload(s, &s->bpos, t.bpos) &&
+         nd_upload(s, &s->pmap, t.pmap) && nd_upload(s, &s->rowsrc, rowsrc) && nd_upload(s, &s->padwhere, padwhere) &&
+         nd_upload(s, &s->fdev, fdev);
+    if (!ok) return SPLPAK_E_NOMEM;
+    if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
+    ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->upd.dev, s->upd.host) &&
+         nd_upload(s, &s->schur.dev, s->schur.host) && nd_upload(s, &s->trinv.dev, s->trinv.host) && nd_upload(s, &s->add.dev, s->add.host) &&
+         nd_upload(s, &s->mv.dev, s->mv.host) && nd_upload(s, &s->fwd.dev, s->fwd.host) && nd_upload(s, &s->dot.dev, s->dot.host) &&
+         nd_upload(s, &s->bwd.dev, s->bwd.host) && nd_upload(s, &s->map.dev, s->map.host);
+    if (!ok) return SPLPAK_E_NOMEM;
+    // the host copies of the big index arrays are no longer needed
+    std::vector<int>().swap(t.ownvar);
+    std::vector<int>().swap(t.bvar);
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    (void)hipStreamCreateWithPriority(&s->sP, hipStreamNonBlocking, hi);
+    (void)hipStreamCreateWithFlags(&s->sU, hipStreamNonBlocking);
+    (void)hipStreamCreateWithPriority(&s->sZ, hipStreamNonBlocking, lo);
+    for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
+    s->evE.assign((size_t)nd + 1, nullptr);
+    s->evZ.assign((size_t)nd + 1, nullptr);
+    for (int d = 0; d <= nd; ++d) {
+        (void)hipEventCreateWithFlags(&s->evE[(size_t)d], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&s->evZ[(size_t)d], hipEventDisableTiming);
+    }
+    if (!s->sP || !s->sU || !s->sZ) { set_error("nested dissection: stream creation failed"); (void)hipGetLastError(); return SPLPAK_E_NODEVICE; }
+    p->expand_fn = nd_assemble;
+    p->factor_fn = nd_factor;
+    p->solve_fn = nd_solve;
+    if (factor_arena) *factor_arena = s->factor;
+    if (factor_doubles) *factor_doubles = t.factor_doubles;
+    if (std::getenv("SPLPAK_DEBUG"))
+        fprintf(stderr, "[splpak] nested dissection: %zu fronts, depth %d, factor %.2f GB, Schur arenas %.2f GB, %.3e flop\n", t.fr.size(),
+                t.maxdepth, 8e-9 * (double)t.factor_doubles, 8e-9 * (double)(t.s_doubles[0] + t.s_doubles[1]), t.flop);
+    return 0;
+}
+
+}  // namespace splpak

@@ -1,0 +1,288 @@
+// Host side of the nested-dissection factorisation: the elimination tree of the node grid (ndtree.hpp).
+// Pure host code (no device calls): it is also what the CPU test tier exercises through
+// splpak_debug_nd_tree (include/splpak_hip.h).
+#include "ndtree.hpp"
+#include "plan.hpp"
+#include <algorithm>
+#include <climits>
+#include <cstring>
+
+namespace splpak {
+
+namespace {
+
+inline int round_up(int v, int m) { return ((v + m - 1) / m) * m; }
+
+struct Builder {
+    NdTree &t;
+    int split_min;
+    int counter = 0;
+
+    // visits the nodes of the box [lo, hi) in natural order (dimension 0 fastest)
+    template <typename F>
+    void for_box(const int *lo, const int *hi, F &&f) const
+    {
+        const Grid &g = t.g;
+        int i[MAXD];
+        for (int d = 0; d < MAXD; ++d) i[d] = d < g.ndim ? lo[d] : 0;
+        for (int d = 0; d < g.ndim; ++d)
+            if (hi[d] <= lo[d]) return;
+        for (;;) {
+            int col = 0;
+            for (int d = 0; d < g.ndim; ++d) col += i[d] * g.colstride[d];
+            f(col, i);
+            int d = 0;
+            while (d < g.ndim) {
+                if (++i[d] < hi[d]) break;
+                i[d] = lo[d];
+                ++d;
+            }
+            if (d == g.ndim) break;
+        }
+    }
+
+    int build(const int *lo, const int *hi, int depth)
+    {
+        const Grid &g = t.g;
+        int k = 0, e = 0;
+        for (int d = 0; d < g.ndim; ++d)
+            if (hi[d] - lo[d] > e) { e = hi[d] - lo[d]; k = d; }
+        NdFront f;
+        for (int d = 0; d < MAXD; ++d) {
+            f.lo[d] = d < g.ndim ? lo[d] : 0;
+            f.hi[d] = d < g.ndim ? hi[d] : 1;
+            f.olo[d] = f.lo[d];
+            f.ohi[d] = f.hi[d];
+        }
+        f.depth = depth;
+        int c0 = -1, c1 = -1;
+        if (e >= split_min) {
+            const int s = lo[k] + (e - 3) / 2;            // separator = [s, s+3) along dimension k
+            int lhi[MAXD], rlo[MAXD];
+            for (int d = 0; d < g.ndim; ++d) { lhi[d] = hi[d]; rlo[d] = lo[d]; }
+            lhi[k] = s;
+            rlo[k] = s + 3;
+            c0 = build(lo, lhi, depth + 1);
+            c1 = build(rlo, hi, depth + 1);
+            f.olo[k] = s;
+            f.ohi[k] = s + 3;
+        }
+        const int id = (int)t.fr.size();
+        f.child[0] = c0;
+        f.child[1] = c1;
+        if (c0 >= 0) { t.fr[(size_t)c0].parent = id; t.fr[(size_t)c0].slot = 0; }
+        if (c1 >= 0) { t.fr[(size_t)c1].parent = id; t.fr[(size_t)c1].slot = 1; }
+        f.own0 = counter;
+        for_box(f.olo, f.ohi, [&](int col, const int *) {
+            t.pos[(size_t)col] = counter++;
+            t.front_of[(size_t)col] = id;
+        });
+        f.w = counter - f.own0;
+        t.fr.push_back(f);
+        if (depth > t.maxdepth) t.maxdepth = depth;
+        return id;
+    }
+};
+
+}  // namespace
+
+bool nd_build(const Grid &g, NdTree &t, int split_min)
+{
+    t = NdTree();
+    t.g = g;
+    if (split_min < 5) split_min = 5;
+    t.pos.assign((size_t)g.ncol, -1);
+    t.front_of.assign((size_t)g.ncol, -1);
+    Builder b{t, split_min};
+    int lo[MAXD] = {0, 0, 0, 0}, hi[MAXD] = {1, 1, 1, 1};
+    for (int d = 0; d < g.ndim; ++d) hi[d] = g.nodes[d];
+    t.root = b.build(lo, hi, 0);
+    if (b.counter != g.ncol) return false;
+    std::vector<int> var_of_pos((size_t)g.ncol);
+    for (int c = 0; c < g.ncol; ++c) {
+        if (t.pos[(size_t)c] < 0) return false;
+        var_of_pos[(size_t)t.pos[(size_t)c]] = c;
+    }
+    // sizes, offsets, own rows
+    t.by_depth.assign((size_t)t.maxdepth + 1, {});
+    std::vector<long long> s_depth((size_t)t.maxdepth + 1, 0);
+    std::vector<int> tmp;
+    for (size_t id = 0; id < t.fr.size(); ++id) {
+        NdFront &f = t.fr[id];
+        // border: nodes within 3 of the region, outside it; all of them are eliminated later than the region
+        int elo[MAXD], ehi[MAXD];
+        for (int d = 0; d < MAXD; ++d) {
+            elo[d] = d < g.ndim ? std::max(0, f.lo[d] - 3) : 0;
+            ehi[d] = d < g.ndim ? std::min(g.nodes[d], f.hi[d] + 3) : 1;
+        }
+        tmp.clear();
+        b.for_box(elo, ehi, [&](int col, const int *i) {
+            bool inside = true;
+            for (int d = 0; d < g.ndim; ++d) inside = inside && i[d] >= f.lo[d] && i[d] < f.hi[d];
+            if (!inside) tmp.push_back(t.pos[(size_t)col]);
+        });
+        std::sort(tmp.begin(), tmp.end());
+        f.h = (int)tmp.size();
+        f.wp = round_up(f.w, 256);
+        f.hp = round_up(f.h, 64);
+        f.fp = f.wp + f.hp;
+        f.ld = f.fp + 16;                       // multiple of 16 doubles, odd multiple of 128 B (fp is a multiple of 64)
+        f.lds = f.hp > 0 ? f.hp + 16 : 0;
+        f.nsteps = f.wp / 256;
+        f.panel_off = t.factor_doubles;
+        t.factor_doubles += f.ld * (long long)f.wp;
+        f.rofs = (long long)t.ownvar.size();
+        f.bofs = (long long)t.bpos.size();
+        f.vofs = t.vec_doubles;
+        t.vec_doubles += f.fp;
+        f.blk0 = t.nblocks;
+        t.nblocks += f.nsteps;
+        t.own_rows += f.wp;
+        t.border_rows += f.hp;
+        for (int r = 0; r < f.wp; ++r) t.ownvar.push_back(r < f.w ? var_of_pos[(size_t)(f.own0 + r)] : -1);
+        for (int i = 0; i < f.hp; ++i) {
+            t.bpos.push_back(i < f.h ? tmp[(size_t)i] : INT_MAX);
+            t.bvar.push_back(i < f.h ? var_of_pos[(size_t)tmp[(size_t)i]] : -1);
+        }
+        f.s_off = s_depth[(size_t)f.depth];
+        s_depth[(size_t)f.depth] += f.lds * (long long)f.hp;
+        t.s_total += f.lds * (long long)f.hp;
+        t.by_depth[(size_t)f.depth].push_back((int)id);
+        const double w = f.w, h = f.h;
+        t.flop_exact += w * w * w / 3.0 + w * w * h + w * h * h;
+        // trailing-update items of the blocked factorisation (64x64x256 each): panel columns right of step k and the Schur buffer
+        for (int k = 0; k < f.nsteps; ++k) {
+            const long long nc = (f.wp - (k + 1) * 256) / 64, nr = (f.fp - (k + 1) * 256) / 64, ns = f.hp / 64;
+            t.flop += 2.0 * 64 * 64 * 256 * (double)(nc * nr - nc * (nc - 1) / 2 + ns * (ns + 1) / 2);
+        }
+    }
+    for (int d = 0; d <= t.maxdepth; ++d) t.s_doubles[d & 1] = std::max(t.s_doubles[d & 1], s_depth[(size_t)d]);
+    // child border row -> parent row
+    t.pmap.assign(t.bpos.size(), -1);
+    for (size_t id = 0; id < t.fr.size(); ++id) {
+        const NdFront &f = t.fr[id];
+        if (f.parent < 0) continue;
+        const NdFront &p = t.fr[(size_t)f.parent];
+        const int *pb = t.bpos.data() + p.bofs;
+        for (int i = 0; i < f.h; ++i) {
+            const int ps = t.bpos[(size_t)(f.bofs + i)];
+            int row = -1;
+            if (ps >= p.own0 && ps < p.own0 + p.w) row = ps - p.own0;
+            else {
+                const int *it = std::lower_bound(pb, pb + p.h, ps);
+                if (it == pb + p.h || *it != ps) return false;
+                row = p.wp + (int)(it - pb);
+            }
+            t.pmap[(size_t)(f.bofs + i)] = row;
+        }
+    }
+    return true;
+}
+
+std::string nd_check(const NdTree &t)
+{
+    const Grid &g = t.g;
+    std::vector<char> seen((size_t)g.ncol, 0);
+    for (size_t id = 0; id < t.fr.size(); ++id) {
+        const NdFront &f = t.fr[id];
+        for (int r = 0; r < f.w; ++r) {
+            const int v = t.ownvar[(size_t)(f.rofs + r)];
+            if (v < 0 || v >= g.ncol || seen[(size_t)v]) return "a node is owned twice or not at all";
+            if (t.pos[(size_t)v] != f.own0 + r || t.front_of[(size_t)v] != (int)id) return "own rows out of order";
+            seen[(size_t)v] = 1;
+        }
+        int last = f.own0 + f.w - 1;                 // the border is eliminated after the own variables, in ascending order
+        for (int i = 0; i < f.h; ++i) {
+            const int ps = t.bpos[(size_t)(f.bofs + i)];
+            if (ps <= last) return "border not ascending / not after the own variables";
+            last = ps;
+        }
+        if (f.parent >= 0) {
+            const NdFront &p = t.fr[(size_t)f.parent];
+            if (p.depth != f.depth - 1) return "depth mismatch";
+            int lastrow = -1;
+            for (int i = 0; i < f.h; ++i) {
+                const int row = t.pmap[(size_t)(f.bofs + i)];
+                if (row <= lastrow || row >= p.fp) return "child -> parent map not monotone";
+                if (row >= p.w && row < p.wp) return "child row mapped onto the parent's padding";
+                const int pv = row < p.wp ? t.ownvar[(size_t)(p.rofs + row)] : t.bvar[(size_t)(p.bofs + row - p.wp)];
+                if (pv != t.bvar[(size_t)(f.bofs + i)]) return "child -> parent map hits another node";
+                lastrow = row;
+            }
+        } else if (f.h != 0) return "the root has a border";
+    }
+    for (int c = 0; c < g.ncol; ++c)
+        if (!seen[(size_t)c]) return "a node is not owned";
+    // every entry of N (7^d stencil) has a place: the column's front holds the row
+    // (checked on a sample of nodes to keep the test fast on big grids)
+    const int step = g.ncol > 200000 ? 97 : 1;
+    for (int c = 0; c < g.ncol; c += step) {
+        int ic[MAXD];
+        for (int d = 0; d < g.ndim; ++d) ic[d] = (c / g.colstride[d]) % g.nodes[d];
+        int o[MAXD] = {-3, -3, -3, -3};
+        for (int d = g.ndim; d < MAXD; ++d) o[d] = 0;
+        for (;;) {
+            bool ok = true;
+            int r = 0;
+            for (int d = 0; d < g.ndim; ++d) {
+                const int j = ic[d] + o[d];
+                if (j < 0 || j >= g.nodes[d]) ok = false;
+                r += j * g.colstride[d];
+            }
+            if (ok && t.pos[(size_t)r] > t.pos[(size_t)c]) {
+                const NdFront &f = t.fr[(size_t)t.front_of[(size_t)c]];
+                const int pr = t.pos[(size_t)r];
+                bool found = pr >= f.own0 && pr < f.own0 + f.w;
+                if (!found) {
+                    const int *pb = t.bpos.data() + f.bofs;
+                    found = std::binary_search(pb, pb + f.h, pr);
+                }
+                if (!found) return "an entry of the normal equations has no row in its column's front";
+            }
+            int d = 0;
+            while (d < g.ndim) {
+                if (++o[d] <= 3) break;
+                o[d] = -3;
+                ++d;
+            }
+            if (d == g.ndim) break;
+        }
+    }
+    return "";
+}
+
+}  // namespace splpak
+
+extern "C" int32_t splpak_debug_nd_tree(int32_t ndim, const int32_t *nodes, int32_t split_min, int32_t check, double *out16)
+{
+    using namespace splpak;
+    double xmin[MAXD] = {0, 0, 0, 0}, xmax[MAXD] = {1, 1, 1, 1};
+    Grid g;
+    if (!nodes || !out16) return SPLPAK_E_BADARG;
+    const int v = build_grid(ndim, nodes, xmin, xmax, g, nullptr, true);
+    if (v != 0) return v;
+    NdTree t;
+    if (!nd_build(g, t, split_min > 0 ? split_min : nd_default_split_min())) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
+    if (check) {
+        const std::string msg = nd_check(t);
+        if (!msg.empty()) { set_error("nested dissection: " + msg); return SPLPAK_E_BADARG; }
+    }
+    int maxw = 0, maxh = 0;
+    for (const NdFront &f : t.fr) { maxw = std::max(maxw, f.w); maxh = std::max(maxh, f.h); }
+    out16[0] = (double)t.fr.size();
+    out16[1] = t.maxdepth;
+    out16[2] = 8.0 * (double)t.factor_doubles;                         // bytes of the factor panels
+    out16[3] = 8.0 * (double)(t.s_doubles[0] + t.s_doubles[1]);       // bytes of the two Schur arenas
+    out16[4] = 8.0 * (double)t.s_total;
+    out16[5] = t.flop;
+    out16[6] = t.flop_exact;
+    out16[7] = maxw;
+    out16[8] = maxh;
+    out16[9] = t.nblocks;
+    out16[10] = (double)t.vec_doubles;
+    out16[11] = (double)t.own_rows;
+    out16[12] = (double)t.border_rows;
+    out16[13] = 2.0 * 8.0 * 65536.0 * t.nblocks + 8.0 * 4096.0 * t.nblocks;   // bytes of the block inverses
+    out16[14] = out16[15] = 0;
+    return 0;
+}

@@ -1,0 +1,82 @@
+// Nested-dissection elimination tree of the node grid (host side; built once per plan).
+//
+// The normal equations N of the fit couple two nodes iff their grid indices differ by at most 3 in every
+// dimension (7^d stencil: windows of 4 basis functions per dimension, src/splpak.F90:821-827 and the column
+// order of :657-666).  The grid is structured, so no symbolic phase is needed: a box of nodes is bisected
+// along its longest dimension by a SEPARATOR SLAB three nodes thick -- the two halves then share no entry of
+// N -- and the halves are bisected again until a box is small.  Eliminating the boxes bottom-up (leaves, then
+// the separators that join them) is a Cholesky factorisation of N in the nested-dissection order; its fill
+// stays inside "fronts":
+//
+//   front of a tree node = [ own variables | border ],   own    = the separator slab (the whole box of a leaf),
+//                                                        border = the nodes within 3 of the node's REGION (the box
+//                                                                 its subtree covers) that lie outside it
+//
+// Every border node belongs to the separator of an ancestor, and the border of a child is contained in
+// own + border of its parent, so the Schur complement a front leaves behind is added into its parent's front
+// (multifrontal method).  All index sets are ordered by elimination position, which makes every child -> parent
+// map monotone: lower triangles map to lower triangles.
+//
+// For 64^3 nodes this needs ~1e13 flop and ~10 GB of factor instead of the band's 4.1e13 / 26.9 GB; for the
+// 4-D grids the gap is an order of magnitude.
+#pragma once
+#include "common.hpp"
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+namespace splpak {
+
+struct NdFront {
+    int lo[MAXD], hi[MAXD];        // region: the box of nodes the subtree covers, [lo, hi) per internal dimension
+    int olo[MAXD], ohi[MAXD];      // own variables: the separator slab, or the whole box of a leaf
+    int parent = -1, child[2] = {-1, -1};
+    int slot = 0;                  // 0 / 1: first or second child of its parent
+    int depth = 0;                 // root = 0
+    int w = 0, wp = 0;             // own variables; padded to a multiple of 256 (identity on the padding)
+    int h = 0, hp = 0;             // border variables; padded to a multiple of 64 (zero rows)
+    int fp = 0;                    // rows of the front = wp + hp
+    int own0 = 0;                  // elimination position of the first own variable
+    long long ld = 0, lds = 0;     // leading dimensions of the panel (fp x wp) and of the Schur buffer (hp x hp)
+    long long panel_off = 0;       // doubles into the factor arena
+    long long s_off = 0;           // doubles into the Schur arena of the front's depth parity
+    long long rofs = 0;            // offset into ownvar (wp entries)
+    long long bofs = 0;            // offset into bvar / bpos / pmap (hp entries)
+    long long vofs = 0;            // offset of the front's local vector (fp entries)
+    int blk0 = 0;                  // index of its first 256x256 diagonal block (inverse storage)
+    int nsteps = 0;                // wp / 256
+};
+
+struct NdTree {
+    Grid g{};
+    std::vector<NdFront> fr;       // postorder: children before parents, the root last
+    int root = -1, maxdepth = 0;
+    std::vector<int> pos;          // [ncol] elimination position of node (natural internal column index)
+    std::vector<int> front_of;     // [ncol] front that owns the node
+    std::vector<int> ownvar;       // [sum wp] node of every own row, -1 on the padding
+    std::vector<int> bvar;         // [sum hp] node of every border row (-1 padding)
+    std::vector<int> bpos;         // [sum hp] its elimination position, ascending (INT_MAX on the padding)
+    std::vector<int> pmap;         // [sum hp] row of the PARENT's front the border row maps to (-1 padding)
+    std::vector<std::vector<int>> by_depth;
+    long long factor_doubles = 0;  // sum ld * wp
+    long long s_doubles[2] = {0, 0};   // Schur arenas by depth parity (max over the depths of that parity)
+    long long s_total = 0;         // sum over all fronts (what one fit zeroes and streams)
+    long long vec_doubles = 0;     // sum fp
+    long long own_rows = 0, border_rows = 0;
+    int nblocks = 0;               // sum nsteps
+    double flop = 0.0;             // 2 * 64^2 * 256 per trailing-update item, all launches
+    double flop_exact = 0.0;       // without the padding: w^3/3 + w^2 h + w h^2 per front
+};
+
+// boxes whose largest extent reaches this are bisected (SPLPAK_ND_SPLIT overrides)
+inline int nd_default_split_min()
+{
+    if (const char *e = std::getenv("SPLPAK_ND_SPLIT")) return atoi(e);
+    return 8;
+}
+// split_min: a box whose largest extent is at least this is bisected (>= 5); returns false on inconsistency
+bool nd_build(const Grid &g, NdTree &t, int split_min);
+// invariants of the tree (every node owned once, borders inside the parent's rows, monotone maps); "" = fine
+std::string nd_check(const NdTree &t);
+
+}  // namespace splpak

@@ -160,14 +160,14 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
                            const double *xmax, double xtrap, int64_t max_ndata,
                            void *comm_buf_dev, int64_t comm_len, splpak_plan **plan)
 {
-    return plan_create_dist(ndim, nodes, xmin, xmax, xtrap, max_ndata, comm_buf_dev, comm_len, 1, 0, 1, plan);
+    return plan_create_dist(ndim, nodes, xmin, xmax, xtrap, max_ndata, comm_buf_dev, comm_len, 1, 0, 1, plan, true);
 }
 
 }  // extern "C"
 
 int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, const double *xmax, double xtrap,
                              long long max_ndata, void *comm_buf_dev, long long comm_len, int R, int r, int c,
-                             splpak_plan **plan)
+                             splpak_plan **plan, bool allow_nd)
 {
     if (!plan || !nodes || !xmin || !xmax) { set_error("null argument"); return SPLPAK_E_BADARG; }
     *plan = nullptr;
@@ -213,7 +213,21 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
         if (dm_owned(p->dm, J)) p->own_blocks_host.push_back(J);
     p->nown = (int)p->own_blocks_host.size();
     if (p->dm.R > 1) p->band.bytes = (size_t)(p->nown > 0 ? p->nown : 1) * NBLK * (size_t)p->dm.ld * sizeof(double) + 4096;
-    ok = ok && dev_alloc(p, &p->band.ab, p->band.bytes / sizeof(double));
+    // Large 3-D / 4-D grids on one GPU: the nested-dissection multifrontal factorisation (ndchol.hip) instead of the
+    // band.  It owns its storage; the factor arena stands in for the band as the home of the Gram scratch.
+    const bool use_nd = allow_nd && p->dm.R == 1 && nd_wanted(g, p->band);
+    if (use_nd && ok) {
+        double *arena = nullptr;
+        long long arena_doubles = 0;
+        const int rc = nd_attach(p, &arena, &arena_doubles);
+        if (rc != 0) {
+            splpak_plan_destroy(p);
+            return rc;
+        }
+        p->band.ab = arena;
+        p->band.bytes = (size_t)arena_doubles * sizeof(double);
+    } else
+        ok = ok && dev_alloc(p, &p->band.ab, p->band.bytes / sizeof(double));
     {
         // scratch of the per-cell Gram blocks: everything at once if <= 8 GB (or if the band storage, which is
         // idle until the gather is done, holds it); otherwise slabs of what there is (launch_gram)
@@ -231,7 +245,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
             p->gscratch_doubles = want;
         }
     }
-    const size_t nloc = (size_t)(p->nown > 0 ? p->nown : 1);
+    const size_t nloc = use_nd ? 0 : (size_t)(p->nown > 0 ? p->nown : 1);      // (the band's block inverses: not with nested dissection)
     ok = ok && dev_alloc(p, &p->band.dinv, nloc * NBLK * NBLK);
     ok = ok && dev_alloc(p, &p->band.dinvt, nloc * NBLK * NBLK);
     ok = ok && dev_alloc(p, &p->band.inv64, nloc * 4 * 64 * 64);
@@ -573,6 +587,7 @@ struct HostFitCache {
     std::mutex mu;
     splpak_plan *plan = nullptr;
     int ndim = 0, nodes[MAXD] = {0, 0, 0, 0}, dev = -1;
+    int nd_env = -1;              // SPLPAK_ND as it was when the plan was created (it selects the factorisation)
     double xmin[MAXD] = {0, 0, 0, 0}, xmax[MAXD] = {0, 0, 0, 0}, xtrap = 0.0;
     double *dx = nullptr, *dy = nullptr, *dw = nullptr, *dc = nullptr;
     long long cap_x = 0, cap_y = 0, cap_w = 0, cap_c = 0;
@@ -612,7 +627,8 @@ static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const
     std::lock_guard<std::mutex> lock(hc.mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
-    bool same = hc.plan && hc.dev == dev && hc.ndim == ndim && hc.xtrap == xtrap && hc.plan->max_ndata >= ndata;
+    const int nd_env = std::getenv("SPLPAK_ND") ? atoi(std::getenv("SPLPAK_ND")) : -1;
+    bool same = hc.plan && hc.dev == dev && hc.ndim == ndim && hc.xtrap == xtrap && hc.plan->max_ndata >= ndata && hc.nd_env == nd_env;
     for (int d = 0; same && d < ndim; ++d)
         same = hc.nodes[d] == nodes[d] && hc.xmin[d] == xmin[d] && hc.xmax[d] == xmax[d];
     if (!same) {
@@ -620,6 +636,7 @@ static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const
         int rc = splpak_plan_create(ndim, nodes, xmin, xmax, xtrap, ndata, nullptr, 0, &hc.plan);
         if (rc != 0) { hc.plan = nullptr; return rc; }
         hc.dev = dev;
+        hc.nd_env = nd_env;
         hc.ndim = ndim;
         hc.xtrap = xtrap;
         for (int d = 0; d < ndim; ++d) { hc.nodes[d] = nodes[d]; hc.xmin[d] = xmin[d]; hc.xmax[d] = xmax[d]; }

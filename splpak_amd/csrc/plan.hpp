@@ -62,7 +62,10 @@ int device_ready();
 // plan for rank r of R (chunks of c block columns); R = 1 is the ordinary single-GPU plan
 int plan_create_dist(int ndim, const int *nodes, const double *xmin, const double *xmax, double xtrap,
                      long long max_ndata, void *comm_buf_dev, long long comm_len, int R, int r, int c,
-                     splpak_plan **plan);
+                     splpak_plan **plan, bool allow_nd = false);
+// large 3-D / 4-D grids on one GPU: nested-dissection multifrontal factorisation (ndchol.hip) instead of the band
+bool nd_wanted(const Grid &g, const Band &band);
+int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles);
 // narrow bands on one GPU: install the two-ended factorisation (twoend.hip) when it shortens the chain
 void twoend_attach(splpak_plan *p);
 void twoend_detach(splpak_plan *p);

@@ -1,0 +1,136 @@
+"""Nested-dissection multifrontal factorisation (csrc/ndtree.hip, csrc/ndchol.hip).
+
+CPU tier: the elimination tree is host code -- its invariants (every node owned once, every entry of the
+7^d-stencil normal equations has a row in its column's front, monotone child -> parent maps) are checked
+without a GPU, and so is what it promises for BASELINE's grids (flops, bytes).
+GPU tier: the fit through that factorisation against the reference goldens, the band factorisation, the
+independent banded CPU solve, and itself (bitwise run-to-run)."""
+import os
+
+import numpy as np
+import pytest
+
+from splpak_amd import capi
+from tests.cases import CASES, make_inputs
+from tests.conftest import load_golden, relmax
+
+COEF_TOL = 1e-10
+
+
+@pytest.mark.parametrize("nodes", [[8, 8, 8], [12, 12, 12], [16, 16, 16], [9, 17, 13], [64, 64], [40, 7], [6, 6, 6, 6],
+                                   [8, 9, 10, 11], [33], [24, 24, 24], [5, 30, 5]])
+def test_tree_invariants(nodes):
+    t = capi.debug_nd_tree(nodes, check=True)
+    n = int(np.prod(nodes))
+    assert t["own_rows"] >= n and t["fronts"] >= 1
+    assert t["flop_exact"] > 0
+
+
+@pytest.mark.parametrize("split", [5, 6, 8, 11])
+def test_tree_invariants_other_leaf_sizes(split):
+    capi.debug_nd_tree([20, 20, 20], split_min=split, check=True)
+    capi.debug_nd_tree([9, 9, 9, 9], split_min=split, check=True)
+
+
+def test_tree_promises_for_the_baseline_grids():
+    """BASELINE config 3 (64^3): at most a third of the band's n p^2 = 4.1e13 flop and under 20 GB of factor;
+    4-D 24^4: under half of the band's 6.2e14 flop."""
+    t = capi.debug_nd_tree([64, 64, 64], check=True)
+    assert t["flop"] < 4.1e13 / 3 and t["factor_bytes"] < 20e9 and t["max_separator"] == 3 * 64 * 64
+    t4 = capi.debug_nd_tree([24, 24, 24, 24], check=False)
+    assert t4["flop"] < 6.2e14 / 2
+
+
+def test_tree_rejects_bad_grids_like_the_fit():
+    with pytest.raises(capi.SplpakError):
+        capi.debug_nd_tree([3, 8])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _fit_env(inp, env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return capi.fit(inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"],
+                        inp["nodes"], inp["xtrap"], want_hist=False)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+ND_GOLDENS = ["3d12", "3d16", "2d64_c2grid", "4d6", "3d8", "3d8_sparse", "3d8_cc_clust", "3d_aniso", "2d32", "2d16_outside",
+              "2d_aniso_box", "4d5_cc", "c1_1d16", "4d4"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ND_GOLDENS)
+def test_nd_fit_matches_golden_and_band(name):
+    """The nested-dissection factorisation forced onto grids the reference covers (trees of 1 .. 127 fronts,
+    1-D .. 4-D, constraint rows, zero weights): the golden at 1e-10, the band factorisation at 1e-12, the same
+    row counts and residual norm."""
+    gold = load_golden(name)
+    inp = make_inputs(CASES[name])
+    c_nd, e_nd, _, i_nd = _fit_env(inp, {"SPLPAK_ND": "1"})
+    c_bd, e_bd, _, i_bd = _fit_env(inp, {"SPLPAK_ND": "0"})
+    assert e_nd == 0 and e_bd == 0
+    err = relmax(c_nd, gold["coef"])
+    print(f"{name}: ND vs golden {err:.2e}, vs band {relmax(c_nd, c_bd):.2e}, steps {i_nd[2]:.0f}, optimality {i_nd[9]:.1e}")
+    assert err < COEF_TOL
+    assert relmax(c_nd, c_bd) < 1e-12
+    assert i_nd[9] < 1e-9
+    assert i_nd[0] == i_bd[0] and i_nd[1] == i_bd[1]
+    assert abs(i_nd[8] - i_bd[8]) <= 1e-9 * max(i_bd[8], 1e-300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", ["5", "6", "11"])
+def test_nd_other_leaf_sizes_match_golden(split):
+    for name in ("3d12", "4d6", "2d32"):
+        gold = load_golden(name)
+        c, e, _, info = _fit_env(make_inputs(CASES[name]), {"SPLPAK_ND": "1", "SPLPAK_ND_SPLIT": split})
+        assert e == 0 and relmax(c, gold["coef"]) < COEF_TOL, (name, split)
+
+
+@pytest.mark.gpu
+def test_nd_is_bitwise_reproducible_and_serial_equals_overlapped():
+    """Every sum of the factorisation has one owner and a fixed order (children add into their parent slot 0
+    first, then slot 1): two fits give identical bits, and so does the fit without stream overlap."""
+    inp = make_inputs(CASES["3d16"])
+    a = _fit_env(inp, {"SPLPAK_ND": "1"})[0]
+    b = _fit_env(inp, {"SPLPAK_ND": "1"})[0]
+    c = _fit_env(inp, {"SPLPAK_ND": "1", "SPLPAK_NO_LOOKAHEAD": "1"})[0]
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+@pytest.mark.gpu
+def test_nd_singular_system_is_107():
+    """No smoothing rows and fewer points than coefficients in part of the grid: a pivot fails somewhere in the
+    tree (or the row count already says so) -> 107 like the band path, never garbage with ierror 0."""
+    from splpak_amd.synth import synth_points
+    nd, nod = 3, 12
+    x, y, w = synth_points(nd, 3000)
+    x = x * 0.5                                  # an empty half of the box: columns without data
+    c, e, _, info = _fit_env(dict(ndim=nd, xdata=x, ydata=y, wdata=w, xmin=[0.0] * nd, xmax=[1.0] * nd, nodes=[nod] * nd,
+                                  xtrap=0.0), {"SPLPAK_ND": "1"})
+    assert e == 107
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nod,m", [(24, 100000), (32, 150000)])
+def test_nd_matches_banded_cpu_beyond_the_dense_oracle(port, nod, m):
+    """24^3 / 32^3 with weights and derivative-constraint rows through the nested-dissection path, against the
+    independent CPU solve of the reference's rows (oracle/splpak_banded.c, pinned to the goldens)."""
+    from splpak_amd.synth import synth_points
+    nd = 3
+    x, y, w = synth_points(nd, m)
+    lo, hi, nodes = [0.0] * nd, [1.0] * nd, [nod] * nd
+    c0, e0, i0 = port.fit_banded(nd, x, y, w, lo, hi, nodes, 1.0)
+    c1, e1, _, i1 = _fit_env(dict(ndim=nd, xdata=x, ydata=y, wdata=w, xmin=lo, xmax=hi, nodes=nodes, xtrap=1.0), {"SPLPAK_ND": "1"})
+    assert e0 == e1 == 0
+    print(f"{nod}^3 ND: vs banded CPU rel={relmax(c1, c0):.2e}; rows {i1[0]:.0f}+{i1[1]:.0f}; fit {i1[5] + i1[6] + i1[7]:.4f} s")
+    assert relmax(c1, c0) < COEF_TOL
+    assert i1[0] == i0[0] and i1[1] == i0[1]
+    assert abs(i1[8] - i0[8]) <= 1e-9 * i0[8]
