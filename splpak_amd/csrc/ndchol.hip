@@ -41,7 +41,7 @@ namespace {
 struct PotrfJob { double *A; double *inv16; long long ld; int k0; int pad; };
 struct TrsmJob { const double *L; double *X; const double *inv16; long long ld; int nrows; int wg0; };
 // C(ti, tj) -= P_ti P_tj^T for the 64-row tiles tj in [0, nc), ti in [tj, nr); K = 256 columns of P
-struct SyrkJob { const double *P; double *C; long long ldp, ldc; int nc, nr; int item0; int pad; };
+struct SyrkJob { const double *P; double *C; long long ldp, ldc; int nc, nr; int item0; int kb; };   // kb = 256-column blocks of P per pass
 struct TrinvJob { const double *L; const double *inv16; double *dinv; double *dinvt; long long ld; };
 // child's Schur buffer -> parent's panel (columns < wpp) / Schur buffer
 struct AddJob { const double *S; const int *pm; double *P; double *Sp; long long lds, ldp, ldsp; int h, nt, wpp, tile0; };
@@ -108,17 +108,58 @@ nd_trinv_kernel(const TrinvJob *__restrict__ jobs)
     trsm_rows<true>(j.L, j.dinv, j.ld, NBLK, j.inv16, j.dinvt, blockIdx.x * 16, xs);
 }
 
-// The trailing update of the multifrontal factorisation: one wave = one 64x64 item of C -= P_i P_j^T with
-// K = 256, in the register-streaming form of bandchol.hip's syrk64_kernel (operands loaded in MFMA fragment
-// shape SD k-steps ahead into a register queue, 16 independent v_mfma_f64_16x16x4_f64 accumulators that start
-// as the C tile; no LDS, no barriers).  P and C have their own base pointers and leading dimensions: P is a
-// block column of a front's panel, C the panel right of it or the front's Schur buffer.  This kernel carries
-// ~97 % of the flops of a large fit and is the roofline kernel of bench.py.
-template <int SD, int WPS>
-__global__ void __launch_bounds__(64, WPS)
-nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs)
+// (XCC, shader engine, CU) of the CU this wave runs on, as a 12-bit index
+__device__ inline unsigned nd_cu_index()
 {
-    const int b = blockIdx.x;
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);
+}
+
+// bitmap of the CUs a CU-masked stream runs on (discovery: many short workgroups on that stream)
+__global__ void __launch_bounds__(64)
+nd_whoami_kernel(unsigned *__restrict__ map)
+{
+    if (threadIdx.x == 0) {
+        const unsigned i = nd_cu_index();
+        atomicOr(&map[i >> 5], 1u << (i & 31));
+    }
+    __builtin_amdgcn_s_sleep(64);
+}
+
+// The trailing update of the multifrontal factorisation: one wave = one 64x64 item of C -= P_i P_j^T, in the
+// register-streaming form of bandchol.hip's syrk64_kernel (operands loaded in MFMA fragment shape ahead of
+// their use, 16 independent v_mfma_f64_16x16x4_f64 accumulators that start as the C tile; no LDS, no barriers).
+// P and C have their own base pointers and leading dimensions: P is a block column of a front's panel (kb
+// consecutive 256-column blocks of it per pass: K = 256 kb, the C tile is read and written once per pass),
+// C the panel right of it or the front's Schur buffer.  SCHUR only names the instantiation: the Schur-buffer
+// passes (K up to 1024, ~85 % of the flops of a large fit, one launch at a time) are the roofline kernel of
+// bench.py, the panel updates (K = 256, on the chain) are listed separately by the profilers.
+// queue != NULL: items are taken from an atomic counter and a wave that finds itself on a CU reserved for the
+// diagonal-block factorisations (resmap) steps aside -- the launch carries `margin` spare waves for that.
+template <int SD, int WPS, bool SCHUR>
+__global__ void __launch_bounds__(64, WPS)
+nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int margin, const unsigned *__restrict__ resmap,
+               int *__restrict__ queue)
+{
+    int b = blockIdx.x;
+    if (queue) {
+        const unsigned ci = nd_cu_index();
+        if (resmap[ci >> 5] & (1u << (ci & 31))) {
+            int e = 0;
+            if (threadIdx.x == 0) e = atomicAdd(&queue[1], 1);
+            e = __builtin_amdgcn_readfirstlane(e);
+            if (e < margin) {
+                __builtin_amdgcn_s_sleep(127);       // do not drain the grid through this CU
+                __builtin_amdgcn_s_sleep(127);
+                return;
+            }
+        }
+        if (threadIdx.x == 0) b = atomicAdd(&queue[0], 1);
+        b = __builtin_amdgcn_readfirstlane(b);
+    }
+    if (b >= nitems) return;
     const int ji = find_job(jobs, njobs, b, [](const SyrkJob &t) { return t.item0; });
     const SyrkJob j = jobs[ji];
     int tj, ti;
@@ -151,15 +192,24 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs)
     for (int d = 0; d < SD; ++d) fetch(d, d);
     constexpr int NSTEP = NBLK / 4;
     static_assert(NSTEP % SD == 0, "queue depth must divide the k-steps");
-    for (int ks = 0; ks < NSTEP; ks += SD) {
+    const int last = j.kb * NSTEP - 1;               // last k-step of the pass
+#pragma unroll 1
+    for (int h = 0; h < j.kb; ++h) {                 // one 256-column block per trip: the unrolled body of K = 256
+        const int base = h * NSTEP;
+        for (int ks = 0; ks < NSTEP; ks += SD) {
 #pragma unroll
-        for (int d = 0; d < SD; ++d) {
+            for (int d = 0; d < SD; ++d) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
-            if (ks + d + SD < NSTEP) fetch(d, ks + d + SD);
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+                if (ks + d + SD < NSTEP) fetch(d, base + ks + d + SD);
+                else {                               // the first steps of the next block (clamped: re-reads in the last one)
+                    const int nx = base + ks + d + SD;
+                    fetch(d, nx < last ? nx : last);
+                }
+            }
         }
     }
 #pragma unroll
@@ -450,10 +500,19 @@ struct NdState {
     JobTable<DotJob> dot;
     JobTable<BwdJob> bwd;
     JobTable<MapJob> map;
-    std::vector<std::vector<Launch>> l_potrf, l_trsm, l_upd, l_schur, l_mv, l_fwd, l_dot, l_bwd;
+    std::vector<std::vector<Launch>> l_potrf, l_trsm, l_upd, l_updr, l_schur, l_mv, l_fwd, l_dot, l_bwd;
+    std::vector<char> lookahead;                   // per depth: no Schur buffers (the root) -> the panel update is split: next block column on the chain, the rest beside it
+    JobTable<SyrkJob> updr;
+    std::vector<hipEvent_t> evW;                   // rest of the panel update of step k done
     std::vector<Launch> l_add[2], l_mapslot[2], l_mapall;     // per depth (of the children)
     // streams / events
-    hipStream_t sP = nullptr, sU = nullptr, sZ = nullptr;
+    hipStream_t sP = nullptr, sU = nullptr, sR = nullptr;   // chain, Schur updates (+ their memsets), CU-masked: diagonal blocks
+    unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
+    int nres = 0;
+    int *queues = nullptr;                         // [nqueues][2] item counters of the update launches of one factorisation
+    int nqueues = 0;
+    hipEvent_t evR0 = nullptr;
+    std::vector<hipEvent_t> evI;                   // potrf of step k done (per step of the current depth)
     std::vector<hipEvent_t> evT;                   // panel of step k solved (per step of the current depth)
     std::vector<hipEvent_t> evE, evZ;              // depth consumed / depth zeroed
     hipEvent_t ev0 = nullptr, evJ = nullptr, evU = nullptr, evZlast = nullptr, evDone = nullptr;
@@ -494,10 +553,10 @@ void nd_destroy(void *user)
     NdState *s = static_cast<NdState *>(user);
     if (!s) return;
     (void)hipDeviceSynchronize();
-    for (hipStream_t *q : {&s->sP, &s->sU, &s->sZ}) if (*q) (void)hipStreamDestroy(*q);
-    for (auto *v : {&s->evT, &s->evE, &s->evZ, &s->evA, &s->evB})
+    for (hipStream_t *q : {&s->sP, &s->sU, &s->sR}) if (*q) (void)hipStreamDestroy(*q);
+    for (auto *v : {&s->evT, &s->evE, &s->evZ, &s->evA, &s->evB, &s->evI, &s->evW})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->f0, s->f1}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->f0, s->f1, s->evR0}) if (e) (void)hipEventDestroy(e);
     for (void *q : s->owned) (void)hipFree(q);
     delete s;
 }
@@ -511,26 +570,42 @@ bool nd_build_jobs(NdState *s)
     const int nd = t.maxdepth + 1;
     int maxsteps = 0;
     for (const NdFront &f : t.fr) maxsteps = std::max(maxsteps, f.nsteps);
-    for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_upd, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) L->assign((size_t)nd, {});
+    for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_upd, &s->l_updr, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) L->assign((size_t)nd, {});
+    s->lookahead.assign((size_t)nd, 0);
     for (int sl = 0; sl < 2; ++sl) { s->l_add[sl].assign((size_t)nd, Launch()); s->l_mapslot[sl].assign((size_t)nd, Launch()); }
     s->l_mapall.assign((size_t)nd, Launch());
     long long part_max = 0;
+    // Schur buffer passes: groups of up to schur_kb panel blocks (K = 1024: the C tiles are read and written once per
+    // group; measured at 64^3: 257.6 ms per factorisation against 262.4 with K = 512 and 270.9 with K = 256; groups that
+    // ramp up 1, 2, 4, 4, .. so that the first pass of a depth starts earlier made no difference)
+    int schur_kb = 4;                                   // SPLPAK_ND_KB: 1 .. 4
+    if (const char *e = std::getenv("SPLPAK_ND_KB")) schur_kb = std::max(1, std::min(4, atoi(e)));
+    auto group_of = [&](int k, int nsteps, int &g0, int &gend) {
+        g0 = (k / schur_kb) * schur_kb;
+        gend = std::min(g0 + schur_kb, nsteps) - 1;
+    };
     for (int d = 0; d < nd; ++d) {
         const std::vector<int> &ids = t.by_depth[(size_t)d];
         int steps = 0;
         for (int id : ids) steps = std::max(steps, t.fr[(size_t)id].nsteps);
-        for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_upd, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) (*L)[(size_t)d].assign((size_t)steps, Launch());
+        for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_upd, &s->l_updr, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) (*L)[(size_t)d].assign((size_t)steps, Launch());
+        bool any_schur = false;
+        for (int id : ids) any_schur = any_schur || t.fr[(size_t)id].hp > 0;
+        const bool la = !any_schur && steps >= 4 && !std::getenv("SPLPAK_ND_NO_ROOT_LOOKAHEAD");
+        s->lookahead[(size_t)d] = la ? 1 : 0;
         for (int k = 0; k < steps; ++k) {
-            Launch lp, lt, lu, ls, lm, lf, ld, lb;
+            Launch lp, lt, lu, lur, ls, lm, lf, ld, lb;
             lp.first = (int)s->potrf.host.size();
             lt.first = (int)s->trsm.host.size();
             lu.first = (int)s->upd.host.size();
+            lur.first = (int)s->updr.host.size();
             ls.first = (int)s->schur.host.size();
             lm.first = (int)s->mv.host.size();
             lf.first = (int)s->fwd.host.size();
             ld.first = (int)s->dot.host.size();
             lb.first = (int)s->bwd.host.size();
-            long long twg = 0, ui = 0, si = 0, fwg = 0, dwg = 0, partofs = 0;
+            long long twg = 0, ui = 0, uri = 0, si = 0, fwg = 0, dwg = 0, partofs = 0;
+            double sflop = 0.0;
             for (int id : ids) {
                 const NdFront &f = t.fr[(size_t)id];
                 if (k >= f.nsteps) continue;
@@ -548,16 +623,29 @@ bool nd_build_jobs(NdState *s)
                 }
                 const int nc = (f.wp - (k + 1) * 256) / 64, nr = nrows / 64;
                 if (nc > 0) {
-                    // panel columns right of block k: rows and columns relative to row (k+1)*256
-                    s->upd.host.push_back(SyrkJob{below, below + (long long)256 * f.ld, f.ld, f.ld, nc, nr, (int)ui, 0});
-                    ui += trapezoid_items(nc, nr);
+                    // panel columns right of block k: rows and columns relative to row (k+1)*256; with look-ahead the next
+                    // block column (4 tile columns) stays on the chain, the rest is a launch of its own
+                    const int ncn = la ? std::min(nc, 4) : nc;
+                    s->upd.host.push_back(SyrkJob{below, below + (long long)256 * f.ld, f.ld, f.ld, ncn, nr, (int)ui, 1});
+                    ui += trapezoid_items(ncn, nr);
                     ++lu.count;
+                    if (nc > ncn) {
+                        s->updr.host.push_back(SyrkJob{below + 256, below + (long long)256 * f.ld + 256 + (long long)256 * f.ld, f.ld, f.ld,
+                                                       nc - 4, nr - 4, (int)uri, 1});
+                        uri += trapezoid_items(nc - 4, nr - 4);
+                        ++lur.count;
+                    }
                 }
+                // Schur buffer: one pass per group of up to schur_kb panel blocks, launched when the group's last block is solved
                 const int ns = f.hp / 64;
-                if (ns > 0) {
-                    s->schur.host.push_back(SyrkJob{panel + f.wp + (long long)k * 256 * f.ld, s->sar[f.depth & 1] + f.s_off, f.ld,
-                                                    f.lds, ns, ns, (int)si, 0});
+                int g0 = 0, gend = 0;
+                group_of(k, f.nsteps, g0, gend);
+                if (ns > 0 && k == gend) {
+                    const int kb = k - g0 + 1;
+                    s->schur.host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s->sar[f.depth & 1] + f.s_off, f.ld,
+                                                    f.lds, ns, ns, (int)si, kb});
                     si += trapezoid_items(ns, ns);
+                    sflop += 2.0 * 64 * 64 * 256 * kb * (double)trapezoid_items(ns, ns);
                     ++ls.count;
                 }
                 // solves
@@ -585,8 +673,10 @@ bool nd_build_jobs(NdState *s)
             lt.grid = (unsigned)twg;
             lu.grid = (unsigned)ui;
             lu.flop = 2.0 * 64 * 64 * 256 * (double)ui;
+            lur.grid = (unsigned)uri;
+            lur.flop = 2.0 * 64 * 64 * 256 * (double)uri;
             ls.grid = (unsigned)si;
-            ls.flop = 2.0 * 64 * 64 * 256 * (double)si;
+            ls.flop = sflop;
             lm.grid = (unsigned)lm.count;
             lf.grid = (unsigned)fwg;
             ld.grid = (unsigned)dwg;
@@ -594,12 +684,14 @@ bool nd_build_jobs(NdState *s)
             // sentinels for the job search (first field of the element after the last job)
             if (lt.count) s->trsm.host.push_back(TrsmJob{nullptr, nullptr, nullptr, 0, 0, (int)twg});
             if (lu.count) s->upd.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)ui, 0});
+            if (lur.count) s->updr.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)uri, 0});
             if (ls.count) s->schur.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)si, 0});
             if (lf.count) s->fwd.host.push_back(FwdJob{nullptr, nullptr, nullptr, 0, 0, (int)fwg});
             if (ld.count) s->dot.host.push_back(DotJob{nullptr, nullptr, nullptr, 0, 0, 0, 0, (int)dwg});
             s->l_potrf[(size_t)d][(size_t)k] = lp;
             s->l_trsm[(size_t)d][(size_t)k] = lt;
             s->l_upd[(size_t)d][(size_t)k] = lu;
+            s->l_updr[(size_t)d][(size_t)k] = lur;
             s->l_schur[(size_t)d][(size_t)k] = ls;
             s->l_mv[(size_t)d][(size_t)k] = lm;
             s->l_fwd[(size_t)d][(size_t)k] = lf;
@@ -651,11 +743,15 @@ bool nd_build_jobs(NdState *s)
     return part_max <= s->part_cap;
 }
 
-void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipStream_t st, CholStats *stats, bool timing)
+// schur: the Schur-buffer passes (timed: the roofline kernel); otherwise the panel update of the chain.
+// pinned: diagonal blocks are being factored on the reserved CUs -- the waves take their items from a queue and
+// step aside there.
+void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipStream_t st, CholStats *stats, bool timing, bool schur,
+                 bool pinned, int &qnext)
 {
     if (l.count == 0 || l.grid == 0) return;
     hipEvent_t a = nullptr, b = nullptr;
-    if (timing) {
+    if (timing && schur) {
         const size_t i = (size_t)stats->syrk_launches;
         while (s->evA.size() <= i) {
             hipEvent_t e;
@@ -671,10 +767,27 @@ void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipS
     }
     if (stats) {
         stats->total_flop += l.flop;
-        stats->bulk_launches += 1;
-        stats->bulk_flop += l.flop;
+        if (schur) {
+            stats->bulk_launches += 1;
+            stats->bulk_flop += l.flop;
+        }
     }
-    hipExtLaunchKernelGGL((nd_syrk_kernel<16, 1>), dim3(l.grid), dim3(64), 0, st, a, b, 0, (const SyrkJob *)(tab.dev + l.first), l.count);
+    int *queue = nullptr;
+    int margin = 0;
+    if (pinned && s->nres > 0 && qnext < s->nqueues) {
+        queue = s->queues + 2 * (qnext++);
+        margin = 256 * s->nres;
+    }
+    const SyrkJob *jobs = tab.dev + l.first;
+    // SD = 4 k-steps of operand look-ahead, two waves per SIMD (244 registers): measured at 64^3 against the 16-deep
+    // queue / one wave per SIMD form the band's bulk update uses -- 257.6 against 282.2 ms per factorisation, because
+    // the queue is carried across the block loop of a K = 1024 pass and then has to live in registers (256 + 180)
+    if (schur)
+        hipExtLaunchKernelGGL((nd_syrk_kernel<4, 2, true>), dim3(l.grid + (unsigned)margin), dim3(64), 0, st, a, b, 0, jobs, l.count,
+                              (int)l.grid, margin, (const unsigned *)s->resmap, queue);
+    else
+        hipLaunchKernelGGL((nd_syrk_kernel<4, 2, false>), dim3(l.grid + (unsigned)margin), dim3(64), 0, st, jobs, l.count, (int)l.grid,
+                           margin, (const unsigned *)s->resmap, queue);
 }
 
 hipError_t nd_assemble(splpak_plan *p, hipStream_t st, void *user)
@@ -707,8 +820,12 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     *stats = CholStats{};
     stats->enabled = enabled;
     const int nd = t.maxdepth + 1;
-    hipStream_t sP = s->sP, sU = s->sU, sZ = s->sZ;
-    if (std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = sU = sZ = st;
+    hipStream_t sP = s->sP, sU = s->sU, sR = s->sR;
+    const bool serial = std::getenv("SPLPAK_NO_LOOKAHEAD") != nullptr;
+    if (serial) sP = sU = st;
+    if (serial || !sR || std::getenv("SPLPAK_NO_PANEL_CU")) sR = nullptr;
+    // potrf goes to the reserved CUs while a depth has at most this many diagonal blocks per step per reserved CU
+    const int pin_rounds = std::getenv("SPLPAK_ND_PIN_ROUNDS") ? atoi(std::getenv("SPLPAK_ND_PIN_ROUNDS")) : 2;
     if (timing) {
         if (!s->f0) { (void)hipEventCreate(&s->f0); (void)hipEventCreate(&s->f1); }
         (void)hipEventRecord(s->f0, st);
@@ -720,10 +837,12 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             if (t.s_doubles[a] > 0) (void)hipMemsetAsync(s->sar[a], 0, sizeof(double) * (size_t)t.s_doubles[a], st);
     }
     s->s_clean = false;
+    if (s->queues) (void)hipMemsetAsync(s->queues, 0, sizeof(int) * 2 * (size_t)s->nqueues, st);
+    int qnext = 0;
     (void)hipEventRecord(s->ev0, st);
     if (sP != st) (void)hipStreamWaitEvent(sP, s->ev0, 0);
     if (sU != st) (void)hipStreamWaitEvent(sU, s->ev0, 0);
-    if (sZ != st) (void)hipStreamWaitEvent(sZ, s->ev0, 0);
+    if (sR) (void)hipStreamWaitEvent(sR, s->ev0, 0);
     auto deepest_with_parity = [&](int par) { int d = t.maxdepth; if ((d & 1) != par) --d; return d; };
     std::vector<char> zeroed_now((size_t)nd + 2, 0);
     for (int d = t.maxdepth; d >= 0; --d) {
@@ -732,39 +851,59 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             hipEvent_t e;
             (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
             s->evT.push_back(e);
+            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            s->evI.push_back(e);
+            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            s->evW.push_back(e);
         }
+        const bool pinned = sR != nullptr && s->nres > 0 && (int)s->l_potrf[(size_t)d][0].grid <= pin_rounds * s->nres;
         for (int k = 0; k < steps; ++k) {
             const Launch &lp = s->l_potrf[(size_t)d][(size_t)k], &lt = s->l_trsm[(size_t)d][(size_t)k];
             const Launch &lu = s->l_upd[(size_t)d][(size_t)k], &ls = s->l_schur[(size_t)d][(size_t)k];
-            hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sP, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
+            if (pinned) {           // two event hops: chain -> reserved CUs -> chain
+                (void)hipEventRecord(s->evR0, sP);
+                (void)hipStreamWaitEvent(sR, s->evR0, 0);
+                hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sR, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
+                (void)hipEventRecord(s->evI[(size_t)k], sR);
+                (void)hipStreamWaitEvent(sP, s->evI[(size_t)k], 0);
+            } else
+                hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sP, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
             if (lt.count)
                 hipLaunchKernelGGL(nd_trsm_kernel, dim3(lt.grid), dim3(64), 0, sP, (const TrsmJob *)(s->trsm.dev + lt.first), lt.count);
-            if (ls.count && sU != sP) {
+            const Launch &lur = s->l_updr[(size_t)d][(size_t)k];
+            if ((ls.count || lur.count) && sU != sP) {
                 (void)hipEventRecord(s->evT[(size_t)k], sP);
                 (void)hipStreamWaitEvent(sU, s->evT[(size_t)k], 0);
             }
-            launch_syrk(s, s->upd, lu, sP, stats, timing);
-            launch_syrk(s, s->schur, ls, sU, stats, timing);
+            // look-ahead (the root): columns beyond the next block column are updated beside the chain of step k + 1;
+            // the next step's update of ITS next block column waits for them (same tiles)
+            if (s->lookahead[(size_t)d] && k > 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evW[(size_t)(k - 1)], 0);
+            launch_syrk(s, s->upd, lu, sP, stats, timing, false, pinned, qnext);
+            if (lur.count) {
+                launch_syrk(s, s->updr, lur, sU, stats, timing, false, pinned, qnext);
+            }
+            if (s->lookahead[(size_t)d] && sU != sP) (void)hipEventRecord(s->evW[(size_t)k], sU);
+            launch_syrk(s, s->schur, ls, sU, stats, timing, true, pinned, qnext);
         }
         if (sU != sP) {                                 // the depth's Schur updates are complete before they are handed on
             (void)hipEventRecord(s->evU, sU);
             (void)hipStreamWaitEvent(sP, s->evU, 0);
         }
         if (d >= 1) {
-            if (zeroed_now[(size_t)(d - 1)] && sZ != sP) (void)hipStreamWaitEvent(sP, s->evZ[(size_t)(d - 1)], 0);
+            if (zeroed_now[(size_t)(d - 1)] && sU != sP) (void)hipStreamWaitEvent(sP, s->evZ[(size_t)(d - 1)], 0);
             for (int sl = 0; sl < 2; ++sl) {
                 const Launch &la = s->l_add[sl][(size_t)d];
                 if (la.count)
                     hipLaunchKernelGGL(nd_extend_add_kernel, dim3(la.grid), dim3(256), 0, sP, (const AddJob *)(s->add.dev + la.first), la.count);
             }
             // depth d is consumed: its arena half is free -- zero what uses it next (depth d - 2, or the deepest depth
-            // of that parity for the NEXT fit), beside the work of depth d - 1
+            // of that parity for the NEXT fit) on the update stream, ahead of the Schur passes of depth d - 1
             (void)hipEventRecord(s->evE[(size_t)d], sP);
             const int target = d - 2 >= 1 ? d - 2 : deepest_with_parity(d & 1);
             if (target >= 1 && s->s_depth_doubles[(size_t)target] > 0) {
-                if (sZ != sP) (void)hipStreamWaitEvent(sZ, s->evE[(size_t)d], 0);
-                (void)hipMemsetAsync(s->sar[target & 1], 0, sizeof(double) * (size_t)s->s_depth_doubles[(size_t)target], sZ);
-                (void)hipEventRecord(s->evZ[(size_t)target], sZ);
+                if (sU != sP) (void)hipStreamWaitEvent(sU, s->evE[(size_t)d], 0);
+                (void)hipMemsetAsync(s->sar[target & 1], 0, sizeof(double) * (size_t)s->s_depth_doubles[(size_t)target], sU);
+                (void)hipEventRecord(s->evZ[(size_t)target], sU);
                 if (target == d - 2) zeroed_now[(size_t)target] = 1;
             }
         }
@@ -773,8 +912,8 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)t.nblocks), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev);
     (void)hipEventRecord(s->evJ, sP);
     if (sP != st) (void)hipStreamWaitEvent(st, s->evJ, 0);
-    if (sZ != st) {
-        (void)hipEventRecord(s->evZlast, sZ);
+    if (sU != st) {                                   // (the memsets for the next fit may still be running: it waits for them)
+        (void)hipEventRecord(s->evZlast, sU);
         s->zlast_valid = true;
     }
     s->s_clean = true;
@@ -881,7 +1020,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
          nd_upload(s, &s->fdev, fdev);
     if (!ok) return SPLPAK_E_NOMEM;
     if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
-    ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->upd.dev, s->upd.host) &&
+    ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) &&
          nd_upload(s, &s->schur.dev, s->schur.host) && nd_upload(s, &s->trinv.dev, s->trinv.host) && nd_upload(s, &s->add.dev, s->add.host) &&
          nd_upload(s, &s->mv.dev, s->mv.host) && nd_upload(s, &s->fwd.dev, s->fwd.host) && nd_upload(s, &s->dot.dev, s->dot.host) &&
          nd_upload(s, &s->bwd.dev, s->bwd.host) && nd_upload(s, &s->map.dev, s->map.host);
@@ -893,23 +1032,54 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     (void)hipStreamCreateWithPriority(&s->sP, hipStreamNonBlocking, hi);
     (void)hipStreamCreateWithFlags(&s->sU, hipStreamNonBlocking);
-    (void)hipStreamCreateWithPriority(&s->sZ, hipStreamNonBlocking, lo);
-    for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
+    for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone, &s->evR0}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
+    // item queues of the update launches (two per step at most)
+    s->nqueues = 3 * t.nblocks + 16;
+    if (!nd_alloc(s, &s->queues, (size_t)2 * s->nqueues) || !nd_alloc(s, &s->resmap, (size_t)128)) return SPLPAK_E_NOMEM;
+    (void)hipMemset(s->resmap, 0, 128 * sizeof(unsigned));
+    // A few CUs are left to the diagonal-block factorisations of the upper tree levels: v_mfma_f64 runs on the same
+    // pipes as f64 VALU code, and the latency-bound potrf workgroups ran 8x slower (1.26 ms instead of 0.16) beside
+    // the update waves (rocprofv3, 64^3).  potrf is pinned to those CUs through a CU-masked stream; the update
+    // waves are not masked, they step aside when they find themselves there (nd_syrk_kernel).  Only trees whose
+    // upper levels are worth it (>= 8 block steps in the root) pay for the extra stream.
+    const int want_res = std::getenv("SPLPAK_ND_RES_CUS") ? atoi(std::getenv("SPLPAK_ND_RES_CUS")) : 8;
+    if (want_res > 0 && t.fr[(size_t)t.root].nsteps >= 8 && !std::getenv("SPLPAK_NO_PANEL_CU")) {
+        hipDeviceProp_t prop;
+        (void)hipGetDeviceProperties(&prop, s->device);
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int i = 0; i < want_res && i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+        if (hipExtStreamCreateWithCUMask(&s->sR, (uint32_t)mask.size(), mask.data()) == hipSuccess) {
+            hipLaunchKernelGGL(nd_whoami_kernel, dim3(64 * (unsigned)want_res), dim3(64), 0, s->sR, s->resmap);
+            unsigned hm[128];
+            if (hipStreamSynchronize(s->sR) == hipSuccess && hipMemcpy(hm, s->resmap, sizeof hm, hipMemcpyDeviceToHost) == hipSuccess)
+                for (unsigned wv : hm) s->nres += __builtin_popcount(wv);
+            if (s->nres == 0 || s->nres > 2 * want_res) {      // the mask did not take: no pinning
+                (void)hipStreamDestroy(s->sR);
+                s->sR = nullptr;
+                s->nres = 0;
+                (void)hipMemset(s->resmap, 0, 128 * sizeof(unsigned));
+            }
+        } else {
+            (void)hipGetLastError();
+            s->sR = nullptr;
+        }
+    }
     s->evE.assign((size_t)nd + 1, nullptr);
     s->evZ.assign((size_t)nd + 1, nullptr);
     for (int d = 0; d <= nd; ++d) {
         (void)hipEventCreateWithFlags(&s->evE[(size_t)d], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&s->evZ[(size_t)d], hipEventDisableTiming);
     }
-    if (!s->sP || !s->sU || !s->sZ) { set_error("nested dissection: stream creation failed"); (void)hipGetLastError(); return SPLPAK_E_NODEVICE; }
+    if (!s->sP || !s->sU) { set_error("nested dissection: stream creation failed"); (void)hipGetLastError(); return SPLPAK_E_NODEVICE; }
     p->expand_fn = nd_assemble;
     p->factor_fn = nd_factor;
     p->solve_fn = nd_solve;
     if (factor_arena) *factor_arena = s->factor;
     if (factor_doubles) *factor_doubles = t.factor_doubles;
     if (std::getenv("SPLPAK_DEBUG"))
-        fprintf(stderr, "[splpak] nested dissection: %zu fronts, depth %d, factor %.2f GB, Schur arenas %.2f GB, %.3e flop\n", t.fr.size(),
-                t.maxdepth, 8e-9 * (double)t.factor_doubles, 8e-9 * (double)(t.s_doubles[0] + t.s_doubles[1]), t.flop);
+        fprintf(stderr, "[splpak] nested dissection: %zu fronts, depth %d, factor %.2f GB, Schur arenas %.2f GB, %.3e flop, %d reserved CUs\n", t.fr.size(),
+                t.maxdepth, 8e-9 * (double)t.factor_doubles, 8e-9 * (double)(t.s_doubles[0] + t.s_doubles[1]), t.flop, s->nres);
     return 0;
 }
 

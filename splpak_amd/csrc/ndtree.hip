@@ -267,6 +267,28 @@ extern "C" int32_t splpak_debug_nd_tree(int32_t ndim, const int32_t *nodes, int3
         const std::string msg = nd_check(t);
         if (!msg.empty()) { set_error("nested dissection: " + msg); return SPLPAK_E_BADARG; }
     }
+    if (std::getenv("SPLPAK_DEBUG")) {
+        for (int d = 0; d <= t.maxdepth; ++d) {
+            double sb = 0, fb = 0, fl = 0, flp = 0;
+            int steps = 0, mw = 0, mh = 0;
+            for (int id : t.by_depth[(size_t)d]) {
+                const NdFront &f = t.fr[(size_t)id];
+                sb += 8.0 * f.lds * f.hp;
+                fb += 8.0 * f.ld * f.wp;
+                const double w = f.w, h = f.h;
+                fl += w * w * w / 3.0 + w * w * h + w * h * h;
+                for (int k = 0; k < f.nsteps; ++k) {
+                    const long long nc = (f.wp - (k + 1) * 256) / 64, nr = (f.fp - (k + 1) * 256) / 64, ns = f.hp / 64;
+                    flp += 2.0 * 64 * 64 * 256 * (double)(nc * nr - nc * (nc - 1) / 2 + ns * (ns + 1) / 2);
+                }
+                steps = std::max(steps, f.nsteps);
+                mw = std::max(mw, f.w);
+                mh = std::max(mh, f.h);
+            }
+            fprintf(stderr, "[nd] depth %2d: %5zu fronts, steps %3d, max w %6d h %6d, S %.2f GB, panels %.2f GB, flop exact %.3e padded %.3e\n", d,
+                    t.by_depth[(size_t)d].size(), steps, mw, mh, sb / 1e9, fb / 1e9, fl, flp);
+        }
+    }
     int maxw = 0, maxh = 0;
     for (const NdFront &f : t.fr) { maxw = std::max(maxw, f.w); maxh = std::max(maxh, f.h); }
     out16[0] = (double)t.fr.size();
