@@ -144,6 +144,11 @@ def _check(rc: int) -> int:
     return rc
 
 
+def shutdown() -> None:
+    """Release the library's cached one-shot plan (28 GB at 64^3), staging buffers and evaluation scratch."""
+    lib().splpak_shutdown()
+
+
 def device_name() -> str:
     buf = C.create_string_buffer(256)
     _check(lib().splpak_device_name(buf, 256))

@@ -977,12 +977,16 @@ hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void
 
 }  // namespace
 
-// SPLPAK_ND: 0 = never, 1 = always; otherwise 3-D / 4-D grids whose band is wide enough for the four-stream
-// band pipeline (below that the two-ended narrow form of twoend.hip is used)
+// SPLPAK_ND: 0 = never, 1 = always; otherwise every 2-D .. 4-D grid of at least 8 192 columns.  Measured on MI355X
+// (tools/nd_crossover.sh, fit time band -> nested dissection): 24^3 11.4 -> 9.0 ms, 32^3 26.3 -> 18.4, 40^3 67.7 ->
+// 42.5, 48^3 166 -> 85, 64^3 831 -> 303, 4-D 12^4 41.9 -> 41.0, 16^4 239 -> 190, 24^4 10.5 s -> 4.9 s, 2-D 256^2
+// 41.5 -> 15.5; the 2-D 64^2 grid of BASELINE config 2 (4 096 columns, block-tridiagonal band) stays with the
+// two-ended band factorisation: 3.28 against 3.55 ms.
 bool nd_wanted(const Grid &g, const Band &band)
 {
+    (void)band;
     if (const char *e = std::getenv("SPLPAK_ND")) return atoi(e) != 0;
-    return g.ndim >= 3 && band.bw >= narrow_band_limit();
+    return g.ndim >= 2 && g.ncol >= 8192;
 }
 
 // Installs the nested-dissection factorisation on a single-GPU plan: builds the tree, allocates the arenas,

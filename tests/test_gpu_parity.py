@@ -513,10 +513,12 @@ def test_pinned_pipeline_24cubed_property():
     out = {}
     for label, pin in (("pinned", "1"), ("unpinned", "1000000")):
         os.environ["SPLPAK_PIN_BW"] = pin
+        os.environ["SPLPAK_ND"] = "0"          # this test is about the BAND pipelines (grids of this size default to nested dissection)
         try:
             c, ierr, _, info = capi.fit(nd, x, f(x), None, [0.0] * nd, [1.0] * nd, [nod] * nd, 0.0)
         finally:
             os.environ.pop("SPLPAK_PIN_BW", None)
+            os.environ.pop("SPLPAK_ND", None)
         assert ierr == 0
         v, _ = capi.evaluate(nd, q, None, c, [0.0] * nd, [1.0] * nd, [nod] * nd)
         assert np.max(np.abs(v - f(q))) < 1e-10, label
@@ -527,12 +529,15 @@ def test_pinned_pipeline_24cubed_property():
 
 def test_c3_full_size_properties():
     """BASELINE config 3 AT FULL SIZE through the code path bench.py times (3-D, 64^3 = 262 144 columns,
-    10^7 points of the seeded stream, pinned-potrf pipeline, band 49 blocks wide).  The dense reference
-    cannot run this grid (550 GB of workspace), so parity is checked through size-independent properties:
+    10^7 points of the seeded stream; round 3: the nested-dissection multifrontal factorisation, 1 023 fronts).
+    The dense reference cannot run this grid (550 GB of workspace), so parity is checked through
+    size-independent properties:
       (a) data sampled from a spline of the grid with RANDOM coefficients (xtrap = 0, so the fit is a
           projection): the coefficients are recovered to 1e-10 max-norm;
       (b) splcc equals splcw with unit weights;
-      (c) the measured optimality residual (info[9]) is at rounding level."""
+      (c) the measured optimality residual (info[9]) is at rounding level;
+      (d) the band factorisation (round 2's path: pinned-potrf pipeline, band 49 blocks wide, SPLPAK_ND=0) gives the
+          same coefficients to 1e-12."""
     import torch
     nd, nod, m = 3, 64, 10_000_000
     nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
@@ -570,6 +575,21 @@ def test_c3_full_size_properties():
         capi.evaluate_dev(nd, q, None, ctrue, lo, hi, nodes, v2, st)
         torch.cuda.synchronize()
         assert float((v1 - v2).abs().max() / v2.abs().max()) < 1e-10
+        import os
+        os.environ["SPLPAK_ND"] = "0"
+        try:
+            band = capi.Plan(nd, nodes, lo, hi, 0.0, m)
+        finally:
+            os.environ.pop("SPLPAK_ND", None)
+        try:
+            coefb = torch.zeros_like(coef)
+            ierr, infob = band.fit(x, y, None, coefb, st)
+            assert ierr == 0
+            dband = float((coefb - coef).abs().max() / coef.abs().max())
+            print(f"64^3: nested dissection vs band {dband:.2e}; factorisation {info[6]:.3f} s vs {infob[6]:.3f} s")
+            assert dband < 1e-12
+        finally:
+            band.close()
     finally:
         plan.close()
 
@@ -602,7 +622,9 @@ def test_fit_matches_banded_cpu_beyond_the_dense_oracle(port, nod, m):
     x, y, w = synth_points(nd, m)
     lo, hi, nodes = [0.0] * nd, [1.0] * nd, [nod] * nd
     c0, e0, i0 = port.fit_banded(nd, x, y, w, lo, hi, nodes, 1.0)
-    c1, e1, _, i1 = capi.fit(nd, x, y, w, lo, hi, nodes, 1.0)
+    # the BAND factorisation (two-ended at these sizes); the nested-dissection path these grids take by default is
+    # held to the same CPU solve in tests/test_nd.py
+    c1, e1, _, i1 = _fit_with_env(dict(ndim=nd, xdata=x, ydata=y, wdata=w, xmin=lo, xmax=hi, nodes=nodes, xtrap=1.0), {"SPLPAK_ND": "0"})
     assert e0 == e1 == 0
     print(f"{nod}^3: GPU vs banded CPU rel={relmax(c1, c0):.2e}; rows {i1[0]:.0f}+{i1[1]:.0f}; reserr GPU {i1[8]:.6e} CPU {i0[8]:.6e}; "
           f"CPU {i0[5] + i0[6] + i0[7]:.1f} s on {i0[9]:.0f} threads")

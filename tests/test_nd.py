@@ -134,3 +134,51 @@ def test_nd_matches_banded_cpu_beyond_the_dense_oracle(port, nod, m):
     assert relmax(c1, c0) < COEF_TOL
     assert i1[0] == i0[0] and i1[1] == i0[1]
     assert abs(i1[8] - i0[8]) <= 1e-9 * i0[8]
+
+
+@pytest.mark.gpu
+def test_nd_4d_24_random_spline_recovery():
+    """4-D, 24^4 = 331 776 columns (BASELINE config 5's dimension count at the largest size whose fronts fit one
+    288 GB GPU next to their Schur arenas: 76 + 132 GB; the 32^4 grid itself needs 476 GB of factor alone,
+    tests/test_gpu_parity.py::test_grid_beyond_one_gpu_is_a_clean_error).  Data sampled from a spline of the grid
+    with RANDOM coefficients, xtrap = 0: the fit is a projection and must give the coefficients back to 1e-10;
+    fresh queries (also outside the box) agree; the measured optimality residual is at rounding level."""
+    import time
+    import torch
+    capi.shutdown()
+    torch.cuda.empty_cache()
+    nd, nod, m = 4, 24, 4_000_000
+    nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.empty((m, nd), dtype=torch.float64, device=dev)
+    capi.synth_points_dev(nd, 0, m, x, None, None, st)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    ctrue = torch.randn(nod ** nd, dtype=torch.float64, device=dev, generator=gen)
+    y = torch.empty(m, dtype=torch.float64, device=dev)
+    capi.evaluate_dev(nd, x, None, ctrue, lo, hi, nodes, y, st)
+    t0 = time.perf_counter()
+    plan = capi.Plan(nd, nodes, lo, hi, 0.0, m)
+    t1 = time.perf_counter()
+    try:
+        coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
+        ierr, info = plan.fit(x, y, None, coef, st)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        assert ierr == 0
+        err = float((coef - ctrue).abs().max() / ctrue.abs().max())
+        print(f"24^4 projection: plan {t1 - t0:.1f} s, fit {t2 - t1:.2f} s (assembly {info[5]:.2f}, factorisation {info[6]:.2f}, "
+              f"solve {info[7]:.2f}); coefficient error {err:.2e}, steps {info[2]:.0f}, optimality {info[9]:.1e}")
+        assert info[0] == m
+        assert err < COEF_TOL
+        assert info[9] < 1e-9
+        q = torch.rand((50000, nd), dtype=torch.float64, device=dev, generator=gen) * 1.2 - 0.1
+        v1 = torch.empty(q.shape[0], dtype=torch.float64, device=dev)
+        v2 = torch.empty_like(v1)
+        capi.evaluate_dev(nd, q, None, coef, lo, hi, nodes, v1, st)
+        capi.evaluate_dev(nd, q, None, ctrue, lo, hi, nodes, v2, st)
+        torch.cuda.synchronize()
+        assert float((v1 - v2).abs().max() / v2.abs().max()) < 1e-10
+    finally:
+        plan.close()
