@@ -7,19 +7,23 @@ on MI355X, BASELINE.json config 3: 3-D, 1e7 scattered weighted points per GPU,
 
 A "step" is one complete fit of this rank's points that are already resident in
 HBM: window binning, Gram assembly, (RCCL all-reduce of the normal equations when
-N > 1), derivative-constraint rows, band Cholesky on the f64 matrix cores,
-solve and iterative refinement, coefficients left in HBM.  For N > 1 the points
-are sharded (weak scaling: every rank holds --ndata points) and the histogram,
-the normal equations and each refinement residual are all-reduced over RCCL; the
+N > 1), derivative-constraint rows, Cholesky of the normal equations on the f64
+matrix cores (nested-dissection multifrontal for this grid, csrc/ndchol.hip),
+solve and iterative refinement against the rows, coefficients left in HBM.  For
+N > 1 the points are sharded (weak scaling: every rank holds --ndata points;
+--gpus 8 defaults to BASELINE config 4: 1e8 points in all) and the histogram, the
+normal equations and each refinement residual are all-reduced over RCCL; the
 factorisation is replicated.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel (syrk64_kernel, f64-MFMA trailing update of the band Cholesky):
-                algorithmic flop / HIP-event time measured inside the timed region
+  roofline      the dominant kernel (nd_syrk_kernel<4,2,true>: f64-MFMA Schur-buffer passes of the
+                multifrontal factorisation): algorithmic flop / HIP-event time measured inside the timed region
   cpu_baseline  the reference itself (oracle/_ref, 1 core; it is single-threaded)
                 on a bounded sample -- the dense reference algorithm cannot run the
                 64^3 grid at all (550 GB workspace)
   eval          batched evaluation throughput (one thread per query) + its HBM roofline
+  strong        (N > 1) config 3's 1e7 points in all, sharded: the fixed-total line beside the weak headline
+  c2, grid32, c5_eval, c5_fit, fit_incl_h2d, dist_band   guarded side legs (N = 1)
 """
 import argparse
 import json
@@ -45,13 +49,43 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ndim", type=int, default=3)
     ap.add_argument("--nodes", type=int, default=64, help="nodes per dimension")
-    ap.add_argument("--ndata", type=int, default=10_000_000, help="points per GPU")
+    ap.add_argument("--ndata", type=int, default=None,
+                    help="points per GPU (default: 1e7 = BASELINE config 3; with --gpus 8 on the 3-D 64^3 grid 1.25e7 = config 4's 1e8 points in all)")
     ap.add_argument("--neval", type=int, default=50_000_000, help="evaluation queries per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the C2 and host-pointer (PCIe-inclusive) legs")
     ap.add_argument("--dist-child", type=str, default="", help=argparse.SUPPRESS)   # internal: "ngpus,nod,m,virtual"
     return ap.parse_args()
+
+
+def default_ndata(world, nd, nod):
+    """Points per GPU when --ndata is not given: BASELINE config 4 (1e8 points over 8 GPUs) at N = 8 on the
+    config's grid, config 3's 1e7 per GPU otherwise."""
+    return 12_500_000 if (world == 8 and nd == 3 and nod == 64) else 10_000_000
+
+
+def workload_label(world, nd, nod, m):
+    """config.workload: which BASELINE config the line is quoted on."""
+    nodes = "x".join([str(nod)] * nd)
+    base = (f"{nd}-D splcw least-squares spline fit, {{pts}} weighted scattered points (Park-Miller stream, seed 42), "
+            f"{nodes} nodes, xtrap=1, real64")
+    if nd == 3 and nod == 64 and world == 1 and m == 10_000_000:
+        return "C3: " + base.format(pts=f"{m}")
+    if nd == 3 and nod == 64 and world * m == 100_000_000 and world == 8:
+        return "C4: " + base.format(pts=f"{world * m} (= {m} per GPU, sharded over {world} GPUs)")
+    if nd == 3 and nod == 64:
+        return (f"C3's grid with {m} points on each of {world} GPUs (weak scaling between config 3 and config 4; config 4 itself "
+                f"is --gpus 8): " + base.format(pts=f"{world * m}"))
+    return base.format(pts=f"{world * m} ({m} per GPU)")
+
+
+def guarded(fn, *a, **k):
+    """A side leg must never take the headline line with it: -> its result, or {"error": ...}."""
+    try:
+        return fn(*a, **k)
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def cpu_baseline(ndim):
@@ -159,6 +193,7 @@ def bench_small(capi, dev, stream, steps, nd, nod, m, weighted, label):
     capi.synth_points_dev(nd, 0, m, x, y, w, stream)
     coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
     plan = capi.Plan(nd, nodes, [0.0] * nd, [1.0] * nd, 1.0, m)
+    fact = plan.factorisation()[1]
     for _ in range(3):
         ierr, info = plan.fit(x, y, w, coef, stream)
         assert ierr == 0, f"{label} fit failed with ierror {ierr}"
@@ -175,8 +210,48 @@ def bench_small(capi, dev, stream, steps, nd, nod, m, weighted, label):
     assert ierr == 0 and info[9] < 1e-9, f"{label}: ierror {ierr}, optimality residual {info[9]:.2e}"
     return {"workload": label, "value": m / dt, "unit": "points/s", "ms_per_fit": 1e3 * dt, "fits_timed": n,
             "phase_ms": {"assembly": 1e3 * phase[0] / n, "factor": 1e3 * phase[1] / n, "solve_refine": 1e3 * phase[2] / n},
-            "factorisation": "two-ended band Cholesky (both ends eliminated concurrently, csrc/twoend.hip)",
+            "factorisation": fact,
             "refine_steps": int(info[2]), "optimality_residual": float(info[9])}
+
+
+def bench_c5_fit(capi, dev, stream):
+    """BASELINE config 5, fit half, on the largest 4-D grid whose nested-dissection fronts fit ONE 288 GB GPU:
+    24^4 nodes (76 GB of factor panels + 132 GB of Schur arenas), 1e7 points of the seeded stream.  Config 5's own
+    32^4 grid needs 476 GB of factor panels and 714 GB of arenas (capi.debug_nd_tree([32]*4)); the plan is refused."""
+    import torch
+    nd, nod, m = 4, 24, 10_000_000
+    nodes = [nod] * nd
+    x = torch.empty((m, nd), dtype=torch.float64, device=dev)
+    y = torch.empty(m, dtype=torch.float64, device=dev)
+    w = torch.empty(m, dtype=torch.float64, device=dev)
+    capi.synth_points_dev(nd, 0, m, x, y, w, stream)
+    coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
+    t0 = time.perf_counter()
+    plan = capi.Plan(nd, nodes, [0.0] * nd, [1.0] * nd, 1.0, m)
+    t_plan = time.perf_counter() - t0
+    try:
+        fact = plan.factorisation()[1]
+        ierr, info = plan.fit(x, y, w, coef, stream)                  # warm-up
+        assert ierr == 0, f"4-D fit failed with ierror {ierr}"
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ierr, info = plan.fit(x, y, w, coef, stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        plan.close()
+    assert ierr == 0 and info[9] < 1e-9, f"4-D fit: ierror {ierr}, optimality residual {info[9]:.2e}"
+    tree = capi.debug_nd_tree(nodes, check=False)
+    big = capi.debug_nd_tree([32] * 4, check=False)
+    return {"workload": "C5 (fit half) on the largest 4-D grid one GPU holds: 4-D splcw fit, 1e7 weighted scattered points, 24^4 nodes "
+                        "(331 776 columns), xtrap=1, real64, resident data",
+            "value": m / dt, "unit": "points/s", "seconds_per_fit": dt, "plan_seconds": t_plan, "factorisation": fact,
+            "phase_seconds": {"assembly": float(info[5]), "factor": float(info[6]), "solve_refine": float(info[7])},
+            "factor_tflops": tree["flop"] / max(float(info[6]), 1e-9) / 1e12,
+            "refine_steps": int(info[2]), "optimality_residual": float(info[9]),
+            "fronts": int(tree["fronts"]), "factor_GB": tree["factor_bytes"] / 1e9, "schur_arenas_GB": tree["arena_bytes"] / 1e9,
+            "config5_32^4_needs": {"factor_GB": big["factor_bytes"] / 1e9, "schur_arenas_GB": big["arena_bytes"] / 1e9,
+                                   "flop": big["flop"], "note": "does not fit one 288 GB GPU; the plan is refused with SPLPAK_E_NOMEM"}}
 
 
 def bench_c2(capi, dev, stream, steps):
@@ -332,7 +407,8 @@ def main():
 
     from splpak_amd import capi
 
-    nd, nod, m = args.ndim, args.nodes, args.ndata
+    nd, nod = args.ndim, args.nodes
+    m = args.ndata if args.ndata is not None else default_ndata(world, nd, nod)
     nodes = [nod] * nd
     lo, hi = [0.0] * nd, [1.0] * nd
     ncol = nod ** nd
@@ -382,6 +458,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * m * args.steps / elapsed
+    fact_code, fact_name = plan.factorisation()
+
+    # strong scaling beside the weak headline (N > 1): config 3's 1e7 points IN ALL, sharded over the ranks
+    strong = None
+    if world > 1:
+        ms_tot = 10_000_000
+        from splpak_amd.dist import shard_range
+        first, cnt = shard_range(ms_tot, rank, world)
+        if cnt <= m:
+            capi.synth_points_dev(nd, first, cnt, x[:cnt], y[:cnt], w[:cnt], stream)
+            ierr_s, _ = plan.fit(x[:cnt], y[:cnt], w[:cnt], coef, stream)
+            barrier()
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                ierr_s, info_s = plan.fit(x[:cnt], y[:cnt], w[:cnt], coef, stream)
+            barrier()
+            el = time.perf_counter() - ts
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            strong = {"workload": f"C3's 1e7 points in all, sharded over {world} GPUs (fixed total)", "scaling": "strong",
+                      "value": ms_tot * args.steps / float(t.item()), "unit": "points/s",
+                      "ms_per_step": 1e3 * float(t.item()) / args.steps, "ierror": int(ierr_s)}
+            capi.synth_points_dev(nd, rank * m, m, x, y, w, stream)      # back to the weak-scaling shard
+            ierr, info = plan.fit(x, y, w, coef, stream)                 # coefficients of the headline workload for the evaluation leg
 
     # ---- evaluation throughput (splfe), queries sharded, no collectives ---------
     nq = args.neval
@@ -458,11 +558,13 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": (f"C3: {nd}-D splcw least-squares spline fit, {m} weighted scattered points per GPU "
-                             f"(Park-Miller stream, seed 42), {'x'.join(map(str, nodes))} nodes, xtrap=1, real64"),
+                "workload": workload_label(world, nd, nod, m),
                 "ncol": ncol, "points_per_gpu": m, "points_total": world * m, "host_numa_node": numa_node,
                 "parallelism": "points sharded per GPU; RCCL all-reduce of histogram, normal equations and "
-                               "refinement residuals; band Cholesky replicated" if world > 1 else "single GPU",
+                               "refinement residuals; factorisation replicated" if world > 1 else "single GPU",
+                "factorisation": fact_name,
+                "collective_backend": (dist.get_backend() if world > 1 else None),
+                "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else 0),
                 "refine_steps": int(info[2]), "last_correction_rel": float(info[3]),
                 "optimality_residual": float(info[9]), "residual_norm": float(info[8]),
                 "data_rows": float(info[0]), "constraint_rows": float(info[1]),
@@ -493,48 +595,75 @@ def main():
                 "binning (keys, scan, scatter, in-cell order)": hbm(m * (2 * bpp + bpp + 4.0), stages["bin_ms"]),
                 "gram blocks + stencil gather": hbm(m * bpp + 8.0 * ncol * hst, stages["gram_ms"]),
                 "constraint rows": {"ms": stages["constraints_ms"]},
-                "band memset + expansion": hbm(8.0 * ncol * hst + 8.0 * ncol * ldband, stages["expand_ms"]),
                 "refinement residual pass": hbm(m * bpp, stages["residual_pass_ms"]),
-                "one solve (two band sweeps)": hbm(2 * 8.0 * ncol * ldband, stages["solve_ms"]),
                 "note": "the Gram stage moves 3.9 GB of per-cell blocks through HBM on top of its algorithmic bytes (PMC: profiles/r02_fit_pmc.json)"
                         if nd == 3 and nod == 64 else "",
             }
+            if fact_code == 4:
+                fbytes = capi.debug_nd_tree(nodes, check=False)["factor_bytes"]
+                line["assembly"]["factor-arena memset + front assembly"] = hbm(8.0 * ncol * hst + fbytes, stages["expand_ms"])
+                line["assembly"]["one solve (forward + backward tree sweep)"] = hbm(2 * fbytes, stages["solve_ms"])
+            else:
+                line["assembly"]["band memset + expansion"] = hbm(8.0 * ncol * hst + 8.0 * ncol * ldband, stages["expand_ms"])
+                line["assembly"]["one solve (two band sweeps)"] = hbm(2 * 8.0 * ncol * ldband, stages["solve_ms"])
         if kt_sum["syrk_ms"] > 0:
             ach = kt_sum["syrk_flop"] / (kt_sum["syrk_ms"] * 1e-3) / 1e12
+            nd_path = fact_code == 4
+            # fabric bytes per launch of the roofline kernel: PMC passes of an earlier run of the same workload, kept
+            # under profiles/ -- NOT measured in this run (counters and kernel timing do not share a run)
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r02_fit_pmc.json")
-            if os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "r03_fit_pmc.json" if nd_path else "r02_fit_pmc.json")
+            if nd == 3 and nod == 64 and os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("bulk_hbm_bytes_per_launch")
+                    pj = json.load(open(pmc))
+                    traffic = {"hbm_bytes_per_launch": pj.get("schur_hbm_bytes_per_launch" if nd_path else "bulk_hbm_bytes_per_launch"),
+                               "algorithmic_bytes_per_launch": pj.get("schur_algorithmic_bytes_per_launch"),
+                               "source": os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same "
+                                         "workload; not measured in this run)"}
                 except Exception:
                     traffic = None
             line["roofline"] = {
-                "kernel": "syrk64_kernel<16,1,4,256> (bulk trailing update C -= P P^T of the band Cholesky, v_mfma_f64_16x16x4_f64; one launch per block step)",
+                "kernel": ("nd_syrk_kernel<4,2,true> (Schur-buffer passes S -= L21 L21^T of the nested-dissection fronts, K = 1024 per pass, "
+                           "v_mfma_f64_16x16x4_f64; one launch at a time per tree depth and block group)") if nd_path else
+                          "syrk64_kernel<16,1,4,256> (bulk trailing update C -= P P^T of the band Cholesky, v_mfma_f64_16x16x4_f64; one launch per block step)",
                 "bound": "mfma", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "timed_launches": kt_sum["syrk_launches"], "launches": kt_sum["bulk_launches"],
-                "timing": "HIP start/stop event pair carried by every bulk launch inside the timed region (hipExtLaunchKernelGGL, on the launch stream)",
+                "timing": "HIP start/stop event pair carried by every launch of this kernel inside the timed region (hipExtLaunchKernelGGL, on the launch stream)",
                 "avg_launch_ms": kt_sum["syrk_ms"] / max(kt_sum["syrk_launches"], 1),
                 "flop_per_launch": kt_sum["syrk_flop"] / max(kt_sum["syrk_launches"], 1),
                 "factor_ms_per_step": kt_sum["factor_ms"] / args.steps,
                 "flop_share_of_factorisation": kt_sum["bulk_flop"] / max(kt_sum["total_flop"], 1.0),
                 "factorisation_tflops": kt_sum["total_flop"] / max(kt_sum["factor_ms"], 1e-9) / 1e9,
+                "factorisation_flop": kt_sum["total_flop"] / args.steps,
             }
+            if nd_path:
+                line["roofline"]["note"] = ("the panel updates of the chain (nd_syrk_kernel<4,2,false>, K = 256) and the diagonal-block / panel-solve "
+                                            "kernels run beside these launches on other streams and share the CUs with them; "
+                                            "the band factorisation of round 2 needed 4.1e13 flop for this grid")
+        if strong is not None:
+            line["strong"] = strong
         if world == 1 and not args.no_side_legs:
             plan.close()                      # the side legs have the GPU to themselves
+            # every side leg is guarded: a failure becomes {"error": ...} inside the line, the headline survives
             # rehearsal of the distributed-band path on this one GPU (2 virtual ranks, reduced size)
-            line["dist_band"] = dist_band_in_child(2, nd, min(nod, 32), 1_000_000, True, args.steps, 180)
-            line["c2"] = bench_c2(capi, dev, stream, args.steps)
-            line["grid32"] = bench_small(capi, dev, stream, args.steps, 3, 32, 1_000_000, True,
-                                         "3-D splcw fit, 1e6 weighted scattered points, 32x32x32 nodes, xtrap=1, real64, resident data")
+            line["dist_band"] = guarded(dist_band_in_child, 2, nd, min(nod, 32), 1_000_000, True, args.steps, 180)
+            line["c2"] = guarded(bench_c2, capi, dev, stream, args.steps)
+            line["grid32"] = guarded(bench_small, capi, dev, stream, args.steps, 3, 32, 1_000_000, True,
+                                     "3-D splcw fit, 1e6 weighted scattered points, 32x32x32 nodes, xtrap=1, real64, resident data")
             del xq, out
             torch.cuda.empty_cache()
-            line["c5_eval"] = bench_c5_eval(capi, dev, stream)
-            line["fit_incl_h2d"] = bench_incl_h2d(capi, x, y, w, lo, hi, nodes)
+            line["fit_incl_h2d"] = guarded(bench_incl_h2d, capi, x, y, w, lo, hi, nodes)
+            del x, y, w
+            capi.shutdown()                   # the one-shot entry's cached plan (35 GB): the 4-D legs need the room
+            torch.cuda.empty_cache()
+            line["c5_eval"] = guarded(bench_c5_eval, capi, dev, stream)
+            torch.cuda.empty_cache()
+            line["c5_fit"] = guarded(bench_c5_fit, capi, dev, stream)
         if dist_leg is not None:
             line["dist_band"] = dist_leg
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(nd)
+            line["cpu_baseline"] = guarded(cpu_baseline, nd)
         print(json.dumps(line), flush=True)
 
     plan.close()

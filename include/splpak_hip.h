@@ -143,6 +143,11 @@ int32_t splpak_plan_fit_dev(splpak_plan *plan, const double *xdata_dev, int32_t 
                             int64_t ndata, double *coef_dev, void *stream, double *info);
 /* device pointer to the (all-reduced) sparse-area histogram of the last fit */
 const double *splpak_plan_hist_dev(const splpak_plan *plan);
+/* Which factorisation of the normal equations the plan uses in place of suprls' triangularisation
+ * (src/splpak.F90:1516-1619): returns 0 band Cholesky (four-stream pipeline), 1 its narrow form, 2 two-ended band,
+ * 3 band distributed over several GPUs, 4 nested-dissection multifrontal (2-D .. 4-D grids of >= 8192 columns);
+ * a description is copied into buf. */
+int32_t splpak_plan_factorisation(const splpak_plan *plan, char *buf, int32_t buflen);
 
 /* Per-kernel accounting of the last splpak_plan_fit_dev call, measured with HIP
  * events on the stream the kernels ran on (bench.py's roofline object).  Every BULK

@@ -27,7 +27,7 @@ SYMBOLS = [
     "splpak_fit_f64", "splpak_fit_f32", "splpak_eval_f64", "splpak_eval_f32",
     "splpak_plan_comm_len", "splpak_plan_create", "splpak_plan_destroy",
     "splpak_plan_set_allreduce", "splpak_plan_set_refine", "splpak_plan_fit_dev",
-    "splpak_plan_hist_dev", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing", "splpak_plan_stage_timing",
+    "splpak_plan_hist_dev", "splpak_plan_factorisation", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing", "splpak_plan_stage_timing",
     "splpak_eval_dev_f64", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
     "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
     L.splpak_plan_fit_dev.argtypes = [vp, vp, i32, vp, vp, i64, vp, vp, _dp]
     L.splpak_plan_hist_dev.restype = vp
     L.splpak_plan_hist_dev.argtypes = [vp]
+    L.splpak_plan_factorisation.restype = i32
+    L.splpak_plan_factorisation.argtypes = [vp, C.c_char_p, i32]
     L.splpak_plan_enable_kernel_timing.restype = None
     L.splpak_plan_enable_kernel_timing.argtypes = [vp, i32]
     L.splpak_plan_kernel_timing.restype = None
@@ -376,6 +378,12 @@ class Plan:
 
         self._cb = ALLREDUCE_FN(_cb)
         self._L.splpak_plan_set_allreduce(self._h, self._cb, None, int(rank), int(world))
+
+    def factorisation(self):
+        """-> (code, description): 0/1 band Cholesky, 2 two-ended band, 3 distributed band, 4 nested dissection."""
+        buf = C.create_string_buffer(256)
+        code = self._L.splpak_plan_factorisation(self._h, buf, 256)
+        return int(code), buf.value.decode()
 
     def enable_kernel_timing(self, on=True):
         self._L.splpak_plan_enable_kernel_timing(self._h, 1 if on else 0)

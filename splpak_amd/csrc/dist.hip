@@ -470,6 +470,8 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
         p->factor_fn = dist_factor;
         p->solve_fn = dist_solve;
         p->fn_user = m;
+        p->fn_name = "band Cholesky distributed over several GPUs by block columns (csrc/dist.hip)";
+        p->fn_code = 3;
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         bool ok = hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) == hipSuccess &&

@@ -1079,6 +1079,8 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     p->expand_fn = nd_assemble;
     p->factor_fn = nd_factor;
     p->solve_fn = nd_solve;
+    p->fn_name = "nested-dissection multifrontal Cholesky (csrc/ndtree.hip, csrc/ndchol.hip)";
+    p->fn_code = 4;
     if (factor_arena) *factor_arena = s->factor;
     if (factor_doubles) *factor_doubles = t.factor_doubles;
     if (std::getenv("SPLPAK_DEBUG"))

@@ -348,6 +348,21 @@ void splpak_plan_stage_timing(const splpak_plan *p, double *out6)
 
 const double *splpak_plan_hist_dev(const splpak_plan *p) { return p ? p->hist : nullptr; }
 
+int32_t splpak_plan_factorisation(const splpak_plan *p, char *buf, int32_t buflen)
+{
+    if (!p) return SPLPAK_E_BADARG;
+    int code = 0;
+    const char *what = "band Cholesky, four-stream look-ahead pipeline (csrc/bandchol.hip)";
+    if (p->fn_name) { code = p->fn_code; what = p->fn_name; }
+    else if (p->dm.R > 1) { code = 3; what = "band Cholesky distributed over several GPUs by block columns (csrc/dist.hip)"; }
+    else if (p->band.bw < narrow_band_limit()) { code = 1; what = "band Cholesky, narrow (chain-bound) form (csrc/bandchol.hip)"; }
+    if (buf && buflen > 0) {
+        std::strncpy(buf, what, (size_t)buflen - 1);
+        buf[buflen - 1] = '\0';
+    }
+    return code;
+}
+
 static int do_allreduce(splpak_plan *p, double *buf, long long count, hipStream_t st)
 {
     if (!p->ar || p->world <= 1) return 0;

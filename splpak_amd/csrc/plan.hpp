@@ -51,6 +51,8 @@ struct splpak_plan {
     hipError_t (*expand_fn)(splpak_plan *p, hipStream_t st, void *user) = nullptr;
     void *fn_user = nullptr;
     void (*fn_destroy)(void *user) = nullptr;      // releases fn_user with the plan (NULL: not the plan's to release)
+    const char *fn_name = nullptr;                 // what the hooks are (splpak_plan_factorisation); fn_code: 2 two-ended band, 4 nested dissection, 3 distributed band
+    int fn_code = 0;
 };
 
 

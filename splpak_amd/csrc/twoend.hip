@@ -298,6 +298,8 @@ void twoend_attach(splpak_plan *p)
     p->solve_fn = te_solve;
     p->fn_user = t;
     p->fn_destroy = te_destroy;
+    p->fn_name = "two-ended band Cholesky (both ends eliminated concurrently, csrc/twoend.hip)";
+    p->fn_code = 2;
 }
 
 // another factorisation takes over the plan (the distributed band of dist.hip, also with one rank): release the
@@ -311,6 +313,8 @@ void twoend_detach(splpak_plan *p)
     p->solve_fn = nullptr;
     p->fn_user = nullptr;
     p->fn_destroy = nullptr;
+    p->fn_name = nullptr;
+    p->fn_code = 0;
 }
 
 // Dense-input debugging entry (splpak_debug_spd_band_solve_f64 with two ends): factor and solve an SPD band
