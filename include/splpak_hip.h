@@ -116,9 +116,11 @@ typedef int32_t (*splpak_allreduce_fn)(void *dev_buf, int64_t count, void *strea
  * larger values return SPLPAK_E_UNSUPPORTED.
  * `comm_buf_dev`/`comm_len`: optional caller-owned device buffer (doubles) the
  * all-reduced quantities live in -- pass a torch tensor's data_ptr so the
- * callback can all-reduce views of it; NULL lets the plan allocate it.  It must be ordinary
- * (coarse-grained) device memory from hipMalloc: the assembly kernels add into it with hardware
- * f64 atomics, which are not defined on fine-grained or host-mapped memory.
+ * callback can all-reduce views of it; NULL lets the plan allocate it.  It must be device memory
+ * the kernels can read and write at full speed (hipMalloc / a torch CUDA tensor): the assembly writes
+ * the half stencil, right-hand side and histogram into it with plain stores (every sum has one owner and
+ * a fixed order since round 2; the only floating-point atomic left is the histogram bump of a point so far
+ * outside the grid that its nearest-node address is not a node of its window, src/splpak.F90:899).
  * `splpak_plan_comm_len` tells the required length. */
 int64_t splpak_plan_comm_len(int32_t ndim, const int32_t *nodes);
 int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmin,
@@ -128,7 +130,7 @@ void    splpak_plan_destroy(splpak_plan *plan);
 void    splpak_plan_set_allreduce(splpak_plan *plan, splpak_allreduce_fn fn, void *user,
                                   int32_t rank, int32_t world);
 /* tuning / test knobs: nominal refinement steps (default 4; 0 = none; a solve that still contracts goes on
- * up to max(steps, 16)) and the tolerance on the (estimated) remaining relative error |dx|/|x| after a
+ * up to max(steps, 30)) and the tolerance on the (estimated) remaining relative error |dx|/|x| after a
  * step (default 1e-11; the parity bar is 1e-10) */
 void    splpak_plan_set_refine(splpak_plan *plan, int32_t max_steps, double tol);
 

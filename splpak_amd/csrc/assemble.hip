@@ -550,9 +550,15 @@ residual_block_kernel(Grid g, const int *__restrict__ offset, const double *__re
         __syncthreads();
     }
     if (tid < NB) rcell[(long long)cell * NB + tid] = racc;
-    if (ssq) {                                   // sum of squared row residuals (the reference's errsum; a diagnostic)
-        e2 = wave_sum(e2);
-        if ((tid & 63) == 0 && e2 != 0.0) atomicAdd(ssq, e2);
+    if (ssq) {                                   // sum of squared row residuals (the reference's errsum; a diagnostic):
+        e2 = wave_sum(e2);                       // the cell's share, its waves added in a fixed order (no atomics: reproducible)
+        if ((tid & 63) == 0) wt[tid >> 6] = e2;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int wv = 0; wv < NT / 64; ++wv) t += wt[wv];
+            ssq[cell] = t;
+        }
     }
 }
 
@@ -773,7 +779,7 @@ constraint_dots_kernel(Grid g, const double *__restrict__ dcw, const unsigned ch
             if (lane == 0) out[pair] = t;
             e2 += t * t;                         // constraint rows have rhs 0
         }
-    if (ssq && lane == 0 && e2 != 0.0) atomicAdd(ssq, e2);
+    if (ssq && lane == 0) ssq[node] = e2;      // the node's share of the squared constraint residuals (summed in a fixed order later)
 }
 
 // rho[i] = sum over the cells that contain node i of their share (CellRange order)
@@ -1025,22 +1031,47 @@ hipError_t launch_constraint_rows(const Grid &g, const double *dcw, const unsign
     return hipGetLastError();
 }
 
+// out[0] = sum of v[0 .. n) in a fixed order: thread t sums the entries t, t + 1024, ..; then a tree over the threads
+__global__ void __launch_bounds__(1024)
+sum_fixed_kernel(const double *__restrict__ v, long long n, double *__restrict__ out)
+{
+    __shared__ double red[1024];
+    double t = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 1024) t += v[i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
 hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rcell,
                            const double *dcw, const unsigned char *spf, bool constraints,
-                           double *tbuf, double *rho, double *ssq, hipStream_t st)
+                           double *tbuf, double *rho, double *ssq, double *e2buf, hipStream_t st)
 {
     dim3 gn((unsigned)((g.ncol + 3) / 4)), bl(256);
+    // sum of squared row residuals (ssq != NULL): every cell and every data-sparse node leaves its share in e2buf
+    // ([ncell] + [ncol]), one workgroup adds them in a fixed order -- no floating-point atomics, reproducible bits
+    double *e2c = (ssq && e2buf) ? e2buf : nullptr, *e2n = e2c ? e2buf + g.ncell : nullptr;
+    if (e2c) {
+        hipError_t e = hipMemsetAsync(e2buf, 0, sizeof(double) * ((size_t)g.ncell + (size_t)g.ncol), st);
+        if (e != hipSuccess) return e;
+    }
     DISPATCH_D(g.ndim, {
         using C = ResCfg<D>;
         hipLaunchKernelGGL(residual_block_kernel<D>, dim3((unsigned)g.ncell), dim3(C::NT), 0, st, g,
                            (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
-                           s.cap, xvec, rcell, ssq);
+                           s.cap, xvec, rcell, e2c);
         if (constraints)
-            hipLaunchKernelGGL(constraint_dots_kernel<D>, gn, bl, 0, st, g, dcw, spf, xvec, tbuf, ssq);
+            hipLaunchKernelGGL(constraint_dots_kernel<D>, gn, bl, 0, st, g, dcw, spf, xvec, tbuf, e2n);
         hipLaunchKernelGGL(rho_gather_kernel<D>, dim3((unsigned)((g.ncol + 255) / 256)), bl, 0, st, g,
                            (const int *)s.offset, (const double *)rcell, dcw, spf,
                            constraints ? (const double *)tbuf : (const double *)nullptr, rho);
     });
+    if (e2c)
+        hipLaunchKernelGGL(sum_fixed_kernel, dim3(1), dim3(1024), 0, st, (const double *)e2buf, (long long)g.ncell + g.ncol, ssq);
     return hipGetLastError();
 }
 

@@ -541,6 +541,12 @@ int32_t splpak_mplan_fit_dev(splpak_mplan *mp, const double *const *xdata_dev, i
     int cur = 0;
     (void)hipGetDevice(&cur);
     mp->abort.store(0);
+    {   // a fit that was abandoned (a rank failed while others stood in the barrier) leaves arrivals counted: every
+        // rank thread of the previous call has been joined, so the barrier can simply start afresh (round-2 advice)
+        std::lock_guard<std::mutex> lk(mp->bar.mu);
+        mp->bar.count = 0;
+        ++mp->bar.phase;
+    }
     mp->coef0 = coef_dev;
     std::vector<std::thread> th;
     for (int r = 0; r < mp->R; ++r) {

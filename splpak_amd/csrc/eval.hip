@@ -506,6 +506,10 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
     if (s.dev != dev || s.cap < chunk || s.capd < D || s.cnt_ints < cnt_need) {
         eval_scratch_shutdown();
         hipError_t e = hipMalloc(&s.xs, sizeof(double) * (size_t)chunk * D);
+        if (e != hipSuccess && release_cached_plan_for_memory()) {      // the one-shot fit's cached plan is in the way
+            (void)hipGetLastError();
+            e = hipMalloc(&s.xs, sizeof(double) * (size_t)chunk * D);
+        }
         if (e == hipSuccess) e = hipMalloc(&s.perm, sizeof(int) * (size_t)chunk);
         if (e == hipSuccess) e = hipMalloc(&s.ints, sizeof(int) * (4 * BIN_MAX + 8));
         // per-workgroup region counts of pass A -> run bases of pass B: [workgroups of a chunk][regions]

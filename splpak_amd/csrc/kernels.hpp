@@ -6,6 +6,9 @@
 
 namespace splpak {
 
+// after a failed allocation: release the plan / staging buffers the one-shot fit entry caches (plan.hip); true = retry
+bool release_cached_plan_for_memory();
+
 // ---- eval.hip
 hipError_t launch_eval(const Grid &g, long long nq, const double *xq, int ldxq, const int *nderiv,
                        const double *coef, double *out, hipStream_t st);
@@ -63,10 +66,11 @@ hipError_t launch_sparse_mark(const Grid &g, const double *hist, const double *s
 hipError_t launch_constraint_rows(const Grid &g, const double *dcw, const unsigned char *spf, double *nst,
                                   double *scal_out, hipStream_t st);
 // refinement residual rho = A^T W (W y - W A x) [- C^T C x when `constraints`]; rcell: [ncell][nb] scratch,
-// tbuf: [ncol][ndim(ndim+1)/2] scratch; ssq != NULL: also accumulate the sum of squared row residuals
+// tbuf: [ncol][ndim(ndim+1)/2] scratch; ssq != NULL: also the sum of squared row residuals, from the per-cell / per-node
+// shares in e2buf ([ncell + ncol] scratch) added in a fixed order
 hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rcell,
                            const double *dcw, const unsigned char *spf, bool constraints,
-                           double *tbuf, double *rho, double *ssq, hipStream_t st);
+                           double *tbuf, double *rho, double *ssq, double *e2buf, hipStream_t st);
 // out[0] = max_i |rho_i| / ((|N||x|)_i + |rhs_i|): componentwise backward error with respect to the rows
 hipError_t launch_backward_error(const Grid &g, const double *nst, const double *xvec, const double *rho,
                                  const double *rhs, double *out, hipStream_t st);

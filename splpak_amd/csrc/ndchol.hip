@@ -528,7 +528,12 @@ bool nd_alloc(NdState *s, T **ptr, size_t count)
 {
     void *q = nullptr;
     if (count == 0) count = 1;
-    if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) {
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess && release_cached_plan_for_memory()) {
+        (void)hipGetLastError();
+        e = hipMalloc(&q, count * sizeof(T));
+    }
+    if (e != hipSuccess) {
         (void)hipGetLastError();
         char buf[160];
         snprintf(buf, sizeof buf, "nested dissection: hipMalloc of %.3f GB failed", (double)(count * sizeof(T)) / 1e9);

@@ -119,6 +119,10 @@ static bool dev_alloc(splpak_plan *p, T **ptr, size_t count)
     void *q = nullptr;
     if (count == 0) count = 1;
     hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess && release_cached_plan_for_memory()) {      // the one-shot entry's cached plan (35 GB at 64^3) is in the way
+        (void)hipGetLastError();
+        e = hipMalloc(&q, count * sizeof(T));
+    }
     if (e != hipSuccess) {
         char buf[160];
         snprintf(buf, sizeof buf, "hipMalloc of %.3f GB failed: %s", (double)(count * sizeof(T)) / 1e9,
@@ -205,6 +209,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     ok = ok && dev_alloc(p, &p->tbuf, (size_t)g.ncol * (g.ndim * (g.ndim + 1) / 2));
     ok = ok && dev_alloc(p, &p->dcw, (size_t)g.ncol);
     ok = ok && dev_alloc(p, &p->spf, (size_t)g.ncol);
+    ok = ok && dev_alloc(p, &p->e2buf, (size_t)g.ncell + (size_t)g.ncol);
     // band: all of it (R = 1) or the block columns dealt to rank r of R
     band_bytes(g.ncol, g.halfbw, &p->band);
     (void)hipGetDevice(&p->device);
@@ -486,11 +491,11 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     // after the nominal number of steps goes on up to max_refine_hard; if even that leaves an estimated
     // error above the parity bar the fit is reported as failed (107) instead of returning coefficients
     // that silently miss it.
-    bool converged = p->max_refine == 0, diverged = false;
+    bool converged = p->max_refine == 0, diverged = false, stagnated = false;
     for (int it = 0; it < p->max_refine_hard && !converged; ++it) {
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, smooth && p->rank == 0,
-                                       p->tbuf, p->rho, nullptr, st), SPLPAK_E_NODEVICE);
+                                       p->tbuf, p->rho, nullptr, nullptr, st), SPLPAK_E_NODEVICE);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
         SPLPAK_HIP_TRY(p->solve_fn ? p->solve_fn(p, p->rho, p->tmp, st, p->fn_user) : band_solve(b, p->rho, p->tmp, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(launch_axpy_absmax(g.ncol, p->xvec, p->rho, p->small, st), SPLPAK_E_NODEVICE);
@@ -508,9 +513,10 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
             // as that estimate is below the tolerance instead of paying for one more solve
             ratio = last_rel / prev_rel;
             if (ratio < 0.9 && last_rel * ratio / (1.0 - ratio) <= p->tol) { converged = true; break; }
-            if (ratio >= 0.9) {                               // stagnation: fine at the rounding floor,
-                diverged = last_rel > 1e-8;                   // a failure if the corrections are still large
-                converged = !diverged;
+            if (ratio >= 0.9) {                               // stagnation: fine at the rounding floor, a failure if the
+                diverged = last_rel > 1e-8;                   // corrections are still large; in between (1e-10 .. 1e-8) the
+                converged = !diverged;                        // MEASURED backward error decides below (round-2 advice: the
+                stagnated = converged && last_rel > 1e-10;    // estimate alone let coefficients that miss the bar through)
                 break;
             }
             // 0.5 .. 0.9: an ill-conditioned grid whose corrections still shrink -- go on (up to max_refine_hard):
@@ -534,21 +540,19 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     //    -- 0 at the minimiser the reference computes; a MEASURED statement about the returned
     //    coefficients (the refinement's stopping rule is an estimate)
     double ssq = 0.0, omega = 0.0;
-    if (info) {
+    if (info || stagnated) {
         double *scalR = p->rho + b.npad;
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
-        hipEvent_t r0 = nullptr, r1 = nullptr;
-        if (stamps && hipEventCreate(&r0) == hipSuccess && hipEventCreate(&r1) == hipSuccess) (void)hipEventRecord(r0, st);
+        hipEvent_t r0 = stamps ? p->evStage[8] : nullptr, r1 = stamps ? p->evStage[9] : nullptr;   // (created with the other stage events)
+        if (r0 && r1) (void)hipEventRecord(r0, st);
         SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, smooth && p->rank == 0,
-                                       p->tbuf, p->rho, scalR, st), SPLPAK_E_NODEVICE);
+                                       p->tbuf, p->rho, scalR, p->e2buf, st), SPLPAK_E_NODEVICE);
         if (r0 && r1) {
             (void)hipEventRecord(r1, st);
             (void)hipEventSynchronize(r1);
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, r0, r1) == hipSuccess) p->stage_ms[4] = ms;
         }
-        if (r0) (void)hipEventDestroy(r0);
-        if (r1) (void)hipEventDestroy(r1);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
         SPLPAK_HIP_TRY(launch_backward_error(g, p->nst, p->xvec, p->rho, p->rhs, p->small + 3, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(hipMemcpyAsync(&ssq, scalR, sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
@@ -577,6 +581,12 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     // (numerically singular normal equations): the reference's "suprls failure"
     if (!(last_rel == last_rel) || diverged) {
         set_error("iterative refinement diverged: numerically singular normal equations");
+        return 107;
+    }
+    if (stagnated && !(omega <= 1e-10)) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "iterative refinement stagnated at corrections of %.2e with a backward error of %.1e > 1e-10", last_rel, omega);
+        set_error(buf);
         return 107;
     }
     if (unconverged) {
@@ -616,6 +626,20 @@ struct HostFitCache {
 };
 HostFitCache g_hostfit;
 }  // namespace
+
+}  // extern "C"
+
+// An allocation failed: give back what the one-shot entry keeps between calls (round-2 advice).  Not while a one-shot
+// fit is running (it holds the lock and has released its old plan itself).  true = something was released.
+bool splpak::release_cached_plan_for_memory()
+{
+    std::unique_lock<std::mutex> lock(g_hostfit.mu, std::try_to_lock);
+    if (!lock.owns_lock() || !g_hostfit.plan) return false;
+    g_hostfit.release();
+    return true;
+}
+
+extern "C" {
 
 static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const double *ydata,
                         const double *wdata, int64_t ndata, const double *xmin, const double *xmax,

@@ -24,6 +24,7 @@ struct splpak_plan {
     double *dcw = nullptr;        // [ncol] constraint weight of every node, spf: [ncol] "data sparse" flags (:923-960)
     unsigned char *spf = nullptr;
     double *rcell = nullptr;      // [ncell][nb] per-cell shares of the refinement residual
+    double *e2buf = nullptr;      // [ncell + ncol] per-cell / per-node shares of the sum of squared row residuals (reserr)
     double *tbuf = nullptr;       // [ncol][ndim(ndim+1)/2] constraint-row dot products of the refinement residual
     int *info = nullptr;
     splpak_allreduce_fn ar = nullptr;
@@ -34,7 +35,7 @@ struct splpak_plan {
     double tol = 1e-11;           // on the ESTIMATED remaining error; the parity bar is 1e-10
     splpak::CholStats stats;
     // stage timing of the assembly and of one residual pass (HIP events on the fit's stream, kernel timing only)
-    hipEvent_t evStage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evStage[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [8], [9]: the diagnostic residual pass
     double stage_ms[6] = {0, 0, 0, 0, 0, 0};    // bin, gram blocks + gather, constraint rows, expand (+ band memset), residual pass, solve
     std::vector<void *> owned;
     // distributed band (dist.hip): this plan holds the block columns DistMap deals to rank dm.r

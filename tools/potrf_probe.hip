@@ -1,6 +1,7 @@
 // Phase timing of potrf_block_kernel (cycle stamps of wave 0): which part of a 16-column panel costs what.
 #define SPLPAK_POTRF_STAMPS 1
 #include "../splpak_amd/csrc/bandchol.hip"
+#include "ablation_kernels.hpp"
 #include <cstdio>
 #include <vector>
 using namespace splpak;

@@ -1,6 +1,7 @@
 // Standalone timing of trailing-update kernel variants on a C3-shaped panel
 // (12544 trailing rows, K = 256), several variants in one process (interleaved rounds).
 #include "../splpak_amd/csrc/bandchol.hip"
+#include "ablation_kernels.hpp"
 #include <cstdio>
 #include <hip/hip_ext.h>
 #include <vector>
@@ -18,7 +19,7 @@ static float run64(double *ab, long long lda, int n64)
     if (ABL & 16) { const int ns = (n64 - 4 + 15) / 16, nsb = ns * (ns + 1) / 2; items = (long long)((nsb + 7) / 8) * 8 * 256; }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, g_stream);
-    hipLaunchKernelGGL((syrk64_kernel<SD, WPS, ABL, KTOT>), dim3((unsigned)items), dim3(64), 0, g_stream, ab, lda, 0, KTOT, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+    hipLaunchKernelGGL((syrk64_abl_kernel<SD, WPS, ABL, KTOT>), dim3((unsigned)items), dim3(64), 0, g_stream, ab, lda, 0, KTOT, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
     (void)hipEventRecord(e1, g_stream); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     return ms;
@@ -30,7 +31,7 @@ static float run64x4(double *ab, long long lda, int n64)
     for (int c = 4; c < n64; ++c) items += n64 - c;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, g_stream);
-    hipLaunchKernelGGL((syrk64_kernel<SD, 1, ABL | 256>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, g_stream, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+    hipLaunchKernelGGL((syrk64_abl_kernel<SD, 1, ABL | 256>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, g_stream, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
     (void)hipEventRecord(e1, g_stream); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     return ms;
@@ -88,13 +89,13 @@ int main()
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < reps; ++r) {
                 if (variant == 0)
-                    hipLaunchKernelGGL((syrk64_kernel<16, 1, 4>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+                    hipLaunchKernelGGL((syrk64_abl_kernel<16, 1, 4>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
                 else if (variant == 1)
-                    hipLaunchKernelGGL((syrk64_kernel<16, 1, 4 | 64>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+                    hipLaunchKernelGGL((syrk64_abl_kernel<16, 1, 4 | 64>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
                 else if (variant == 2)
-                    hipLaunchKernelGGL((syrk64_kernel<16, 1, 4 | 64, 512>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, 512, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+                    hipLaunchKernelGGL((syrk64_abl_kernel<16, 1, 4 | 64, 512>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, 512, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
                 else
-                    hipLaunchKernelGGL((syrk64_kernel<16, 1, 4 | 1024, 512>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, 512, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+                    hipLaunchKernelGGL((syrk64_abl_kernel<16, 1, 4 | 1024, 512>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, 512, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
             }
             (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -131,7 +132,7 @@ int main()
         hipEvent_t a[reps], c[reps];
         for (int r = 0; r < reps; ++r) { (void)hipEventCreate(&a[r]); (void)hipEventCreate(&c[r]); }
         for (int r = 0; r < reps; ++r)
-            hipExtLaunchKernelGGL((syrk64_kernel<16, 1, 4>), dim3((unsigned)items), dim3(64), 0, st, a[r], c[r], 0, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+            hipExtLaunchKernelGGL((syrk64_abl_kernel<16, 1, 4>), dim3((unsigned)items), dim3(64), 0, st, a[r], c[r], 0, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
         (void)hipStreamSynchronize(st);
         for (int r = 0; r < reps; ++r) {
             float d = 0, g = 0;
@@ -152,7 +153,7 @@ int main()
         for (int r = 0; r < reps; ++r) {
             unsigned long long *pb = buf + 2 * items * r;
             (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_syrk_clock_probe), &pb, sizeof(pb), 0, hipMemcpyHostToDevice, st);
-            hipExtLaunchKernelGGL((syrk64_kernel<16, 1, 4 | 128>), dim3((unsigned)items), dim3(64), 0, st, a[r], c[r], 0, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+            hipExtLaunchKernelGGL((syrk64_abl_kernel<16, 1, 4 | 128>), dim3((unsigned)items), dim3(64), 0, st, a[r], c[r], 0, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
         }
         (void)hipStreamSynchronize(st);
         std::vector<unsigned long long> h(2 * items * reps);
@@ -179,9 +180,9 @@ int main()
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < reps; ++r) {
                 if (variant == 0)
-                    hipLaunchKernelGGL((syrk64_kernel<16, 1, 4>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+                    hipLaunchKernelGGL((syrk64_abl_kernel<16, 1, 4>), dim3((unsigned)items), dim3(64), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
                 else if (variant == 1)
-                    hipLaunchKernelGGL((syrk64_kernel<16, 1, 4 | 256>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
+                    hipLaunchKernelGGL((syrk64_abl_kernel<16, 1, 4 | 256>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, ab, lda, 0, NBLK, 4, n64, 0, n64, (int)items, 0, ~0u, (int *)nullptr);
                 else
                     hipLaunchKernelGGL(syrk_kernel, dim3(nt * (nt + 1) / 2 - (nt + nt - 1)), dim3(256), 0, st, ab, lda, 0, NBLK, nt, 2);
             }
