@@ -143,6 +143,9 @@ class Port(_Base):
         L.oracle_splcw_banded.restype = C.c_int
         L.oracle_splcw_banded.argtypes = [C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _ip, C.c_double, _dp,
                                           C.c_int, C.c_int, _dp]
+        L.oracle_rows_gradient.restype = C.c_int
+        L.oracle_rows_gradient.argtypes = [C.c_int, _dp, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _ip, C.c_double, _dp, C.c_int,
+                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
         L.oracle_bascmp.restype = C.c_double
         L.oracle_bascmp.argtypes = [C.c_int, _dp, _ip, _ip, _dp, _dp, _ip, _ip]
 
@@ -183,6 +186,26 @@ class Port(_Base):
                                             xdata.shape[0], _ptr(xmin, _dp), _ptr(xmax, _dp), _ptr(nodes, _ip),
                                             float(xtrap), _ptr(coef, _dp), ncol, int(nthreads), _ptr(info, _dp))
         return coef, ierr, info
+
+    def rows_gradient(self, ndim, xdata, ydata, wdata, xmin, xmax, nodes, xtrap, coef, nthreads=0):
+        """Optimality of GIVEN coefficients w.r.t. the reference's rows (data + constraint rows, generated as in
+        fit_banded), computed on the host without storing the rows -> (omega, sqrt(ssq), data rows, constraint rows);
+        omega = max_i |A^T (b - A x)|_i / (|A|^T (|A||x| + |b|))_i."""
+        xdata = np.ascontiguousarray(xdata, dtype=np.float64)
+        ydata = np.ascontiguousarray(ydata, dtype=np.float64)
+        w = np.ascontiguousarray(wdata, dtype=np.float64) if wdata is not None else np.array([-1.0])
+        xmin = np.ascontiguousarray(xmin, dtype=np.float64)
+        xmax = np.ascontiguousarray(xmax, dtype=np.float64)
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        om, s2 = C.c_double(0.0), C.c_double(0.0)
+        nr = (C.c_long * 2)()
+        rc = self.lib.oracle_rows_gradient(ndim, _ptr(xdata, _dp), xdata.shape[1], _ptr(ydata, _dp), _ptr(w, _dp), xdata.shape[0],
+                                          _ptr(xmin, _dp), _ptr(xmax, _dp), _ptr(nodes, _ip), float(xtrap), _ptr(coef, _dp),
+                                          int(nthreads), C.byref(om), C.byref(s2), nr)
+        if rc != 0:
+            raise MemoryError("oracle_rows_gradient")
+        return om.value, float(np.sqrt(s2.value)), int(nr[0]), int(nr[1])
 
     def evaluate(self, ndim, xq, nderiv, coef, xmin, xmax, nodes):
         xq = np.ascontiguousarray(xq, dtype=np.float64)

@@ -55,10 +55,30 @@ static int rows_push(rows_t *R, int nz, const int *col, const double *val, doubl
     return 0;
 }
 
-/* rows of the reference's least-squares system, in the reference's order */
+/* A consumer of rows: 0 = go on.  build_rows stores them (rows_push); oracle_rows_gradient accumulates the
+ * gradient of the least-squares functional without storing anything. */
+typedef int (*row_sink)(void *ctx, int nz, const int *col, const double *val, double rhs);
+static int sink_push(void *ctx, int nz, const int *col, const double *val, double rhs)
+{
+    return rows_push((rows_t *)ctx, nz, col, val, rhs);
+}
+
+/* rows of the reference's least-squares system, in the reference's order; data rows of the points [i0, i1),
+ * the constraint rows (which need the histogram of ALL points) only when `with_constraints` */
+static int emit_rows(int ndim, const double *xdata, int l1xdat, const double *ydata, const double *wdata,
+                     int ndata, int i0, int i1, int with_constraints, const double *xmin, const double *xmax,
+                     const int *nodes, double xtrap, row_sink sink, void *R, long *ncons);
+
 static int build_rows(int ndim, const double *xdata, int l1xdat, const double *ydata, const double *wdata,
                       int ndata, const double *xmin, const double *xmax, const int *nodes, double xtrap,
                       rows_t *R, long *ncons)
+{
+    return emit_rows(ndim, xdata, l1xdat, ydata, wdata, ndata, 0, ndata, 1, xmin, xmax, nodes, xtrap, sink_push, R, ncons);
+}
+
+static int emit_rows(int ndim, const double *xdata, int l1xdat, const double *ydata, const double *wdata,
+                     int ndata, int i0, int i1, int with_constraints, const double *xmin, const double *xmax,
+                     const int *nodes, double xtrap, row_sink sink, void *R, long *ncons)
 {
     double dx[BMAXD], dxin[BMAXD], x[BMAXD];
     int nderiv[BMAXD], ib[BMAXD], ibmn[BMAXD], ibmx[BMAXD], in[BMAXD], inmx[BMAXD];
@@ -73,7 +93,7 @@ static int build_rows(int ndim, const double *xdata, int l1xdat, const double *y
     }
     const int weighted = wdata && wdata[0] >= 0.0;
     double rowwt = 1.0;
-    for (int idata = 0; idata < ndata; ++idata) {                 /* :788-855 */
+    for (int idata = i0; idata < i1; ++idata) {                   /* :788-855 */
         if (weighted) {
             rowwt = wdata[idata];
             if (rowwt == 0.0) continue;
@@ -99,10 +119,10 @@ static int build_rows(int ndim, const double *xdata, int l1xdat, const double *y
             }
             if (d == ndim) break;
         }
-        if (rows_push(R, nz, col, val, rowwt * ydata[idata])) return 1;
+        if (sink(R, nz, col, val, rowwt * ydata[idata])) return 1;
     }
     *ncons = 0;
-    if (xtrap != 0.0) {                                            /* :862-1046 */
+    if (xtrap != 0.0 && with_constraints) {                        /* :862-1046 */
         long nrect = 1;
         for (int d = 0; d < ndim; ++d) { in[d] = 0; inmx[d] = nodes[d] - 1; nrect *= inmx[d]; }
         double *hist = calloc((size_t)ncol, sizeof(double));
@@ -160,7 +180,7 @@ static int build_rows(int ndim, const double *xdata, int l1xdat, const double *y
                             }
                             if (d == ndim) break;
                         }
-                        if (rows_push(R, nz, col, val, 0.0)) { free(hist); return 1; }
+                        if (sink(R, nz, col, val, 0.0)) { free(hist); return 1; }
                         ++*ncons;
                     }
                 for (int d = 0; d < ndim; ++d) nderiv[d] = 0;
@@ -373,4 +393,73 @@ int oracle_splcw_banded(int ndim, const double *xdata, int l1xdat, const double 
     free(ab); free(rhs); free(x); free(rho);
     free(R.ptr); free(R.col); free(R.val); free(R.rhs);
     return rc;
+}
+
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Optimality of GIVEN coefficients with respect to the reference's rows, on the host, nothing stored:
+ *     rho   = sum over rows  a_r (b_r - a_r . x)            (the gradient of 1/2 |A x - b|^2, sign flipped)
+ *     denom = sum over rows  |a_r| (|a_r| . |x| + |b_r|)    (the size of the terms that cancel in rho)
+ * omega = max_i |rho_i| / denom_i is a componentwise backward error of x: 0 at the reference's minimiser.
+ * Rows are generated exactly as for oracle_splcw_banded (emit_rows: data rows :788-855, histogram and constraint
+ * rows :862-1046); the data rows are spread over the host threads.  Used by the GPU test tier to check a fit at
+ * BASELINE's full size independently of the GPU's own residual kernels.
+ * Returns 0; *omega_out, *ssq_out (sum of squared row residuals), nrows_out[2] (data, constraint rows). */
+typedef struct { const double *x; double *rho, *den; double ssq; long nrows; } grad_t;
+static int sink_grad(void *ctx, int nz, const int *col, const double *val, double rhs)
+{
+    grad_t *G = (grad_t *)ctx;
+    double dot = 0.0, adot = 0.0;
+    for (int k = 0; k < nz; ++k) { dot += val[k] * G->x[col[k]]; adot += fabs(val[k]) * fabs(G->x[col[k]]); }
+    const double res = rhs - dot;
+    for (int k = 0; k < nz; ++k) {
+        G->rho[col[k]] += val[k] * res;
+        G->den[col[k]] += fabs(val[k]) * (adot + fabs(rhs));
+    }
+    G->ssq += res * res;
+    ++G->nrows;
+    return 0;
+}
+
+int oracle_rows_gradient(int ndim, const double *xdata, int l1xdat, const double *ydata, const double *wdata, int ndata,
+                         const double *xmin, const double *xmax, const int *nodes, double xtrap, const double *coef,
+                         int nthreads, double *omega_out, double *ssq_out, long *nrows_out)
+{
+    long ncol = 1;
+    for (int d = 0; d < ndim; ++d) ncol *= nodes[d];
+    if (nthreads < 1) nthreads = omp_get_max_threads();
+    if (nthreads > 64) nthreads = 64;
+    double *rho = calloc((size_t)ncol * (size_t)nthreads, sizeof(double));
+    double *den = calloc((size_t)ncol * (size_t)nthreads, sizeof(double));
+    double *ssq = calloc((size_t)nthreads, sizeof(double));
+    long *nr = calloc((size_t)nthreads, sizeof(long));
+    if (!rho || !den || !ssq || !nr) return 1;
+    int bad = 0;
+#pragma omp parallel num_threads(nthreads) reduction(|:bad)
+    {
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+        const long i0 = (long)ndata * t / T, i1 = (long)ndata * (t + 1) / T;
+        grad_t G = {coef, rho + (size_t)ncol * t, den + (size_t)ncol * t, 0.0, 0};
+        long nc = 0;
+        bad |= emit_rows(ndim, xdata, l1xdat, ydata, wdata, ndata, (int)i0, (int)i1, 0, xmin, xmax, nodes, xtrap, sink_grad, &G, &nc);
+        ssq[t] = G.ssq;
+        nr[t] = G.nrows;
+    }
+    /* constraint rows (need the histogram of all points): one pass, thread 0's arrays */
+    grad_t G = {coef, rho, den, 0.0, 0};
+    long ncons = 0;
+    bad |= emit_rows(ndim, xdata, l1xdat, ydata, wdata, ndata, 0, 0, 1, xmin, xmax, nodes, xtrap, sink_grad, &G, &ncons);
+    double omega = 0.0, s2 = G.ssq;
+    long ndat = 0;
+    for (int t = 0; t < nthreads; ++t) { s2 += ssq[t]; ndat += nr[t]; }
+    for (long i = 0; i < ncol; ++i) {
+        double r = 0.0, d = 0.0;
+        for (int t = 0; t < nthreads; ++t) { r += rho[(size_t)ncol * t + i]; d += den[(size_t)ncol * t + i]; }
+        if (d > 0.0 && fabs(r) / d > omega) omega = fabs(r) / d;
+    }
+    free(rho); free(den); free(ssq); free(nr);
+    if (omega_out) *omega_out = omega;
+    if (ssq_out) *ssq_out = s2;
+    if (nrows_out) { nrows_out[0] = ndat; nrows_out[1] = ncons; }
+    return bad;
 }

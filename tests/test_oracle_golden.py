@@ -172,3 +172,23 @@ def test_banded_cpu_solver_matches_reference_golden(port, name):
     assert relmax(coef, gold["coef"]) < COEF_TOL
     nd_rows = inp["xdata"].shape[0] if inp["wdata"] is None else int(np.count_nonzero(inp["wdata"]))
     assert info[0] == nd_rows
+
+
+@pytest.mark.parametrize("name", ["c1_1d16", "2d16_sparse", "3d8", "3d8_cc_clust", "3d12", "4d4", "2d16_outside", "2d16_zero_w"])
+def test_host_rows_gradient_vanishes_at_the_reference_coefficients(port, name):
+    """oracle_rows_gradient (the host optimality check the GPU tier uses at BASELINE's full size) pinned to the
+    reference: at the golden coefficients the gradient of the least-squares functional over the reference's rows
+    is at rounding level, the row counts are the reference's, and a perturbed coefficient is seen."""
+    from tests.cases import CASES, make_inputs
+    from tests.conftest import load_golden
+    inp = make_inputs(CASES[name])
+    g = load_golden(name)
+    om, reserr, nrow, ncons = port.rows_gradient(inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"],
+                                                 inp["nodes"], inp["xtrap"], g["coef"])
+    assert om < 1e-12, om
+    w = inp["wdata"]
+    assert nrow == (int(np.count_nonzero(w)) if w is not None else inp["xdata"].shape[0])
+    c2 = g["coef"].copy()
+    c2[0] += 1e-6 * np.abs(c2).max()
+    assert port.rows_gradient(inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"], inp["nodes"],
+                              inp["xtrap"], c2)[0] > 1e-9
