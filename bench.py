@@ -374,6 +374,9 @@ def bench_incl_h2d(capi, x, y, w, lo, hi, nodes):
 
 def main():
     args = parse()
+    if os.environ.get("SPLPAK_BENCH_WATCHDOG"):       # a hang ends with the Python stacks of every thread instead of silence
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SPLPAK_BENCH_WATCHDOG"]), exit=True)
     if args.dist_child:
         from splpak_amd import capi
         ng, nod_c, m_c, virt = (int(v) for v in args.dist_child.split(","))

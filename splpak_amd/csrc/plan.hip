@@ -368,11 +368,31 @@ int32_t splpak_plan_factorisation(const splpak_plan *p, char *buf, int32_t bufle
     return code;
 }
 
+// SPLPAK_DEBUG_SUMS: sum and absolute sum of a device buffer, printed with a label (diagnosing the sharded fit)
+static void debug_sum(const splpak_plan *p, const char *what, const double *buf, long long count, hipStream_t st)
+{
+    if (!std::getenv("SPLPAK_DEBUG_SUMS")) return;
+    std::vector<double> h((size_t)count);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost);
+    double s = 0.0, a = 0.0;
+    for (double v : h) { s += v; a += std::fabs(v); }
+    fprintf(stderr, "[splpak rank %d] %s: sum %.17g abs %.17g\n", p->rank, what, s, a);
+}
+
 static int do_allreduce(splpak_plan *p, double *buf, long long count, hipStream_t st)
 {
     if (!p->ar || p->world <= 1) return 0;
+    debug_sum(p, "before all-reduce", buf, count, st);
+    // The buffer is complete before the hook sees it and the reduced values are in place before the fit goes on,
+    // whatever the hook's own ordering is worth: the rehearsal of `bench.py --gpus 2` on ONE device over gloo summed
+    // buffers the fit's kernels were still writing (round 3; a host synchronisation costs ~10 us, a fit issues
+    // 3 + refinement steps of these)
+    SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
     const int r = p->ar(buf, count, (void *)st, p->ar_user);
     if (r != 0) { set_error("all-reduce callback failed"); return SPLPAK_E_COMM; }
+    SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+    debug_sum(p, "after  all-reduce", buf, count, st);
     return 0;
 }
 
@@ -493,7 +513,8 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     // that silently miss it.
     bool converged = p->max_refine == 0, diverged = false, stagnated = false;
     for (int it = 0; it < p->max_refine_hard && !converged; ++it) {
-        SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
+        // (the scalars behind rho travel with it through the all-reduce: zeroed too, or every collective doubles them)
+        SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, smooth && p->rank == 0,
                                        p->tbuf, p->rho, nullptr, nullptr, st), SPLPAK_E_NODEVICE);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;

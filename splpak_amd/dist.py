@@ -29,7 +29,20 @@ def make_allreduce(comm, dist, group=None):
     def _fn(offset: int, count: int):
         if offset < 0 or offset + count > comm.numel():
             raise ValueError(f"all-reduce window [{offset}, {offset + count}) outside the buffer")
-        dist.all_reduce(comm[offset:offset + count], group=group)
+        view = comm[offset:offset + count]
+        if comm.is_cuda and dist.get_backend(group) != "nccl":
+            # A host backend (gloo: the CPU tests and the one-GPU rehearsal of the multi-rank path) on a device buffer:
+            # stage through host memory with explicit synchronisation.  gloo's own device-tensor path only orders its
+            # copies by stream events, and two ranks sharing ONE GPU were seen to sum a buffer that the fit's kernels
+            # had not finished writing (round 3: garbage normal equations in `bench.py --gpus 2` on one device).
+            import torch
+            torch.cuda.current_stream().synchronize()
+            host = view.cpu()
+            dist.all_reduce(host, group=group)
+            view.copy_(host)
+            torch.cuda.current_stream().synchronize()
+            return
+        dist.all_reduce(view, group=group)       # RCCL: enqueued behind the current (= the library's) stream
     return _fn
 
 
