@@ -307,6 +307,18 @@ def bench_dist_band(capi, ngpus, nd, nod, m_total, virtual, steps):
             os.environ.pop("SPLPAK_VIRTUAL_GPUS", None)
 
 
+def c5_traffic():
+    """Fabric bytes of the 4-D evaluation passes from the committed PMC profile (not measured in this run)."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_eval_pmc.json")))["4d_32"]
+        return {"kernel": "eval_binned_kernel<4,true>", "bytes_per_launch": pm["kernels"]["eval_binned_kernel<4, true>"]["hbm_bytes"],
+                "queries_per_launch": pm["queries_per_launch"], "bytes_per_query_all_passes": pm["hbm_bytes_per_query_all_passes"],
+                "algorithmic_bytes_per_query": 40.0,
+                "source": "profiles/r03_eval_pmc.json (rocprofv3 --pmc passes of tools/eval_profile.py 4 32 100000000; not measured in this run)"}
+    except Exception:
+        return None
+
+
 def bench_c5_eval(capi, dev, stream):
     """BASELINE config 5, evaluation half at full size: 4-D 32^4 coefficients (8 MB), 1e8 queries of the
     seeded stream, splfe and two splde derivative patterns; real64 resident data.  (The fit half of
@@ -332,7 +344,7 @@ def bench_c5_eval(capi, dev, stream):
     return {"workload": "C5 (evaluation half): 4-D, 32^4 nodes, 1e8 queries, real64, resident data", "unit": "evals/s",
             "value": res["splfe"], **{k + "_evals_per_s": v for k, v in res.items()},
             "roofline": {"bound": "hbm", "achieved": 40.0 * res["splfe"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": 40.0 * res["splfe"] / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+                         "frac": 40.0 * res["splfe"] / 1e9 / HBM_PEAK_GBS, "traffic": c5_traffic()}}
 
 
 def dist_band_in_child(ngpus, nd, nod, m_total, virtual, steps, timeout):
@@ -515,13 +527,15 @@ def main():
     evals_per_s = world * nq / (ev_ms * 1e-3)
     ev_bytes = 8.0 * (nd + 1) * nq
 
-    # fabric bytes per launch of the dominant evaluation kernel (PMC passes, profiles/r02_eval_pmc.json)
+    # fabric bytes of the evaluation passes: PMC passes of an earlier run of the same workload, kept under profiles/ --
+    # NOT measured in this run
     eval_traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_eval_pmc.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_eval_pmc.json")))["3d_64"]
         eval_traffic = {"kernel": "eval_binned_kernel<3,true>", "bytes_per_launch": pm["kernels"]["eval_binned_kernel<3, true>"]["hbm_bytes"],
                         "queries_per_launch": pm["queries_per_launch"],
-                        "bytes_per_query_all_passes": pm["hbm_bytes_per_query_all_passes"], "algorithmic_bytes_per_query": 8.0 * (nd + 1)}
+                        "bytes_per_query_all_passes": pm["hbm_bytes_per_query_all_passes"], "algorithmic_bytes_per_query": 8.0 * (nd + 1),
+                        "source": "profiles/r03_eval_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload; not measured in this run)"}
     except Exception:
         pass
     dist_leg = None
