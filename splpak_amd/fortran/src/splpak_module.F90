@@ -5,8 +5,10 @@
 !!
 !! Argument lists, `ierror` codes and the text printed on `output_unit` follow the
 !! reference (splcw :512-513, splcc :421-422, splde :1089, splfe :1258, cfaerr :399-407).
-!! The fit and every batched evaluation run on the GPU; there is no host fallback: without a GPU
-!! those calls fail with a negative `ierror` and the library's message is printed.  The SCALAR
+!! The fit and every batched evaluation run on the GPU and never fall back: without a GPU those calls
+!! fail with a negative `ierror` and the library's message is printed.  A separate HOST solver
+!! (splpak_host.F90, written from scratch for this package) runs only when the caller selects it
+!! explicitly with `call solver%set_host(.true.)`, and in a -DREAL128 build (no GPU arithmetic).  The SCALAR
 !! `evaluate` (one point per call, the reference's splfe/splde) is computed on the host by this
 !! module itself (SURVEY 7.2 H6: one kernel launch per point would cost 10^4 x its arithmetic);
 !! `evaluate_many` is the GPU path.
@@ -22,12 +24,13 @@
 !!    `last_fit_info` returns the diagnostics of the last fit (the residual norm `reserr` that the
 !!    reference computes, suprls :1693, and drops, splcw :690; row counts; refinement steps).
 !!
-!! Build with -DREAL32 for single precision storage (as the reference, :33-41);
-!! REAL128 has no GPU path and is rejected at compile time.
+!! Build with -DREAL32 for single precision storage (as the reference, :33-41); -DREAL128 builds the
+!! module on the host solver alone (quad precision has no MI355X arithmetic).
 module splpak_module
 
     use iso_c_binding
-    use iso_fortran_env, only: real32, real64, output_unit
+    use iso_fortran_env, only: real32, real64, real128, output_unit
+    use splpak_host_solver, only: hk, host_basis, host_fit
 
     implicit none
 
@@ -36,7 +39,7 @@ module splpak_module
 #ifdef REAL32
     integer,parameter :: wp = real32
 #elif REAL128
-#error "REAL128 has no MI355X path; build the reference for quad precision"
+    integer,parameter :: wp = real128
 #else
     integer,parameter :: wp = real64
 #endif
@@ -48,6 +51,11 @@ module splpak_module
         integer :: mdim = 0    !! dimension of the last call (the reference keeps scratch here, :95-111)
         real(real64) :: info(10) = 0.0_real64   !! diagnostics of the last fit (include/splpak_hip.h, `info`)
         integer :: ngpus = 1   !! GPUs of this node the fit is spread over (set_gpus)
+#ifdef REAL128
+        logical :: host = .true.    !! quad precision: the host solver is the only path
+#else
+        logical :: host = .false.   !! .true. after set_host(.true.): fits and batches run on the host solver (never a fallback)
+#endif
     contains
         private
         generic,public   :: initialize    => splcc, splcw        !! fit
@@ -57,6 +65,7 @@ module splpak_module
         procedure,public :: destroy       => destroy_splpak
         procedure,public :: last_fit_info => splpak_last_fit_info   !! reserr, row counts, ... of the last fit (additive)
         procedure,public :: set_gpus      => splpak_set_gpus        !! spread the following fits over n GPUs of this node (additive)
+        procedure,public :: set_host      => splpak_set_host        !! run the following calls on the host solver (additive; explicit, never a fallback)
         procedure,private :: splcc
         procedure,private :: splcw
         procedure,private :: splfe
@@ -66,6 +75,7 @@ module splpak_module
         procedure,private :: splpak_derivs_many
     end type splpak_type
 
+#ifndef REAL128
     interface
 #ifdef REAL32
         integer(c_int32_t) function c_fit(ndim,xdata,l1xdat,ydata,wdata,ndata,xmin,xmax,nodes,xtrap,&
@@ -122,6 +132,7 @@ module splpak_module
             integer(c_int32_t),value :: buflen
         end function c_last_error
     end interface
+#endif
 
     contains
 
@@ -135,10 +146,26 @@ module splpak_module
         me%info = 0.0_real64
         if (present(ndim)) then
             me%mdim = ndim
+#ifndef REAL128
         else
             call c_shutdown()
+#endif
         end if
     end subroutine destroy_splpak
+
+    !> `call solver%set_host(.true.)`: the following `initialize` / `evaluate_many` / `evaluate_derivatives` calls of this
+    !! object run on the HOST solver (splpak_host.F90: banded normal equations + Cholesky + refinement against the rows,
+    !! real64 arithmetic) instead of the MI355X -- for machines without a GPU and for small problems.  Explicit only: the
+    !! GPU path never falls back to it.  `.false.` returns to the GPU (ignored in a -DREAL128 build, which has no GPU path).
+    subroutine splpak_set_host(me,flag)
+        class(splpak_type),intent(inout) :: me
+        logical,intent(in) :: flag
+#ifdef REAL128
+        me%host = .true.
+#else
+        me%host = flag
+#endif
+    end subroutine splpak_set_host
 
     !> The following `initialize` calls of this object use `n` GPUs of the node: the points are sharded
     !! and the band of the normal equations is distributed over them (include/splpak_hip.h,
@@ -152,13 +179,15 @@ module splpak_module
     !> Diagnostics of the last `initialize` of this object.  `reserr` is the residual norm
     !! ||rows*coef - rhs||_2 over data and constraint rows that the reference computes in suprls
     !! (:1693) and drops in splcw (:690, :1052).
-    subroutine splpak_last_fit_info(me,reserr,ndata_rows,nconstraint_rows,refine_steps,optimality)
+    subroutine splpak_last_fit_info(me,reserr,ndata_rows,nconstraint_rows,refine_steps,optimality,on_host)
         class(splpak_type),intent(in) :: me
         real(wp),intent(out),optional :: reserr        !! residual norm of the fitted system
         integer,intent(out),optional :: ndata_rows       !! data rows used (non-zero weight)
         integer,intent(out),optional :: nconstraint_rows !! derivative-constraint rows of data-sparse nodes (:921-1046)
         integer,intent(out),optional :: refine_steps     !! iterative-refinement steps taken
         real(wp),intent(out),optional :: optimality      !! componentwise backward error of coef w.r.t. the rows
+        logical,intent(out),optional :: on_host          !! .true. if this object's fits run on the host solver (set_host)
+        if (present(on_host)) on_host = me%host
         if (present(reserr)) reserr = real(me%info(9),wp)
         if (present(ndata_rows)) ndata_rows = int(me%info(1))
         if (present(nconstraint_rows)) nconstraint_rows = int(me%info(2))
@@ -181,7 +210,11 @@ module splpak_module
         character(kind=c_char) :: buf(512)
         character(len=512) :: msg
         integer :: n, i
+        n = 0
+        buf = ' '
+#ifndef REAL128
         n = c_last_error(buf, 512_c_int32_t)
+#endif
         msg = ''
         do i = 1, min(n,511)
             msg(i:i) = buf(i)
@@ -271,6 +304,11 @@ module splpak_module
             ncol = ncol*int(max(nodes(idim),1),c_int64_t)
         end do
         if (ndim >= 1 .and. xtrap /= 0.0_wp .and. int(nwrk,c_int64_t) >= ncol) hist = c_loc(work)
+        if (me%host) then
+            call fit_on_host(me,ndim,xdata,l1xdat,ydata,wdata,ndata,xmin,xmax,nodes,xtrap,coef,ncf,work,nwrk,ierror)
+            return
+        end if
+#ifndef REAL128
 #ifndef REAL32
         if (me%ngpus > 1) then
             rc = c_fit_multi(int(me%ngpus,c_int32_t), int(ndim,c_int32_t), xdata, int(l1xdat,c_int32_t), ydata, wdata, &
@@ -290,7 +328,71 @@ module splpak_module
         else if (rc < 0) then
             call report_library_failure(ierror,'splcc or splcw')
         end if
+#endif
     end subroutine fit_common
+
+    !> The fit on the host solver (set_host / REAL128): the reference's argument checks in its order (:716-781), then
+    !! splpak_host_solver's banded normal equations.  Same `ierror` codes and messages as the GPU path.
+    subroutine fit_on_host(me,ndim,xdata,l1xdat,ydata,wdata,ndata,xmin,xmax,nodes,xtrap,coef,ncf,work,nwrk,ierror)
+        class(splpak_type),intent(inout) :: me
+        integer,intent(in) :: ndim, l1xdat, ncf, nwrk, ndata
+        type(c_ptr),intent(in) :: xdata, ydata, wdata, xmin, xmax
+        integer,intent(in) :: nodes(*)
+        real(wp),intent(in) :: xtrap
+        real(wp) :: coef(*), work(*)
+        integer,intent(out) :: ierror
+        real(wp),pointer :: px(:,:), py(:), pw(:), pmin(:), pmax(:)
+        real(wp),target :: wdummy(1)
+        real(wp),allocatable :: hst(:)
+        integer :: idim, nwrk1
+        integer(c_int64_t) :: ncol
+        logical :: weighted, want
+        ierror = 0
+        if (ndim < 1) ierror = 101
+        if (ierror == 0) then
+            call c_f_pointer(xmin, pmin, [ndim])
+            call c_f_pointer(xmax, pmax, [ndim])
+            ncol = 1
+            do idim = 1, ndim
+                if (nodes(idim) < 4) then
+                    ierror = 102
+                    exit
+                end if
+                if (pmax(idim) - pmin(idim) == 0.0_wp) then
+                    ierror = 103
+                    exit
+                end if
+                ncol = ncol*int(nodes(idim),c_int64_t)
+            end do
+        end if
+        if (ierror == 0) then
+            if (ncol > int(ncf,c_int64_t)) ierror = 104
+        end if
+        if (ierror == 0 .and. ndata < 1) ierror = 105
+        if (ierror == 0) then
+            nwrk1 = 1
+            if (xtrap /= 0.0_wp) nwrk1 = int(min(ncol+1, int(huge(1),c_int64_t)))
+            if (nwrk - nwrk1 + 1 < 1) ierror = 106
+        end if
+        if (ierror /= 0) then
+            call report_fit(ierror)
+            return
+        end if
+        call c_f_pointer(xdata, px, [l1xdat, ndata])
+        call c_f_pointer(ydata, py, [ndata])
+        weighted = c_associated(wdata)
+        if (weighted) then
+            call c_f_pointer(wdata, pw, [ndata])
+        else
+            wdummy = -1.0_wp
+            pw => wdummy
+        end if
+        want = xtrap /= 0.0_wp .and. int(nwrk,c_int64_t) >= ncol
+        allocate(hst(int(ncol)))
+        call host_fit(ndim, px, l1xdat, py, pw, weighted, ndata, pmin, pmax, nodes, xtrap, coef, hst, want, me%info, ierror)
+        if (want) work(1:int(ncol)) = hst
+        if (ierror /= 0) call report_fit(ierror)
+    end subroutine fit_on_host
 
     !> Spline value at one point; same arguments as the reference's splfe (:1258).  Host computation.
     function splfe(me,ndim,x,coef,xmin,xmax,nodes,ierror)
@@ -321,81 +423,6 @@ module splpak_module
         splde = eval_point(me,ndim,x,nderiv,coef,xmin,xmax,nodes,ierror)
     end function splde
 
-    !> One 1-D factor of the tensor-product basis: the natural-spline basis function centred on node
-    !! `ib` of a dimension with `nod` nodes, spacing 1/s, or its first / second derivative, at `xx`.
-    !! Closed forms of SURVEY appendix A (reference bascmp :231-381): interior functions are the
-    !! cubic "chapeau" B-splines, the two functions at either end are cubic inside and straight lines
-    !! outside (natural boundary, linear extrapolation).  Strict inequalities as in the reference.
-    pure function basis_factor(ib,nod,ider,xx,xnode,s) result(b)
-        integer,intent(in) :: ib, nod, ider
-        real(real64),intent(in) :: xx, xnode, s
-        real(real64) :: b, z, z1, f
-        b = 0.0_real64
-        if (ib >= 2 .and. ib <= nod-3) then                 ! chapeau (:253-300)
-            select case (ider)
-            case (0)
-                z = abs(s*(xx-xnode)) - 2.0_real64
-                if (z < 0.0_real64) then
-                    b = -0.25_real64*z**3
-                    z1 = z + 1.0_real64
-                    if (z1 < 0.0_real64) b = b + z1**3
-                end if
-            case (1)
-                f = s
-                if (xx-xnode < 0.0_real64) f = -s
-                z = f*(xx-xnode) - 2.0_real64
-                if (z < 0.0_real64) then
-                    b = -0.75_real64*z**2
-                    z1 = z + 1.0_real64
-                    if (z1 < 0.0_real64) b = b + 3.0_real64*z1**2
-                    b = b*f
-                end if
-            case default
-                z = s*abs(xx-xnode) - 2.0_real64
-                if (z < 0.0_real64) then
-                    b = -1.5_real64*z
-                    z1 = z + 1.0_real64
-                    if (z1 < 0.0_real64) b = b + 6.0_real64*z1
-                    b = b*s*s
-                end if
-            end select
-            return
-        end if
-        f = s                                               ! end functions: left (ib <= 1) mirrors right (:302-379)
-        if (ib <= 1) f = -s
-        z = f*(xx-xnode) + 2.0_real64
-        select case (ider)
-        case (0)
-            if (z > 0.0_real64) then
-                if (z < 2.0_real64) then
-                    b = 0.5_real64*z**3
-                    z1 = z - 1.0_real64
-                    if (z1 > 0.0_real64) b = b - z1**3
-                else
-                    b = 3.0_real64*z - 3.0_real64
-                end if
-            end if
-        case (1)
-            if (z > 0.0_real64) then
-                if (z < 2.0_real64) then
-                    b = 1.5_real64*z**2
-                    z1 = z - 1.0_real64
-                    if (z1 > 0.0_real64) b = b - 3.0_real64*z1**2
-                    b = b*f
-                else
-                    b = 3.0_real64*f
-                end if
-            end if
-        case default
-            z1 = z - 1.0_real64
-            if (abs(z1) < 1.0_real64) then
-                b = 3.0_real64*z
-                if (z1 > 0.0_real64) b = b - 6.0_real64*z1
-                b = b*f*f
-            end if
-        end select
-    end function basis_factor
-
     !> The scalar evaluation: checks and `ierror` as splde (:1166-1194: 101/102/103 return 0, 104 is
     !! reported and the value is still computed), then the separable form of the reference's window
     !! sum (:1197-1236): per dimension the (at most) four 1-D factors of the window
@@ -411,7 +438,7 @@ module splpak_module
         integer,intent(in) :: nodes(*)
         integer,intent(out) :: ierror
         real(wp) :: f
-        real(real64) :: tab(4,max(ndim,1)), dx, s, t, prod, acc
+        real(hk) :: tab(4,max(ndim,1)), dx, s, t, prod, acc
         integer :: first(max(ndim,1)), width(max(ndim,1)), k(max(ndim,1)), stride(max(ndim,1))
         integer :: idim, it, ibmn, ibmx, j, icol, ider
         f = 0.0_wp
@@ -445,30 +472,30 @@ module splpak_module
         do idim = 1, ndim
             stride(idim) = icol
             icol = icol*nodes(idim)
-            dx = (real(xmax(idim),real64) - real(xmin(idim),real64))/real(nodes(idim)-1,real64)
-            s = 1.0_real64/dx
-            t = s*(real(x(idim),real64) - real(xmin(idim),real64))
-            it = int(max(min(t,2.0e9_real64),-2.0e9_real64))     ! truncation toward zero, saturating
+            dx = (real(xmax(idim),hk) - real(xmin(idim),hk))/real(nodes(idim)-1,hk)
+            s = 1.0_hk/dx
+            t = s*(real(x(idim),hk) - real(xmin(idim),hk))
+            it = int(max(min(t,2.0e9_hk),-2.0e9_hk))     ! truncation toward zero, saturating
             ibmn = min(max(it-1,0),nodes(idim)-2)
             ibmx = max(min(it+2,nodes(idim)-1),1)
             first(idim) = ibmn
             width(idim) = ibmx - ibmn + 1
             ider = min(max(nderiv(idim),0),2)
             do j = 1, width(idim)
-                tab(j,idim) = basis_factor(ibmn+j-1, nodes(idim), ider, real(x(idim),real64), &
-                                           real(xmin(idim),real64) + real(ibmn+j-1,real64)*dx, s)
+                tab(j,idim) = host_basis(ibmn+j-1, nodes(idim), ider, real(x(idim),hk), &
+                                         real(xmin(idim),hk) + real(ibmn+j-1,hk)*dx, s)
             end do
         end do
-        acc = 0.0_real64
+        acc = 0.0_hk
         k = 1
         do
-            prod = 1.0_real64
+            prod = 1.0_hk
             icol = 1
             do idim = 1, ndim
                 prod = prod*tab(k(idim),idim)
                 icol = icol + (first(idim) + k(idim) - 1)*stride(idim)
             end do
-            acc = acc + real(coef(icol),real64)*prod
+            acc = acc + real(coef(icol),hk)*prod
             idim = 1                                        ! odometer, first dimension fastest (:1228-1232)
             do while (idim <= ndim)
                 k(idim) = k(idim) + 1
@@ -524,10 +551,48 @@ module splpak_module
         real(wp),intent(out),target :: f(ldf,*)
         integer,intent(out) :: ierror
         integer(c_int32_t) :: rc
+        integer :: iq, idm, jdm, col, nder(max(ndim,1)), ie
         me%mdim = ndim
+        if (me%host) then             ! host solver selected: every column is the scalar splde of its pattern
+            ierror = 0
+            if (order < 1 .or. order > 2 .or. ldf < 1 + ndim + merge(ndim*(ndim+1)/2, 0, order == 2)) then
+                ierror = -3
+                call report(ierror,' evaluate_derivatives - order must be 1 or 2 and ldf large enough')
+                return
+            end if
+            do iq = 1, nq
+                nder = 0
+                f(1,iq) = eval_point(me,ndim,x(:,iq),nder,coef,xmin,xmax,nodes,ie)
+                if (ie /= 0) then
+                    ierror = ie
+                    return
+                end if
+                do idm = 1, ndim
+                    nder = 0
+                    nder(idm) = 1
+                    f(1+idm,iq) = eval_point(me,ndim,x(:,iq),nder,coef,xmin,xmax,nodes,ie)
+                end do
+                if (order == 2) then
+                    col = 1 + ndim
+                    do idm = 1, ndim
+                        do jdm = idm, ndim
+                            nder = 0
+                            nder(idm) = nder(idm) + 1
+                            nder(jdm) = nder(jdm) + 1
+                            col = col + 1
+                            f(col,iq) = eval_point(me,ndim,x(:,iq),nder,coef,xmin,xmax,nodes,ie)
+                        end do
+                    end do
+                end if
+            end do
+            return
+        end if
+        rc = -1
+#ifndef REAL128
         rc = c_eval_derivs(int(ndim,c_int32_t), int(nq,c_int64_t), c_loc(x), int(ldx,c_int32_t), &
                            int(order,c_int32_t), c_loc(coef), c_loc(xmin), c_loc(xmax), c_loc(nodes), &
                            c_loc(f), int(ldf,c_int32_t))
+#endif
         ierror = int(rc)
         select case (ierror)
         case (0)
@@ -546,8 +611,39 @@ module splpak_module
         type(c_ptr),intent(in) :: x, nderiv, coef, xmin, xmax, nodes, f
         integer,intent(out) :: ierror
         integer(c_int32_t) :: rc
+        real(wp),pointer :: px(:,:), pc(:), pmin(:), pmax(:), pf(:)
+        integer,pointer :: pn(:), pd(:)
+        integer :: iq, ie, zero(max(ndim,1)), ncol, idim
         me%mdim = ndim
+        if (me%host .and. ndim >= 1) then         ! host solver selected: a loop over the scalar evaluation
+            call c_f_pointer(nodes, pn, [ndim])
+            ncol = 1
+            do idim = 1, ndim
+                ncol = ncol*max(pn(idim),1)
+            end do
+            call c_f_pointer(x, px, [ldx, int(nq)])
+            call c_f_pointer(coef, pc, [ncol])
+            call c_f_pointer(xmin, pmin, [ndim])
+            call c_f_pointer(xmax, pmax, [ndim])
+            call c_f_pointer(f, pf, [int(nq)])
+            zero = 0
+            ierror = 0
+            do iq = 1, int(nq)
+                if (c_associated(nderiv)) then
+                    call c_f_pointer(nderiv, pd, [ndim])
+                    pf(iq) = eval_point(me,ndim,px(:,iq),pd,pc,pmin,pmax,pn,ie)
+                else
+                    pf(iq) = eval_point(me,ndim,px(:,iq),zero,pc,pmin,pmax,pn,ie)
+                end if
+                if (ie /= 0) ierror = ie
+                if (ie /= 0 .and. ie /= 104) return
+            end do
+            return
+        end if
+        rc = -1
+#ifndef REAL128
         rc = c_eval(int(ndim,c_int32_t), nq, x, int(ldx,c_int32_t), nderiv, coef, xmin, xmax, nodes, f)
+#endif
         ierror = int(rc)
         select case (ierror)
         case (0)

@@ -9,6 +9,11 @@ program test_api
     real(wp) :: xs(2,50), fs(50), jet(6,50)
     integer(8) :: s
     type(splpak_type) :: solver
+    character(len=16) :: backend
+
+    ! `<program> host`: the same scenario on the module's HOST solver (set_host; no GPU needed)
+    call get_command_argument(1, backend)
+    if (trim(backend) == 'host') call solver%set_host(.true.)
 
     nbad = 0
     s = 42_8

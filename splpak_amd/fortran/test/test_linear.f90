@@ -15,6 +15,11 @@ program test_linear
     integer :: i, ierror
     integer(8) :: t0, t1, rate
     type(splpak_type) :: solver
+    character(len=16) :: backend
+
+    ! `<program> host`: the same scenario on the module's HOST solver (set_host; no GPU needed)
+    call get_command_argument(1, backend)
+    if (trim(backend) == 'host') call solver%set_host(.true.)
 
     xmin = 0.0_wp; xmax = 1.0_wp
     do i = 1, nxdata

@@ -13,6 +13,11 @@ program test_noisy
     integer(8) :: s
     integer :: i, ierror
     type(splpak_type) :: solver
+    character(len=16) :: backend
+
+    ! `<program> host`: the same scenario on the module's HOST solver (set_host; no GPU needed)
+    call get_command_argument(1, backend)
+    if (trim(backend) == 'host') call solver%set_host(.true.)
 
     xmin = 0.0_wp; xmax = 1.0_wp
     s = 42_8

@@ -1,7 +1,8 @@
 """The Fortran drop-in `splpak_module` (splpak_amd/fortran) over the C ABI.
 
 CPU tier : the module and its test programs build with amdflang, link against the HIP
-           library, and FAIL LOUDLY without a GPU (no host fallback).
+           library, and FAIL LOUDLY without a GPU (the GPU path never falls back); the module's separate HOST solver
+           (`set_host(.true.)`, splpak_host.F90; the only path of a -DREAL128 build) is held to the reference's goldens.
 GPU tier : the three test programs -- re-creations of the reference's own tests
            (test/splpak_test_linear.f90, test/splpak_test.f90) plus an API/ierror test --
            pass on the MI355X.
@@ -17,7 +18,7 @@ from tests.conftest import ROOT
 FDIR = os.path.join(ROOT, "splpak_amd", "fortran")
 BUILD = os.path.join(FDIR, "build")
 PROGS = ["test_linear", "test_noisy", "test_api", "test_info"]
-ALL_PROGS = PROGS + ["test_evalfix"]
+ALL_PROGS = PROGS + ["test_evalfix", "test_hostfit"]
 
 
 def _ensure_built():
@@ -55,6 +56,63 @@ def test_fortran_scalar_evaluate_matches_reference_goldens_3d_4d():
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASS test_evalfix" in r.stdout
+
+
+def _fit_fixtures():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "fit_*.txt")))
+
+
+def test_fortran_host_solver_matches_reference_goldens():
+    """`call solver%set_host(.true.)`: the from-scratch host solver inside the Fortran package (banded normal equations,
+    Cholesky, refinement against the rows) against the reference's coefficients and sparse-area histograms
+    of 15 golden cases (1-D .. 4-D, weighted / unweighted, xtrap 0 / /= 0, zero weights, points outside the box,
+    clustered data): 1e-10 max-norm on the coefficients, 1e-12 on the histogram.  No GPU, and not the oracle."""
+    _ensure_built()
+    fx = _fit_fixtures()
+    assert len(fx) >= 15
+    r = subprocess.run([os.path.join(BUILD, "test_hostfit")] + fx, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASS test_hostfit" in r.stdout
+
+
+@pytest.mark.parametrize("prog", ["test_linear", "test_noisy", "test_api"])
+def test_fortran_reference_scenarios_on_the_host_solver(prog):
+    """The reference's own test scenarios (test/splpak_test_linear.f90: slope 2 +- 1e-12; test/splpak_test.f90) and the
+    API / ierror test, run with `host` = set_host(.true.): they pass on a machine without a GPU."""
+    _ensure_built()
+    r = subprocess.run([os.path.join(BUILD, prog), "host"], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"PASS {prog}" in r.stdout
+
+
+def test_fortran_real128_build_runs_on_the_host_solver():
+    """-DREAL128 (reference: README.md:24-36, src/splpak.F90:33-41): no GPU arithmetic exists for quad precision, the
+    module is built on the host solver alone (no HIP library linked) and reproduces the real64 goldens to their own
+    rounding, with a backward error at quad-precision level."""
+    if not os.path.exists("/opt/rocm/bin/amdflang"):
+        pytest.skip("amdflang not available")
+    subprocess.check_call(["make", "-C", FDIR, "build/r128/test_hostfit"])
+    fx = [f for f in _fit_fixtures() if any(k in f for k in ("fit_3d8.txt", "fit_2d16_sparse.txt", "fit_c1_1d16.txt"))]
+    r = subprocess.run([os.path.join(BUILD, "r128", "test_hostfit")] + fx, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASS test_hostfit" in r.stdout
+    import re as _re
+    for om in _re.findall(r"backward error\s+(\S+)", r.stdout):
+        assert float(om) < 1e-25
+
+
+def test_consumer_example_builds_without_fpm():
+    """examples/consumer: a caller's program compiled against the module files and linked to build/libsplpak.so with a
+    plain Makefile (fpm is absent from the image), run on the host solver."""
+    _ensure_built()
+    ex = os.path.join(ROOT, "examples", "consumer")
+    subprocess.check_call(["make", "-C", ex])
+    r = subprocess.run([os.path.join(ex, "fit_surface"), "host"], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-1000:], r.stderr[-1000:])
+    assert r.returncode == 0 and "OK fit_surface" in r.stdout
 
 
 @pytest.mark.gpu
