@@ -119,8 +119,11 @@ __device__ unsigned long long g_strip_cycles[8];
 // A = the diagonal block (A(r,c) = A[r + c*lda], r >= c); k0 only labels the pivot index reported through info.
 // The minimum pivot is tracked with an integer atomic on the bit pattern (positive doubles order like their
 // bits), so that several blocks may be factored by concurrent workgroups (the batched launches of ndchol.hip).
+// ncols (1 .. 256): the columns from ncols on are identity padding (a front of the nested-dissection factorisation whose
+// own variables do not fill its last block): strips that hold nothing else are skipped -- their part of L is the identity
+// the assembly left there, and the leaf inverses at the end read it.
 __device__ __forceinline__ void potrf_strip_body(double *__restrict__ A, long long lda, int k0, int *__restrict__ info,
-                                                 double *__restrict__ minpiv, double *__restrict__ inv16)
+                                                 double *__restrict__ minpiv, double *__restrict__ inv16, int ncols = NBLK)
 {
     __shared__ double Ls[IB * (IB + 1)];
     __shared__ double Lrd[IB];               // reciprocals of the leaf's diagonal
@@ -131,7 +134,8 @@ __device__ __forceinline__ void potrf_strip_body(double *__restrict__ A, long lo
     __builtin_amdgcn_s_setprio(3);
     STRIP_T0();
 
-    for (int c0 = 0; c0 < NBLK; c0 += SPW) {
+    const int cend = ((ncols + SPW - 1) / SPW) * SPW;        // first column of the first all-padding strip
+    for (int c0 = 0; c0 < cend; c0 += SPW) {
         // ---- strip -> LDS (whole rectangle rows >= c0; the part above the diagonal is never used):
         // one row per thread, 16 columns in flight at a time
         if (c0 + tid < NBLK) {
@@ -265,7 +269,7 @@ __device__ __forceinline__ void potrf_strip_body(double *__restrict__ A, long lo
         }
         STRIP_ACC(4);
         // ---- the block right of the strip: C -= S S^T with K = 64 (strip_trailing_update above)
-        strip_trailing_update(A, lda, (lds_cptr)S, c0, wave, l15, q);
+        if (c0 + SPW < cend) strip_trailing_update(A, lda, (lds_cptr)S, c0, wave, l15, q);     // (right of it: padding only)
         __syncthreads();        // everybody is done with the strip (and its stores are issued) before it is replaced
         __threadfence_block();
         STRIP_ACC(5);
@@ -321,8 +325,8 @@ __device__ __forceinline__ void potrf_strip_body(double *__restrict__ A, long lo
 template <bool EYE>
 __device__ __forceinline__ void trsm_rows(const double *__restrict__ L, double *__restrict__ Xbase, long long lda,
                                           long long ldx, const double *__restrict__ inv16, double *__restrict__ Xt,
-                                          int r0, double *__restrict__ xs)
-{
+                                          int r0, double *__restrict__ xs, int ncb = NBLK / 16)
+{   // ncb: 16-column blocks to solve (the columns beyond are identity padding of a front: their X is the zero already there)
     const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
     double *__restrict__ Xr = Xbase + r0 + l15;          // Xr[c*ldx] = X(row, c)
     constexpr int NCB = NBLK / 16;
@@ -332,9 +336,9 @@ __device__ __forceinline__ void trsm_rows(const double *__restrict__ L, double *
 #pragma unroll
     for (int v = 0; v < 4; ++v) Tn[v] = EYE ? (r0 + l15 == q + 4 * v ? 1.0 : 0.0) : Xr[(long long)(q + 4 * v) * ldx];
 #pragma unroll 1
-    for (int cb = 0; cb < NCB; ++cb) {          // stays rolled: the code must stay small (cold I-cache)
+    for (int cb = 0; cb < ncb; ++cb) {          // stays rolled: the code must stay small (cold I-cache)
         d4_t T = Tn;
-        const bool more = cb + 1 < NCB;
+        const bool more = cb + 1 < ncb;
         const double *__restrict__ Inv = inv16 + cb * 256;           // Inv[row + 16*col]
         double iv[4];
 #pragma unroll

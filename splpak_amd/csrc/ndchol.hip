@@ -38,10 +38,11 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------------------
 // job tables (device PODs)
-struct PotrfJob { double *A; double *inv16; long long ld; int k0; int pad; };
-struct TrsmJob { const double *L; double *X; const double *inv16; long long ld; int nrows; int wg0; };
+struct PotrfJob { double *A; double *inv16; long long ld; int k0; int ncols; };      // ncols: real columns of the block (the rest is identity padding)
+struct TrsmJob { const double *L; double *X; const double *inv16; long long ld; int nrows; int wg0; int ncb; int pad; };   // ncb: 16-column blocks that hold real columns
 // C(ti, tj) -= P_ti P_tj^T for the 64-row tiles tj in [0, nc), ti in [tj, nr); K = 256 columns of P
-struct SyrkJob { const double *P; double *C; long long ldp, ldc; int nc, nr; int item0; int kb; };   // kb = 256-column blocks of P per pass
+struct SyrkJob { const double *P; double *C; long long ldp, ldc; int nc, nr; int item0; int kb; int ksl; int pad; };   // kb = 256-column blocks of P per pass, ksl = k-steps (4 columns each, multiple of 4) of the LAST of them that hold real columns
+struct ZeroJob { double *S; long long lds; int nt; int tile0; };
 struct TrinvJob { const double *L; const double *inv16; double *dinv; double *dinvt; long long ld; };
 // child's Schur buffer -> parent's panel (columns < wpp) / Schur buffer
 struct AddJob { const double *S; const int *pm; double *P; double *Sp; long long lds, ldp, ldsp; int h, nt, wpp, tile0; };
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(256)
 nd_potrf_kernel(const PotrfJob *__restrict__ jobs, int *__restrict__ info, double *__restrict__ minpiv)
 {
     const PotrfJob j = jobs[blockIdx.x];
-    potrf_strip_body(j.A, j.ld, j.k0, info, minpiv, j.inv16);
+    potrf_strip_body(j.A, j.ld, j.k0, info, minpiv, j.inv16, j.ncols);
 }
 
 __global__ void __launch_bounds__(64)
@@ -97,7 +98,7 @@ nd_trsm_kernel(const TrsmJob *__restrict__ jobs, int njobs)
     const int r0 = (b - j.wg0) * 16;
     if (r0 >= j.nrows) return;
     __builtin_amdgcn_s_setprio(3);
-    trsm_rows<false>(j.L, j.X, j.ld, j.ld, j.inv16, nullptr, r0, xs);
+    trsm_rows<false>(j.L, j.X, j.ld, j.ld, j.inv16, nullptr, r0, xs, j.ncb);
 }
 
 __global__ void __launch_bounds__(64)
@@ -196,7 +197,9 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
 #pragma unroll 1
     for (int h = 0; h < j.kb; ++h) {                 // one 256-column block per trip: the unrolled body of K = 256
         const int base = h * NSTEP;
+        const int kend = (h == j.kb - 1) ? j.ksl : NSTEP;      // the columns beyond are identity padding: zero in these rows
         for (int ks = 0; ks < NSTEP; ks += SD) {
+            if (ks >= kend) break;
 #pragma unroll
             for (int d = 0; d < SD; ++d) {
 #pragma unroll
@@ -312,6 +315,23 @@ nd_extend_add_kernel(const AddJob *__restrict__ jobs, int njobs)
                                    : j.Sp + (prow - j.wpp) + (long long)(pcol - j.wpp) * j.ldsp;
         *dst += v;
     }
+}
+
+// zeroes the lower-triangle 64x64 tiles of Schur buffers (what the updates and the extend-add read): half the bytes of a
+// memset of the square buffers
+__global__ void __launch_bounds__(256)
+nd_zero_kernel(const ZeroJob *__restrict__ jobs, int njobs)
+{
+    const int b = blockIdx.x;
+    const int ji = find_job(jobs, njobs, b, [](const ZeroJob &t) { return t.tile0; });
+    const ZeroJob j = jobs[ji];
+    int tj, ti;
+    trapezoid_decode(b - j.tile0, j.nt, tj, ti);
+    if (tj >= j.nt || ti >= j.nt) return;
+    double *__restrict__ S = j.S + (long long)(ti * 64) + (long long)(tj * 64) * j.lds;
+    const int r2 = (threadIdx.x & 31) * 2, c0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<d2_t *>(S + r2 + (long long)(c0 + 8 * u) * j.lds) = (d2_t){0.0, 0.0};
 }
 
 // ---- solves ---------------------------------------------------------------------------------------------
@@ -495,6 +515,7 @@ struct NdState {
     JobTable<SyrkJob> upd, schur;
     JobTable<TrinvJob> trinv;
     JobTable<AddJob> add;
+    JobTable<ZeroJob> zero;
     JobTable<MvJob> mv;
     JobTable<FwdJob> fwd;
     JobTable<DotJob> dot;
@@ -505,6 +526,7 @@ struct NdState {
     JobTable<SyrkJob> updr;
     std::vector<hipEvent_t> evW;                   // rest of the panel update of step k done
     std::vector<Launch> l_add[2], l_mapslot[2], l_mapall;     // per depth (of the children)
+    std::vector<Launch> l_zero;                    // per depth: zero the lower-triangle tiles of its Schur buffers
     // streams / events
     hipStream_t sP = nullptr, sU = nullptr, sR = nullptr;   // chain, Schur updates (+ their memsets), CU-masked: diagonal blocks
     unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
@@ -579,6 +601,7 @@ bool nd_build_jobs(NdState *s)
     s->lookahead.assign((size_t)nd, 0);
     for (int sl = 0; sl < 2; ++sl) { s->l_add[sl].assign((size_t)nd, Launch()); s->l_mapslot[sl].assign((size_t)nd, Launch()); }
     s->l_mapall.assign((size_t)nd, Launch());
+    s->l_zero.assign((size_t)nd, Launch());
     long long part_max = 0;
     // Schur buffer passes: groups of up to schur_kb panel blocks (K = 1024: the C tiles are read and written once per
     // group; measured at 64^3: 257.6 ms per factorisation against 262.4 with K = 512 and 270.9 with K = 256; groups that
@@ -619,10 +642,11 @@ bool nd_build_jobs(NdState *s)
                 double *below = diag + 256;
                 const int nrows = f.fp - (k + 1) * 256;
                 double *i16 = s->inv16 + (long long)(f.blk0 + k) * 4096;
-                s->potrf.host.push_back(PotrfJob{diag, i16, f.ld, f.own0 + k * 256, 0});
+                const int ncols = std::max(1, std::min(256, f.w - k * 256));     // real columns of block k (w > 256 (nsteps - 1) by construction)
+                s->potrf.host.push_back(PotrfJob{diag, i16, f.ld, f.own0 + k * 256, ncols});
                 ++lp.count;
                 if (nrows > 0) {
-                    s->trsm.host.push_back(TrsmJob{diag, below, i16, f.ld, nrows, (int)twg});
+                    s->trsm.host.push_back(TrsmJob{diag, below, i16, f.ld, nrows, (int)twg, (ncols + 15) / 16, 0});
                     twg += nrows / 16;
                     ++lt.count;
                 }
@@ -631,12 +655,12 @@ bool nd_build_jobs(NdState *s)
                     // panel columns right of block k: rows and columns relative to row (k+1)*256; with look-ahead the next
                     // block column (4 tile columns) stays on the chain, the rest is a launch of its own
                     const int ncn = la ? std::min(nc, 4) : nc;
-                    s->upd.host.push_back(SyrkJob{below, below + (long long)256 * f.ld, f.ld, f.ld, ncn, nr, (int)ui, 1});
+                    s->upd.host.push_back(SyrkJob{below, below + (long long)256 * f.ld, f.ld, f.ld, ncn, nr, (int)ui, 1, 64, 0});
                     ui += trapezoid_items(ncn, nr);
                     ++lu.count;
                     if (nc > ncn) {
                         s->updr.host.push_back(SyrkJob{below + 256, below + (long long)256 * f.ld + 256 + (long long)256 * f.ld, f.ld, f.ld,
-                                                       nc - 4, nr - 4, (int)uri, 1});
+                                                       nc - 4, nr - 4, (int)uri, 1, 64, 0});
                         uri += trapezoid_items(nc - 4, nr - 4);
                         ++lur.count;
                     }
@@ -647,10 +671,12 @@ bool nd_build_jobs(NdState *s)
                 group_of(k, f.nsteps, g0, gend);
                 if (ns > 0 && k == gend) {
                     const int kb = k - g0 + 1;
+                    // (the last block of a front holds ncols real columns: the k-loop stops behind them, in chunks of 16 columns)
+                    const int ksl = (k == f.nsteps - 1) ? 4 * ((ncols + 15) / 16) : 64;
                     s->schur.host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s->sar[f.depth & 1] + f.s_off, f.ld,
-                                                    f.lds, ns, ns, (int)si, kb});
+                                                    f.lds, ns, ns, (int)si, kb, ksl, 0});
                     si += trapezoid_items(ns, ns);
-                    sflop += 2.0 * 64 * 64 * 256 * kb * (double)trapezoid_items(ns, ns);
+                    sflop += 2.0 * 64 * 64 * (256.0 * (kb - 1) + 4.0 * ksl) * (double)trapezoid_items(ns, ns);
                     ++ls.count;
                 }
                 // solves
@@ -687,10 +713,10 @@ bool nd_build_jobs(NdState *s)
             ld.grid = (unsigned)dwg;
             lb.grid = (unsigned)lb.count;
             // sentinels for the job search (first field of the element after the last job)
-            if (lt.count) s->trsm.host.push_back(TrsmJob{nullptr, nullptr, nullptr, 0, 0, (int)twg});
-            if (lu.count) s->upd.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)ui, 0});
-            if (lur.count) s->updr.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)uri, 0});
-            if (ls.count) s->schur.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)si, 0});
+            if (lt.count) s->trsm.host.push_back(TrsmJob{nullptr, nullptr, nullptr, 0, 0, (int)twg, 0, 0});
+            if (lu.count) s->upd.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)ui, 0, 0, 0});
+            if (lur.count) s->updr.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)uri, 0, 0, 0});
+            if (ls.count) s->schur.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)si, 0, 0, 0});
             if (lf.count) s->fwd.host.push_back(FwdJob{nullptr, nullptr, nullptr, 0, 0, (int)fwg});
             if (ld.count) s->dot.host.push_back(DotJob{nullptr, nullptr, nullptr, 0, 0, 0, 0, (int)dwg});
             s->l_potrf[(size_t)d][(size_t)k] = lp;
@@ -702,6 +728,24 @@ bool nd_build_jobs(NdState *s)
             s->l_fwd[(size_t)d][(size_t)k] = lf;
             s->l_dot[(size_t)d][(size_t)k] = ld;
             s->l_bwd[(size_t)d][(size_t)k] = lb;
+        }
+        // lower-triangle tiles of the depth's Schur buffers
+        {
+            Launch lz;
+            lz.first = (int)s->zero.host.size();
+            long long tiles = 0;
+            for (int id : ids) {
+                const NdFront &f = t.fr[(size_t)id];
+                if (f.hp == 0) continue;
+                const int nt = f.hp / 64;
+                s->zero.host.push_back(ZeroJob{s->sar[f.depth & 1] + f.s_off, f.lds, nt, (int)tiles});
+                tiles += trapezoid_items(nt, nt);
+                ++lz.count;
+            }
+            if (tiles > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+            lz.grid = (unsigned)tiles;
+            if (lz.count) s->zero.host.push_back(ZeroJob{nullptr, 0, 0, (int)tiles});
+            s->l_zero[(size_t)d] = lz;
         }
         // children at depth d -> parents at depth d - 1
         if (d >= 1) {
@@ -907,7 +951,11 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             const int target = d - 2 >= 1 ? d - 2 : deepest_with_parity(d & 1);
             if (target >= 1 && s->s_depth_doubles[(size_t)target] > 0) {
                 if (sU != sP) (void)hipStreamWaitEvent(sU, s->evE[(size_t)d], 0);
-                (void)hipMemsetAsync(s->sar[target & 1], 0, sizeof(double) * (size_t)s->s_depth_doubles[(size_t)target], sU);
+                const Launch &lz = s->l_zero[(size_t)target];
+                if (lz.count && !std::getenv("SPLPAK_ND_MEMSET"))
+                    hipLaunchKernelGGL(nd_zero_kernel, dim3(lz.grid), dim3(256), 0, sU, (const ZeroJob *)(s->zero.dev + lz.first), lz.count);
+                else
+                    (void)hipMemsetAsync(s->sar[target & 1], 0, sizeof(double) * (size_t)s->s_depth_doubles[(size_t)target], sU);
                 (void)hipEventRecord(s->evZ[(size_t)target], sU);
                 if (target == d - 2) zeroed_now[(size_t)target] = 1;
             }
@@ -1030,7 +1078,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     if (!ok) return SPLPAK_E_NOMEM;
     if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
     ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) &&
-         nd_upload(s, &s->schur.dev, s->schur.host) && nd_upload(s, &s->trinv.dev, s->trinv.host) && nd_upload(s, &s->add.dev, s->add.host) &&
+         nd_upload(s, &s->schur.dev, s->schur.host) && nd_upload(s, &s->trinv.dev, s->trinv.host) && nd_upload(s, &s->add.dev, s->add.host) && nd_upload(s, &s->zero.dev, s->zero.host) &&
          nd_upload(s, &s->mv.dev, s->mv.host) && nd_upload(s, &s->fwd.dev, s->fwd.host) && nd_upload(s, &s->dot.dev, s->dot.host) &&
          nd_upload(s, &s->bwd.dev, s->bwd.host) && nd_upload(s, &s->map.dev, s->map.host);
     if (!ok) return SPLPAK_E_NOMEM;
