@@ -41,7 +41,13 @@ namespace {
 struct PotrfJob { double *A; double *inv16; long long ld; int k0; int ncols; };      // ncols: real columns of the block (the rest is identity padding)
 struct TrsmJob { const double *L; double *X; const double *inv16; long long ld; int nrows; int wg0; int ncb; int pad; };   // ncb: 16-column blocks that hold real columns
 // C(ti, tj) -= P_ti P_tj^T for the 64-row tiles tj in [0, nc), ti in [tj, nr); K = 256 columns of P
-struct SyrkJob { const double *P; double *C; long long ldp, ldc; int nc, nr; int item0; int kb; int ksl; int pad; };   // kb = 256-column blocks of P per pass, ksl = k-steps (4 columns each, multiple of 4) of the LAST of them that hold real columns
+struct SyrkJob {
+    const double *P; double *C; long long ldp, ldc; int nc, nr; int item0; int kb; int ksl; int zinit;
+    // final pass of a front fused with its extend-add (pm != NULL): the finished tile is ADDED into the parent's panel
+    // (columns < wpp) / Schur buffer through the child -> parent row map instead of being stored back; zinit: the front has
+    // no children, its Schur buffer is never materialised (the tile starts as zero)
+    const int *pm; double *Pp; double *Sp; long long ldpp, ldsp; int wpp; int h;
+};   // kb = 256-column blocks of P per pass, ksl = k-steps (4 columns each, multiple of 4) of the LAST of them that hold real columns
 struct ZeroJob { double *S; long long lds; int nt; int tile0; };
 struct TrinvJob { const double *L; const double *inv16; double *dinv; double *dinvt; long long ld; };
 // child's Schur buffer -> parent's panel (columns < wpp) / Schur buffer
@@ -179,7 +185,7 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                acc[m][n][v] = __builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * ldc]);
+                acc[m][n][v] = (SCHUR && j.zinit) ? 0.0 : __builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * ldc]);
     double qa[SD][4], qb[SD][4];
     auto fetch = [&](int slot, int step) {
         const long long off = (long long)(4 * step) * ldp;
@@ -214,6 +220,35 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
                 }
             }
         }
+    }
+    if (SCHUR && j.pm) {
+        // the front's last pass: its Schur complement goes straight into the parent (extend-add), every entry once --
+        // the parent's entries of THIS child are touched by no other wave of the launch (the map is injective, the
+        // launch holds children of one slot only), so plain read-modify-writes are safe and the order of the sums is
+        // fixed: child of slot 0, then child of slot 1
+        int prow[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int r = ti * 64 + n * 16 + l15;
+            prow[n] = r < j.h ? j.pm[r] : -1;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int cc = m * 16 + q + 4 * v, c = tj * 64 + cc;
+                const int pcol = c < j.h ? j.pm[c] : -1;
+                if (pcol < 0) continue;
+                double *__restrict__ colp = pcol < j.wpp ? j.Pp + (long long)pcol * j.ldpp
+                                                         : j.Sp + (long long)(pcol - j.wpp) * j.ldsp - j.wpp;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int rr = n * 16 + l15;
+                    if (prow[n] < 0 || (diag && rr < cc)) continue;
+                    colp[prow[n]] += acc[m][n][v];
+                }
+            }
+        return;
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -524,6 +559,9 @@ struct NdState {
     std::vector<std::vector<Launch>> l_potrf, l_trsm, l_upd, l_updr, l_schur, l_mv, l_fwd, l_dot, l_bwd;
     std::vector<char> lookahead;                   // per depth: no Schur buffers (the root) -> the panel update is split: next block column on the chain, the rest beside it
     JobTable<SyrkJob> updr;
+    JobTable<SyrkJob> fin[2];                      // final Schur passes fused with the extend-add, by child slot
+    std::vector<std::vector<Launch>> l_fin[2];
+    bool fused = true;                             // SPLPAK_ND_NO_FUSE (read when the plan is created): separate extend-add launches
     std::vector<hipEvent_t> evW;                   // rest of the panel update of step k done
     std::vector<Launch> l_add[2], l_mapslot[2], l_mapall;     // per depth (of the children)
     std::vector<Launch> l_zero;                    // per depth: zero the lower-triangle tiles of its Schur buffers
@@ -599,6 +637,8 @@ bool nd_build_jobs(NdState *s)
     for (const NdFront &f : t.fr) maxsteps = std::max(maxsteps, f.nsteps);
     for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_upd, &s->l_updr, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) L->assign((size_t)nd, {});
     s->lookahead.assign((size_t)nd, 0);
+    s->fused = std::getenv("SPLPAK_ND_NO_FUSE") == nullptr;
+    for (int sl = 0; sl < 2; ++sl) s->l_fin[sl].assign((size_t)nd, {});
     for (int sl = 0; sl < 2; ++sl) { s->l_add[sl].assign((size_t)nd, Launch()); s->l_mapslot[sl].assign((size_t)nd, Launch()); }
     s->l_mapall.assign((size_t)nd, Launch());
     s->l_zero.assign((size_t)nd, Launch());
@@ -617,12 +657,16 @@ bool nd_build_jobs(NdState *s)
         int steps = 0;
         for (int id : ids) steps = std::max(steps, t.fr[(size_t)id].nsteps);
         for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_upd, &s->l_updr, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) (*L)[(size_t)d].assign((size_t)steps, Launch());
+        for (int sl = 0; sl < 2; ++sl) s->l_fin[sl][(size_t)d].assign((size_t)steps, Launch());
         bool any_schur = false;
         for (int id : ids) any_schur = any_schur || t.fr[(size_t)id].hp > 0;
         const bool la = !any_schur && steps >= 4 && !std::getenv("SPLPAK_ND_NO_ROOT_LOOKAHEAD");
         s->lookahead[(size_t)d] = la ? 1 : 0;
         for (int k = 0; k < steps; ++k) {
-            Launch lp, lt, lu, lur, ls, lm, lf, ld, lb;
+            Launch lp, lt, lu, lur, ls, lm, lf, ld, lb, lfin[2];
+            long long fi[2] = {0, 0};
+            double fflop[2] = {0.0, 0.0};
+            for (int sl = 0; sl < 2; ++sl) lfin[sl].first = (int)s->fin[sl].host.size();
             lp.first = (int)s->potrf.host.size();
             lt.first = (int)s->trsm.host.size();
             lu.first = (int)s->upd.host.size();
@@ -655,12 +699,12 @@ bool nd_build_jobs(NdState *s)
                     // panel columns right of block k: rows and columns relative to row (k+1)*256; with look-ahead the next
                     // block column (4 tile columns) stays on the chain, the rest is a launch of its own
                     const int ncn = la ? std::min(nc, 4) : nc;
-                    s->upd.host.push_back(SyrkJob{below, below + (long long)256 * f.ld, f.ld, f.ld, ncn, nr, (int)ui, 1, 64, 0});
+                    s->upd.host.push_back(SyrkJob{below, below + (long long)256 * f.ld, f.ld, f.ld, ncn, nr, (int)ui, 1, 64, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
                     ui += trapezoid_items(ncn, nr);
                     ++lu.count;
                     if (nc > ncn) {
                         s->updr.host.push_back(SyrkJob{below + 256, below + (long long)256 * f.ld + 256 + (long long)256 * f.ld, f.ld, f.ld,
-                                                       nc - 4, nr - 4, (int)uri, 1, 64, 0});
+                                                       nc - 4, nr - 4, (int)uri, 1, 64, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
                         uri += trapezoid_items(nc - 4, nr - 4);
                         ++lur.count;
                     }
@@ -673,11 +717,26 @@ bool nd_build_jobs(NdState *s)
                     const int kb = k - g0 + 1;
                     // (the last block of a front holds ncols real columns: the k-loop stops behind them, in chunks of 16 columns)
                     const int ksl = (k == f.nsteps - 1) ? 4 * ((ncols + 15) / 16) : 64;
-                    s->schur.host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s->sar[f.depth & 1] + f.s_off, f.ld,
-                                                    f.lds, ns, ns, (int)si, kb, ksl, 0});
-                    si += trapezoid_items(ns, ns);
-                    sflop += 2.0 * 64 * 64 * (256.0 * (kb - 1) + 4.0 * ksl) * (double)trapezoid_items(ns, ns);
-                    ++ls.count;
+                    const double jflop = 2.0 * 64 * 64 * (256.0 * (kb - 1) + 4.0 * ksl) * (double)trapezoid_items(ns, ns);
+                    if (s->fused && k == f.nsteps - 1 && f.parent >= 0) {
+                        // the front's last pass carries its Schur complement into the parent itself
+                        const NdFront &pf = t.fr[(size_t)f.parent];
+                        const int sl = f.slot;
+                        const int leaf = (f.child[0] < 0 && g0 == 0) ? 1 : 0;       // no children, one pass: the buffer is never materialised
+                        s->fin[sl].host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s->sar[f.depth & 1] + f.s_off, f.ld,
+                                                          f.lds, ns, ns, (int)fi[sl], kb, ksl, leaf, s->pmap + f.bofs,
+                                                          s->factor + pf.panel_off, pf.hp > 0 ? s->sar[pf.depth & 1] + pf.s_off : nullptr,
+                                                          pf.ld, pf.lds, pf.wp, f.h});
+                        fi[sl] += trapezoid_items(ns, ns);
+                        fflop[sl] += jflop;
+                        ++lfin[sl].count;
+                    } else {
+                        s->schur.host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s->sar[f.depth & 1] + f.s_off, f.ld,
+                                                        f.lds, ns, ns, (int)si, kb, ksl, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
+                        si += trapezoid_items(ns, ns);
+                        sflop += jflop;
+                        ++ls.count;
+                    }
                 }
                 // solves
                 double *Vf = s->V + f.vofs, *Yf = s->Y + f.vofs;
@@ -714,9 +773,16 @@ bool nd_build_jobs(NdState *s)
             lb.grid = (unsigned)lb.count;
             // sentinels for the job search (first field of the element after the last job)
             if (lt.count) s->trsm.host.push_back(TrsmJob{nullptr, nullptr, nullptr, 0, 0, (int)twg, 0, 0});
-            if (lu.count) s->upd.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)ui, 0, 0, 0});
-            if (lur.count) s->updr.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)uri, 0, 0, 0});
-            if (ls.count) s->schur.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)si, 0, 0, 0});
+            if (lu.count) s->upd.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)ui, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
+            if (lur.count) s->updr.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)uri, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
+            if (ls.count) s->schur.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)si, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
+            for (int sl = 0; sl < 2; ++sl) {
+                if (fi[sl] > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+                lfin[sl].grid = (unsigned)fi[sl];
+                lfin[sl].flop = fflop[sl];
+                if (lfin[sl].count) s->fin[sl].host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)fi[sl], 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
+                s->l_fin[sl][(size_t)d][(size_t)k] = lfin[sl];
+            }
             if (lf.count) s->fwd.host.push_back(FwdJob{nullptr, nullptr, nullptr, 0, 0, (int)fwg});
             if (ld.count) s->dot.host.push_back(DotJob{nullptr, nullptr, nullptr, 0, 0, 0, 0, (int)dwg});
             s->l_potrf[(size_t)d][(size_t)k] = lp;
@@ -737,6 +803,7 @@ bool nd_build_jobs(NdState *s)
             for (int id : ids) {
                 const NdFront &f = t.fr[(size_t)id];
                 if (f.hp == 0) continue;
+                if (s->fused && f.child[0] < 0 && f.nsteps <= schur_kb) continue;       // a leaf's buffer is never materialised (fused last pass)
                 const int nt = f.hp / 64;
                 s->zero.host.push_back(ZeroJob{s->sar[f.depth & 1] + f.s_off, f.lds, nt, (int)tiles});
                 tiles += trapezoid_items(nt, nt);
@@ -759,11 +826,10 @@ bool nd_build_jobs(NdState *s)
                     if (f.slot != sl || f.h == 0) continue;
                     const NdFront &p = t.fr[(size_t)f.parent];
                     const int nt = f.hp / 64;
-                    s->add.host.push_back(AddJob{s->sar[f.depth & 1] + f.s_off, s->pmap + f.bofs, s->factor + p.panel_off,
+                    if (!s->fused) s->add.host.push_back(AddJob{s->sar[f.depth & 1] + f.s_off, s->pmap + f.bofs, s->factor + p.panel_off,
                                                  p.hp > 0 ? s->sar[p.depth & 1] + p.s_off : nullptr, f.lds, p.ld, p.lds, f.h, nt, p.wp,
                                                  (int)tiles});
-                    tiles += trapezoid_items(nt, nt);
-                    ++la.count;
+                    if (!s->fused) { tiles += trapezoid_items(nt, nt); ++la.count; }
                     s->map.host.push_back(MapJob{s->V + f.vofs + f.wp, s->V + p.vofs, s->pmap + f.bofs, f.h, 0});
                     ++lmj.count;
                 }
@@ -920,7 +986,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             if (lt.count)
                 hipLaunchKernelGGL(nd_trsm_kernel, dim3(lt.grid), dim3(64), 0, sP, (const TrsmJob *)(s->trsm.dev + lt.first), lt.count);
             const Launch &lur = s->l_updr[(size_t)d][(size_t)k];
-            if ((ls.count || lur.count) && sU != sP) {
+            if ((ls.count || lur.count || s->l_fin[0][(size_t)d][(size_t)k].count || s->l_fin[1][(size_t)d][(size_t)k].count) && sU != sP) {
                 (void)hipEventRecord(s->evT[(size_t)k], sP);
                 (void)hipStreamWaitEvent(sU, s->evT[(size_t)k], 0);
             }
@@ -933,6 +999,8 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             }
             if (s->lookahead[(size_t)d] && sU != sP) (void)hipEventRecord(s->evW[(size_t)k], sU);
             launch_syrk(s, s->schur, ls, sU, stats, timing, true, pinned, qnext);
+            for (int sl = 0; sl < 2; ++sl)          // final passes, fused with the extend-add: slot 0, then slot 1
+                launch_syrk(s, s->fin[sl], s->l_fin[sl][(size_t)d][(size_t)k], sU, stats, timing, true, pinned, qnext);
         }
         if (sU != sP) {                                 // the depth's Schur updates are complete before they are handed on
             (void)hipEventRecord(s->evU, sU);
@@ -1077,7 +1145,8 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
          nd_upload(s, &s->fdev, fdev);
     if (!ok) return SPLPAK_E_NOMEM;
     if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
-    ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) &&
+    ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) && nd_upload(s, &s->fin[0].dev, s->fin[0].host) &&
+         nd_upload(s, &s->fin[1].dev, s->fin[1].host) &&
          nd_upload(s, &s->schur.dev, s->schur.host) && nd_upload(s, &s->trinv.dev, s->trinv.host) && nd_upload(s, &s->add.dev, s->add.host) && nd_upload(s, &s->zero.dev, s->zero.host) &&
          nd_upload(s, &s->mv.dev, s->mv.host) && nd_upload(s, &s->fwd.dev, s->fwd.host) && nd_upload(s, &s->dot.dev, s->dot.host) &&
          nd_upload(s, &s->bwd.dev, s->bwd.host) && nd_upload(s, &s->map.dev, s->map.host);

@@ -188,15 +188,17 @@ def test_nd_4d_24_random_spline_recovery():
 def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
     """32^3 (root separator 3 072 columns = 12 block steps): the diagonal blocks of the upper levels are factored on
     reserved CUs while the update waves take their items from a queue and step aside there, and the root's panel
-    update is split for look-ahead.  None of that may change a bit: the same fit without reserved CUs, without the
-    root look-ahead, with K = 256 Schur passes and entirely serial gives identical coefficients."""
+    update is split for look-ahead.  The last Schur pass of every front adds its result into the parent itself.  None of that may
+    change a bit: the same fit without reserved CUs, without the root look-ahead, with K = 256 Schur passes, with separate
+    extend-add launches and entirely serial gives identical coefficients."""
     from splpak_amd.synth import synth_points
     nd, nod, m = 3, 32, 200000
     x, y, w = synth_points(nd, m)
     inp = dict(ndim=nd, xdata=x, ydata=y, wdata=w, xmin=[0.0] * nd, xmax=[1.0] * nd, nodes=[nod] * nd, xtrap=1.0)
     ref, e, _, info = _fit_env(inp, {"SPLPAK_ND": "1"})
     assert e == 0 and info[9] < 1e-9
-    for env in ({"SPLPAK_NO_PANEL_CU": "1"}, {"SPLPAK_ND_NO_ROOT_LOOKAHEAD": "1"}, {"SPLPAK_ND_KB": "1"},
+    for env in ({"SPLPAK_NO_PANEL_CU": "1"}, {"SPLPAK_ND_NO_ROOT_LOOKAHEAD": "1"}, {"SPLPAK_ND_KB": "1"}, {"SPLPAK_ND_NO_FUSE": "1"},
+                {"SPLPAK_ND_NO_FUSE": "1", "SPLPAK_ND_MEMSET": "1", "SPLPAK_ND_KB": "2"},
                 {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_RES_CUS": "3", "SPLPAK_ND_PIN_ROUNDS": "8"}):
         c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1"))
         assert e == 0 and np.array_equal(c, ref), env
