@@ -191,50 +191,51 @@ bin_count_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int l
         }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < rg.nbins; b += 256) cnt[(long long)b * ldw + blockIdx.x] = lh[b];   // row b = region b
+    (void)ldw;
+    for (int b = threadIdx.x; b < rg.nbins; b += 256) cnt[(long long)blockIdx.x * rg.nbins + b] = lh[b];   // row = this workgroup, consecutive regions: coalesced
 }
 
-// hist[b] = sum_w cnt[b][w]: one workgroup per region, no atomics
+// The count matrix is cnt[workgroup][region] (round 3: the transposed layout made every workgroup of pass A write, and of
+// pass B read, one 4-byte word per 32-byte sector -- 680 MB of traffic each for the 85 MB matrix of a 4-D batch: 1 296
+// regions x 16 384 workgroups; profiles/r03_eval_pmc.json).  Column sums and prefixes over a row-major matrix: a thread
+// owns a region (consecutive threads = consecutive regions = coalesced rows), workgroups own chunks of BIN_ROWS rows.
+constexpr int BIN_ROWS = 128;
+// part[c][b] = sum of cnt[w][b] over the rows w of chunk c; grid (ceil(nbins / 256), nchunk)
 __global__ void __launch_bounds__(256)
-bin_total_kernel(int nwg, int ldw, const int *__restrict__ cnt, int *__restrict__ hist)
+bin_colsum_kernel(int nwg, int nbins, const int *__restrict__ cnt, int *__restrict__ part)
 {
-    __shared__ int part[256];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbins) return;
+    const int w0 = blockIdx.y * BIN_ROWS, w1 = (w0 + BIN_ROWS < nwg) ? w0 + BIN_ROWS : nwg;
     int sum = 0;
-    for (int w = t; w < nwg; w += 256) sum += cnt[(long long)b * ldw + w];
-    part[t] = sum;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) part[t] += part[t + o];
-        __syncthreads();
-    }
-    if (t == 0) hist[b] = part[0];
+    for (int w = w0; w < w1; ++w) sum += cnt[(long long)w * nbins + b];
+    part[(long long)blockIdx.y * nbins + b] = sum;
 }
-
-// cnt[b][w] <- off[b] + sum_{w' < w} cnt[b][w']: first sorted position of workgroup w's run of region b.
-// One workgroup per region.
+// hist[b] = sum_c part[c][b];  part[c][b] <- sum_{c' < c} part[c'][b]   (thread = region)
 __global__ void __launch_bounds__(256)
-bin_wgbase_kernel(int nwg, int ldw, const int *__restrict__ off, int *__restrict__ cnt)
+bin_total_kernel(int nchunk, int nbins, int *__restrict__ part, int *__restrict__ hist)
 {
-    __shared__ int part[256];
-    const int b = blockIdx.x, t = threadIdx.x;
-    int *__restrict__ row = cnt + (long long)b * ldw;
-    const int per = (nwg + 255) / 256;
-    const int w0 = t * per, w1 = (w0 + per < nwg) ? w0 + per : nwg;
-    int sum = 0;
-    for (int w = w0; w < w1; ++w) sum += row[w];
-    part[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const int v = (t >= o) ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbins) return;
+    int run = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        const int v = part[(long long)c * nbins + b];
+        part[(long long)c * nbins + b] = run;
+        run += v;
     }
-    int run = off[b] + part[t] - sum;
+    hist[b] = run;
+}
+// cnt[w][b] <- off[b] + (queries of region b in the workgroups before w): first sorted position of workgroup w's run
+__global__ void __launch_bounds__(256)
+bin_wgbase_kernel(int nwg, int nbins, const int *__restrict__ off, const int *__restrict__ part, int *__restrict__ cnt)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbins) return;
+    const int w0 = blockIdx.y * BIN_ROWS, w1 = (w0 + BIN_ROWS < nwg) ? w0 + BIN_ROWS : nwg;
+    int run = off[b] + part[(long long)blockIdx.y * nbins + b];
     for (int w = w0; w < w1; ++w) {
-        const int c = row[w];
-        row[w] = run;
+        const int c = cnt[(long long)w * nbins + b];
+        cnt[(long long)w * nbins + b] = run;
         run += c;
     }
 }
@@ -329,7 +330,7 @@ bin_scatter_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int
     for (int b = b0; b < b0 + per && b < rg.nbins; ++b) {
         const int c = lh[b];
         lh[b] = q;
-        lbase[b] = wgbase[(long long)b * ldw + blockIdx.x] - q;
+        lbase[b] = wgbase[(long long)blockIdx.x * rg.nbins + b] - q;
         q += c;
     }
     const int total = sscan[255];
@@ -502,7 +503,7 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
     // the scratch is regrown when a later grid has more regions than the one it was sized for (round-2 advice:
     // a 40^3 spline followed by a 64^3 one wrote past the allocation)
     const int ldw = (int)(chunk / (256 * ScatterShape<D>::QPT) + 2);
-    const long long cnt_need = (long long)ldw * rg.nbins;
+    const long long cnt_need = (long long)ldw * rg.nbins + (long long)(ldw / BIN_ROWS + 2) * rg.nbins;     // count matrix + chunk sums
     if (s.dev != dev || s.cap < chunk || s.capd < D || s.cnt_ints < cnt_need) {
         eval_scratch_shutdown();
         hipError_t e = hipMalloc(&s.xs, sizeof(double) * (size_t)chunk * D);
@@ -529,9 +530,12 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
         const double *xc = xq + c0 * ldxq;
         const unsigned nbs = (unsigned)((n + 256 * ScatterShape<D>::QPT - 1) / (256 * ScatterShape<D>::QPT));
         hipLaunchKernelGGL((bin_count_kernel<D>), dim3(nbs), dim3(256), 0, st, g, rg, n, xc, ldxq, s.cnt, ldw);
-        hipLaunchKernelGGL(bin_total_kernel, dim3(rg.nbins), dim3(256), 0, st, (int)nbs, ldw, (const int *)s.cnt, hist);
+        int *part = s.cnt + (long long)ldw * rg.nbins;
+        const unsigned nchunk = (nbs + BIN_ROWS - 1) / BIN_ROWS, nbg = (unsigned)((rg.nbins + 255) / 256);
+        hipLaunchKernelGGL(bin_colsum_kernel, dim3(nbg, nchunk), dim3(256), 0, st, (int)nbs, rg.nbins, (const int *)s.cnt, part);
+        hipLaunchKernelGGL(bin_total_kernel, dim3(nbg), dim3(256), 0, st, (int)nchunk, rg.nbins, part, hist);
         hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, st, rg.nbins, (const int *)hist, off, cursor, wgoff);
-        hipLaunchKernelGGL(bin_wgbase_kernel, dim3(rg.nbins), dim3(256), 0, st, (int)nbs, ldw, (const int *)off, s.cnt);
+        hipLaunchKernelGGL(bin_wgbase_kernel, dim3(nbg, nchunk), dim3(256), 0, st, (int)nbs, rg.nbins, (const int *)off, (const int *)part, s.cnt);
         hipLaunchKernelGGL((bin_scatter_kernel<D>), dim3(nbs), dim3(256), 2 * sizeof(int) * rg.nbins, st, g, rg, n, xc, ldxq,
                            (const int *)s.cnt, ldw, s.xs, s.cap, s.perm);
         const unsigned nw = (unsigned)(n / EVAL_QPW + rg.nbins + 1);

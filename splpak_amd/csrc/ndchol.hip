@@ -47,7 +47,9 @@ struct SyrkJob {
     // (columns < wpp) / Schur buffer through the child -> parent row map instead of being stored back; zinit: the front has
     // no children, its Schur buffer is never materialised (the tile starts as zero)
     const int *pm; double *Pp; double *Sp; long long ldpp, ldsp; int wpp; int h;
-};   // kb = 256-column blocks of P per pass, ksl = k-steps (4 columns each, multiple of 4) of the LAST of them that hold real columns
+};
+// (a job of the root's look-ahead may be a RECTANGLE of tiles instead: zinit < 0 means tile rows start at rb = -zinit for every
+//  one of its nc <= rb tile columns)   // kb = 256-column blocks of P per pass, ksl = k-steps (4 columns each, multiple of 4) of the LAST of them that hold real columns
 struct ZeroJob { double *S; long long lds; int nt; int tile0; };
 struct TrinvJob { const double *L; const double *inv16; double *dinv; double *dinvt; long long ld; };
 // child's Schur buffer -> parent's panel (columns < wpp) / Schur buffer
@@ -170,7 +172,12 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
     const int ji = find_job(jobs, njobs, b, [](const SyrkJob &t) { return t.item0; });
     const SyrkJob j = jobs[ji];
     int tj, ti;
-    trapezoid_decode(b - j.item0, j.nr, tj, ti);
+    if (!SCHUR && j.zinit < 0) {                     // rectangle: tile rows rb .. nr-1 of the tile columns 0 .. nc-1
+        const int rb = -j.zinit, per = j.nr - rb, it = b - j.item0;
+        tj = it / per;
+        ti = rb + it - tj * per;
+    } else
+        trapezoid_decode(b - j.item0, j.nr, tj, ti);
     if (tj >= j.nc || ti >= j.nr) return;
     const bool diag = ti == tj;
     const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
@@ -546,7 +553,7 @@ struct NdState {
     std::vector<long long> s_depth_doubles;         // Schur doubles of every depth (a prefix of its arena)
     // job tables; launches indexed [depth][step]
     JobTable<PotrfJob> potrf;
-    JobTable<TrsmJob> trsm;
+    JobTable<TrsmJob> trsm, trsmb;                 // trsmb: the rows beyond the next diagonal block, beside the chain (root look-ahead)
     JobTable<SyrkJob> upd, schur;
     JobTable<TrinvJob> trinv;
     JobTable<AddJob> add;
@@ -556,7 +563,7 @@ struct NdState {
     JobTable<DotJob> dot;
     JobTable<BwdJob> bwd;
     JobTable<MapJob> map;
-    std::vector<std::vector<Launch>> l_potrf, l_trsm, l_upd, l_updr, l_schur, l_mv, l_fwd, l_dot, l_bwd;
+    std::vector<std::vector<Launch>> l_potrf, l_trsm, l_trsmb, l_upd, l_updr, l_schur, l_mv, l_fwd, l_dot, l_bwd;
     std::vector<char> lookahead;                   // per depth: no Schur buffers (the root) -> the panel update is split: next block column on the chain, the rest beside it
     JobTable<SyrkJob> updr;
     JobTable<SyrkJob> fin[2];                      // final Schur passes fused with the extend-add, by child slot
@@ -635,7 +642,7 @@ bool nd_build_jobs(NdState *s)
     const int nd = t.maxdepth + 1;
     int maxsteps = 0;
     for (const NdFront &f : t.fr) maxsteps = std::max(maxsteps, f.nsteps);
-    for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_upd, &s->l_updr, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) L->assign((size_t)nd, {});
+    for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) L->assign((size_t)nd, {});
     s->lookahead.assign((size_t)nd, 0);
     s->fused = std::getenv("SPLPAK_ND_NO_FUSE") == nullptr;
     for (int sl = 0; sl < 2; ++sl) s->l_fin[sl].assign((size_t)nd, {});
@@ -656,14 +663,16 @@ bool nd_build_jobs(NdState *s)
         const std::vector<int> &ids = t.by_depth[(size_t)d];
         int steps = 0;
         for (int id : ids) steps = std::max(steps, t.fr[(size_t)id].nsteps);
-        for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_upd, &s->l_updr, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) (*L)[(size_t)d].assign((size_t)steps, Launch());
+        for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) (*L)[(size_t)d].assign((size_t)steps, Launch());
         for (int sl = 0; sl < 2; ++sl) s->l_fin[sl][(size_t)d].assign((size_t)steps, Launch());
         bool any_schur = false;
         for (int id : ids) any_schur = any_schur || t.fr[(size_t)id].hp > 0;
         const bool la = !any_schur && steps >= 4 && !std::getenv("SPLPAK_ND_NO_ROOT_LOOKAHEAD");
         s->lookahead[(size_t)d] = la ? 1 : 0;
         for (int k = 0; k < steps; ++k) {
-            Launch lp, lt, lu, lur, ls, lm, lf, ld, lb, lfin[2];
+            Launch lp, lt, ltb, lu, lur, ls, lm, lf, ld, lb, lfin[2];
+            long long tbwg = 0;
+            ltb.first = (int)s->trsmb.host.size();
             long long fi[2] = {0, 0};
             double fflop[2] = {0.0, 0.0};
             for (int sl = 0; sl < 2; ++sl) lfin[sl].first = (int)s->fin[sl].host.size();
@@ -689,24 +698,53 @@ bool nd_build_jobs(NdState *s)
                 const int ncols = std::max(1, std::min(256, f.w - k * 256));     // real columns of block k (w > 256 (nsteps - 1) by construction)
                 s->potrf.host.push_back(PotrfJob{diag, i16, f.ld, f.own0 + k * 256, ncols});
                 ++lp.count;
-                if (nrows > 0) {
-                    s->trsm.host.push_back(TrsmJob{diag, below, i16, f.ld, nrows, (int)twg, (ncols + 15) / 16, 0});
-                    twg += nrows / 16;
-                    ++lt.count;
-                }
                 const int nc = (f.wp - (k + 1) * 256) / 64, nr = nrows / 64;
+                if (nrows > 0) {
+                    // with look-ahead (the root) only the rows of the NEXT diagonal block are solved on the chain, the rest beside it
+                    const int ntop = (la && nc > 0) ? std::min(nrows, 256) : nrows;
+                    s->trsm.host.push_back(TrsmJob{diag, below, i16, f.ld, ntop, (int)twg, (ncols + 15) / 16, 0});
+                    twg += ntop / 16;
+                    ++lt.count;
+                    if (nrows > ntop) {
+                        s->trsmb.host.push_back(TrsmJob{diag, below + ntop, i16, f.ld, nrows - ntop, (int)tbwg, (ncols + 15) / 16, 0});
+                        tbwg += (nrows - ntop) / 16;
+                        ++ltb.count;
+                    }
+                }
                 if (nc > 0) {
-                    // panel columns right of block k: rows and columns relative to row (k+1)*256; with look-ahead the next
-                    // block column (4 tile columns) stays on the chain, the rest is a launch of its own
-                    const int ncn = la ? std::min(nc, 4) : nc;
-                    s->upd.host.push_back(SyrkJob{below, below + (long long)256 * f.ld, f.ld, f.ld, ncn, nr, (int)ui, 1, 64, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
-                    ui += trapezoid_items(ncn, nr);
-                    ++lu.count;
-                    if (nc > ncn) {
-                        s->updr.host.push_back(SyrkJob{below + 256, below + (long long)256 * f.ld + 256 + (long long)256 * f.ld, f.ld, f.ld,
-                                                       nc - 4, nr - 4, (int)uri, 1, 64, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
-                        uri += trapezoid_items(nc - 4, nr - 4);
-                        ++lur.count;
+                    // panel columns right of block k: rows and columns relative to row (k+1)*256.  With look-ahead only the next
+                    // DIAGONAL BLOCK (4 x 4 tiles) is updated on the chain; the rows below it in that block column (a rectangle
+                    // of tiles) and the columns beyond (a trapezoid) are one launch beside the chain
+                    const SyrkJob proto{below, below + (long long)256 * f.ld, f.ld, f.ld, 0, 0, 0, 1, 64, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+                    if (!la) {
+                        SyrkJob a = proto;
+                        a.nc = nc; a.nr = nr; a.item0 = (int)ui;
+                        s->upd.host.push_back(a);
+                        ui += trapezoid_items(nc, nr);
+                        ++lu.count;
+                    } else {
+                        const int n4 = std::min(nc, 4);
+                        SyrkJob a = proto;                                   // next diagonal block
+                        a.nc = n4; a.nr = std::min(nr, 4); a.item0 = (int)ui;
+                        s->upd.host.push_back(a);
+                        ui += trapezoid_items(a.nc, a.nr);
+                        ++lu.count;
+                        if (nr > 4) {                                        // rows below it in the next block column
+                            SyrkJob r = proto;
+                            r.nc = n4; r.nr = nr; r.item0 = (int)uri; r.zinit = -4;
+                            s->updr.host.push_back(r);
+                            uri += (long long)n4 * (nr - 4);
+                            ++lur.count;
+                        }
+                        if (nc > 4) {                                        // the columns beyond
+                            SyrkJob t2 = proto;
+                            t2.P = below + 256;
+                            t2.C = below + (long long)256 * f.ld + 256 + (long long)256 * f.ld;
+                            t2.nc = nc - 4; t2.nr = nr - 4; t2.item0 = (int)uri;
+                            s->updr.host.push_back(t2);
+                            uri += trapezoid_items(nc - 4, nr - 4);
+                            ++lur.count;
+                        }
                     }
                 }
                 // Schur buffer: one pass per group of up to schur_kb panel blocks, launched when the group's last block is solved
@@ -761,6 +799,9 @@ bool nd_build_jobs(NdState *s)
             part_max = std::max(part_max, partofs);
             lp.grid = (unsigned)lp.count;
             lt.grid = (unsigned)twg;
+            ltb.grid = (unsigned)tbwg;
+            if (ltb.count) s->trsmb.host.push_back(TrsmJob{nullptr, nullptr, nullptr, 0, 0, (int)tbwg, 0, 0});
+            s->l_trsmb[(size_t)d][(size_t)k] = ltb;
             lu.grid = (unsigned)ui;
             lu.flop = 2.0 * 64 * 64 * 256 * (double)ui;
             lur.grid = (unsigned)uri;
@@ -983,6 +1024,17 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
                 (void)hipStreamWaitEvent(sP, s->evI[(size_t)k], 0);
             } else
                 hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sP, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
+            const Launch &ltb = s->l_trsmb[(size_t)d][(size_t)k];
+            if (ltb.count) {            // look-ahead: the panel rows beyond the next diagonal block are solved beside the chain
+                if (sU != sP) {
+                    if (!pinned) (void)hipEventRecord(s->evI[(size_t)k], sP);
+                    (void)hipStreamWaitEvent(sU, s->evI[(size_t)k], 0);
+                }
+                hipLaunchKernelGGL(nd_trsm_kernel, dim3(ltb.grid), dim3(64), 0, sU, (const TrsmJob *)(s->trsmb.dev + ltb.first), ltb.count);
+            }
+            // look-ahead (the root): everything of step k - 1 that is not the next diagonal block ran beside the chain; the
+            // panel rows this step solves and the block it updates were last written there
+            if (s->lookahead[(size_t)d] && k > 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evW[(size_t)(k - 1)], 0);
             if (lt.count)
                 hipLaunchKernelGGL(nd_trsm_kernel, dim3(lt.grid), dim3(64), 0, sP, (const TrsmJob *)(s->trsm.dev + lt.first), lt.count);
             const Launch &lur = s->l_updr[(size_t)d][(size_t)k];
@@ -990,9 +1042,6 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
                 (void)hipEventRecord(s->evT[(size_t)k], sP);
                 (void)hipStreamWaitEvent(sU, s->evT[(size_t)k], 0);
             }
-            // look-ahead (the root): columns beyond the next block column are updated beside the chain of step k + 1;
-            // the next step's update of ITS next block column waits for them (same tiles)
-            if (s->lookahead[(size_t)d] && k > 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evW[(size_t)(k - 1)], 0);
             launch_syrk(s, s->upd, lu, sP, stats, timing, false, pinned, qnext);
             if (lur.count) {
                 launch_syrk(s, s->updr, lur, sU, stats, timing, false, pinned, qnext);
@@ -1145,7 +1194,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
          nd_upload(s, &s->fdev, fdev);
     if (!ok) return SPLPAK_E_NOMEM;
     if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
-    ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) && nd_upload(s, &s->fin[0].dev, s->fin[0].host) &&
+    ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->trsmb.dev, s->trsmb.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) && nd_upload(s, &s->fin[0].dev, s->fin[0].host) &&
          nd_upload(s, &s->fin[1].dev, s->fin[1].host) &&
          nd_upload(s, &s->schur.dev, s->schur.host) && nd_upload(s, &s->trinv.dev, s->trinv.host) && nd_upload(s, &s->add.dev, s->add.host) && nd_upload(s, &s->zero.dev, s->zero.host) &&
          nd_upload(s, &s->mv.dev, s->mv.host) && nd_upload(s, &s->fwd.dev, s->fwd.host) && nd_upload(s, &s->dot.dev, s->dot.host) &&

@@ -200,6 +200,28 @@ def test_eval_binned_path_is_bit_identical_to_direct(port, nodes):
         capi.set_eval_mode(7)
 
 
+def test_eval_binned_scratch_regrows_for_a_grid_with_more_regions():
+    """the binned path's per-workgroup count matrix was sized for the regions of whichever grid
+    allocated it; a later grid with MORE regions and the same batch size wrote past it.  A 3-D 28^3 spline (8 regions),
+    then 64^3 (125 regions), then a 4-D 24^4 one (625 regions) with the same number of queries and chunk, in one
+    process: every batch must return the bits of the direct kernel."""
+    rng = np.random.default_rng(321)
+    nq = 300_000
+    try:
+        for nodes in ((28, 28, 28), (64, 64, 64), (24, 24, 24, 24), (16, 16, 16)):
+            nd = len(nodes)
+            coef = rng.standard_normal(int(np.prod(nodes)))
+            q = -0.1 + 1.2 * rng.random((nq, nd))
+            capi.set_eval_mode(capi.EVAL_BINNED, 1 << 17)
+            vb, rc = capi.evaluate(nd, q, None, coef, [0.0] * nd, [1.0] * nd, nodes)
+            assert rc == 0
+            capi.set_eval_mode(capi.EVAL_DIRECT)
+            vd, rc = capi.evaluate(nd, q, None, coef, [0.0] * nd, [1.0] * nd, nodes)
+            assert rc == 0 and np.array_equal(vb, vd), nodes
+    finally:
+        capi.set_eval_mode(capi.EVAL_AUTO)
+
+
 @pytest.mark.parametrize("nodes", [(20, 17, 30), (12, 9, 8, 14), (70, 40)])
 def test_eval_derivs_binned_path_is_bit_identical_to_direct(nodes):
     """Value + gradient + Hessian through the region sort (LDS tiles) must return the bits of the direct

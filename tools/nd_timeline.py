@@ -20,32 +20,27 @@ for r in sel[:nshow]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     print(f"{s/1e3:10.1f} us dur {(e-s)/1e3:9.1f} q={r['Queue_Id']:>2} grid={r['Grid_Size_X']:>9} {short(r['Kernel_Name'])}")
 print(f"factorisation span {(int(rows[it]['End_Timestamp']) - t0)/1e6:.1f} ms")
-# depth segments: split at the end of each pair of extend-add launches
-segs, cur = [], []
-for r in sel:
-    cur.append(r)
-    if "nd_extend_add" in r["Kernel_Name"]:
-        pass
-segstart = t0
+# depth segments: the diagonal-block launches carry one workgroup per front, so their grid size (256 threads each) tells
+# the depth: a new segment starts when it drops
 depth_rows = collections.OrderedDict()
-d = 0
-last_add_end = None
-prev_was_add = False
+d = -1
+cur = None
 for r in sel:
     k = short(r["Kernel_Name"])
-    if k == "potrf" and prev_was_add:
-        d += 1
-    if k == "extend_add": prev_was_add = True
-    elif k == "potrf": prev_was_add = False
-    depth_rows.setdefault(d, []).append(r)
+    if k == "potrf":
+        g = int(r["Grid_Size_X"]) // 256
+        if cur is None or g < cur:
+            d += 1
+            cur = g
+    depth_rows.setdefault(max(d, 0), []).append(r)
 for d, rs in depth_rows.items():
     a = min(int(r["Start_Timestamp"]) for r in rs); b = max(int(r["End_Timestamp"]) for r in rs)
     tot = collections.Counter(); cnt = collections.Counter()
     for r in rs:
         tot[short(r["Kernel_Name"])] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); cnt[short(r["Kernel_Name"])] += 1
-    # union busy
     iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rs)
     busy, ce = 0, a
-    for s, e in iv:
-        if e > ce: busy += e - max(s, ce); ce = e
-    print(f"segment {d:2d}: span {(b-a)/1e6:7.2f} ms busy {busy/1e6:7.2f} | " + " ".join(f"{k}:{cnt[k]}x{v/1e6:.2f}" for k, v in tot.most_common(7)))
+    for s0, e0 in iv:
+        if e0 > ce: busy += e0 - max(s0, ce); ce = e0
+    nf = [int(r["Grid_Size_X"]) // 256 for r in rs if short(r["Kernel_Name"]) == "potrf"]
+    print(f"segment {d:2d} ({max(nf) if nf else 0:4d} fronts): span {(b-a)/1e6:7.2f} ms busy {busy/1e6:7.2f} | " + " ".join(f"{k}:{cnt[k]}x{v/1e6:.2f}" for k, v in tot.most_common(7)))
