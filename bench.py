@@ -340,9 +340,24 @@ def bench_c5_eval(capi, dev, stream):
         capi.evaluate_dev(nd, xq, pat, coef, lo, hi, nodes, out, stream)
         torch.cuda.synchronize()
         res[label] = nq / (time.perf_counter() - t0)
-    del xq, out
+    # the tolerance sweep's other half: the same 1e8 queries in REAL32 storage (float queries, coefficients, results; double
+    # arithmetic), and how far its values are from the real64 ones
+    capi.evaluate_dev(nd, xq, None, coef, lo, hi, nodes, out, stream)
+    x32, c32 = xq.float(), coef.float()
+    o32 = torch.empty(nq, dtype=torch.float32, device=dev)
+    capi.evaluate_dev(nd, x32, None, c32, lo, hi, nodes, o32, stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    capi.evaluate_dev(nd, x32, None, c32, lo, hi, nodes, o32, stream)
+    torch.cuda.synchronize()
+    res32 = nq / (time.perf_counter() - t0)
+    dev32 = float((o32[:10_000_000].double() - out[:10_000_000]).abs().max() / out[:10_000_000].abs().max())
+    del xq, out, x32, c32, o32
     return {"workload": "C5 (evaluation half): 4-D, 32^4 nodes, 1e8 queries, real64, resident data", "unit": "evals/s",
             "value": res["splfe"], **{k + "_evals_per_s": v for k, v in res.items()},
+            "real32": {"splfe_evals_per_s": res32, "max_rel_deviation_from_real64": dev32,
+                       "roofline": {"bound": "hbm", "achieved": 20.0 * res32 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": 20.0 * res32 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_query": 20.0}},
             "roofline": {"bound": "hbm", "achieved": 40.0 * res["splfe"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": 40.0 * res["splfe"] / 1e9 / HBM_PEAK_GBS, "traffic": c5_traffic()}}
 

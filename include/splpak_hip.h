@@ -213,6 +213,13 @@ int32_t splpak_eval_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int3
                             const double *coef_dev, const double *xmin, const double *xmax,
                             const int32_t *nodes, double *out_dev, void *stream);
 
+/* The same for REAL32 storage (queries, coefficients and results in single precision, arithmetic in double:
+ * the batched counterpart of the -DREAL32 build of splfe / splde, src/splpak.F90:33-41). */
+int32_t splpak_eval_dev_f32(int32_t ndim, int64_t nq, const float *xq_dev, int32_t ldxq,
+                            const int32_t *nderiv /* host, may be NULL */,
+                            const float *coef_dev, const float *xmin, const float *xmax,
+                            const int32_t *nodes, float *out_dev, void *stream);
+
 /* Value, gradient and (order 2) Hessian of the spline at a batch of points in one pass over the
  * window -- SURVEY 8f: what a caller otherwise obtains from 1 + ndim (+ ndim(ndim+1)/2) splde calls
  * (:1089-1240) per point.  order = 1 or 2.  Row i of `out` (ldout apart, ldout >= number of entries):

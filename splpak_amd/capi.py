@@ -28,7 +28,7 @@ SYMBOLS = [
     "splpak_plan_comm_len", "splpak_plan_create", "splpak_plan_destroy",
     "splpak_plan_set_allreduce", "splpak_plan_set_refine", "splpak_plan_fit_dev",
     "splpak_plan_hist_dev", "splpak_plan_factorisation", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing", "splpak_plan_stage_timing",
-    "splpak_eval_dev_f64", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
+    "splpak_eval_dev_f64", "splpak_eval_dev_f32", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
     "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
     "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_shutdown", "splpak_set_eval_mode",
@@ -95,6 +95,8 @@ def lib() -> C.CDLL:
     L.splpak_plan_stage_timing.argtypes = [vp, _dp]
     L.splpak_eval_dev_f64.restype = i32
     L.splpak_eval_dev_f64.argtypes = [i32, i64, vp, i32, _ip, vp, _dp, _dp, _ip, vp, vp]
+    L.splpak_eval_dev_f32.restype = i32
+    L.splpak_eval_dev_f32.argtypes = [i32, i64, vp, i32, _ip, vp, _fp, _fp, _ip, vp, vp]
     L.splpak_eval_derivs_f64.restype = i32
     L.splpak_eval_derivs_f64.argtypes = [i32, i64, _dp, i32, i32, _dp, _dp, _dp, _ip, _dp, i32]
     L.splpak_eval_derivs_f32.restype = i32
@@ -414,10 +416,15 @@ class Plan:
 
 
 def evaluate_dev(ndim, xq, nderiv, coef, xmin, xmax, nodes, out, stream=0):
-    """Batched evaluation on torch device tensors (asynchronous on `stream`)."""
-    xmin, xmax, nodes = _grid(ndim, xmin, xmax, nodes)
+    """Batched evaluation on torch device tensors (asynchronous on `stream`); float32 tensors take the REAL32 entry."""
     nd = None if nderiv is None else np.ascontiguousarray(nderiv, dtype=np.int32)
     nq, ldx = xq.shape
+    if str(xq.dtype).endswith("float32"):
+        xmin, xmax, nodes = _grid(ndim, xmin, xmax, nodes, np.float32)
+        return _check(lib().splpak_eval_dev_f32(ndim, int(nq), xq.data_ptr(), int(ldx), _p(nd, _ip),
+                                                coef.data_ptr(), _p(xmin, _fp), _p(xmax, _fp),
+                                                _p(nodes, _ip), out.data_ptr(), C.c_void_p(stream)))
+    xmin, xmax, nodes = _grid(ndim, xmin, xmax, nodes)
     return _check(lib().splpak_eval_dev_f64(ndim, int(nq), xq.data_ptr(), int(ldx), _p(nd, _ip),
                                             coef.data_ptr(), _p(xmin, _dp), _p(xmax, _dp),
                                             _p(nodes, _ip), out.data_ptr(), C.c_void_p(stream)))

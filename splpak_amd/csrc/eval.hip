@@ -173,9 +173,9 @@ template <int D> struct ScatterShape { static constexpr int QPT = D == 4 ? 4 : 8
 // (bin_wgbase_kernel) then tells every pass-B workgroup where each of its runs starts.  No workgroup
 // ever waits on a global atomic (round 2: 2 050 workgroups taking turns on 125 cursor words cost 42 of
 // the 80 us of pass B), and the sorted order is a function of the input alone.
-template <int D>
+template <int D, typename T>
 __global__ void __launch_bounds__(256)
-bin_count_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int ldxq, int *__restrict__ cnt, int ldw)
+bin_count_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq, int *__restrict__ cnt, int ldw)
 {
     constexpr int QPT = ScatterShape<D>::QPT;
     __shared__ int lh[BIN_MAX];
@@ -188,7 +188,7 @@ bin_count_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int l
         if (i < n) {
             double x[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) x[d] = xq[(long long)i * ldxq + d];
+            for (int d = 0; d < D; ++d) x[d] = (double)xq[(long long)i * ldxq + d];
             atomicAdd(&lh[region_of<D>(g, rg, x)], 1);
         }
     }
@@ -285,9 +285,9 @@ bin_scan_kernel(int nbins, const int *__restrict__ hist, int *__restrict__ off, 
 // memory walks every region's run with consecutive lanes on consecutive addresses (the
 // straightforward per-query scatter issued one 8-byte store request per coordinate and was
 // bound by the request rate, not by bytes).
-template <int D>
+template <int D, typename T>
 __global__ void __launch_bounds__(256)
-bin_scatter_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int ldxq,
+bin_scatter_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq,
                    const int *__restrict__ wgbase, int ldw, double *__restrict__ xs, long long ldp, int *__restrict__ perm)
 {
     constexpr int QPT = ScatterShape<D>::QPT, QPW = 256 * QPT;
@@ -309,7 +309,7 @@ bin_scatter_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int
         rank[j] = 0;
         if (i < n) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) xr[j][d] = xq[(long long)i * ldxq + d];
+            for (int d = 0; d < D; ++d) xr[j][d] = (double)xq[(long long)i * ldxq + d];
             rid[j] = region_of<D>(g, rg, xr[j]);
             rank[j] = atomicAdd(&lh[rid[j]], 1);
         }
@@ -359,11 +359,13 @@ bin_scatter_kernel(Grid g, Regions rg, int n, const double *__restrict__ xq, int
 }
 
 constexpr int EVAL_WG = 1024;          // threads per workgroup in pass C (value path): 16 waves share one 32 KB tile (A/B: 256 -> 512 threads +3 %, 1024 +5 %)
-template <int D, bool VAL>
+// T = storage type of the coefficients and the results (double, or float for the REAL32 entry points: widened when the
+// tile is filled / narrowed when a result is stored; the sorted coordinates are always double, the arithmetic too)
+template <int D, bool VAL, typename T>
 __global__ void __launch_bounds__(EVAL_WG)
-eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coef,
+eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
                    const double *__restrict__ xs, long long ldp, const int *__restrict__ perm,
-                   const int *__restrict__ off, const int *__restrict__ wgoff, double *__restrict__ out)
+                   const int *__restrict__ off, const int *__restrict__ wgoff, T *__restrict__ out)
 {
     constexpr int TILE_ELEMS = tile_elems<D>();
     __shared__ double tile[TILE_ELEMS];
@@ -397,7 +399,7 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coe
             ok = ok && node < g.nodes[d];
             idx += node * g.colstride[d];
         }
-        tile[e] = ok ? coef[idx] : 0.0;
+        tile[e] = ok ? (double)coef[idx] : 0.0;
     }
     __syncthreads();
     const int qb = off[r] + part * EVAL_QPW;
@@ -439,7 +441,7 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const double *__restrict__ coe
             lds_cvd q = (lds_cvd)tile + (base + k1 * t1 + k2 * t2 + k3 * t3);
             c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[3];
         });
-        out[p] = sum;
+        out[p] = (T)sum;
         j = jn;
     }
 }
@@ -486,9 +488,9 @@ void set_eval_mode(int mode, long long chunk)
 }
 
 // order == 0: one nderiv pattern (nd) -> out[nq]; order 1 / 2: value + gradient (+ Hessian) -> out[nq][ldout]
-template <int D>
-static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, const double *xq, int ldxq,
-                              const NDeriv &nd, const double *coef, double *out, hipStream_t st,
+template <int D, typename T = double>
+static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, const T *xq, int ldxq,
+                              const NDeriv &nd, const T *coef, T *out, hipStream_t st,
                               int order = 0, int ldout = 1)
 {
     // default chunk: 2^24 queries (measured best at 64^3: large enough that the ~8 000 evaluation
@@ -530,29 +532,31 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
     int *hist = s.ints, *off = hist + BIN_MAX, *cursor = off + BIN_MAX + 1, *wgoff = cursor + BIN_MAX;
     for (long long c0 = 0; c0 < nq; c0 += chunk) {
         const int n = (int)(nq - c0 < chunk ? nq - c0 : chunk);
-        const double *xc = xq + c0 * ldxq;
+        const T *xc = xq + c0 * ldxq;
         const unsigned nbs = (unsigned)((n + 256 * ScatterShape<D>::QPT - 1) / (256 * ScatterShape<D>::QPT));
-        hipLaunchKernelGGL((bin_count_kernel<D>), dim3(nbs), dim3(256), 0, st, g, rg, n, xc, ldxq, s.cnt, ldw);
+        hipLaunchKernelGGL((bin_count_kernel<D, T>), dim3(nbs), dim3(256), 0, st, g, rg, n, xc, ldxq, s.cnt, ldw);
         int *part = s.cnt + (long long)ldw * rg.nbins;
         const unsigned nchunk = (nbs + BIN_ROWS - 1) / BIN_ROWS, nbg = (unsigned)((rg.nbins + 255) / 256);
         hipLaunchKernelGGL(bin_colsum_kernel, dim3(nbg, nchunk), dim3(256), 0, st, (int)nbs, rg.nbins, (const int *)s.cnt, part);
         hipLaunchKernelGGL(bin_total_kernel, dim3(nbg), dim3(256), 0, st, (int)nchunk, rg.nbins, part, hist);
         hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, st, rg.nbins, (const int *)hist, off, cursor, wgoff);
         hipLaunchKernelGGL(bin_wgbase_kernel, dim3(nbg, nchunk), dim3(256), 0, st, (int)nbs, rg.nbins, (const int *)off, (const int *)part, s.cnt);
-        hipLaunchKernelGGL((bin_scatter_kernel<D>), dim3(nbs), dim3(256), 2 * sizeof(int) * rg.nbins, st, g, rg, n, xc, ldxq,
+        hipLaunchKernelGGL((bin_scatter_kernel<D, T>), dim3(nbs), dim3(256), 2 * sizeof(int) * rg.nbins, st, g, rg, n, xc, ldxq,
                            (const int *)s.cnt, ldw, s.xs, s.cap, s.perm);
         const unsigned nw = (unsigned)(n / EVAL_QPW + rg.nbins + 1);
-        if (order == 1)
-            hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 1>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs, s.cap,
-                               (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
-        else if (order == 2)
-            hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 2>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs, s.cap,
-                               (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
-        else if (value_only)
-            hipLaunchKernelGGL((eval_binned_kernel<D, true>), dim3(nw), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
+        if constexpr (sizeof(T) == 8) {
+            if (order == 1)
+                hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 1>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs, s.cap,
+                                   (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
+            else if (order == 2)
+                hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 2>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs, s.cap,
+                                   (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
+        }
+        if (order == 0 && value_only)
+            hipLaunchKernelGGL((eval_binned_kernel<D, true, T>), dim3(nw), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
                                (const double *)s.xs, s.cap, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
-        else
-            hipLaunchKernelGGL((eval_binned_kernel<D, false>), dim3(nw), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
+        else if (order == 0)
+            hipLaunchKernelGGL((eval_binned_kernel<D, false, T>), dim3(nw), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
                                (const double *)s.xs, s.cap, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
     }
     (void)hipEventRecord(s.last, st);
@@ -830,8 +834,9 @@ static hipError_t launch_eval_t(const Grid &g, long long nq, const T *xq, int ld
         int v = (nderiv && d < g.ndim) ? nderiv[d] : 0;
         nd.v[d] = v < 0 ? 0 : (v > 2 ? 2 : v);
     }
-    if constexpr (sizeof(T) == 8) {
-        // binned path: large batches on grids whose coefficients are far beyond the L1 (auto), or forced
+    {
+        // binned path: large batches on grids whose coefficients are far beyond the L1 (auto), or forced (both storage kinds:
+        // the REAL32 entry points widen their inputs in the sort passes and the tile fill, same arithmetic as their direct kernel)
         Regions rg;
         bool can = false;
         if (g.ndim == 2) can = make_regions<2>(g, rg);
@@ -841,9 +846,9 @@ static hipError_t launch_eval_t(const Grid &g, long long nq, const T *xq, int ld
         // the sort pays for itself once the batch is large and the coefficients are far beyond L1
         const bool want = g_eval_mode == 2 || (g_eval_mode == 0 && g.ndim >= 3 && nq >= (1LL << 20) && g.ncol > 32768);
         if (can && want) {
-            hipError_t e = g.ndim == 2   ? eval_binned<2>(g, rg, nq, xq, ldxq, nd, coef, out, st)
-                           : g.ndim == 3 ? eval_binned<3>(g, rg, nq, xq, ldxq, nd, coef, out, st)
-                                         : eval_binned<4>(g, rg, nq, xq, ldxq, nd, coef, out, st);
+            hipError_t e = g.ndim == 2   ? eval_binned<2, T>(g, rg, nq, xq, ldxq, nd, coef, out, st)
+                           : g.ndim == 3 ? eval_binned<3, T>(g, rg, nq, xq, ldxq, nd, coef, out, st)
+                                         : eval_binned<4, T>(g, rg, nq, xq, ldxq, nd, coef, out, st);
             // no room for the sort scratch: the binned path is an optimisation, fall through to the direct one
             if (e != hipErrorOutOfMemory) return e;
             (void)hipGetLastError();

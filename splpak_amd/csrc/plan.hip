@@ -805,6 +805,29 @@ int32_t splpak_eval_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int3
     return v;
 }
 
+int32_t splpak_eval_dev_f32(int32_t ndim, int64_t nq, const float *xq_dev, int32_t ldxq,
+                            const int32_t *nderiv, const float *coef_dev, const float *xmin_f,
+                            const float *xmax_f, const int32_t *nodes, float *out_dev, void *stream)
+{
+    if (!nodes || !xmin_f || !xmax_f) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (ndim < 1) return 101;
+    if (ndim > MAXD) return SPLPAK_E_UNSUPPORTED;
+    double xmin[MAXD], xmax[MAXD];
+    for (int d = 0; d < ndim; ++d) { xmin[d] = (double)xmin_f[d]; xmax[d] = (double)xmax_f[d]; }
+    Grid g;
+    const int v = eval_validate(ndim, nderiv, xmin, xmax, nodes, g);
+    if (v != 0 && v != 104) {
+        if (v > 0 && out_dev && nq > 0) (void)hipMemsetAsync(out_dev, 0, sizeof(float) * (size_t)nq, (hipStream_t)stream);
+        return v;
+    }
+    if (nq <= 0) return v;
+    if (!xq_dev || !coef_dev || !out_dev) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (ldxq < ndim) { set_error("ldxq smaller than ndim"); return SPLPAK_E_BADARG; }
+    if (int r = device_ready()) return r;
+    SPLPAK_HIP_TRY(launch_eval_f32(g, nq, xq_dev, ldxq, nderiv, coef_dev, out_dev, (hipStream_t)stream), SPLPAK_E_NODEVICE);
+    return v;
+}
+
 static int derivs_nout(int ndim, int order) { return 1 + ndim + (order == 2 ? ndim * (ndim + 1) / 2 : 0); }
 
 int32_t splpak_eval_derivs_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int32_t ldxq, int32_t order,

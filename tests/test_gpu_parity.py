@@ -200,6 +200,41 @@ def test_eval_binned_path_is_bit_identical_to_direct(port, nodes):
         capi.set_eval_mode(7)
 
 
+@pytest.mark.parametrize("nodes", [(40, 40, 40), (20, 20, 20, 20)])
+def test_eval_real32_binned_path_is_bit_identical_to_direct(nodes):
+    """REAL32 storage (float queries, coefficients, results; double arithmetic) through the region sort: the bits of the
+    REAL32 direct kernel, and the real64 values to single-precision rounding (BASELINE config 5's tolerance sweep runs
+    its 1e8 queries through this path)."""
+    import torch
+    nd = len(nodes)
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(17)
+    nq = 400_000
+    coef = torch.randn(int(np.prod(nodes)), dtype=torch.float64, device=dev, generator=gen)
+    xq = torch.rand((nq, nd), dtype=torch.float64, device=dev, generator=gen) * 1.2 - 0.1
+    c32, x32 = coef.float(), xq.float()
+    lo, hi = [0.0] * nd, [1.0] * nd
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    try:
+        for pat in (None, [1] + [0] * (nd - 1), [0] * (nd - 1) + [2]):
+            for mode in (capi.EVAL_BINNED, capi.EVAL_DIRECT):
+                capi.set_eval_mode(mode, 1 << 16)
+                o = torch.empty(nq, dtype=torch.float32, device=dev)
+                assert capi.evaluate_dev(nd, x32, pat, c32, lo, hi, nodes, o, st) == 0
+                torch.cuda.synchronize()
+                out[mode] = o
+            assert torch.equal(out[capi.EVAL_BINNED], out[capi.EVAL_DIRECT]), (nodes, pat)
+            o64 = torch.empty(nq, dtype=torch.float64, device=dev)
+            capi.evaluate_dev(nd, x32.double(), pat, c32.double(), lo, hi, nodes, o64, st)
+            torch.cuda.synchronize()
+            scale = float(o64.abs().max())
+            assert float((out[capi.EVAL_BINNED].double() - o64).abs().max()) <= 2e-7 * scale
+    finally:
+        capi.set_eval_mode(capi.EVAL_AUTO)
+
+
 def test_eval_binned_scratch_regrows_for_a_grid_with_more_regions():
     """the binned path's per-workgroup count matrix was sized for the regions of whichever grid
     allocated it; a later grid with MORE regions and the same batch size wrote past it.  A 3-D 28^3 spline (8 regions),
