@@ -1147,16 +1147,17 @@ hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void
 
 }  // namespace
 
-// SPLPAK_ND: 0 = never, 1 = always; otherwise every 2-D .. 4-D grid of at least 8 192 columns.  Measured on MI355X
-// (tools/nd_crossover.sh, fit time band -> nested dissection): 24^3 11.4 -> 9.0 ms, 32^3 26.3 -> 18.4, 40^3 67.7 ->
-// 42.5, 48^3 166 -> 85, 64^3 831 -> 303, 4-D 12^4 41.9 -> 41.0, 16^4 239 -> 190, 24^4 10.5 s -> 4.9 s, 2-D 256^2
-// 41.5 -> 15.5; the 2-D 64^2 grid of BASELINE config 2 (4 096 columns, block-tridiagonal band) stays with the
-// two-ended band factorisation: 3.28 against 3.55 ms.
+// SPLPAK_ND: 0 = never, 1 = always; otherwise 2-D / 3-D grids of at least 4 096 columns and 4-D grids of at least 20 000.
+// Measured on MI355X (tools/nd_crossover.sh, fit time band -> nested dissection): 2-D 48^2 2.08 -> 2.27 ms (band stays),
+// 64^2 (BASELINE config 2) 3.29 -> 2.46, 90^2 5.7 -> 4.3, 128^2 10.4 -> 5.1, 256^2 41.5 -> 13.1; 3-D 16^3 4.3 -> 3.7, 20^3 6.6 ->
+// 5.9, 24^3 11.4 -> 9.0, 32^3 26.3 -> 17.8, 40^3 67.7 -> 42.5, 48^3 166 -> 85, 64^3 831 -> 280; 4-D 8^4 10.9 -> 11.2 and 10^4
+// 19.5 -> 20.3 (band stays), 12^4 41.9 -> 41.0, 16^4 239 -> 184, 24^4 10.5 s -> 4.9 s.
 bool nd_wanted(const Grid &g, const Band &band)
 {
     (void)band;
     if (const char *e = std::getenv("SPLPAK_ND")) return atoi(e) != 0;
-    return g.ndim >= 2 && g.ncol >= 8192;
+    if (g.ndim == 2 || g.ndim == 3) return g.ncol >= 4096;
+    return g.ndim == 4 && g.ncol >= 20000;
 }
 
 // Installs the nested-dissection factorisation on a single-GPU plan: builds the tree, allocates the arenas,
@@ -1168,7 +1169,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     (void)hipGetDevice(&s->device);
     p->fn_user = s;
     p->fn_destroy = nd_destroy;
-    if (!nd_build(p->g, s->t, nd_default_split_min())) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
+    if (!nd_build(p->g, s->t, nd_default_split_min(p->g.ndim))) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
     NdTree &t = s->t;
     const int nd = t.maxdepth + 1;
     s->s_depth_doubles.assign((size_t)nd, 0);

@@ -262,7 +262,7 @@ extern "C" int32_t splpak_debug_nd_tree(int32_t ndim, const int32_t *nodes, int3
     const int v = build_grid(ndim, nodes, xmin, xmax, g, nullptr, true);
     if (v != 0) return v;
     NdTree t;
-    if (!nd_build(g, t, split_min > 0 ? split_min : nd_default_split_min())) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
+    if (!nd_build(g, t, split_min > 0 ? split_min : nd_default_split_min(ndim))) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
     if (check) {
         const std::string msg = nd_check(t);
         if (!msg.empty()) { set_error("nested dissection: " + msg); return SPLPAK_E_BADARG; }

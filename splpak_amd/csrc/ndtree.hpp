@@ -68,11 +68,14 @@ struct NdTree {
     double flop_exact = 0.0;       // without the padding: w^3/3 + w^2 h + w h^2 per front
 };
 
-// boxes whose largest extent reaches this are bisected (SPLPAK_ND_SPLIT overrides)
-inline int nd_default_split_min()
+// boxes whose largest extent reaches this are bisected (SPLPAK_ND_SPLIT overrides).  3-D / 4-D: 8 (leaves of 5 .. 7 nodes
+// per dimension: deeper trees cost flops nowhere, shallower ones +25 % at 64^3).  2-D grids are launch bound, not flop
+// bound: leaves of up to 15 x 15 nodes (one 256-column block) save two tree levels -- 64^2 / 1e6 points (BASELINE config 2)
+// 2.86 -> 2.46 ms per fit.
+inline int nd_default_split_min(int ndim = 3)
 {
     if (const char *e = std::getenv("SPLPAK_ND_SPLIT")) return atoi(e);
-    return 8;
+    return ndim <= 2 ? 16 : 8;
 }
 // split_min: a box whose largest extent is at least this is bisected (>= 5); returns false on inconsistency
 bool nd_build(const Grid &g, NdTree &t, int split_min);

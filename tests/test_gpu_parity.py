@@ -546,6 +546,7 @@ def test_headline_pipeline_variants_match_golden(name):
     res = {}
     for label, env in (("pinned", {"SPLPAK_PIN_BW": "1"}), ("unpinned", {"SPLPAK_PIN_BW": "1000000"}),
                        ("serial", {"SPLPAK_NO_LOOKAHEAD": "1"})):
+        env = dict(env, SPLPAK_ND="0")       # the BAND pipelines (3d16 and 2d64 take nested dissection by default since round 3)
         coef, ierr, _, info = _fit_with_env(inp, env)
         assert ierr == 0, (label, ierr)
         err = relmax(coef, gold["coef"])
