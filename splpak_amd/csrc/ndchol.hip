@@ -543,14 +543,23 @@ struct NdState {
     NdTree t;
     int device = 0;
     // arenas
-    double *factor = nullptr, *sar[2] = {nullptr, nullptr}, *dinv = nullptr, *dinvt = nullptr, *inv16 = nullptr;
+    double *factor = nullptr, *dinv = nullptr, *dinvt = nullptr, *inv16 = nullptr;
+    // Two PIPELINES = the two subtrees below the root, eliminated side by side: each has its own chain stream, their
+    // Schur passes alternate on one stream, so the chain of one runs beside the passes of the other (npipe = 1: small
+    // trees, separate extend-add launches).  Schur arenas per pipeline and depth parity; stage = pipeline * depths + depth.
+    int npipe = 1;
+    std::vector<int> pipe_of;                      // [front] (the root: 0)
+    std::vector<long long> soff;                   // [front] doubles into its pipeline's arena of its depth parity
+    double *sarp[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    long long sarp_doubles[2][2] = {{0, 0}, {0, 0}};
+    std::vector<long long> s_stage_doubles;        // [stage] extent of its Schur buffers (a prefix of its arena)
+    std::vector<std::vector<int>> stage_ids;       // [stage] its fronts
     double *V = nullptr, *Y = nullptr, *part = nullptr;
     long long part_cap = 0;                        // doubles of the backward sweep's partial sums (one launch at a time)
     int *pos = nullptr, *front_of = nullptr, *bpos = nullptr, *pmap = nullptr, *rowsrc = nullptr;
     long long *padwhere = nullptr;
     int npad = 0;
     FrontDev *fdev = nullptr;
-    std::vector<long long> s_depth_doubles;         // Schur doubles of every depth (a prefix of its arena)
     // job tables; launches indexed [depth][step]
     JobTable<PotrfJob> potrf;
     JobTable<TrsmJob> trsm, trsmb;                 // trsmb: the rows beyond the next diagonal block, beside the chain (root look-ahead)
@@ -574,6 +583,9 @@ struct NdState {
     std::vector<Launch> l_zero;                    // per depth: zero the lower-triangle tiles of its Schur buffers
     // streams / events
     hipStream_t sP = nullptr, sU = nullptr, sR = nullptr;   // chain, Schur updates (+ their memsets), CU-masked: diagonal blocks
+    hipStream_t sP2 = nullptr;                     // chain of the second pipeline
+    std::vector<hipEvent_t> evT2, evI2, evF[2];    // second pipeline's step events; evF[p][d]: the fused last passes of stage (p, d) are done
+    hipEvent_t evR02 = nullptr;
     unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
     int nres = 0;
     int *queues = nullptr;                         // [nqueues][2] item counters of the update launches of one factorisation
@@ -625,10 +637,10 @@ void nd_destroy(void *user)
     NdState *s = static_cast<NdState *>(user);
     if (!s) return;
     (void)hipDeviceSynchronize();
-    for (hipStream_t *q : {&s->sP, &s->sU, &s->sR}) if (*q) (void)hipStreamDestroy(*q);
-    for (auto *v : {&s->evT, &s->evE, &s->evZ, &s->evA, &s->evB, &s->evI, &s->evW})
+    for (hipStream_t *q : {&s->sP, &s->sU, &s->sR, &s->sP2}) if (*q) (void)hipStreamDestroy(*q);
+    for (auto *v : {&s->evT, &s->evE, &s->evZ, &s->evA, &s->evB, &s->evI, &s->evW, &s->evT2, &s->evI2, &s->evF[0], &s->evF[1]})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->f0, s->f1, s->evR0}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->f0, s->f1, s->evR0, s->evR02}) if (e) (void)hipEventDestroy(e);
     for (void *q : s->owned) (void)hipFree(q);
     delete s;
 }
@@ -636,20 +648,22 @@ void nd_destroy(void *user)
 long long trapezoid_items(long long nc, long long nr) { return nc * nr - nc * (nc - 1) / 2; }
 
 // builds every job table from the tree and the arena pointers
-bool nd_build_jobs(NdState *s)
+// Schur buffer of front `id`: its pipeline's arena of its depth parity
+inline double *s_ptr(NdState *s, int id)
+{
+    const NdFront &f = s->t.fr[(size_t)id];
+    return f.hp > 0 ? s->sarp[s->pipe_of[(size_t)id]][f.depth & 1] + s->soff[(size_t)id] : nullptr;
+}
+
+// Job tables of the FACTORISATION: one set of launches per stage = (pipeline, tree depth) and block step.
+bool nd_build_factor_jobs(NdState *s)
 {
     NdTree &t = s->t;
-    const int nd = t.maxdepth + 1;
-    int maxsteps = 0;
-    for (const NdFront &f : t.fr) maxsteps = std::max(maxsteps, f.nsteps);
-    for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) L->assign((size_t)nd, {});
-    s->lookahead.assign((size_t)nd, 0);
-    s->fused = std::getenv("SPLPAK_ND_NO_FUSE") == nullptr;
-    for (int sl = 0; sl < 2; ++sl) s->l_fin[sl].assign((size_t)nd, {});
-    for (int sl = 0; sl < 2; ++sl) { s->l_add[sl].assign((size_t)nd, Launch()); s->l_mapslot[sl].assign((size_t)nd, Launch()); }
-    s->l_mapall.assign((size_t)nd, Launch());
-    s->l_zero.assign((size_t)nd, Launch());
-    long long part_max = 0;
+    const int nd = t.maxdepth + 1, nstage = s->npipe * nd;
+    for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_schur}) L->assign((size_t)nstage, {});
+    s->lookahead.assign((size_t)nstage, 0);
+    for (int sl = 0; sl < 2; ++sl) { s->l_fin[sl].assign((size_t)nstage, {}); s->l_add[sl].assign((size_t)nstage, Launch()); }
+    s->l_zero.assign((size_t)nstage, Launch());
     // Schur buffer passes: groups of up to schur_kb panel blocks (K = 1024: the C tiles are read and written once per
     // group; measured at 64^3: 257.6 ms per factorisation against 262.4 with K = 512 and 270.9 with K = 256; groups that
     // ramp up 1, 2, 4, 4, .. so that the first pass of a depth starts earlier made no difference)
@@ -659,34 +673,30 @@ bool nd_build_jobs(NdState *s)
         g0 = (k / schur_kb) * schur_kb;
         gend = std::min(g0 + schur_kb, nsteps) - 1;
     };
-    for (int d = 0; d < nd; ++d) {
-        const std::vector<int> &ids = t.by_depth[(size_t)d];
+    const SyrkJob syrk_end{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    for (int stg = 0; stg < nstage; ++stg) {
+        const std::vector<int> &ids = s->stage_ids[(size_t)stg];
+        const int d = stg % nd;
         int steps = 0;
         for (int id : ids) steps = std::max(steps, t.fr[(size_t)id].nsteps);
-        for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_schur, &s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) (*L)[(size_t)d].assign((size_t)steps, Launch());
-        for (int sl = 0; sl < 2; ++sl) s->l_fin[sl][(size_t)d].assign((size_t)steps, Launch());
+        for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_schur}) (*L)[(size_t)stg].assign((size_t)steps, Launch());
+        for (int sl = 0; sl < 2; ++sl) s->l_fin[sl][(size_t)stg].assign((size_t)steps, Launch());
         bool any_schur = false;
         for (int id : ids) any_schur = any_schur || t.fr[(size_t)id].hp > 0;
         const bool la = !any_schur && steps >= 4 && !std::getenv("SPLPAK_ND_NO_ROOT_LOOKAHEAD");
-        s->lookahead[(size_t)d] = la ? 1 : 0;
+        s->lookahead[(size_t)stg] = la ? 1 : 0;
         for (int k = 0; k < steps; ++k) {
-            Launch lp, lt, ltb, lu, lur, ls, lm, lf, ld, lb, lfin[2];
-            long long tbwg = 0;
-            ltb.first = (int)s->trsmb.host.size();
+            Launch lp, lt, ltb, lu, lur, ls, lfin[2];
+            long long tbwg = 0, twg = 0, ui = 0, uri = 0, si = 0;
             long long fi[2] = {0, 0};
-            double fflop[2] = {0.0, 0.0};
+            double fflop[2] = {0.0, 0.0}, sflop = 0.0;
+            ltb.first = (int)s->trsmb.host.size();
             for (int sl = 0; sl < 2; ++sl) lfin[sl].first = (int)s->fin[sl].host.size();
             lp.first = (int)s->potrf.host.size();
             lt.first = (int)s->trsm.host.size();
             lu.first = (int)s->upd.host.size();
             lur.first = (int)s->updr.host.size();
             ls.first = (int)s->schur.host.size();
-            lm.first = (int)s->mv.host.size();
-            lf.first = (int)s->fwd.host.size();
-            ld.first = (int)s->dot.host.size();
-            lb.first = (int)s->bwd.host.size();
-            long long twg = 0, ui = 0, uri = 0, si = 0, fwg = 0, dwg = 0, partofs = 0;
-            double sflop = 0.0;
             for (int id : ids) {
                 const NdFront &f = t.fr[(size_t)id];
                 if (k >= f.nsteps) continue;
@@ -761,22 +771,133 @@ bool nd_build_jobs(NdState *s)
                         const NdFront &pf = t.fr[(size_t)f.parent];
                         const int sl = f.slot;
                         const int leaf = (f.child[0] < 0 && g0 == 0) ? 1 : 0;       // no children, one pass: the buffer is never materialised
-                        s->fin[sl].host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s->sar[f.depth & 1] + f.s_off, f.ld,
+                        s->fin[sl].host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s_ptr(s, id), f.ld,
                                                           f.lds, ns, ns, (int)fi[sl], kb, ksl, leaf, s->pmap + f.bofs,
-                                                          s->factor + pf.panel_off, pf.hp > 0 ? s->sar[pf.depth & 1] + pf.s_off : nullptr,
-                                                          pf.ld, pf.lds, pf.wp, f.h});
+                                                          s->factor + pf.panel_off, s_ptr(s, f.parent), pf.ld, pf.lds, pf.wp, f.h});
                         fi[sl] += trapezoid_items(ns, ns);
                         fflop[sl] += jflop;
                         ++lfin[sl].count;
                     } else {
-                        s->schur.host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s->sar[f.depth & 1] + f.s_off, f.ld,
+                        s->schur.host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s_ptr(s, id), f.ld,
                                                         f.lds, ns, ns, (int)si, kb, ksl, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
                         si += trapezoid_items(ns, ns);
                         sflop += jflop;
                         ++ls.count;
                     }
                 }
-                // solves
+            }
+            if (twg > 0x7fffffffLL || ui > 0x7fffffffLL || si > 0x7fffffffLL || uri > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+            lp.grid = (unsigned)lp.count;
+            lt.grid = (unsigned)twg;
+            ltb.grid = (unsigned)tbwg;
+            lu.grid = (unsigned)ui;
+            lu.flop = 2.0 * 64 * 64 * 256 * (double)ui;
+            lur.grid = (unsigned)uri;
+            lur.flop = 2.0 * 64 * 64 * 256 * (double)uri;
+            ls.grid = (unsigned)si;
+            ls.flop = sflop;
+            // sentinels for the job search (first field of the element after the last job)
+            if (lt.count) s->trsm.host.push_back(TrsmJob{nullptr, nullptr, nullptr, 0, 0, (int)twg, 0, 0});
+            if (ltb.count) s->trsmb.host.push_back(TrsmJob{nullptr, nullptr, nullptr, 0, 0, (int)tbwg, 0, 0});
+            SyrkJob e = syrk_end;
+            e.item0 = (int)ui;
+            if (lu.count) s->upd.host.push_back(e);
+            e.item0 = (int)uri;
+            if (lur.count) s->updr.host.push_back(e);
+            e.item0 = (int)si;
+            if (ls.count) s->schur.host.push_back(e);
+            for (int sl = 0; sl < 2; ++sl) {
+                if (fi[sl] > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+                lfin[sl].grid = (unsigned)fi[sl];
+                lfin[sl].flop = fflop[sl];
+                e.item0 = (int)fi[sl];
+                if (lfin[sl].count) s->fin[sl].host.push_back(e);
+                s->l_fin[sl][(size_t)stg][(size_t)k] = lfin[sl];
+            }
+            s->l_potrf[(size_t)stg][(size_t)k] = lp;
+            s->l_trsm[(size_t)stg][(size_t)k] = lt;
+            s->l_trsmb[(size_t)stg][(size_t)k] = ltb;
+            s->l_upd[(size_t)stg][(size_t)k] = lu;
+            s->l_updr[(size_t)stg][(size_t)k] = lur;
+            s->l_schur[(size_t)stg][(size_t)k] = ls;
+        }
+        // lower-triangle tiles of the stage's Schur buffers
+        {
+            Launch lz;
+            lz.first = (int)s->zero.host.size();
+            long long tiles = 0;
+            for (int id : ids) {
+                const NdFront &f = t.fr[(size_t)id];
+                if (f.hp == 0) continue;
+                if (s->fused && f.child[0] < 0 && f.nsteps <= schur_kb) continue;       // a leaf's buffer is never materialised (fused last pass)
+                const int nt = f.hp / 64;
+                s->zero.host.push_back(ZeroJob{s_ptr(s, id), f.lds, nt, (int)tiles});
+                tiles += trapezoid_items(nt, nt);
+                ++lz.count;
+            }
+            if (tiles > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+            lz.grid = (unsigned)tiles;
+            if (lz.count) s->zero.host.push_back(ZeroJob{nullptr, 0, 0, (int)tiles});
+            s->l_zero[(size_t)stg] = lz;
+        }
+        // separate extend-add launches (SPLPAK_ND_NO_FUSE): children of this stage -> their parents
+        if (d >= 1 && !s->fused) {
+            for (int sl = 0; sl < 2; ++sl) {
+                Launch la2;
+                la2.first = (int)s->add.host.size();
+                long long tiles = 0;
+                for (int id : ids) {
+                    const NdFront &f = t.fr[(size_t)id];
+                    if (f.slot != sl || f.h == 0) continue;
+                    const NdFront &p = t.fr[(size_t)f.parent];
+                    const int nt = f.hp / 64;
+                    s->add.host.push_back(AddJob{s_ptr(s, id), s->pmap + f.bofs, s->factor + p.panel_off, s_ptr(s, f.parent), f.lds, p.ld,
+                                                 p.lds, f.h, nt, p.wp, (int)tiles});
+                    tiles += trapezoid_items(nt, nt);
+                    ++la2.count;
+                }
+                if (tiles > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+                la2.grid = (unsigned)tiles;
+                if (la2.count) s->add.host.push_back(AddJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, (int)tiles});
+                s->l_add[sl][(size_t)stg] = la2;
+            }
+        }
+    }
+    for (const NdFront &f : t.fr)
+        for (int k = 0; k < f.nsteps; ++k) {
+            const double *diag = s->factor + f.panel_off + (long long)k * 256 + (long long)k * 256 * f.ld;
+            s->trinv.host.push_back(TrinvJob{diag, s->inv16 + (long long)(f.blk0 + k) * 4096, s->dinv + (long long)(f.blk0 + k) * 65536,
+                                             s->dinvt + (long long)(f.blk0 + k) * 65536, f.ld});
+        }
+    return true;
+}
+
+// Job tables of the SOLVES: per tree depth (all fronts of the depth, whatever their pipeline) and block step.
+bool nd_build_solve_jobs(NdState *s)
+{
+    NdTree &t = s->t;
+    const int nd = t.maxdepth + 1;
+    for (auto *L : {&s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) L->assign((size_t)nd, {});
+    for (int sl = 0; sl < 2; ++sl) s->l_mapslot[sl].assign((size_t)nd, Launch());
+    s->l_mapall.assign((size_t)nd, Launch());
+    long long part_max = 0;
+    for (int d = 0; d < nd; ++d) {
+        const std::vector<int> &ids = t.by_depth[(size_t)d];
+        int steps = 0;
+        for (int id : ids) steps = std::max(steps, t.fr[(size_t)id].nsteps);
+        for (auto *L : {&s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) (*L)[(size_t)d].assign((size_t)steps, Launch());
+        for (int k = 0; k < steps; ++k) {
+            Launch lm, lf, ld, lb;
+            lm.first = (int)s->mv.host.size();
+            lf.first = (int)s->fwd.host.size();
+            ld.first = (int)s->dot.host.size();
+            lb.first = (int)s->bwd.host.size();
+            long long fwg = 0, dwg = 0, partofs = 0;
+            for (int id : ids) {
+                const NdFront &f = t.fr[(size_t)id];
+                if (k >= f.nsteps) continue;
+                const double *below = s->factor + f.panel_off + (long long)k * 256 + (long long)k * 256 * f.ld + 256;
+                const int nrows = f.fp - (k + 1) * 256;
                 double *Vf = s->V + f.vofs, *Yf = s->Y + f.vofs;
                 s->mv.host.push_back(MvJob{s->dinv + (long long)(f.blk0 + k) * 65536, Vf + k * 256, Yf + k * 256});
                 ++lm.count;
@@ -795,90 +916,32 @@ bool nd_build_jobs(NdState *s)
                 s->bwd.host.push_back(BwdJob{s->dinvt + (long long)(f.blk0 + k) * 65536, Yf + k * 256, partp, Vf + k * 256, nsplit, 0});
                 ++lb.count;
             }
-            if (twg > 0x7fffffffLL || ui > 0x7fffffffLL || si > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+            if (fwg > 0x7fffffffLL || dwg > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
             part_max = std::max(part_max, partofs);
-            lp.grid = (unsigned)lp.count;
-            lt.grid = (unsigned)twg;
-            ltb.grid = (unsigned)tbwg;
-            if (ltb.count) s->trsmb.host.push_back(TrsmJob{nullptr, nullptr, nullptr, 0, 0, (int)tbwg, 0, 0});
-            s->l_trsmb[(size_t)d][(size_t)k] = ltb;
-            lu.grid = (unsigned)ui;
-            lu.flop = 2.0 * 64 * 64 * 256 * (double)ui;
-            lur.grid = (unsigned)uri;
-            lur.flop = 2.0 * 64 * 64 * 256 * (double)uri;
-            ls.grid = (unsigned)si;
-            ls.flop = sflop;
             lm.grid = (unsigned)lm.count;
             lf.grid = (unsigned)fwg;
             ld.grid = (unsigned)dwg;
             lb.grid = (unsigned)lb.count;
-            // sentinels for the job search (first field of the element after the last job)
-            if (lt.count) s->trsm.host.push_back(TrsmJob{nullptr, nullptr, nullptr, 0, 0, (int)twg, 0, 0});
-            if (lu.count) s->upd.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)ui, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
-            if (lur.count) s->updr.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)uri, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
-            if (ls.count) s->schur.host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)si, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
-            for (int sl = 0; sl < 2; ++sl) {
-                if (fi[sl] > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
-                lfin[sl].grid = (unsigned)fi[sl];
-                lfin[sl].flop = fflop[sl];
-                if (lfin[sl].count) s->fin[sl].host.push_back(SyrkJob{nullptr, nullptr, 0, 0, 0, 0, (int)fi[sl], 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
-                s->l_fin[sl][(size_t)d][(size_t)k] = lfin[sl];
-            }
             if (lf.count) s->fwd.host.push_back(FwdJob{nullptr, nullptr, nullptr, 0, 0, (int)fwg});
             if (ld.count) s->dot.host.push_back(DotJob{nullptr, nullptr, nullptr, 0, 0, 0, 0, (int)dwg});
-            s->l_potrf[(size_t)d][(size_t)k] = lp;
-            s->l_trsm[(size_t)d][(size_t)k] = lt;
-            s->l_upd[(size_t)d][(size_t)k] = lu;
-            s->l_updr[(size_t)d][(size_t)k] = lur;
-            s->l_schur[(size_t)d][(size_t)k] = ls;
             s->l_mv[(size_t)d][(size_t)k] = lm;
             s->l_fwd[(size_t)d][(size_t)k] = lf;
             s->l_dot[(size_t)d][(size_t)k] = ld;
             s->l_bwd[(size_t)d][(size_t)k] = lb;
         }
-        // lower-triangle tiles of the depth's Schur buffers
-        {
-            Launch lz;
-            lz.first = (int)s->zero.host.size();
-            long long tiles = 0;
-            for (int id : ids) {
-                const NdFront &f = t.fr[(size_t)id];
-                if (f.hp == 0) continue;
-                if (s->fused && f.child[0] < 0 && f.nsteps <= schur_kb) continue;       // a leaf's buffer is never materialised (fused last pass)
-                const int nt = f.hp / 64;
-                s->zero.host.push_back(ZeroJob{s->sar[f.depth & 1] + f.s_off, f.lds, nt, (int)tiles});
-                tiles += trapezoid_items(nt, nt);
-                ++lz.count;
-            }
-            if (tiles > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
-            lz.grid = (unsigned)tiles;
-            if (lz.count) s->zero.host.push_back(ZeroJob{nullptr, 0, 0, (int)tiles});
-            s->l_zero[(size_t)d] = lz;
-        }
-        // children at depth d -> parents at depth d - 1
+        // children at depth d <-> parents at depth d - 1 (border values of the sweeps)
         if (d >= 1) {
             for (int sl = 0; sl < 2; ++sl) {
-                Launch la, lmj;
-                la.first = (int)s->add.host.size();
+                Launch lmj;
                 lmj.first = (int)s->map.host.size();
-                long long tiles = 0;
                 for (int id : ids) {
                     const NdFront &f = t.fr[(size_t)id];
                     if (f.slot != sl || f.h == 0) continue;
                     const NdFront &p = t.fr[(size_t)f.parent];
-                    const int nt = f.hp / 64;
-                    if (!s->fused) s->add.host.push_back(AddJob{s->sar[f.depth & 1] + f.s_off, s->pmap + f.bofs, s->factor + p.panel_off,
-                                                 p.hp > 0 ? s->sar[p.depth & 1] + p.s_off : nullptr, f.lds, p.ld, p.lds, f.h, nt, p.wp,
-                                                 (int)tiles});
-                    if (!s->fused) { tiles += trapezoid_items(nt, nt); ++la.count; }
                     s->map.host.push_back(MapJob{s->V + f.vofs + f.wp, s->V + p.vofs, s->pmap + f.bofs, f.h, 0});
                     ++lmj.count;
                 }
-                if (tiles > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
-                la.grid = (unsigned)tiles;
                 lmj.grid = (unsigned)lmj.count;
-                if (la.count) s->add.host.push_back(AddJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, (int)tiles});
-                s->l_add[sl][(size_t)d] = la;
                 s->l_mapslot[sl][(size_t)d] = lmj;
             }
             // backward: both slots at once = the two consecutive runs of map jobs
@@ -889,14 +952,12 @@ bool nd_build_jobs(NdState *s)
             s->l_mapall[(size_t)d] = all;
         }
     }
-    for (const NdFront &f : t.fr)
-        for (int k = 0; k < f.nsteps; ++k) {
-            const double *diag = s->factor + f.panel_off + (long long)k * 256 + (long long)k * 256 * f.ld;
-            s->trinv.host.push_back(TrinvJob{diag, s->inv16 + (long long)(f.blk0 + k) * 4096, s->dinv + (long long)(f.blk0 + k) * 65536,
-                                             s->dinvt + (long long)(f.blk0 + k) * 65536, f.ld});
-        }
-    (void)maxsteps;
     return part_max <= s->part_cap;
+}
+
+bool nd_build_jobs(NdState *s)
+{
+    return nd_build_factor_jobs(s) && nd_build_solve_jobs(s);
 }
 
 // schur: the Schur-buffer passes (timed: the roofline kernel); otherwise the panel update of the chain.
@@ -975,11 +1036,14 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     const bool enabled = stats->enabled;
     *stats = CholStats{};
     stats->enabled = enabled;
-    const int nd = t.maxdepth + 1;
-    hipStream_t sP = s->sP, sU = s->sU, sR = s->sR;
+    const int nd = t.maxdepth + 1, np = s->npipe;
     const bool serial = std::getenv("SPLPAK_NO_LOOKAHEAD") != nullptr;
-    if (serial) sP = sU = st;
+    hipStream_t sPp[2] = {s->sP, s->sP2 ? s->sP2 : s->sP}, sU = s->sU, sR = s->sR;
+    if (serial) sPp[0] = sPp[1] = sU = st;
     if (serial || !sR || std::getenv("SPLPAK_NO_PANEL_CU")) sR = nullptr;
+    hipStream_t sP = sPp[0];
+    std::vector<hipEvent_t> *evTp[2] = {&s->evT, &s->evT2}, *evIp[2] = {&s->evI, &s->evI2};
+    hipEvent_t evR0p[2] = {s->evR0, s->evR02};
     // potrf goes to the reserved CUs while a depth has at most this many diagonal blocks per step per reserved CU
     const int pin_rounds = std::getenv("SPLPAK_ND_PIN_ROUNDS") ? atoi(std::getenv("SPLPAK_ND_PIN_ROUNDS")) : 2;
     if (timing) {
@@ -988,35 +1052,118 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     }
     if (s->used && s->evDone) (void)hipStreamWaitEvent(st, s->evDone, 0);
     if (s->zlast_valid) (void)hipStreamWaitEvent(st, s->evZlast, 0);
-    if (!s->s_clean) {          // first fit, or the previous one was abandoned: zero both arenas
-        for (int a = 0; a < 2; ++a)
-            if (t.s_doubles[a] > 0) (void)hipMemsetAsync(s->sar[a], 0, sizeof(double) * (size_t)t.s_doubles[a], st);
+    if (!s->s_clean) {          // first fit, or the previous one was abandoned: zero every arena
+        for (int q = 0; q < 2; ++q)
+            for (int a = 0; a < 2; ++a)
+                if (s->sarp_doubles[q][a] > 0) (void)hipMemsetAsync(s->sarp[q][a], 0, sizeof(double) * (size_t)s->sarp_doubles[q][a], st);
     }
     s->s_clean = false;
     if (s->queues) (void)hipMemsetAsync(s->queues, 0, sizeof(int) * 2 * (size_t)s->nqueues, st);
     int qnext = 0;
     (void)hipEventRecord(s->ev0, st);
-    if (sP != st) (void)hipStreamWaitEvent(sP, s->ev0, 0);
-    if (sU != st) (void)hipStreamWaitEvent(sU, s->ev0, 0);
+    for (hipStream_t q : {sPp[0], sPp[1], sU})
+        if (q != st) (void)hipStreamWaitEvent(q, s->ev0, 0);
     if (sR) (void)hipStreamWaitEvent(sR, s->ev0, 0);
+    auto ensure_events = [&](int steps) {
+        for (auto *v : {&s->evT, &s->evI, &s->evW, &s->evT2, &s->evI2})
+            while ((int)v->size() < steps) {
+                hipEvent_t e;
+                (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+                v->push_back(e);
+            }
+    };
+    // the Schur buffers of stage (q, target) are zeroed on the update stream (their arena half is free there: stream order)
+    auto zero_stage = [&](int q, int target) {
+        if (target < 1) return;
+        const int stg = q * nd + target;
+        if (s->s_stage_doubles[(size_t)stg] <= 0) return;
+        const Launch &lz = s->l_zero[(size_t)stg];
+        if (std::getenv("SPLPAK_ND_MEMSET"))
+            (void)hipMemsetAsync(s->sarp[q][target & 1], 0, sizeof(double) * (size_t)s->s_stage_doubles[(size_t)stg], sU);
+        else if (lz.count)
+            hipLaunchKernelGGL(nd_zero_kernel, dim3(lz.grid), dim3(256), 0, sU, (const ZeroJob *)(s->zero.dev + lz.first), lz.count);
+    };
     auto deepest_with_parity = [&](int par) { int d = t.maxdepth; if ((d & 1) != par) --d; return d; };
-    std::vector<char> zeroed_now((size_t)nd + 2, 0);
-    for (int d = t.maxdepth; d >= 0; --d) {
-        const int steps = (int)s->l_potrf[(size_t)d].size();
-        while ((int)s->evT.size() < steps) {
-            hipEvent_t e;
-            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-            s->evT.push_back(e);
-            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-            s->evI.push_back(e);
-            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-            s->evW.push_back(e);
+    // one block step of a stage's chain: potrf (on the reserved CUs when pinned) -> panel solve -> panel update, on the
+    // pipeline's chain stream; the Schur passes that become ready go to the update stream
+    auto chain_step = [&](int q, int stg, int k, bool pinned) {
+        hipStream_t sC = sPp[q];
+        const Launch &lp = s->l_potrf[(size_t)stg][(size_t)k], &lt = s->l_trsm[(size_t)stg][(size_t)k];
+        const Launch &lu = s->l_upd[(size_t)stg][(size_t)k], &ls = s->l_schur[(size_t)stg][(size_t)k];
+        const Launch &lf0 = s->l_fin[0][(size_t)stg][(size_t)k], &lf1 = s->l_fin[1][(size_t)stg][(size_t)k];
+        if (pinned) {           // two event hops: chain -> reserved CUs -> chain
+            (void)hipEventRecord(evR0p[q], sC);
+            (void)hipStreamWaitEvent(sR, evR0p[q], 0);
+            hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sR, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
+            (void)hipEventRecord((*evIp[q])[(size_t)k], sR);
+            (void)hipStreamWaitEvent(sC, (*evIp[q])[(size_t)k], 0);
+        } else
+            hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sC, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
+        if (lt.count)
+            hipLaunchKernelGGL(nd_trsm_kernel, dim3(lt.grid), dim3(64), 0, sC, (const TrsmJob *)(s->trsm.dev + lt.first), lt.count);
+        if ((ls.count || lf0.count || lf1.count) && sU != sC) {
+            (void)hipEventRecord((*evTp[q])[(size_t)k], sC);
+            (void)hipStreamWaitEvent(sU, (*evTp[q])[(size_t)k], 0);
         }
-        const bool pinned = sR != nullptr && s->nres > 0 && (int)s->l_potrf[(size_t)d][0].grid <= pin_rounds * s->nres;
+        launch_syrk(s, s->upd, lu, sC, stats, timing, false, pinned, qnext);
+        launch_syrk(s, s->schur, ls, sU, stats, timing, true, pinned, qnext);
+        launch_syrk(s, s->fin[0], lf0, sU, stats, timing, true, pinned, qnext);      // final passes, fused with the extend-add:
+        launch_syrk(s, s->fin[1], lf1, sU, stats, timing, true, pinned, qnext);      // children of slot 0, then of slot 1
+    };
+    // ---- depths maxdepth .. 1: the pipelines step through a depth together, their Schur passes alternate on sU
+    for (int d = t.maxdepth; d >= 1; --d) {
+        int steps = 0, nfront0 = 0;
+        for (int q = 0; q < np; ++q) {
+            const auto &lv = s->l_potrf[(size_t)(q * nd + d)];
+            steps = std::max(steps, (int)lv.size());
+            if (!lv.empty()) nfront0 += (int)lv[0].grid;
+        }
+        ensure_events(steps);
+        const bool pinned = sR != nullptr && s->nres > 0 && nfront0 <= pin_rounds * s->nres;
+        if (s->fused && d < t.maxdepth)
+            for (int q = 0; q < np; ++q)
+                if (sU != sPp[q]) (void)hipStreamWaitEvent(sPp[q], s->evF[q][(size_t)(d + 1)], 0);     // the children's last passes
+        for (int k = 0; k < steps; ++k)
+            for (int q = 0; q < np; ++q) {
+                const int stg = q * nd + d, sq = (int)s->l_potrf[(size_t)stg].size();
+                if (k < sq) chain_step(q, stg, k, pinned);
+                if (s->fused && k == std::max(sq, 1) - 1) {
+                    // stage (q, d) is done on the update stream (stream order): its parents may start, and the arena half
+                    // it used is free -- zero what uses it next (depth d - 2, or the deepest depth of that parity for the NEXT fit)
+                    (void)hipEventRecord(s->evF[q][(size_t)d], sU);
+                    zero_stage(q, d - 2 >= 1 ? d - 2 : deepest_with_parity(d & 1));
+                }
+            }
+        if (!s->fused) {        // separate extend-add launches (one pipeline): the depth's passes, then slot 0, then slot 1
+            if (sU != sP) {
+                (void)hipEventRecord(s->evU, sU);
+                (void)hipStreamWaitEvent(sP, s->evU, 0);
+            }
+            for (int sl = 0; sl < 2; ++sl) {
+                const Launch &la = s->l_add[sl][(size_t)d];
+                if (la.count)
+                    hipLaunchKernelGGL(nd_extend_add_kernel, dim3(la.grid), dim3(256), 0, sP, (const AddJob *)(s->add.dev + la.first), la.count);
+            }
+            (void)hipEventRecord(s->evE[(size_t)d], sP);
+            if (sU != sP) (void)hipStreamWaitEvent(sU, s->evE[(size_t)d], 0);
+            zero_stage(0, d - 2 >= 1 ? d - 2 : deepest_with_parity(d & 1));
+            // (the zero launches of a depth precede its children's extend-add: sU -> evU -> sP at the end of the next depth)
+        }
+    }
+    // ---- the root: after both pipelines; no Schur buffer to hide its chain behind, hence the look-ahead split
+    if (s->fused && t.maxdepth >= 1)
+        for (int q = 0; q < np; ++q)
+            if (sU != sP) (void)hipStreamWaitEvent(sP, s->evF[q][1], 0);
+    {
+        const int steps = (int)s->l_potrf[0].size();
+        ensure_events(steps);
+        const bool pinned = sR != nullptr && s->nres > 0 && (int)s->l_potrf[0][0].grid <= pin_rounds * s->nres;
+        const bool la = s->lookahead[0] != 0;
         for (int k = 0; k < steps; ++k) {
-            const Launch &lp = s->l_potrf[(size_t)d][(size_t)k], &lt = s->l_trsm[(size_t)d][(size_t)k];
-            const Launch &lu = s->l_upd[(size_t)d][(size_t)k], &ls = s->l_schur[(size_t)d][(size_t)k];
-            if (pinned) {           // two event hops: chain -> reserved CUs -> chain
+            if (!la) { chain_step(0, 0, k, pinned); continue; }
+            const Launch &lp = s->l_potrf[0][(size_t)k], &lt = s->l_trsm[0][(size_t)k], &ltb = s->l_trsmb[0][(size_t)k];
+            const Launch &lu = s->l_upd[0][(size_t)k], &lur = s->l_updr[0][(size_t)k];
+            if (pinned) {
                 (void)hipEventRecord(s->evR0, sP);
                 (void)hipStreamWaitEvent(sR, s->evR0, 0);
                 hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sR, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
@@ -1024,65 +1171,36 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
                 (void)hipStreamWaitEvent(sP, s->evI[(size_t)k], 0);
             } else
                 hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sP, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
-            const Launch &ltb = s->l_trsmb[(size_t)d][(size_t)k];
-            if (ltb.count) {            // look-ahead: the panel rows beyond the next diagonal block are solved beside the chain
+            if (ltb.count) {            // the panel rows beyond the next diagonal block are solved beside the chain
                 if (sU != sP) {
                     if (!pinned) (void)hipEventRecord(s->evI[(size_t)k], sP);
                     (void)hipStreamWaitEvent(sU, s->evI[(size_t)k], 0);
                 }
                 hipLaunchKernelGGL(nd_trsm_kernel, dim3(ltb.grid), dim3(64), 0, sU, (const TrsmJob *)(s->trsmb.dev + ltb.first), ltb.count);
             }
-            // look-ahead (the root): everything of step k - 1 that is not the next diagonal block ran beside the chain; the
-            // panel rows this step solves and the block it updates were last written there
-            if (s->lookahead[(size_t)d] && k > 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evW[(size_t)(k - 1)], 0);
+            // everything of step k - 1 that is not the next diagonal block ran beside the chain; the panel rows this step
+            // solves and the block it updates were last written there
+            if (k > 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evW[(size_t)(k - 1)], 0);
             if (lt.count)
                 hipLaunchKernelGGL(nd_trsm_kernel, dim3(lt.grid), dim3(64), 0, sP, (const TrsmJob *)(s->trsm.dev + lt.first), lt.count);
-            const Launch &lur = s->l_updr[(size_t)d][(size_t)k];
-            if ((ls.count || lur.count || s->l_fin[0][(size_t)d][(size_t)k].count || s->l_fin[1][(size_t)d][(size_t)k].count) && sU != sP) {
+            if (lur.count && sU != sP) {
                 (void)hipEventRecord(s->evT[(size_t)k], sP);
                 (void)hipStreamWaitEvent(sU, s->evT[(size_t)k], 0);
             }
             launch_syrk(s, s->upd, lu, sP, stats, timing, false, pinned, qnext);
-            if (lur.count) {
-                launch_syrk(s, s->updr, lur, sU, stats, timing, false, pinned, qnext);
-            }
-            if (s->lookahead[(size_t)d] && sU != sP) (void)hipEventRecord(s->evW[(size_t)k], sU);
-            launch_syrk(s, s->schur, ls, sU, stats, timing, true, pinned, qnext);
-            for (int sl = 0; sl < 2; ++sl)          // final passes, fused with the extend-add: slot 0, then slot 1
-                launch_syrk(s, s->fin[sl], s->l_fin[sl][(size_t)d][(size_t)k], sU, stats, timing, true, pinned, qnext);
+            launch_syrk(s, s->updr, lur, sU, stats, timing, false, pinned, qnext);
+            if (sU != sP) (void)hipEventRecord(s->evW[(size_t)k], sU);
         }
-        if (sU != sP) {                                 // the depth's Schur updates are complete before they are handed on
+        if (sU != sP) {
             (void)hipEventRecord(s->evU, sU);
             (void)hipStreamWaitEvent(sP, s->evU, 0);
-        }
-        if (d >= 1) {
-            if (zeroed_now[(size_t)(d - 1)] && sU != sP) (void)hipStreamWaitEvent(sP, s->evZ[(size_t)(d - 1)], 0);
-            for (int sl = 0; sl < 2; ++sl) {
-                const Launch &la = s->l_add[sl][(size_t)d];
-                if (la.count)
-                    hipLaunchKernelGGL(nd_extend_add_kernel, dim3(la.grid), dim3(256), 0, sP, (const AddJob *)(s->add.dev + la.first), la.count);
-            }
-            // depth d is consumed: its arena half is free -- zero what uses it next (depth d - 2, or the deepest depth
-            // of that parity for the NEXT fit) on the update stream, ahead of the Schur passes of depth d - 1
-            (void)hipEventRecord(s->evE[(size_t)d], sP);
-            const int target = d - 2 >= 1 ? d - 2 : deepest_with_parity(d & 1);
-            if (target >= 1 && s->s_depth_doubles[(size_t)target] > 0) {
-                if (sU != sP) (void)hipStreamWaitEvent(sU, s->evE[(size_t)d], 0);
-                const Launch &lz = s->l_zero[(size_t)target];
-                if (lz.count && !std::getenv("SPLPAK_ND_MEMSET"))
-                    hipLaunchKernelGGL(nd_zero_kernel, dim3(lz.grid), dim3(256), 0, sU, (const ZeroJob *)(s->zero.dev + lz.first), lz.count);
-                else
-                    (void)hipMemsetAsync(s->sar[target & 1], 0, sizeof(double) * (size_t)s->s_depth_doubles[(size_t)target], sU);
-                (void)hipEventRecord(s->evZ[(size_t)target], sU);
-                if (target == d - 2) zeroed_now[(size_t)target] = 1;
-            }
         }
     }
     // inverses of all diagonal blocks (the solves' operands)
     hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)t.nblocks), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev);
     (void)hipEventRecord(s->evJ, sP);
     if (sP != st) (void)hipStreamWaitEvent(st, s->evJ, 0);
-    if (sU != st) {                                   // (the memsets for the next fit may still be running: it waits for them)
+    if (sU != st) {                                   // (the zero launches for the next fit may still be running: it waits for them)
         (void)hipEventRecord(s->evZlast, sU);
         s->zlast_valid = true;
     }
@@ -1172,10 +1290,39 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     if (!nd_build(p->g, s->t, nd_default_split_min(p->g.ndim))) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
     NdTree &t = s->t;
     const int nd = t.maxdepth + 1;
-    s->s_depth_doubles.assign((size_t)nd, 0);
-    for (const NdFront &f : t.fr) s->s_depth_doubles[(size_t)f.depth] = std::max(s->s_depth_doubles[(size_t)f.depth], f.s_off + f.lds * (long long)f.hp);
-    bool ok = nd_alloc(s, &s->factor, (size_t)t.factor_doubles + 64) && nd_alloc(s, &s->sar[0], (size_t)t.s_doubles[0] + 64) &&
-              nd_alloc(s, &s->sar[1], (size_t)t.s_doubles[1] + 64) && nd_alloc(s, &s->dinv, (size_t)t.nblocks * 65536) &&
+    // pipelines: SPLPAK_ND_PIPES=2 eliminates the two subtrees below the root side by side (trees of depth >= 3 whose last
+    // Schur passes are fused with the extend-add).  Measured at 64^3 (alternating runs, one box): 235.0 ms per factorisation
+    // with two pipelines against 234.9 with one -- the 20 ms without any matrix-core kernel in flight (rocprofv3 trace) shrink,
+    // but every Schur launch is half as large and the total stays at what 1.1e13 flop take at the power-limited rate.
+    // One pipeline is the default.
+    s->fused = std::getenv("SPLPAK_ND_NO_FUSE") == nullptr;
+    s->npipe = (t.maxdepth >= 3 && s->fused && std::getenv("SPLPAK_ND_PIPES") && atoi(std::getenv("SPLPAK_ND_PIPES")) == 2) ? 2 : 1;
+    s->pipe_of.assign(t.fr.size(), 0);
+    if (s->npipe == 2)
+        for (int id = (int)t.fr.size() - 1; id >= 0; --id) {          // parents have larger ids than their children (postorder)
+            const NdFront &f = t.fr[(size_t)id];
+            if (f.parent < 0) s->pipe_of[(size_t)id] = 0;
+            else if (t.fr[(size_t)f.parent].parent < 0) s->pipe_of[(size_t)id] = f.slot;
+            else s->pipe_of[(size_t)id] = s->pipe_of[(size_t)f.parent];
+        }
+    const int nstage = s->npipe * nd;
+    s->stage_ids.assign((size_t)nstage, {});
+    s->s_stage_doubles.assign((size_t)nstage, 0);
+    s->soff.assign(t.fr.size(), 0);
+    for (int d = 0; d < nd; ++d)
+        for (int id : t.by_depth[(size_t)d]) {
+            const NdFront &f = t.fr[(size_t)id];
+            const int stg = s->pipe_of[(size_t)id] * nd + d;
+            s->stage_ids[(size_t)stg].push_back(id);
+            s->soff[(size_t)id] = s->s_stage_doubles[(size_t)stg];
+            s->s_stage_doubles[(size_t)stg] += f.lds * (long long)f.hp;
+        }
+    for (int p = 0; p < s->npipe; ++p)
+        for (int d = 0; d < nd; ++d)
+            s->sarp_doubles[p][d & 1] = std::max(s->sarp_doubles[p][d & 1], s->s_stage_doubles[(size_t)(p * nd + d)]);
+    bool ok = nd_alloc(s, &s->factor, (size_t)t.factor_doubles + 64) && nd_alloc(s, &s->sarp[0][0], (size_t)s->sarp_doubles[0][0] + 64) &&
+              nd_alloc(s, &s->sarp[0][1], (size_t)s->sarp_doubles[0][1] + 64) && nd_alloc(s, &s->sarp[1][0], (size_t)s->sarp_doubles[1][0] + 64) &&
+              nd_alloc(s, &s->sarp[1][1], (size_t)s->sarp_doubles[1][1] + 64) && nd_alloc(s, &s->dinv, (size_t)t.nblocks * 65536) &&
               nd_alloc(s, &s->dinvt, (size_t)t.nblocks * 65536) && nd_alloc(s, &s->inv16, (size_t)t.nblocks * 4096) &&
               nd_alloc(s, &s->V, (size_t)t.vec_doubles) && nd_alloc(s, &s->Y, (size_t)t.vec_doubles) &&
               nd_alloc(s, &s->part, (size_t)(s->part_cap = t.vec_doubles / 4 + 256LL * (long long)t.fr.size() + 4096));
@@ -1208,9 +1355,14 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     (void)hipStreamCreateWithPriority(&s->sP, hipStreamNonBlocking, hi);
     (void)hipStreamCreateWithFlags(&s->sU, hipStreamNonBlocking);
-    for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone, &s->evR0}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
+    if (s->npipe == 2) (void)hipStreamCreateWithPriority(&s->sP2, hipStreamNonBlocking, hi);
+    for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone, &s->evR0, &s->evR02}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
+    for (int p = 0; p < 2; ++p) {
+        s->evF[p].assign((size_t)nd + 1, nullptr);
+        for (int d = 0; d <= nd; ++d) (void)hipEventCreateWithFlags(&s->evF[p][(size_t)d], hipEventDisableTiming);
+    }
     // item queues of the update launches (two per step at most)
-    s->nqueues = 3 * t.nblocks + 16;
+    s->nqueues = 8 * t.nblocks + 64;
     if (!nd_alloc(s, &s->queues, (size_t)2 * s->nqueues) || !nd_alloc(s, &s->resmap, (size_t)128)) return SPLPAK_E_NOMEM;
     (void)hipMemset(s->resmap, 0, 128 * sizeof(unsigned));
     // A few CUs are left to the diagonal-block factorisations of the upper tree levels: v_mfma_f64 runs on the same
@@ -1257,7 +1409,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     if (factor_doubles) *factor_doubles = t.factor_doubles;
     if (std::getenv("SPLPAK_DEBUG"))
         fprintf(stderr, "[splpak] nested dissection: %zu fronts, depth %d, factor %.2f GB, Schur arenas %.2f GB, %.3e flop, %d reserved CUs\n", t.fr.size(),
-                t.maxdepth, 8e-9 * (double)t.factor_doubles, 8e-9 * (double)(t.s_doubles[0] + t.s_doubles[1]), t.flop, s->nres);
+                t.maxdepth, 8e-9 * (double)t.factor_doubles, 8e-9 * (double)(s->sarp_doubles[0][0] + s->sarp_doubles[0][1] + s->sarp_doubles[1][0] + s->sarp_doubles[1][1]), t.flop, s->nres);
     return 0;
 }
 

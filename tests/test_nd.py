@@ -190,7 +190,8 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
     reserved CUs while the update waves take their items from a queue and step aside there, and the root's panel
     update is split for look-ahead.  The last Schur pass of every front adds its result into the parent itself.  None of that may
     change a bit: the same fit without reserved CUs, without the root look-ahead, with K = 256 Schur passes, with separate
-    extend-add launches and entirely serial gives identical coefficients."""
+    extend-add launches, with the two subtrees below the root as two pipelines (SPLPAK_ND_PIPES=2) and entirely serial gives
+    identical coefficients."""
     from splpak_amd.synth import synth_points
     nd, nod, m = 3, 32, 200000
     x, y, w = synth_points(nd, m)
@@ -198,6 +199,7 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
     ref, e, _, info = _fit_env(inp, {"SPLPAK_ND": "1"})
     assert e == 0 and info[9] < 1e-9
     for env in ({"SPLPAK_NO_PANEL_CU": "1"}, {"SPLPAK_ND_NO_ROOT_LOOKAHEAD": "1"}, {"SPLPAK_ND_KB": "1"}, {"SPLPAK_ND_NO_FUSE": "1"},
+                {"SPLPAK_ND_PIPES": "2"}, {"SPLPAK_ND_PIPES": "2", "SPLPAK_NO_LOOKAHEAD": "1"},
                 {"SPLPAK_ND_NO_FUSE": "1", "SPLPAK_ND_MEMSET": "1", "SPLPAK_ND_KB": "2"},
                 {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_RES_CUS": "3", "SPLPAK_ND_PIN_ROUNDS": "8"}):
         c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1"))
