@@ -489,6 +489,17 @@ def main():
         elapsed = float(t.item())
     value = world * m * args.steps / elapsed
     fact_code, fact_name = plan.factorisation()
+    # the roofline kernel with the chip to itself: one extra fit OUTSIDE the timed region with every launch of the
+    # factorisation on one stream (SPLPAK_NO_LOOKAHEAD, read at every call), so that no chain kernel shares the CUs with it
+    kt_alone = None
+    if world == 1 and not args.no_kernel_timing:
+        os.environ["SPLPAK_NO_LOOKAHEAD"] = "1"
+        try:
+            ierr_a, _ = plan.fit(x, y, w, coef, stream)
+            kt_alone = plan.kernel_timing() if ierr_a == 0 else None
+        finally:
+            os.environ.pop("SPLPAK_NO_LOOKAHEAD", None)
+        ierr, info = plan.fit(x, y, w, coef, stream)          # (the plan's streams and the reported diagnostics: back to the timed form)
 
     # strong scaling beside the weak headline (N > 1): config 3's 1e7 points IN ALL, sharded over the ranks
     strong = None
@@ -669,6 +680,13 @@ def main():
                 "factorisation_tflops": kt_sum["total_flop"] / max(kt_sum["factor_ms"], 1e-9) / 1e9,
                 "factorisation_flop": kt_sum["total_flop"] / args.steps,
             }
+            if kt_alone is not None and kt_alone["syrk_ms"] > 0:
+                al = kt_alone["syrk_flop"] / (kt_alone["syrk_ms"] * 1e-3) / 1e12
+                line["roofline"]["kernel_alone"] = {
+                    "achieved": al, "frac": al / F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": kt_alone["syrk_launches"],
+                    "factor_ms": kt_alone["factor_ms"],
+                    "what": "the same launches in one extra fit outside the timed region with the whole factorisation on ONE stream "
+                            "(SPLPAK_NO_LOOKAHEAD=1): every launch has the chip to itself"}
             if nd_path:
                 line["roofline"]["note"] = ("the panel updates of the chain (nd_syrk_kernel<4,2,false>, K = 256) and the diagonal-block / panel-solve "
                                             "kernels run beside these launches on other streams and share the CUs with them; "

@@ -572,9 +572,10 @@ struct NdState {
     JobTable<DotJob> dot;
     JobTable<BwdJob> bwd;
     JobTable<MapJob> map;
-    std::vector<std::vector<Launch>> l_potrf, l_trsm, l_trsmb, l_upd, l_updr, l_schur, l_mv, l_fwd, l_dot, l_bwd;
+    std::vector<std::vector<Launch>> l_potrf, l_trsm, l_trsmb, l_upd, l_updr, l_updo, l_schur, l_mv, l_fwd, l_dot, l_bwd;
     std::vector<char> lookahead;                   // per depth: no Schur buffers (the root) -> the panel update is split: next block column on the chain, the rest beside it
     JobTable<SyrkJob> updr;
+    JobTable<SyrkJob> updo;                        // outer panel passes: K = 1024 update of the panel columns right of a group of blocks
     JobTable<SyrkJob> fin[2];                      // final Schur passes fused with the extend-add, by child slot
     std::vector<std::vector<Launch>> l_fin[2];
     bool fused = true;                             // SPLPAK_ND_NO_FUSE (read when the plan is created): separate extend-add launches
@@ -660,7 +661,8 @@ bool nd_build_factor_jobs(NdState *s)
 {
     NdTree &t = s->t;
     const int nd = t.maxdepth + 1, nstage = s->npipe * nd;
-    for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_schur}) L->assign((size_t)nstage, {});
+    for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_updo, &s->l_schur}) L->assign((size_t)nstage, {});
+    const bool two_level = std::getenv("SPLPAK_ND_NO_OUTER") == nullptr;
     s->lookahead.assign((size_t)nstage, 0);
     for (int sl = 0; sl < 2; ++sl) { s->l_fin[sl].assign((size_t)nstage, {}); s->l_add[sl].assign((size_t)nstage, Launch()); }
     s->l_zero.assign((size_t)nstage, Launch());
@@ -679,15 +681,17 @@ bool nd_build_factor_jobs(NdState *s)
         const int d = stg % nd;
         int steps = 0;
         for (int id : ids) steps = std::max(steps, t.fr[(size_t)id].nsteps);
-        for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_schur}) (*L)[(size_t)stg].assign((size_t)steps, Launch());
+        for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_updo, &s->l_schur}) (*L)[(size_t)stg].assign((size_t)steps, Launch());
         for (int sl = 0; sl < 2; ++sl) s->l_fin[sl][(size_t)stg].assign((size_t)steps, Launch());
         bool any_schur = false;
         for (int id : ids) any_schur = any_schur || t.fr[(size_t)id].hp > 0;
         const bool la = !any_schur && steps >= 4 && !std::getenv("SPLPAK_ND_NO_ROOT_LOOKAHEAD");
         s->lookahead[(size_t)stg] = la ? 1 : 0;
         for (int k = 0; k < steps; ++k) {
-            Launch lp, lt, ltb, lu, lur, ls, lfin[2];
-            long long tbwg = 0, twg = 0, ui = 0, uri = 0, si = 0;
+            Launch lp, lt, ltb, lu, lur, luo, ls, lfin[2];
+            long long tbwg = 0, twg = 0, ui = 0, uri = 0, uoi = 0, si = 0;
+            double uoflop = 0.0;
+            luo.first = (int)s->updo.host.size();
             long long fi[2] = {0, 0};
             double fflop[2] = {0.0, 0.0}, sflop = 0.0;
             ltb.first = (int)s->trsmb.host.size();
@@ -726,7 +730,33 @@ bool nd_build_factor_jobs(NdState *s)
                     // DIAGONAL BLOCK (4 x 4 tiles) is updated on the chain; the rows below it in that block column (a rectangle
                     // of tiles) and the columns beyond (a trapezoid) are one launch beside the chain
                     const SyrkJob proto{below, below + (long long)256 * f.ld, f.ld, f.ld, 0, 0, 0, 1, 64, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0};
-                    if (!la) {
+                    if (!la && two_level) {
+                        // TWO-LEVEL blocking of the panel (round 3): block k updates only the columns of its own group of
+                        // schur_kb blocks here (K = 256); the columns beyond the group receive all of the group's blocks in ONE
+                        // pass of K = 256 kb when its last block is solved -- the same sums in the same order (the accumulators
+                        // start as the tile and subtract block after block), a quarter of the read-modify-writes, and launches
+                        // that run at the rate of the Schur passes instead of 34 TFLOP/s (rocprofv3, 64^3)
+                        int pg0 = 0, pgend = 0;
+                        group_of(k, f.nsteps, pg0, pgend);
+                        const int nc_in = std::min(nc, (pgend - k) * 4);
+                        if (nc_in > 0) {
+                            SyrkJob a = proto;
+                            a.nc = nc_in; a.nr = nr; a.item0 = (int)ui;
+                            s->upd.host.push_back(a);
+                            ui += trapezoid_items(nc_in, nr);
+                            ++lu.count;
+                        }
+                        if (k == pgend) {             // nc > 0: columns remain beyond the group
+                            SyrkJob o = proto;
+                            o.P = panel + (long long)(k + 1) * 256 + (long long)pg0 * 256 * f.ld;
+                            o.kb = k - pg0 + 1;
+                            o.nc = nc; o.nr = nr; o.item0 = (int)uoi;
+                            s->updo.host.push_back(o);
+                            uoi += trapezoid_items(nc, nr);
+                            uoflop += 2.0 * 64 * 64 * 256.0 * o.kb * (double)trapezoid_items(nc, nr);
+                            ++luo.count;
+                        }
+                    } else if (!la) {
                         SyrkJob a = proto;
                         a.nc = nc; a.nr = nr; a.item0 = (int)ui;
                         s->upd.host.push_back(a);
@@ -786,7 +816,7 @@ bool nd_build_factor_jobs(NdState *s)
                     }
                 }
             }
-            if (twg > 0x7fffffffLL || ui > 0x7fffffffLL || si > 0x7fffffffLL || uri > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+            if (twg > 0x7fffffffLL || ui > 0x7fffffffLL || si > 0x7fffffffLL || uri > 0x7fffffffLL || uoi > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
             lp.grid = (unsigned)lp.count;
             lt.grid = (unsigned)twg;
             ltb.grid = (unsigned)tbwg;
@@ -794,6 +824,8 @@ bool nd_build_factor_jobs(NdState *s)
             lu.flop = 2.0 * 64 * 64 * 256 * (double)ui;
             lur.grid = (unsigned)uri;
             lur.flop = 2.0 * 64 * 64 * 256 * (double)uri;
+            luo.grid = (unsigned)uoi;
+            luo.flop = uoflop;
             ls.grid = (unsigned)si;
             ls.flop = sflop;
             // sentinels for the job search (first field of the element after the last job)
@@ -804,6 +836,8 @@ bool nd_build_factor_jobs(NdState *s)
             if (lu.count) s->upd.host.push_back(e);
             e.item0 = (int)uri;
             if (lur.count) s->updr.host.push_back(e);
+            e.item0 = (int)uoi;
+            if (luo.count) s->updo.host.push_back(e);
             e.item0 = (int)si;
             if (ls.count) s->schur.host.push_back(e);
             for (int sl = 0; sl < 2; ++sl) {
@@ -819,6 +853,7 @@ bool nd_build_factor_jobs(NdState *s)
             s->l_trsmb[(size_t)stg][(size_t)k] = ltb;
             s->l_upd[(size_t)stg][(size_t)k] = lu;
             s->l_updr[(size_t)stg][(size_t)k] = lur;
+            s->l_updo[(size_t)stg][(size_t)k] = luo;
             s->l_schur[(size_t)stg][(size_t)k] = ls;
         }
         // lower-triangle tiles of the stage's Schur buffers
@@ -1106,6 +1141,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             (void)hipStreamWaitEvent(sU, (*evTp[q])[(size_t)k], 0);
         }
         launch_syrk(s, s->upd, lu, sC, stats, timing, false, pinned, qnext);
+        launch_syrk(s, s->updo, s->l_updo[(size_t)stg][(size_t)k], sC, stats, timing, false, pinned, qnext);     // the group's outer panel pass
         launch_syrk(s, s->schur, ls, sU, stats, timing, true, pinned, qnext);
         launch_syrk(s, s->fin[0], lf0, sU, stats, timing, true, pinned, qnext);      // final passes, fused with the extend-add:
         launch_syrk(s, s->fin[1], lf1, sU, stats, timing, true, pinned, qnext);      // children of slot 0, then of slot 1
@@ -1342,7 +1378,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
          nd_upload(s, &s->fdev, fdev);
     if (!ok) return SPLPAK_E_NOMEM;
     if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
-    ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->trsmb.dev, s->trsmb.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) && nd_upload(s, &s->fin[0].dev, s->fin[0].host) &&
+    ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->trsmb.dev, s->trsmb.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) && nd_upload(s, &s->updo.dev, s->updo.host) && nd_upload(s, &s->fin[0].dev, s->fin[0].host) &&
          nd_upload(s, &s->fin[1].dev, s->fin[1].host) &&
          nd_upload(s, &s->schur.dev, s->schur.host) && nd_upload(s, &s->trinv.dev, s->trinv.host) && nd_upload(s, &s->add.dev, s->add.host) && nd_upload(s, &s->zero.dev, s->zero.host) &&
          nd_upload(s, &s->mv.dev, s->mv.host) && nd_upload(s, &s->fwd.dev, s->fwd.host) && nd_upload(s, &s->dot.dev, s->dot.host) &&
