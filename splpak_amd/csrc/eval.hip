@@ -13,6 +13,7 @@
 // path sorts large batches by grid region and gathers from LDS (see below).
 #include "basis.hpp"
 #include "kernels.hpp"
+#include <type_traits>
 #include <cstdlib>
 
 namespace splpak {
@@ -152,6 +153,46 @@ constexpr int EVAL_QPW = 2048;         // queries per workgroup in pass C
 
 struct Regions { int nreg[MAXD]; int nbins; };
 
+// A sorted query is ONE record of D + 1 doubles: its coordinates and, in the low half of the last word, its position in the
+// caller's batch (round 3: coordinate planes + a separate permutation made pass B issue D + 1 scattered 8-byte stores per
+// query -- 99 B of HBM writes for the 36-byte payload of a 4-D query, runs of 1.6 queries per workgroup and region; a record
+// is one 32- / 40-byte store and one load in pass C).
+typedef double rec2u_t __attribute__((ext_vector_type(2), aligned(8)));     // 40-byte records: 8-byte aligned pieces
+typedef double rec2a_t __attribute__((ext_vector_type(2), aligned(16)));    // 32-byte records: aligned 16-byte pieces
+template <int D>
+__device__ inline void store_record(double *__restrict__ dst, const double (&x)[D], int idx)
+{
+    using rec2_t = typename std::conditional<(D + 1) % 2 == 0, rec2a_t, rec2u_t>::type;
+    double v[D + 1];
+#pragma unroll
+    for (int d = 0; d < D; ++d) v[d] = x[d];
+    v[D] = __longlong_as_double((long long)idx);
+    constexpr int N = D + 1;
+#pragma unroll
+    for (int k = 0; k + 1 < N; k += 2) {
+        rec2_t t;
+        t[0] = v[k]; t[1] = v[k + 1];
+        *reinterpret_cast<rec2_t *>(dst + k) = t;
+    }
+    if constexpr (N % 2 == 1) dst[N - 1] = v[N - 1];
+}
+template <int D>
+__device__ inline int load_record(const double *__restrict__ src, double (&x)[D])
+{
+    constexpr int N = D + 1;
+    using rec2_t = typename std::conditional<(D + 1) % 2 == 0, rec2a_t, rec2u_t>::type;
+    double v[N];
+#pragma unroll
+    for (int k = 0; k + 1 < N; k += 2) {
+        const rec2_t t = *reinterpret_cast<const rec2_t *>(src + k);
+        v[k] = t[0]; v[k + 1] = t[1];
+    }
+    if constexpr (N % 2 == 1) v[N - 1] = src[N - 1];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = v[d];
+    return (int)__double_as_longlong(v[D]);
+}
+
 template <int D>
 __device__ inline int region_of(const Grid &g, const Regions &rg, const double *__restrict__ x)
 {
@@ -288,7 +329,7 @@ bin_scan_kernel(int nbins, const int *__restrict__ hist, int *__restrict__ off, 
 template <int D, typename T>
 __global__ void __launch_bounds__(256)
 bin_scatter_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq,
-                   const int *__restrict__ wgbase, int ldw, double *__restrict__ xs, long long ldp, int *__restrict__ perm)
+                   const int *__restrict__ wgbase, int ldw, double *__restrict__ xs)
 {
     constexpr int QPT = ScatterShape<D>::QPT, QPW = 256 * QPT;
     __shared__ double sx[QPW * D];
@@ -348,13 +389,13 @@ bin_scatter_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq
         srid[lp] = (unsigned short)rid[j];
     }
     __syncthreads();
-    // copy-out: the sorted image goes to D coordinate planes (xs[d*ldp + position]) and the permutation;
-    // consecutive lanes walk a region's run on consecutive addresses in every plane
+    // copy-out: consecutive lanes walk a region's run, one record each (consecutive 32- / 40-byte pieces)
     for (int lp = threadIdx.x; lp < total; lp += 256) {
         const long long gpos = lp + lbase[srid[lp]];
+        double x[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) xs[(long long)d * ldp + gpos] = sx[d * QPW + lp];
-        perm[gpos] = sidx[lp];
+        for (int d = 0; d < D; ++d) x[d] = sx[d * QPW + lp];
+        store_record<D>(xs + gpos * (D + 1), x, sidx[lp]);
     }
 }
 
@@ -364,7 +405,7 @@ constexpr int EVAL_WG = 1024;          // threads per workgroup in pass C (value
 template <int D, bool VAL, typename T>
 __global__ void __launch_bounds__(EVAL_WG)
 eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
-                   const double *__restrict__ xs, long long ldp, const int *__restrict__ perm,
+                   const double *__restrict__ xs,
                    const int *__restrict__ off, const int *__restrict__ wgoff, T *__restrict__ out)
 {
     constexpr int TILE_ELEMS = tile_elems<D>();
@@ -410,22 +451,14 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
     int j = qb + threadIdx.x;
     double xn[D];
     int pn = 0;
-    if (j < qe) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) xn[d] = xs[(long long)d * ldp + j];
-        pn = perm[j];
-    }
+    if (j < qe) pn = load_record<D>(xs + (long long)j * (D + 1), xn);
     while (j < qe) {
         double x[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) x[d] = xn[d];
         const int p = pn;
         const int jn = j + EVAL_WG;
-        if (jn < qe) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) xn[d] = xs[(long long)d * ldp + jn];
-            pn = perm[jn];
-        }
+        if (jn < qe) pn = load_record<D>(xs + (long long)jn * (D + 1), xn);
         double b[D][4];
         int base = 0, m = 1;
 #pragma unroll
@@ -449,14 +482,13 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
 // pass C of the fused value / gradient / Hessian evaluation (defined with eval_derivs_kernel below)
 template <int D, int ORDER>
 __global__ void eval_derivs_binned_kernel(Grid g, Regions rg, const double *__restrict__ coef, const double *__restrict__ xs,
-                                          long long ldp, const int *__restrict__ perm, const int *__restrict__ off,
+                                          const int *__restrict__ off,
                                           const int *__restrict__ wgoff, double *__restrict__ out, int ldout);
 
 // scratch of the binned path: per thread, grown on demand, released by splpak_shutdown
 namespace {
 struct EvalScratch {
-    double *xs = nullptr;
-    int *perm = nullptr;
+    double *xs = nullptr;         // sorted records of a chunk: (capd + 1) doubles each
     int *ints = nullptr;          // hist | off | cursor | wgoff
     int *cnt = nullptr;           // per-workgroup region counts / run bases
     long long cap = 0;            // queries per chunk the buffers hold
@@ -474,7 +506,6 @@ void eval_scratch_shutdown()
 {
     EvalScratch &s = g_scratch;
     if (s.xs) (void)hipFree(s.xs);
-    if (s.perm) (void)hipFree(s.perm);
     if (s.ints) (void)hipFree(s.ints);
     if (s.cnt) (void)hipFree(s.cnt);
     if (s.last) (void)hipEventDestroy(s.last);
@@ -511,12 +542,11 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
     const long long cnt_need = (long long)ldw * rg.nbins + (long long)(ldw / BIN_ROWS + 2) * rg.nbins;     // count matrix + chunk sums
     if (s.dev != dev || s.cap < chunk || s.capd < D || s.cnt_ints < cnt_need) {
         eval_scratch_shutdown();
-        hipError_t e = hipMalloc(&s.xs, sizeof(double) * (size_t)chunk * D);
+        hipError_t e = hipMalloc(&s.xs, sizeof(double) * (size_t)chunk * (D + 1));
         if (e != hipSuccess && release_cached_plan_for_memory()) {      // the one-shot fit's cached plan is in the way
             (void)hipGetLastError();
-            e = hipMalloc(&s.xs, sizeof(double) * (size_t)chunk * D);
+            e = hipMalloc(&s.xs, sizeof(double) * (size_t)chunk * (D + 1));
         }
-        if (e == hipSuccess) e = hipMalloc(&s.perm, sizeof(int) * (size_t)chunk);
         if (e == hipSuccess) e = hipMalloc(&s.ints, sizeof(int) * (4 * BIN_MAX + 8));
         // per-workgroup region counts of pass A -> run bases of pass B: [workgroups of a chunk][regions]
         if (e == hipSuccess) e = hipMalloc(&s.cnt, sizeof(int) * (size_t)cnt_need);
@@ -542,22 +572,22 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
         hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, st, rg.nbins, (const int *)hist, off, cursor, wgoff);
         hipLaunchKernelGGL(bin_wgbase_kernel, dim3(nbg, nchunk), dim3(256), 0, st, (int)nbs, rg.nbins, (const int *)off, (const int *)part, s.cnt);
         hipLaunchKernelGGL((bin_scatter_kernel<D, T>), dim3(nbs), dim3(256), 2 * sizeof(int) * rg.nbins, st, g, rg, n, xc, ldxq,
-                           (const int *)s.cnt, ldw, s.xs, s.cap, s.perm);
+                           (const int *)s.cnt, ldw, s.xs);
         const unsigned nw = (unsigned)(n / EVAL_QPW + rg.nbins + 1);
         if constexpr (sizeof(T) == 8) {
             if (order == 1)
-                hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 1>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs, s.cap,
-                                   (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
+                hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 1>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs,
+                                   (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
             else if (order == 2)
-                hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 2>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs, s.cap,
-                                   (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
+                hipLaunchKernelGGL((eval_derivs_binned_kernel<D, 2>), dim3(nw), dim3(256), 0, st, g, rg, coef, (const double *)s.xs,
+                                   (const int *)off, (const int *)wgoff, out + c0 * ldout, ldout);
         }
         if (order == 0 && value_only)
             hipLaunchKernelGGL((eval_binned_kernel<D, true, T>), dim3(nw), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
-                               (const double *)s.xs, s.cap, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
+                               (const double *)s.xs, (const int *)off, (const int *)wgoff, out + c0);
         else if (order == 0)
             hipLaunchKernelGGL((eval_binned_kernel<D, false, T>), dim3(nw), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
-                               (const double *)s.xs, s.cap, (const int *)s.perm, (const int *)off, (const int *)wgoff, out + c0);
+                               (const double *)s.xs, (const int *)off, (const int *)wgoff, out + c0);
     }
     (void)hipEventRecord(s.last, st);
     return hipGetLastError();
@@ -702,7 +732,7 @@ eval_derivs_kernel(Grid g, long long nq, const T *__restrict__ xq, int ldxq, con
 template <int D, int ORDER>
 __global__ void __launch_bounds__(256)
 eval_derivs_binned_kernel(Grid g, Regions rg, const double *__restrict__ coef, const double *__restrict__ xs,
-                          long long ldp, const int *__restrict__ perm, const int *__restrict__ off,
+                          const int *__restrict__ off,
                           const int *__restrict__ wgoff, double *__restrict__ out, int ldout)
 {
     constexpr int NOUT = 1 + D + (ORDER == 2 ? D * (D + 1) / 2 : 0);
@@ -751,9 +781,11 @@ eval_derivs_binned_kernel(Grid g, Regions rg, const double *__restrict__ coef, c
     for (int j = qb + threadIdx.x; j < qe; j += 256) {
         double b[ORDER + 1][D][4];
         int base = 0;
+        double xr[D];
+        const long long p = load_record<D>(xs + (long long)j * (D + 1), xr);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const double x = xs[(long long)d * ldp + j];
+            const double x = xr[d];
             int ws = 0;
 #pragma unroll
             for (int aa = 0; aa <= ORDER; ++aa) ws = window_table(g, d, x, aa, b[aa][d]);
@@ -768,7 +800,6 @@ eval_derivs_binned_kernel(Grid g, Regions rg, const double *__restrict__ coef, c
             lds_cvd q = (lds_cvd)tile + o;
             c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[3];
         }, acc);
-        const long long p = perm[j];
 #pragma unroll
         for (int jj = 0; jj < NOUT; ++jj) out[p * ldout + jj] = acc[jj];
     }

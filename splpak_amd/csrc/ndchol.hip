@@ -147,11 +147,16 @@ nd_whoami_kernel(unsigned *__restrict__ map)
 // bench.py, the panel updates (K = 256, on the chain) are listed separately by the profilers.
 // queue != NULL: items are taken from an atomic counter and a wave that finds itself on a CU reserved for the
 // diagonal-block factorisations (resmap) steps aside -- the launch carries `margin` spare waves for that.
-template <int SD, int WPS, bool SCHUR>
+// SPLIT = 1: a wave computes a whole 64 x 64 item.  SPLIT = 4 / 16: four / sixteen waves share an item (one 16-column slice of
+// it each, or one 16 x 16 tile each) -- for launches of a few hundred items, which otherwise leave most of the chip's 1 024
+// SIMDs idle while one wave per item works through its 1 024 MFMAs of 64 cycles each (27 us per K = 256, measured 30-57 us
+// per launch at BASELINE config 2).  Every element sees the same sequence of operations: bitwise the same result.
+template <int SD, int WPS, bool SCHUR, int SPLIT = 1>
 __global__ void __launch_bounds__(64, WPS)
 nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int margin, const unsigned *__restrict__ resmap,
                int *__restrict__ queue)
 {
+    constexpr int M = SPLIT == 1 ? 4 : 1, N = SPLIT == 16 ? 1 : 4;
     int b = blockIdx.x;
     if (queue) {
         const unsigned ci = nd_cu_index();
@@ -169,6 +174,9 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
         b = __builtin_amdgcn_readfirstlane(b);
     }
     if (b >= nitems) return;
+    const int sub = SPLIT == 1 ? 0 : b % SPLIT;
+    if (SPLIT > 1) b /= SPLIT;
+    const int m0 = SPLIT == 1 ? 0 : (SPLIT == 4 ? sub : sub >> 2), n0 = SPLIT == 16 ? (sub & 3) : 0;
     const int ji = find_job(jobs, njobs, b, [](const SyrkJob &t) { return t.item0; });
     const SyrkJob j = jobs[ji];
     int tj, ti;
@@ -180,27 +188,27 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
         trapezoid_decode(b - j.item0, j.nr, tj, ti);
     if (tj >= j.nc || ti >= j.nr) return;
     const bool diag = ti == tj;
+    if (SPLIT == 16 && diag && n0 < m0) return;      // a 16 x 16 tile above the diagonal
     const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
-    const double *__restrict__ pJ = j.P + (long long)(tj * 64 + l15) + (long long)q * j.ldp;
-    const double *__restrict__ pI = j.P + (long long)(ti * 64 + l15) + (long long)q * j.ldp;
+    const double *__restrict__ pJ = j.P + (long long)(tj * 64 + 16 * m0 + l15) + (long long)q * j.ldp;
+    const double *__restrict__ pI = j.P + (long long)(ti * 64 + 16 * n0 + l15) + (long long)q * j.ldp;
     double *__restrict__ C = j.C + (long long)(ti * 64) + (long long)(tj * 64) * j.ldc;
     const long long ldp = j.ldp, ldc = j.ldc;
-    d4_t acc[4][4];
+    d4_t acc[M][N];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < M; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < N; ++n)
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                acc[m][n][v] = (SCHUR && j.zinit) ? 0.0 : __builtin_nontemporal_load(&C[(n * 16 + l15) + (long long)(m * 16 + q + 4 * v) * ldc]);
-    double qa[SD][4], qb[SD][4];
+                acc[m][n][v] = (SCHUR && j.zinit) ? 0.0 : __builtin_nontemporal_load(&C[((n0 + n) * 16 + l15) + (long long)((m0 + m) * 16 + q + 4 * v) * ldc]);
+    double qa[SD][M], qb[SD][N];
     auto fetch = [&](int slot, int step) {
         const long long off = (long long)(4 * step) * ldp;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            qa[slot][m] = -pJ[off + 16 * m];
-            qb[slot][m] = pI[off + 16 * m];
-        }
+        for (int m = 0; m < M; ++m) qa[slot][m] = -pJ[off + 16 * m];
+#pragma unroll
+        for (int n = 0; n < N; ++n) qb[slot][n] = pI[off + 16 * n];
     };
 #pragma unroll
     for (int d = 0; d < SD; ++d) fetch(d, d);
@@ -216,9 +224,9 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
 #pragma unroll
             for (int d = 0; d < SD; ++d) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < M; ++m)
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
+                    for (int n = 0; n < N; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
                 if (ks + d + SD < NSTEP) fetch(d, base + ks + d + SD);
                 else {                               // the first steps of the next block (clamped: re-reads in the last one)
@@ -233,24 +241,24 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
         // the parent's entries of THIS child are touched by no other wave of the launch (the map is injective, the
         // launch holds children of one slot only), so plain read-modify-writes are safe and the order of the sums is
         // fixed: child of slot 0, then child of slot 1
-        int prow[4];
+        int prow[N];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int r = ti * 64 + n * 16 + l15;
+        for (int n = 0; n < N; ++n) {
+            const int r = ti * 64 + (n0 + n) * 16 + l15;
             prow[n] = r < j.h ? j.pm[r] : -1;
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < M; ++m)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int cc = m * 16 + q + 4 * v, c = tj * 64 + cc;
+                const int cc = (m0 + m) * 16 + q + 4 * v, c = tj * 64 + cc;
                 const int pcol = c < j.h ? j.pm[c] : -1;
                 if (pcol < 0) continue;
                 double *__restrict__ colp = pcol < j.wpp ? j.Pp + (long long)pcol * j.ldpp
                                                          : j.Sp + (long long)(pcol - j.wpp) * j.ldsp - j.wpp;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int rr = n * 16 + l15;
+                for (int n = 0; n < N; ++n) {
+                    const int rr = (n0 + n) * 16 + l15;
                     if (prow[n] < 0 || (diag && rr < cc)) continue;
                     colp[prow[n]] += acc[m][n][v];
                 }
@@ -258,13 +266,13 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
         return;
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < M; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int r = n * 16 + l15;
+        for (int n = 0; n < N; ++n) {
+            const int r = (n0 + n) * 16 + l15;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int c = m * 16 + q + 4 * v;
+                const int c = (m0 + m) * 16 + q + 4 * v;
                 if (!diag || r >= c) __builtin_nontemporal_store(acc[m][n][v], &C[r + (long long)c * ldc]);
             }
         }
@@ -589,6 +597,7 @@ struct NdState {
     hipEvent_t evR02 = nullptr;
     unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
     int nres = 0;
+    int small_grid = 1024;                         // update launches of at most this many items are split over 4 waves per item, a quarter of it: 16
     int *queues = nullptr;                         // [nqueues][2] item counters of the update launches of one factorisation
     int nqueues = 0;
     hipEvent_t evR0 = nullptr;
@@ -1034,12 +1043,24 @@ void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipS
     // SD = 4 k-steps of operand look-ahead, two waves per SIMD (244 registers): measured at 64^3 against the 16-deep
     // queue / one wave per SIMD form the band's bulk update uses -- 257.6 against 282.2 ms per factorisation, because
     // the queue is carried across the block loop of a K = 1024 pass and then has to live in registers (256 + 180)
-    if (schur)
-        hipExtLaunchKernelGGL((nd_syrk_kernel<4, 2, true>), dim3(l.grid + (unsigned)margin), dim3(64), 0, st, a, b, 0, jobs, l.count,
-                              (int)l.grid, margin, (const unsigned *)s->resmap, queue);
-    else
-        hipLaunchKernelGGL((nd_syrk_kernel<4, 2, false>), dim3(l.grid + (unsigned)margin), dim3(64), 0, st, jobs, l.count, (int)l.grid,
-                           margin, (const unsigned *)s->resmap, queue);
+    // Launches of a few hundred items leave most SIMDs idle while one wave per item works through its MFMAs: they are split
+    // over 4 / 16 waves per item (SPLIT above; same arithmetic order, bitwise the same result)
+    const int split = (int)l.grid * 4 <= s->small_grid ? 16 : ((int)l.grid <= s->small_grid ? 4 : 1);
+    const dim3 grid(l.grid * (unsigned)split + (unsigned)margin);
+    const int nit = (int)l.grid * split;
+#define ND_SYRK_GO(SCH, SPL)                                                                                                   \
+    do {                                                                                                                       \
+        if (SCH) hipExtLaunchKernelGGL((nd_syrk_kernel<4, 2, SCH, SPL>), grid, dim3(64), 0, st, a, b, 0, jobs, l.count, nit, margin,  \
+                                       (const unsigned *)s->resmap, queue);                                                    \
+        else hipLaunchKernelGGL((nd_syrk_kernel<4, 2, SCH, SPL>), grid, dim3(64), 0, st, jobs, l.count, nit, margin,            \
+                                (const unsigned *)s->resmap, queue);                                                           \
+    } while (0)
+    if (schur) {
+        if (split == 16) ND_SYRK_GO(true, 16); else if (split == 4) ND_SYRK_GO(true, 4); else ND_SYRK_GO(true, 1);
+    } else {
+        if (split == 16) ND_SYRK_GO(false, 16); else if (split == 4) ND_SYRK_GO(false, 4); else ND_SYRK_GO(false, 1);
+    }
+#undef ND_SYRK_GO
 }
 
 hipError_t nd_assemble(splpak_plan *p, hipStream_t st, void *user)
@@ -1399,6 +1420,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     }
     // item queues of the update launches (two per step at most)
     s->nqueues = 8 * t.nblocks + 64;
+    if (const char *e = std::getenv("SPLPAK_ND_SMALL_GRID")) s->small_grid = atoi(e);
     if (!nd_alloc(s, &s->queues, (size_t)2 * s->nqueues) || !nd_alloc(s, &s->resmap, (size_t)128)) return SPLPAK_E_NOMEM;
     (void)hipMemset(s->resmap, 0, 128 * sizeof(unsigned));
     // A few CUs are left to the diagonal-block factorisations of the upper tree levels: v_mfma_f64 runs on the same
