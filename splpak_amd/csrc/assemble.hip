@@ -504,12 +504,10 @@ hist_total_kernel(const double *__restrict__ hist, int n, double *__restrict__ s
 
 template <int D>
 struct ResCfg;
-template <> struct ResCfg<1> { static constexpr int NB = 4,   NT = 64,  PCH = 64; };
-template <> struct ResCfg<2> { static constexpr int NB = 16,  NT = 256, PCH = 128; };
-template <> struct ResCfg<3> { static constexpr int NB = 64,  NT = 256, PCH = 64; };
 template <> struct ResCfg<4> { static constexpr int NB = 256, NT = 256, PCH = 16; };
 
-// per-cell share of rho = A^T W (W y - W A x): rcell[cell][c] (plain stores; empty cells are skipped by the gather)
+// per-cell share of rho = A^T W (W y - W A x): rcell[cell][c] (plain stores; empty cells are skipped by the gather).
+// Workgroup per cell: the 4-D form (256 window functions); 1-D .. 3-D grids use residual_wave_kernel below.
 template <int D>
 __global__ void __launch_bounds__(ResCfg<D>::NT)
 residual_block_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
@@ -559,6 +557,99 @@ residual_block_kernel(Grid g, const int *__restrict__ offset, const double *__re
             for (int wv = 0; wv < NT / 64; ++wv) t += wt[wv];
             ssq[cell] = t;
         }
+    }
+}
+
+// The same per-cell share for 1-D .. 3-D grids (NB = 4^D <= 64), ONE WAVE per cell, four cells per workgroup, no
+// workgroup barriers (round 3: the workgroup-per-cell form above spent 1.67 ms per pass at C3 -- 227 000 workgroups of 256
+// threads for 44 points each, staged through five __syncthreads -- for 0.4 GB of points; four passes per fit).
+//   phase 1  lane = point:  the D window tables (parked in the wave's LDS slice), t = sum over the window in factorised form
+//            against the cell's 4^D coefficients (LDS broadcast reads), e = w y - w t
+//   phase 2  lane = (window function c, point group):  racc_c += prod_d table_d[c_d] * (w e)  over the points
+// Sums in a fixed order: reproducible bits.
+template <int D>
+__global__ void __launch_bounds__(256)
+residual_wave_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
+                     const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
+                     const double *__restrict__ xvec, double *__restrict__ rcell, double *__restrict__ ssq)
+{
+    static_assert(D >= 1 && D <= 3, "one lane per window function");
+    constexpr int NB = 1 << (2 * D), G = 64 / NB, PCH = 64, LDT = 4 * D + 1;
+    __shared__ double s_tab[4][PCH * LDT];
+    __shared__ double s_we[4][PCH];
+    __shared__ double s_x[4][NB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * 4 + wave;
+    if (cell >= g.ncell) return;
+    const long long beg = offset[cell], end = offset[cell + 1];
+    if (beg == end) return;
+    double *tab = s_tab[wave], *we = s_we[wave], *xl = s_x[wave];
+    int colbase = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) colbase += ((cell / g.cellstride[d]) % g.cells[d]) * g.colstride[d];
+    if (lane < NB) xl[lane] = xvec[local_col<D>(g, colbase, lane)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int c = lane % NB, grp = lane / NB;
+    double racc = 0.0, e2 = 0.0;
+    for (long long p0 = beg; p0 < end; p0 += PCH) {
+        const int np = (int)((end - p0 < PCH) ? (end - p0) : PCH);
+        if (lane < np) {
+            double b[D][4];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                window_table_value(g, d, xs[(long long)d * cap + p0 + lane], b[d]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tab[lane * LDT + 4 * d + k] = b[d][k];
+            }
+            double t = 0.0;
+            if constexpr (D == 1) {
+#pragma unroll
+                for (int k0 = 0; k0 < 4; ++k0) t = fma(b[0][k0], xl[k0], t);
+            } else if constexpr (D == 2) {
+#pragma unroll
+                for (int k1 = 0; k1 < 4; ++k1) {
+                    double r = 0.0;
+#pragma unroll
+                    for (int k0 = 0; k0 < 4; ++k0) r = fma(b[0][k0], xl[k0 + 4 * k1], r);
+                    t = fma(b[1][k1], r, t);
+                }
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    double r2 = 0.0;
+#pragma unroll
+                    for (int k1 = 0; k1 < 4; ++k1) {
+                        double r = 0.0;
+#pragma unroll
+                        for (int k0 = 0; k0 < 4; ++k0) r = fma(b[0][k0], xl[k0 + 4 * k1 + 16 * k2], r);
+                        r2 = fma(b[1][k1], r, r2);
+                    }
+                    t = fma(b[2][k2], r2, t);
+                }
+            }
+            const double wv = ws[p0 + lane];
+            const double e = wv * ys[p0 + lane] - wv * t;         // row residual  w y - (w b) . x
+            we[lane] = wv * e;
+            e2 = fma(e, e, e2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int p = grp; p < np; p += G) {
+            double prod = tab[p * LDT + (c & 3)];
+#pragma unroll
+            for (int d = 1; d < D; ++d) prod *= tab[p * LDT + 4 * d + ((c >> (2 * d)) & 3)];
+            racc = fma(prod, we[p], racc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int o = NB; o < 64; o <<= 1) racc += __shfl_xor(racc, o, 64);
+    if (lane < NB) rcell[(long long)cell * NB + lane] = racc;
+    if (ssq) {
+        e2 = wave_sum(e2);
+        if (lane == 0) ssq[cell] = e2;
     }
 }
 
@@ -1047,6 +1138,20 @@ sum_fixed_kernel(const double *__restrict__ v, long long n, double *__restrict__
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+template <int D>
+static void residual_cells(const Grid &g, const SortScratch &s, const double *xvec, double *rcell, double *e2c, hipStream_t st)
+{
+    if constexpr (D <= 3) {
+        hipLaunchKernelGGL(residual_wave_kernel<D>, dim3((unsigned)((g.ncell + 3) / 4)), dim3(256), 0, st, g,
+                           (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
+                           s.cap, xvec, rcell, e2c);
+    } else {
+        hipLaunchKernelGGL(residual_block_kernel<D>, dim3((unsigned)g.ncell), dim3(ResCfg<D>::NT), 0, st, g,
+                           (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
+                           s.cap, xvec, rcell, e2c);
+    }
+}
+
 hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rcell,
                            const double *dcw, const unsigned char *spf, bool constraints,
                            double *tbuf, double *rho, double *ssq, double *e2buf, hipStream_t st)
@@ -1060,10 +1165,7 @@ hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xv
         if (e != hipSuccess) return e;
     }
     DISPATCH_D(g.ndim, {
-        using C = ResCfg<D>;
-        hipLaunchKernelGGL(residual_block_kernel<D>, dim3((unsigned)g.ncell), dim3(C::NT), 0, st, g,
-                           (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
-                           s.cap, xvec, rcell, e2c);
+        residual_cells<D>(g, s, xvec, rcell, e2c, st);
         if (constraints)
             hipLaunchKernelGGL(constraint_dots_kernel<D>, gn, bl, 0, st, g, dcw, spf, xvec, tbuf, e2n);
         hipLaunchKernelGGL(rho_gather_kernel<D>, dim3((unsigned)((g.ncol + 255) / 256)), bl, 0, st, g,
