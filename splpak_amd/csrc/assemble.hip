@@ -15,7 +15,7 @@
 // scattered 8-byte atomics (round 1: 3.8 GB of them at 64^3, 19.8 ms).
 //
 //   keys_kernel            window key per point + per-cell counts (integer atomics only)
-//   scan_kernel            exclusive scan of the counts
+//   scan_partials/segments exclusive scan of the counts (two launches over 256 segments)
 //   scatter_kernel         counting-sort scatter into cell-ordered SoA copies (+ original index)
 //   cell_order_kernel      orders the points INSIDE every cell by original index: the scatter's
 //                          cursor order is not reproducible, the per-cell sums below must be
@@ -34,16 +34,33 @@
 // HBM roofline: 8*(ndim+1+[weighted]) algorithmic bytes per point and streaming pass.
 #include "basis.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace splpak {
 
 namespace {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
 
 __device__ inline double wave_sum(double v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// sum of v[t], v[t + nt], v[t + 2 nt], .. below n, eight loads in flight (eight partial sums, combined in a fixed order):
+// the single-workgroup reductions below were bound by one dependent load + add per element (round 3)
+__device__ inline double strided_sum8(const double *__restrict__ v, long long n, int t, int nt)
+{
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    long long i = t;
+    for (; i + 7LL * nt < n; i += 8LL * nt) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += v[i + (long long)u * nt];
+    }
+    for (int u = 0; i < n; i += nt, ++u) a[u] += v[i];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
 // ---------------------------------------------------------------------------
@@ -81,28 +98,57 @@ keys_kernel(Grid g, long long m, const double *__restrict__ x, int ldx,
     }
 }
 
-// exclusive scan of count[0..n) into offset[0..n], single workgroup
-__global__ void __launch_bounds__(1024)
-scan_kernel(const int *__restrict__ count, int *__restrict__ offset, int n)
+// exclusive scan of count[0..n) into offset[0..n] in two launches over SCAN_SEG segments (round 3: one workgroup walking
+// 227 000 cells took 0.35 ms per fit at 64^3): segment sums, then every workgroup scans its own segment on top of the
+// sum of the segments before it
+constexpr int SCAN_SEG = 256;
+__global__ void __launch_bounds__(256)
+scan_partials_kernel(const int *__restrict__ count, int *__restrict__ part, int n)
 {
-    __shared__ int part[1024];
-    const int t = threadIdx.x;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = t * chunk;
-    const int hi = (lo + chunk < n) ? lo + chunk : n;
+    __shared__ int red[4];
+    const int per = (n + SCAN_SEG - 1) / SCAN_SEG;
+    const int lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
     int s = 0;
-    for (int i = lo; i < hi; ++i) s += count[i];
-    part[t] = s;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) s += count[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {        // Hillis-Steele inclusive scan
-        int v = (t >= o) ? part[t - o] : 0;
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(256)
+scan_segments_kernel(const int *__restrict__ count, const int *__restrict__ part, int *__restrict__ offset, int n)
+{
+    __shared__ int sc[256];
+    __shared__ int sbase;
+    const int t = threadIdx.x;
+    {   // sum of the segments before this one
+        int v = (t < (int)blockIdx.x) ? part[t] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((t & 63) == 0) sc[t >> 6] = v;
         __syncthreads();
-        part[t] += v;
+        if (t == 0) sbase = sc[0] + sc[1] + sc[2] + sc[3];
         __syncthreads();
     }
-    int run = part[t] - s;                      // exclusive prefix of this chunk
-    for (int i = lo; i < hi; ++i) { offset[i] = run; run += count[i]; }
-    if (t == 1023) offset[n] = part[1023];
+    const int per = (n + SCAN_SEG - 1) / SCAN_SEG;
+    const int lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    const int chunk = (per + 255) / 256;                  // consecutive entries per thread
+    const int a = lo + t * chunk, b = (a + chunk < hi) ? a + chunk : hi;
+    int s = 0;
+    for (int i = a; i < b; ++i) s += count[i];
+    __syncthreads();
+    sc[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {         // Hillis-Steele inclusive scan
+        const int v = (t >= o) ? sc[t - o] : 0;
+        __syncthreads();
+        sc[t] += v;
+        __syncthreads();
+    }
+    int run = sbase + sc[t] - s;
+    for (int i = a; i < b; ++i) { offset[i] = run; run += count[i]; }
+    if (blockIdx.x == SCAN_SEG - 1 && t == 255) offset[n] = sbase + sc[255];
 }
 
 template <int D>
@@ -357,6 +403,134 @@ gram_block_kernel(Grid g, const int *__restrict__ offset, const double *__restri
     }
 }
 
+// The same per-cell blocks for 2-D and 3-D grids (NB = 16 / 64) on the f64 matrix cores, ONE WAVE per cell, four cells per
+// workgroup, no workgroup barriers (round 3).  The block is B^T B with B = the cell's weighted rows
+// (points x NB), i.e. a product with K = points: per 4 points one v_mfma_f64_16x16x4_f64 per 16 x 16 tile of the lower
+// triangle (10 tiles at NB = 64).  The operands are never staged: lane (l15, q) of k-step s needs
+// B[p = 4 s + q][16 m + l15] = (w_p b0[l15 & 3] b1[l15 >> 2]) * b2[m] -- three table reads from the wave's LDS slice and
+// one multiplication per tile block.  The result tiles have consecutive lanes on consecutive entries of a packed row
+// (first MFMA operand = the row block), so they leave with plain coalesced stores.  The workgroup-per-cell form above
+// read 8 LDS values per 16 FMAs, used 136 of its 256 threads in the triangle and passed five barriers per cell: 3.56 ms
+// at C3 for 0.65 ms of matrix-pipe time.  Right-hand side and histogram shares: lane = window function, points in
+// storage order, as before.
+template <int D>
+__global__ void __launch_bounds__(256)
+gram_wave_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
+                 const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
+                 double *__restrict__ blk, double *__restrict__ rblk, double *__restrict__ hblk,
+                 double *__restrict__ hist, int cell0, int ncells)
+{
+    static_assert(D == 2 || D == 3, "16 or 64 window functions");
+    constexpr int NB = 1 << (2 * D), MT = NB / 16, NTILE = MT * (MT + 1) / 2, PCH = 64, LDT = 4 * D + 1;
+    constexpr long long TRI = (long long)NB * (NB + 1) / 2;
+    __shared__ double s_tab[4][PCH * LDT];
+    __shared__ double s_w[4][PCH];
+    __shared__ double s_wy[4][PCH];
+    __shared__ int s_slot[4][PCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
+    const int rel = blockIdx.x * 4 + wave;
+    if (rel >= ncells) return;
+    const int cell = cell0 + rel;
+    const long long beg = offset[cell], end = offset[cell + 1];
+    if (beg == end) return;                    // the gather skips empty cells
+    double *tab = s_tab[wave], *sw = s_w[wave], *swy = s_wy[wave];
+    int *sslot = s_slot[wave];
+    const bool hist_on = hblk != nullptr;
+
+    d4_t acc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+    double racc = 0.0, hacc = 0.0;
+    for (long long p0 = beg; p0 < end; p0 += PCH) {
+        const int np = (int)((end - p0 < PCH) ? (end - p0) : PCH);
+        // ---- lane = point: window tables, weight, w^2 y, histogram slot (zero rows beyond np pad the last k-step)
+        {
+            double b[D][4], wv = 0.0, wyv = 0.0;
+            int sl = -2;
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b[d][k] = 0.0;
+            if (lane < np) {
+                double xv[D];
+                wv = ws[p0 + lane];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    xv[d] = xs[(long long)d * cap + p0 + lane];
+                    window_table(g, d, xv[d], 0, b[d]);
+                }
+                wyv = wv * ys[p0 + lane];
+                if (hist_on) {
+                    sl = nearest_slot<D>(g, xv);
+                    if (sl < 0) {                       // rare: far outside the grid (:899); the only atomic left
+                        double xr[MAXD] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int d = 0; d < D; ++d) xr[g.perm[d]] = xv[d];
+                        atomicAdd(&hist[nearest_node_address(g, xr)], wv);       // :905
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tab[lane * LDT + 4 * d + k] = b[d][k];
+            sw[lane] = wv;
+            swy[lane] = wyv;
+            sslot[lane] = sl;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- matrix cores: K = the chunk's points, four per step
+        const int nsteps = (np + 3) >> 2;
+        for (int s4 = 0; s4 < nsteps; ++s4) {
+            const int p = 4 * s4 + q;
+            const double u = (sw[p] * tab[p * LDT + (l15 & 3)]) * tab[p * LDT + 4 + (l15 >> 2)];
+            double op[MT];
+            if constexpr (D == 2) op[0] = u;
+            else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) op[m] = u * tab[p * LDT + 8 + m];
+            }
+            int t = 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = m; n < MT; ++n, ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[n], op[m], acc[t], 0, 0, 0);
+        }
+        // ---- right-hand side and histogram shares: lane = window function, points in storage order
+        if (lane < NB) {
+            for (int p = 0; p < np; ++p) {
+                double prod = tab[p * LDT + (lane & 3)];
+#pragma unroll
+                for (int d = 1; d < D; ++d) prod *= tab[p * LDT + 4 * d + ((lane >> (2 * d)) & 3)];
+                racc += (sw[p] * prod) * swy[p];
+                if (hist_on) hacc += (sslot[p] == lane) ? sw[p] : 0.0;       // :905
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // packed lower triangle: tile (m, n), register v of lane (l15, q) = entry (r, c) = (16 n + q + 4 v, 16 m + l15)
+    double *__restrict__ out = blk + (long long)rel * TRI;
+    {
+        int t = 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = m; n < MT; ++n, ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = 16 * n + q + 4 * v, c = 16 * m + l15;
+                    if (c <= r) out[r * (r + 1) / 2 + c] = acc[t][v];
+                }
+    }
+    if (lane < NB) {
+        rblk[(long long)rel * NB + lane] = racc;
+        if (hist_on) hblk[(long long)rel * NB + lane] = hacc;
+    }
+}
+
 // Cells whose window contains node `in`: window starts ws_d in [max(in_d - 3, 0), min(in_d, cells_d - 1)],
 // enumerated with dimension 0 fastest -- THE fixed summation order of every gather below.
 template <int D>
@@ -491,8 +665,7 @@ hist_total_kernel(const double *__restrict__ hist, int n, double *__restrict__ s
 {
     __shared__ double part[1024];
     const int t = threadIdx.x;
-    double s = 0.0;
-    for (int i = t; i < n; i += 1024) s += hist[i];
+    const double s = strided_sum8(hist, n, t, 1024);
     part[t] = s;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
@@ -563,9 +736,9 @@ residual_block_kernel(Grid g, const int *__restrict__ offset, const double *__re
 // The same per-cell share for 1-D .. 3-D grids (NB = 4^D <= 64), ONE WAVE per cell, four cells per workgroup, no
 // workgroup barriers (round 3: the workgroup-per-cell form above spent 1.67 ms per pass at C3 -- 227 000 workgroups of 256
 // threads for 44 points each, staged through five __syncthreads -- for 0.4 GB of points; four passes per fit).
-//   phase 1  lane = point:  the D window tables (parked in the wave's LDS slice), t = sum over the window in factorised form
-//            against the cell's 4^D coefficients (LDS broadcast reads), e = w y - w t
-//   phase 2  lane = (window function c, point group):  racc_c += prod_d table_d[c_d] * (w e)  over the points
+//   phase 1  lane = point:  the D window tables (parked in the wave's LDS slice), t = (w b) . x against the cell's 4^D
+//            coefficients (LDS broadcast reads), e = w y - t
+//   phase 2  lane = (window function c, point group):  racc_c += (w b)_c * e  over the points
 // Sums in a fixed order: reproducible bits.
 template <int D>
 __global__ void __launch_bounds__(256)
@@ -577,13 +750,14 @@ residual_wave_kernel(Grid g, const int *__restrict__ offset, const double *__res
     constexpr int NB = 1 << (2 * D), G = 64 / NB, PCH = 64, LDT = 4 * D + 1;
     __shared__ double s_tab[4][PCH * LDT];
     __shared__ double s_we[4][PCH];
+    __shared__ double s_wt[4][PCH];
     __shared__ double s_x[4][NB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + wave;
     if (cell >= g.ncell) return;
     const long long beg = offset[cell], end = offset[cell + 1];
     if (beg == end) return;
-    double *tab = s_tab[wave], *we = s_we[wave], *xl = s_x[wave];
+    double *tab = s_tab[wave], *we = s_we[wave], *sw = s_wt[wave], *xl = s_x[wave];
     int colbase = 0;
 #pragma unroll
     for (int d = 0; d < D; ++d) colbase += ((cell / g.cellstride[d]) % g.cells[d]) * g.colstride[d];
@@ -602,41 +776,44 @@ residual_wave_kernel(Grid g, const int *__restrict__ offset, const double *__res
 #pragma unroll
                 for (int k = 0; k < 4; ++k) tab[lane * LDT + 4 * d + k] = b[d][k];
             }
+            // t = (w b) . x with the row entries rounded exactly as the Gram kernel rounds them, ((w b0) b1) b2: the
+            // refinement iterates with the operator whose Gram matrix was factored.  (Measured at C3: the contraction
+            // factor is the same 2.2e-4 with the factorised window sum -- it is set by the Gram sums and the
+            // factorisation, not by the rounding of the row entries; the consistent form costs nothing measurable.)
+            const double wv = ws[p0 + lane];
             double t = 0.0;
             if constexpr (D == 1) {
 #pragma unroll
-                for (int k0 = 0; k0 < 4; ++k0) t = fma(b[0][k0], xl[k0], t);
-            } else if constexpr (D == 2) {
-#pragma unroll
-                for (int k1 = 0; k1 < 4; ++k1) {
-                    double r = 0.0;
-#pragma unroll
-                    for (int k0 = 0; k0 < 4; ++k0) r = fma(b[0][k0], xl[k0 + 4 * k1], r);
-                    t = fma(b[1][k1], r, t);
-                }
+                for (int k0 = 0; k0 < 4; ++k0) t = fma(wv * b[0][k0], xl[k0], t);
             } else {
+                double u[4][4];
 #pragma unroll
-                for (int k2 = 0; k2 < 4; ++k2) {
-                    double r2 = 0.0;
+                for (int k1 = 0; k1 < 4; ++k1)
 #pragma unroll
-                    for (int k1 = 0; k1 < 4; ++k1) {
-                        double r = 0.0;
+                    for (int k0 = 0; k0 < 4; ++k0) u[k1][k0] = (wv * b[0][k0]) * b[1][k1];
+                if constexpr (D == 2) {
 #pragma unroll
-                        for (int k0 = 0; k0 < 4; ++k0) r = fma(b[0][k0], xl[k0 + 4 * k1 + 16 * k2], r);
-                        r2 = fma(b[1][k1], r, r2);
-                    }
-                    t = fma(b[2][k2], r2, t);
+                    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+                        for (int k0 = 0; k0 < 4; ++k0) t = fma(u[k1][k0], xl[k0 + 4 * k1], t);
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2)
+#pragma unroll
+                        for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+                            for (int k0 = 0; k0 < 4; ++k0) t = fma(u[k1][k0] * b[2][k2], xl[k0 + 4 * k1 + 16 * k2], t);
                 }
             }
-            const double wv = ws[p0 + lane];
-            const double e = wv * ys[p0 + lane] - wv * t;         // row residual  w y - (w b) . x
-            we[lane] = wv * e;
+            const double e = wv * ys[p0 + lane] - t;              // row residual  w y - (w b) . x
+            we[lane] = e;
+            sw[lane] = wv;
             e2 = fma(e, e, e2);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int p = grp; p < np; p += G) {
-            double prod = tab[p * LDT + (c & 3)];
+            double prod = sw[p] * tab[p * LDT + (c & 3)];
 #pragma unroll
             for (int d = 1; d < D; ++d) prod *= tab[p * LDT + 4 * d + ((c >> (2 * d)) & 3)];
             racc = fma(prod, we[p], racc);
@@ -933,6 +1110,9 @@ rho_gather_kernel(Grid g, const int *__restrict__ offset, const double *__restri
 // denominator is the size of the terms whose sum rho_i is (the basis functions are non-negative, so
 // |A|^T |A| = N on the data rows): omega is at rounding level exactly when x minimises the
 // least-squares functional to working precision, whatever the grading of the constraint weights.
+// (Thread per node on purpose: neighbouring threads walk neighbouring rows code by code, so every 128-byte line of nst that
+// is fetched serves 16 iterations of the same wave from the L1.  A wave per node with the lanes over the codes -- coalesced
+// for the node's own row -- reads every line of the transposed part for ONE entry: 3.0 instead of 1.3 ms at 64^3, round 3.)
 template <int D>
 __global__ void __launch_bounds__(256)
 backward_error_kernel(Grid g, const double *__restrict__ nst, const double *__restrict__ xvec,
@@ -1056,7 +1236,8 @@ hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ld
         dim3 gr(grid_for(m, 256)), bl(256);
         DISPATCH_D(g.ndim, hipLaunchKernelGGL(keys_kernel<D>, gr, bl, 0, st, g, m, x, ldx, w, s.key, s.count, scal));
     }
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, s.count, s.offset, g.ncell + 1);
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(SCAN_SEG), dim3(256), 0, st, (const int *)s.count, s.scanpart, g.ncell + 1);
+    hipLaunchKernelGGL(scan_segments_kernel, dim3(SCAN_SEG), dim3(256), 0, st, (const int *)s.count, (const int *)s.scanpart, s.offset, g.ncell + 1);
     if (m > 0) {
         dim3 gr(grid_for(m, 256)), bl(256);
         DISPATCH_D(g.ndim, hipLaunchKernelGGL(scatter_kernel<D>, gr, bl, 0, st, g, m, x, ldx, y, w,
@@ -1070,6 +1251,25 @@ hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ld
 long long gram_scratch_min_doubles(const Grid &g)
 {   // one hyper-row of cells along the slowest dimension
     return (long long)g.cellstride[g.ndim - 1] * (gram_tri(g.nb) + 2LL * g.nb);
+}
+
+template <int D>
+static void gram_cells(const Grid &g, const SortScratch &s, double *blk, double *rblk, double *hblk, double *hist, int cell0,
+                       int ncells, hipStream_t st)
+{
+    static const bool old_form = std::getenv("SPLPAK_GRAM_VALU") != nullptr;       // A/B switch: the workgroup-per-cell form
+    if constexpr (D == 2 || D == 3) {
+        if (!old_form) {
+            hipLaunchKernelGGL(gram_wave_kernel<D>, dim3((unsigned)((ncells + 3) / 4)), dim3(256), 0, st, g, (const int *)s.offset,
+                               (const double *)s.xs, (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist,
+                               cell0, ncells);
+            return;
+        }
+    }
+    using C = GramCfg<D>;
+    dim3 gr((unsigned)ncells, (unsigned)(C::NB / (C::NTX * C::TC)));
+    hipLaunchKernelGGL(gram_block_kernel<D>, gr, dim3(C::NT), 0, st, g, (const int *)s.offset, (const double *)s.xs,
+                       (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist, cell0);
 }
 
 hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, long long scratch_doubles, bool smooth,
@@ -1093,10 +1293,7 @@ hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, lon
         double *rblk = blk + (long long)ncells * gram_tri(g.nb);
         double *hblk = smooth ? rblk + (long long)ncells * g.nb : nullptr;
         DISPATCH_D(g.ndim, {
-            using C = GramCfg<D>;
-            dim3 gr((unsigned)ncells, (unsigned)(C::NB / (C::NTX * C::TC)));
-            hipLaunchKernelGGL(gram_block_kernel<D>, gr, dim3(C::NT), 0, st, g, (const int *)s.offset, (const double *)s.xs,
-                               (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist, cell0);
+            gram_cells<D>(g, s, blk, rblk, hblk, hist, cell0, ncells, st);
             hipLaunchKernelGGL(stencil_gather_kernel<D>, dim3((unsigned)((node1 - node0 + 3) / 4)), dim3(256), 0, st, g,
                                (const int *)s.offset, (const double *)blk, (const double *)rblk, (const double *)hblk,
                                nst, rhs, hist, cell0, cell1, node0, node1);
@@ -1127,9 +1324,7 @@ __global__ void __launch_bounds__(1024)
 sum_fixed_kernel(const double *__restrict__ v, long long n, double *__restrict__ out)
 {
     __shared__ double red[1024];
-    double t = 0.0;
-    for (long long i = threadIdx.x; i < n; i += 1024) t += v[i];
-    red[threadIdx.x] = t;
+    red[threadIdx.x] = strided_sum8(v, n, (int)threadIdx.x, 1024);
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];

@@ -39,6 +39,7 @@ struct SortScratch {
     int *count;      // [ncell + 2]
     int *offset;     // [ncell + 2] exclusive scan of count
     int *cursor;     // [ncell + 1]
+    int *scanpart;   // [256] segment sums of the scan
     double *xs;      // [ndim][cap] sorted coordinates, SoA (internal dimension order)
     double *ys;      // [cap]
     double *ws;      // [cap]

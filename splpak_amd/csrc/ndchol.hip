@@ -151,28 +151,51 @@ nd_whoami_kernel(unsigned *__restrict__ map)
 // it each, or one 16 x 16 tile each) -- for launches of a few hundred items, which otherwise leave most of the chip's 1 024
 // SIMDs idle while one wave per item works through its 1 024 MFMAs of 64 cycles each (27 us per K = 256, measured 30-57 us
 // per launch at BASELINE config 2).  Every element sees the same sequence of operations: bitwise the same result.
-template <int SD, int WPS, bool SCHUR, int SPLIT = 1>
-__global__ void __launch_bounds__(64, WPS)
+template <int SD, int WPS, bool SCHUR, int SPLIT = 1, int WGW = 1>
+__global__ void __launch_bounds__(64 * WGW, WPS)
 nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int margin, const unsigned *__restrict__ resmap,
                int *__restrict__ queue)
 {
+    // WGW = 4: four waves per workgroup take four CONSECUTIVE items -- items are stored tile column by tile column, so the
+    // four share their column operand, which then comes from the CU's L1 three times out of four (less operand traffic
+    // = less power = a higher clock in the long power-limited Schur launches; round 2 measured +7 % for the band's bulk
+    // update in sustained runs)
     constexpr int M = SPLIT == 1 ? 4 : 1, N = SPLIT == 16 ? 1 : 4;
     int b = blockIdx.x;
     if (queue) {
-        const unsigned ci = nd_cu_index();
-        if (resmap[ci >> 5] & (1u << (ci & 31))) {
-            int e = 0;
-            if (threadIdx.x == 0) e = atomicAdd(&queue[1], 1);
-            e = __builtin_amdgcn_readfirstlane(e);
-            if (e < margin) {
-                __builtin_amdgcn_s_sleep(127);       // do not drain the grid through this CU
+        if constexpr (WGW == 1) {
+            const unsigned ci = nd_cu_index();
+            if (resmap[ci >> 5] & (1u << (ci & 31))) {
+                int e = 0;
+                if (threadIdx.x == 0) e = atomicAdd(&queue[1], 1);
+                e = __builtin_amdgcn_readfirstlane(e);
+                if (e < margin) {
+                    __builtin_amdgcn_s_sleep(127);       // do not drain the grid through this CU
+                    __builtin_amdgcn_s_sleep(127);
+                    return;
+                }
+            }
+            if (threadIdx.x == 0) b = atomicAdd(&queue[0], 1);
+            b = __builtin_amdgcn_readfirstlane(b);
+        } else {
+            __shared__ int s_b[2];
+            if (threadIdx.x == 0) {
+                int skip = 0;
+                const unsigned ci = nd_cu_index();
+                if (resmap[ci >> 5] & (1u << (ci & 31))) skip = atomicAdd(&queue[1], 1) < margin ? 1 : 0;
+                s_b[1] = skip;
+                s_b[0] = skip ? 0 : atomicAdd(&queue[0], 1);
+            }
+            __syncthreads();
+            if (s_b[1]) {
+                __builtin_amdgcn_s_sleep(127);
                 __builtin_amdgcn_s_sleep(127);
                 return;
             }
+            b = s_b[0];
         }
-        if (threadIdx.x == 0) b = atomicAdd(&queue[0], 1);
-        b = __builtin_amdgcn_readfirstlane(b);
     }
+    if constexpr (WGW > 1) b = b * WGW + (int)(threadIdx.x >> 6);
     if (b >= nitems) return;
     const int sub = SPLIT == 1 ? 0 : b % SPLIT;
     if (SPLIT > 1) b /= SPLIT;
@@ -597,6 +620,8 @@ struct NdState {
     hipEvent_t evR02 = nullptr;
     unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
     int nres = 0;
+    int pinned_split = 4;                          // most waves per item of a small launch that runs beside a bulk update
+    int wg4 = 0;                                   // 1: Schur launches in 4-wave workgroups, 2: the panel updates too
     int small_grid = 1024;                         // update launches of at most this many items are split over 4 waves per item, a quarter of it: 16
     int *queues = nullptr;                         // [nqueues][2] item counters of the update launches of one factorisation
     int nqueues = 0;
@@ -604,8 +629,10 @@ struct NdState {
     std::vector<hipEvent_t> evI;                   // potrf of step k done (per step of the current depth)
     std::vector<hipEvent_t> evT;                   // panel of step k solved (per step of the current depth)
     std::vector<hipEvent_t> evE, evZ;              // depth consumed / depth zeroed
-    hipEvent_t ev0 = nullptr, evJ = nullptr, evU = nullptr, evZlast = nullptr, evDone = nullptr;
+    hipEvent_t ev0 = nullptr, evJ = nullptr, evU = nullptr, evZlast = nullptr, evDone = nullptr, evPre = nullptr, evTail = nullptr;
     bool zlast_valid = false, used = false;
+    bool tail_pending = false;                     // nd_prefit is clearing factor[head_doubles ..) on sU (evTail)
+    long long head_doubles = 0;
     bool s_clean = false;                          // the Schur buffers of the two deepest levels are zero
     std::vector<hipEvent_t> evA, evB;              // start / stop of the timed update launches
     hipEvent_t f0 = nullptr, f1 = nullptr;
@@ -650,7 +677,7 @@ void nd_destroy(void *user)
     for (hipStream_t *q : {&s->sP, &s->sU, &s->sR, &s->sP2}) if (*q) (void)hipStreamDestroy(*q);
     for (auto *v : {&s->evT, &s->evE, &s->evZ, &s->evA, &s->evB, &s->evI, &s->evW, &s->evT2, &s->evI2, &s->evF[0], &s->evF[1]})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->f0, s->f1, s->evR0, s->evR02}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->evPre, s->evTail, s->f0, s->f1, s->evR0, s->evR02}) if (e) (void)hipEventDestroy(e);
     for (void *q : s->owned) (void)hipFree(q);
     delete s;
 }
@@ -1045,29 +1072,65 @@ void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipS
     // the queue is carried across the block loop of a K = 1024 pass and then has to live in registers (256 + 180)
     // Launches of a few hundred items leave most SIMDs idle while one wave per item works through its MFMAs: they are split
     // over 4 / 16 waves per item (SPLIT above; same arithmetic order, bitwise the same result)
-    const int split = (int)l.grid * 4 <= s->small_grid ? 16 : ((int)l.grid <= s->small_grid ? 4 : 1);
-    const dim3 grid(l.grid * (unsigned)split + (unsigned)margin);
+    // (beside a bulk update that fills every wave slot -- `pinned` -- the waves of this launch are placed as slots retire,
+    // ~37 per us at 64^3: sixteen waves per item then wait longer than they save; four per item there)
+    int split = (int)l.grid * 4 <= s->small_grid ? 16 : ((int)l.grid <= s->small_grid ? 4 : 1);
+    if (pinned && split > s->pinned_split) split = s->pinned_split;
     const int nit = (int)l.grid * split;
-#define ND_SYRK_GO(SCH, SPL)                                                                                                   \
+    const bool wg4 = split == 1 && (s->wg4 >= 2 || (s->wg4 == 1 && schur));
+    const dim3 grid((wg4 ? (l.grid + 3) / 4 : l.grid * (unsigned)split) + (unsigned)margin);
+    // operand look-ahead in k-steps: a split wave issues 1 (4) MFMA per step, so 4 steps cover 256 (1 024) cycles -- less than
+    // one memory round trip: 77 us per K = 256 launch of the root's look-ahead block.  32 (16) steps in flight instead.
+#define ND_SD(SPL) ((SPL) == 16 ? 32 : ((SPL) == 4 ? 16 : 4))
+#define ND_SYRK_GO(SCH, SPL, WW)                                                                                               \
     do {                                                                                                                       \
-        if (SCH) hipExtLaunchKernelGGL((nd_syrk_kernel<4, 2, SCH, SPL>), grid, dim3(64), 0, st, a, b, 0, jobs, l.count, nit, margin,  \
+        if (SCH) hipExtLaunchKernelGGL((nd_syrk_kernel<ND_SD(SPL), 2, SCH, SPL, WW>), grid, dim3(64 * WW), 0, st, a, b, 0, jobs, l.count, nit, margin,  \
                                        (const unsigned *)s->resmap, queue);                                                    \
-        else hipLaunchKernelGGL((nd_syrk_kernel<4, 2, SCH, SPL>), grid, dim3(64), 0, st, jobs, l.count, nit, margin,            \
+        else hipLaunchKernelGGL((nd_syrk_kernel<ND_SD(SPL), 2, SCH, SPL, WW>), grid, dim3(64 * WW), 0, st, jobs, l.count, nit, margin,   \
                                 (const unsigned *)s->resmap, queue);                                                           \
     } while (0)
     if (schur) {
-        if (split == 16) ND_SYRK_GO(true, 16); else if (split == 4) ND_SYRK_GO(true, 4); else ND_SYRK_GO(true, 1);
+        if (split == 16) ND_SYRK_GO(true, 16, 1); else if (split == 4) ND_SYRK_GO(true, 4, 1); else if (wg4) ND_SYRK_GO(true, 1, 4); else ND_SYRK_GO(true, 1, 1);
     } else {
-        if (split == 16) ND_SYRK_GO(false, 16); else if (split == 4) ND_SYRK_GO(false, 4); else ND_SYRK_GO(false, 1);
+        if (split == 16) ND_SYRK_GO(false, 16, 1); else if (split == 4) ND_SYRK_GO(false, 4, 1); else if (wg4) ND_SYRK_GO(false, 1, 4); else ND_SYRK_GO(false, 1, 1);
     }
 #undef ND_SYRK_GO
+#undef ND_SD
+}
+
+// The panels start from zero (14 GB at 64^3: 2.2 ms of memset).  Only the head of the arena is busy during the assembly -- the
+// per-cell Gram blocks live there until the stencil gather has read them -- so the rest is cleared on the second stream
+// while the points are binned and the blocks computed, and nd_assemble clears the head.
+hipError_t nd_prefit(splpak_plan *p, hipStream_t st, void *user)
+{
+    NdState *s = static_cast<NdState *>(user);
+    s->tail_pending = false;
+    if (!s->sU || !s->evPre || std::getenv("SPLPAK_ND_NO_EARLY_CLEAR")) return hipSuccess;
+    long long head = 0;
+    if (p->gscratch == s->factor) head = p->gscratch_doubles < s->t.factor_doubles ? p->gscratch_doubles : s->t.factor_doubles;
+    else if (p->gscratch >= s->factor && p->gscratch < s->factor + s->t.factor_doubles) return hipSuccess;     // (not laid out that way)
+    if (head >= s->t.factor_doubles) return hipSuccess;
+    hipError_t e = hipEventRecord(s->evPre, st);                 // the previous fit's solves have read the factor by now
+    if (e == hipSuccess) e = hipStreamWaitEvent(s->sU, s->evPre, 0);
+    if (e == hipSuccess) e = hipMemsetAsync(s->factor + head, 0, sizeof(double) * (size_t)(s->t.factor_doubles - head), s->sU);
+    if (e == hipSuccess) e = hipEventRecord(s->evTail, s->sU);
+    if (e != hipSuccess) return e;
+    s->tail_pending = true;
+    s->head_doubles = head;
+    return hipSuccess;
 }
 
 hipError_t nd_assemble(splpak_plan *p, hipStream_t st, void *user)
 {
     NdState *s = static_cast<NdState *>(user);
     const Grid &g = p->g;
-    hipError_t e = hipMemsetAsync(s->factor, 0, sizeof(double) * (size_t)s->t.factor_doubles, st);
+    hipError_t e = hipSuccess;
+    if (s->tail_pending) {
+        if (s->head_doubles > 0) e = hipMemsetAsync(s->factor, 0, sizeof(double) * (size_t)s->head_doubles, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, s->evTail, 0);
+        s->tail_pending = false;
+    } else
+        e = hipMemsetAsync(s->factor, 0, sizeof(double) * (size_t)s->t.factor_doubles, st);
     if (e != hipSuccess) return e;
     const long long total = (long long)g.ncol * g.hstencil;
     long long blocks = (total + 255) / 256;
@@ -1413,7 +1476,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     (void)hipStreamCreateWithPriority(&s->sP, hipStreamNonBlocking, hi);
     (void)hipStreamCreateWithFlags(&s->sU, hipStreamNonBlocking);
     if (s->npipe == 2) (void)hipStreamCreateWithPriority(&s->sP2, hipStreamNonBlocking, hi);
-    for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone, &s->evR0, &s->evR02}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
+    for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone, &s->evPre, &s->evTail, &s->evR0, &s->evR02}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
     for (int p = 0; p < 2; ++p) {
         s->evF[p].assign((size_t)nd + 1, nullptr);
         for (int d = 0; d <= nd; ++d) (void)hipEventCreateWithFlags(&s->evF[p][(size_t)d], hipEventDisableTiming);
@@ -1421,6 +1484,8 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     // item queues of the update launches (two per step at most)
     s->nqueues = 8 * t.nblocks + 64;
     if (const char *e = std::getenv("SPLPAK_ND_SMALL_GRID")) s->small_grid = atoi(e);
+    if (const char *e = std::getenv("SPLPAK_ND_WG4")) s->wg4 = atoi(e);
+    if (const char *e = std::getenv("SPLPAK_ND_PINNED_SPLIT")) s->pinned_split = atoi(e);
     if (!nd_alloc(s, &s->queues, (size_t)2 * s->nqueues) || !nd_alloc(s, &s->resmap, (size_t)128)) return SPLPAK_E_NOMEM;
     (void)hipMemset(s->resmap, 0, 128 * sizeof(unsigned));
     // A few CUs are left to the diagonal-block factorisations of the upper tree levels: v_mfma_f64 runs on the same
@@ -1459,6 +1524,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     }
     if (!s->sP || !s->sU) { set_error("nested dissection: stream creation failed"); (void)hipGetLastError(); return SPLPAK_E_NODEVICE; }
     p->expand_fn = nd_assemble;
+    p->prefit_fn = nd_prefit;
     p->factor_fn = nd_factor;
     p->solve_fn = nd_solve;
     p->fn_name = "nested-dissection multifrontal Cholesky (csrc/ndtree.hip, csrc/ndchol.hip)";

@@ -199,6 +199,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     p->s.cap = max_ndata;
     ok = ok && dev_alloc(p, &p->s.key, (size_t)max_ndata);
     ok = ok && dev_alloc(p, &p->s.count, (size_t)g.ncell + 2);
+    ok = ok && dev_alloc(p, &p->s.scanpart, (size_t)256);
     ok = ok && dev_alloc(p, &p->s.offset, (size_t)g.ncell + 2);
     ok = ok && dev_alloc(p, &p->s.cursor, (size_t)g.ncell + 2);
     ok = ok && dev_alloc(p, &p->s.xs, (size_t)max_ndata * g.ndim);
@@ -425,6 +426,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         for (hipEvent_t &e : p->evStage)
             if (!e) SPLPAK_HIP_TRY(hipEventCreate(&e), SPLPAK_E_NODEVICE);
     auto stamp = [&](int i) { if (stamps) (void)hipEventRecord(p->evStage[i], st); };
+    if (p->prefit_fn) SPLPAK_HIP_TRY(p->prefit_fn(p, st, p->fn_user), SPLPAK_E_NODEVICE);
     SPLPAK_HIP_TRY(hipMemsetAsync(p->comm, 0, sizeof(double) * (size_t)(p->lenG + p->lenH), st), SPLPAK_E_NODEVICE);
     stamp(0);
     SPLPAK_HIP_TRY(launch_bin_points(g, ndata, x, l1xdat, y, w, p->s, p->scalH, st), SPLPAK_E_NODEVICE);
@@ -689,7 +691,7 @@ static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const
     (void)hipGetDevice(&dev);
     // switches that are read when a plan is created (they select or shape the factorisation): part of the cache key
     int nd_env = std::getenv("SPLPAK_ND") ? atoi(std::getenv("SPLPAK_ND")) : -1;
-    for (const char *v : {"SPLPAK_ND_SPLIT", "SPLPAK_ND_KB", "SPLPAK_ND_RES_CUS", "SPLPAK_NO_PANEL_CU", "SPLPAK_ND_NO_ROOT_LOOKAHEAD", "SPLPAK_ND_NO_FUSE", "SPLPAK_ND_PIPES", "SPLPAK_ND_NO_OUTER", "SPLPAK_ND_SMALL_GRID"})
+    for (const char *v : {"SPLPAK_ND_SPLIT", "SPLPAK_ND_KB", "SPLPAK_ND_RES_CUS", "SPLPAK_NO_PANEL_CU", "SPLPAK_ND_NO_ROOT_LOOKAHEAD", "SPLPAK_ND_NO_FUSE", "SPLPAK_ND_PIPES", "SPLPAK_ND_NO_OUTER", "SPLPAK_ND_SMALL_GRID", "SPLPAK_ND_WG4", "SPLPAK_ND_NO_EARLY_CLEAR", "SPLPAK_ND_PINNED_SPLIT"})
         if (const char *e = std::getenv(v)) nd_env = nd_env * 31 + 7 * atoi(e) + (int)v[10];
     bool same = hc.plan && hc.dev == dev && hc.ndim == ndim && hc.xtrap == xtrap && hc.plan->max_ndata >= ndata && hc.nd_env == nd_env;
     for (int d = 0; same && d < ndim; ++d)

@@ -50,6 +50,8 @@ struct splpak_plan {
     hipError_t (*solve_fn)(splpak_plan *p, double *x, double *tmp, hipStream_t st, void *user) = nullptr;
     // half stencil -> band storage, when the factorisation keeps its own (twoend.hip); NULL = launch_expand
     hipError_t (*expand_fn)(splpak_plan *p, hipStream_t st, void *user) = nullptr;
+    // called first thing in a fit (work that depends on nothing of it: clearing the factor storage beside the assembly); optional
+    hipError_t (*prefit_fn)(splpak_plan *p, hipStream_t st, void *user) = nullptr;
     void *fn_user = nullptr;
     void (*fn_destroy)(void *user) = nullptr;      // releases fn_user with the plan (NULL: not the plan's to release)
     const char *fn_name = nullptr;                 // what the hooks are (splpak_plan_factorisation); fn_code: 2 two-ended band, 4 nested dissection, 3 distributed band
