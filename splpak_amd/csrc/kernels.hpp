@@ -64,13 +64,17 @@ hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, lon
 // dcw[node] / spf[node]: constraint weight xtrap (expect - have) and "data sparse" flag of every node (:923-960)
 hipError_t launch_sparse_mark(const Grid &g, const double *hist, const double *scal, double xtrap, double *dcw,
                               unsigned char *spf, hipStream_t st);
-hipError_t launch_constraint_rows(const Grid &g, const double *dcw, const unsigned char *spf, double *nst,
+// ctab: the per-dimension factors of the constraint-row entries, tabulated once per plan (launch_constraint_table;
+// constraint_table_doubles entries); NULL = evaluate them in place
+hipError_t launch_constraint_rows(const Grid &g, const double *dcw, const unsigned char *spf, const double *ctab, double *nst,
                                   double *scal_out, hipStream_t st);
+long long constraint_table_doubles(const Grid &g);
+hipError_t launch_constraint_table(const Grid &g, double *ctab, hipStream_t st);
 // refinement residual rho = A^T W (W y - W A x) [- C^T C x when `constraints`]; rcell: [ncell][nb] scratch,
 // tbuf: [ncol][ndim(ndim+1)/2] scratch; ssq != NULL: also the sum of squared row residuals, from the per-cell / per-node
 // shares in e2buf ([ncell + ncol] scratch) added in a fixed order
 hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rcell,
-                           const double *dcw, const unsigned char *spf, bool constraints,
+                           const double *dcw, const unsigned char *spf, const double *ctab, bool constraints,
                            double *tbuf, double *rho, double *ssq, double *e2buf, hipStream_t st);
 // out[0] = max_i |rho_i| / ((|N||x|)_i + |rhs_i|): componentwise backward error with respect to the rows
 hipError_t launch_backward_error(const Grid &g, const double *nst, const double *xvec, const double *rho,

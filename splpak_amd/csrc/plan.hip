@@ -209,6 +209,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     ok = ok && dev_alloc(p, &p->rcell, (size_t)g.ncell * g.nb);
     ok = ok && dev_alloc(p, &p->tbuf, (size_t)g.ncol * (g.ndim * (g.ndim + 1) / 2));
     ok = ok && dev_alloc(p, &p->dcw, (size_t)g.ncol);
+    ok = ok && dev_alloc(p, &p->ctab, (size_t)constraint_table_doubles(g));
     ok = ok && dev_alloc(p, &p->spf, (size_t)g.ncol);
     ok = ok && dev_alloc(p, &p->e2buf, (size_t)g.ncell + (size_t)g.ncol);
     // band: all of it (R = 1) or the block columns dealt to rank r of R
@@ -294,6 +295,12 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     p->hist = p->scalG + SC_COUNT;
     p->scalH = p->hist + g.ncol;
     p->rho = p->scalH + SC_COUNT;
+    if (std::getenv("SPLPAK_NO_CONSTRAINT_TABLE")) p->ctab = nullptr;      // (A/B switch; the allocation stays with the plan's list)
+    else if (!hip_ok(launch_constraint_table(g, p->ctab, nullptr), "constraint table") ||
+             !hip_ok(hipStreamSynchronize(nullptr), "constraint table")) {
+        splpak_plan_destroy(p);
+        return SPLPAK_E_NODEVICE;
+    }
     twoend_attach(p);
     *plan = p;
     return 0;
@@ -449,7 +456,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     }
     if (smooth && p->rank == 0) {
         SPLPAK_HIP_TRY(launch_sparse_mark(g, p->hist, p->scalH, p->xtrap, p->dcw, p->spf, st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(launch_constraint_rows(g, p->dcw, p->spf, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_constraint_rows(g, p->dcw, p->spf, p->ctab, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
     }
     stamp(3);
     if (int r = do_allreduce(p, p->nst, p->lenG, st)) return r;
@@ -517,7 +524,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     for (int it = 0; it < p->max_refine_hard && !converged; ++it) {
         // (the scalars behind rho travel with it through the all-reduce: zeroed too, or every collective doubles them)
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, smooth && p->rank == 0,
+        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, p->ctab, smooth && p->rank == 0,
                                        p->tbuf, p->rho, nullptr, nullptr, st), SPLPAK_E_NODEVICE);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
         SPLPAK_HIP_TRY(p->solve_fn ? p->solve_fn(p, p->rho, p->tmp, st, p->fn_user) : band_solve(b, p->rho, p->tmp, st), SPLPAK_E_NODEVICE);
@@ -568,7 +575,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
         hipEvent_t r0 = stamps ? p->evStage[8] : nullptr, r1 = stamps ? p->evStage[9] : nullptr;   // (created with the other stage events)
         if (r0 && r1) (void)hipEventRecord(r0, st);
-        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, smooth && p->rank == 0,
+        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, p->ctab, smooth && p->rank == 0,
                                        p->tbuf, p->rho, scalR, p->e2buf, st), SPLPAK_E_NODEVICE);
         if (r0 && r1) {
             (void)hipEventRecord(r1, st);

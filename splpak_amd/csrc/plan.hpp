@@ -21,6 +21,7 @@ struct splpak_plan {
     double *gscratch = nullptr;   // per-cell Gram blocks: the band storage itself when it is large enough (it is only
                                   // filled after the gather), a buffer of its own otherwise
     long long gscratch_doubles = 0;
+    double *ctab = nullptr;       // per-dimension factors of the constraint-row entries (grid only: filled once, launch_constraint_table)
     double *dcw = nullptr;        // [ncol] constraint weight of every node, spf: [ncol] "data sparse" flags (:923-960)
     unsigned char *spf = nullptr;
     double *rcell = nullptr;      // [ncell][nb] per-cell shares of the refinement residual
