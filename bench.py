@@ -16,7 +16,7 @@ normal equations and each refinement residual are all-reduced over RCCL; the
 factorisation is replicated.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel (nd_syrk_kernel<4,2,true>: f64-MFMA Schur-buffer passes of the
+  roofline      the dominant kernel (nd_syrk_kernel<4,2,true,1,1>: f64-MFMA Schur-buffer passes of the
                 multifrontal factorisation): algorithmic flop / HIP-event time measured inside the timed region
   cpu_baseline  the reference itself (oracle/_ref, 1 core; it is single-threaded)
                 on a bounded sample -- the dense reference algorithm cannot run the
@@ -311,7 +311,7 @@ def c5_traffic():
     """Fabric bytes of the 4-D evaluation passes from the committed PMC profile (not measured in this run)."""
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r03_eval_pmc.json")))["4d_32"]
-        return {"kernel": "eval_binned_kernel<4,true>", "bytes_per_launch": pm["kernels"]["eval_binned_kernel<4, true>"]["hbm_bytes"],
+        return {"kernel": "eval_binned_kernel<4,true>", "bytes_per_launch": next(v for k, v in pm["kernels"].items() if k.startswith("eval_binned_kernel<4, true"))["hbm_bytes"],
                 "queries_per_launch": pm["queries_per_launch"], "bytes_per_query_all_passes": pm["hbm_bytes_per_query_all_passes"],
                 "algorithmic_bytes_per_query": 40.0,
                 "source": "profiles/r03_eval_pmc.json (rocprofv3 --pmc passes of tools/eval_profile.py 4 32 100000000; not measured in this run)"}
@@ -558,7 +558,7 @@ def main():
     eval_traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r03_eval_pmc.json")))["3d_64"]
-        eval_traffic = {"kernel": "eval_binned_kernel<3,true>", "bytes_per_launch": pm["kernels"]["eval_binned_kernel<3, true>"]["hbm_bytes"],
+        eval_traffic = {"kernel": "eval_binned_kernel<3,true>", "bytes_per_launch": next(v for k, v in pm["kernels"].items() if k.startswith("eval_binned_kernel<3, true"))["hbm_bytes"],
                         "queries_per_launch": pm["queries_per_launch"],
                         "bytes_per_query_all_passes": pm["hbm_bytes_per_query_all_passes"], "algorithmic_bytes_per_query": 8.0 * (nd + 1),
                         "source": "profiles/r03_eval_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload; not measured in this run)"}
@@ -666,7 +666,7 @@ def main():
                 except Exception:
                     traffic = None
             line["roofline"] = {
-                "kernel": ("nd_syrk_kernel<4,2,true> (Schur-buffer passes S -= L21 L21^T of the nested-dissection fronts, K = 1024 per pass, "
+                "kernel": ("nd_syrk_kernel<4,2,true,1,1> (Schur-buffer passes S -= L21 L21^T of the nested-dissection fronts, K = 1024 per pass, "
                            "v_mfma_f64_16x16x4_f64; one launch at a time per tree depth and block group)") if nd_path else
                           "syrk64_kernel<16,1,4,256> (bulk trailing update C -= P P^T of the band Cholesky, v_mfma_f64_16x16x4_f64; one launch per block step)",
                 "bound": "mfma", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -16,3 +16,4 @@ bash tools/pmc.sh r03/eval4_fetch "FETCH_SIZE" "eval|bin_" python3 /root/repo/to
 bash tools/pmc.sh r03/eval4_write "WRITE_SIZE" "eval|bin_" python3 /root/repo/tools/eval_profile.py 4 32 100000000 > /dev/null
 echo "eval pmc done"
 ls gpurun_out/r03
+python3 tools/r03_pmc_json.py gpurun_out/r03 gpurun_out/r03 > gpurun_out/r03/pmc_json.log 2>&1
