@@ -147,7 +147,16 @@ template <> struct TileShape<3> { static constexpr int T[4] = {16, 16, 16, 1}; }
 // 4-D: 8 x 8 x 8 x 16 coefficients (64 KB) serve 5 x 5 x 5 x 13 window starts -- 648 regions at 32^4 instead of the 1 296 of an
 // 8^4 tile (round 3): half the bins in the sort passes, 2.6 x the window starts per tile fill
 template <> struct TileShape<4> { static constexpr int T[4] = {8, 8, 8, 16}; };
-template <int D> constexpr int tile_elems() { return TileShape<D>::T[0] * TileShape<D>::T[1] * TileShape<D>::T[2] * TileShape<D>::T[3]; }
+// LDS strides of the tile dimensions.  4-D: padded (8 -> 67 -> 539 instead of 64 -> 512) so that the tile offset of a window
+// start, taken mod 32 doubles = its LDS bank class for ds_read_b64, is uniform over the 5 x 5 x 5 x 13 starts of a region (50-52
+// per class; the dense strides give 20 classes, five of them double: SQ_LDS_BANK_CONFLICT was 80 % of SQ_LDS_IDX_ACTIVE and
+// the LDS pipe 90 % of the evaluation pass, round 3).  The evaluation pass then deals its queries to the lanes BY CLASS
+// (eval_binned_kernel), which makes every window read conflict free.
+template <int D> struct TileStride { static constexpr int S[4] = {1, TileShape<D>::T[0], TileShape<D>::T[0] * TileShape<D>::T[1],
+                                                                  TileShape<D>::T[0] * TileShape<D>::T[1] * TileShape<D>::T[2]}; };
+template <> struct TileStride<4> { static constexpr int S[4] = {1, 8, 67, 539}; };
+template <int D> constexpr int tile_elems() { return TileStride<D>::S[D - 1] * TileShape<D>::T[D - 1]; }
+template <int D> constexpr int tile_cells() { return TileShape<D>::T[0] * TileShape<D>::T[1] * TileShape<D>::T[2] * TileShape<D>::T[3]; }
 constexpr int BIN_MAX = 2048;          // regions per grid handled by the LDS histograms
 constexpr int EVAL_QPW = 2048;         // queries per workgroup in pass C
 
@@ -429,8 +438,12 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
             rr /= rg.nreg[d];
         }
     }
-    for (int e = threadIdx.x; e < TILE_ELEMS; e += EVAL_WG) {
-        int rem = e, idx = 0;
+    using TT = TileStride<D>;
+    __shared__ int s_cnt[32], s_off[32], s_fre[33];
+    __shared__ unsigned short s_list[D == 4 ? EVAL_QPW : 1], s_ovf[D == 4 ? EVAL_QPW : 1];
+    if (D == 4 && threadIdx.x < 32) s_cnt[threadIdx.x] = 0;
+    for (int e = threadIdx.x; e < tile_cells<D>(); e += EVAL_WG) {
+        int rem = e, idx = 0, te = 0;
         bool ok = true;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -439,13 +452,103 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
             const int node = a[d] + l;
             ok = ok && node < g.nodes[d];
             idx += node * g.colstride[d];
+            te += l * TT::S[d];
         }
-        tile[e] = ok ? (double)coef[idx] : 0.0;
+        tile[te] = ok ? (double)coef[idx] : 0.0;
     }
     __syncthreads();
     const int qb = off[r] + part * EVAL_QPW;
     const int qe = min(off[r + 1], qb + EVAL_QPW);
-    constexpr int t1 = TS::T[0], t2 = TS::T[0] * TS::T[1], t3 = TS::T[0] * TS::T[1] * TS::T[2];
+    constexpr int t1 = TT::S[1], t2 = TT::S[2], t3 = TT::S[3];
+    auto evaluate = [&](const double (&x)[D], int p) {
+        double b[D][4];
+        int base = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int ws = eval_table<VAL>(g, d, x[d], nd.v[d], b[d]);
+            base += (ws - a[d]) * TT::S[d];
+        }
+        const double sum = window_sum<D>(b, [&](int k1, int k2, int k3, double (&c)[4]) {
+            // four ds_read_b64 (2 LDS cycles each, 64 banks) instead of the two ds_read2_b64 the
+            // compiler would merge them into (8 cycles each, 32 banks): volatile keeps them apart
+            typedef const volatile __attribute__((address_space(3))) double *lds_cvd;
+            lds_cvd q = (lds_cvd)tile + (base + k1 * t1 + k2 * t2 + k3 * t3);
+            c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[3];
+        });
+        out[p] = (T)sum;
+    };
+    if constexpr (D == 4) {
+        // Queries dealt to the lanes by bank class: lane h of every 32-lane half takes the queries whose tile offset is
+        // h mod 32 (counting sort of the workgroup's <= 2 048 queries by that class in LDS).  The 64 window rows of a query are
+        // read at the same constant offsets from its base by every lane, so lanes with distinct base classes never meet on a
+        // bank: 2 LDS cycles per read instead of the ~10 of random windows.  Same arithmetic per query: identical bits.
+        // A class holds 64 +- 8 of the 2 048 queries; every lane has exactly two rounds (64 slots per class = one per
+        // half-wave and round), so what a class holds beyond 64 goes to the free slots of the short classes -- those few
+        // lanes meet the lane of their own class on a bank (one extra LDS cycle), nobody idles.
+        static_assert(EVAL_QPW == 2 * EVAL_WG && EVAL_WG == 32 * 32, "two rounds of 32 half-waves x 32 classes");
+        const int nq = qe - qb;
+        int key[2] = {-1, -1}, rk[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int jj = (int)threadIdx.x + u * EVAL_WG;
+            if (jj < nq) {
+                double x[D];
+                (void)load_record<D>(xs + (long long)(qb + jj) * (D + 1), x);
+                int base = 0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    int lo, hi;
+                    base += (window_start(g, d, x[d], lo, hi) - a[d]) * TT::S[d];
+                }
+                key[u] = base & 31;
+                rk[u] = atomicAdd(&s_cnt[key[u]], 1);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {             // exclusive scans over the 32 classes: surplus (beyond 64) and free slots
+            const int n = s_cnt[threadIdx.x];
+            const int sur = n > 64 ? n - 64 : 0, fre = n < 64 ? 64 - n : 0;
+            int is = sur, ifr = fre;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const int ts = __shfl_up(is, o, 32), tf = __shfl_up(ifr, o, 32);
+                if ((int)threadIdx.x >= o) { is += ts; ifr += tf; }
+            }
+            s_off[threadIdx.x] = is - sur;          // first surplus position of the class
+            s_fre[threadIdx.x] = ifr - fre;         // first surplus entry its free slots take
+            if (threadIdx.x == 31) s_fre[32] = is;  // surplus entries in all
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (key[u] >= 0) {
+                const unsigned short id = (unsigned short)((int)threadIdx.x + u * EVAL_WG);
+                if (rk[u] < 64) s_list[key[u] * 64 + rk[u]] = id;
+                else s_ovf[s_off[key[u]] + rk[u] - 64] = id;
+            }
+        __syncthreads();
+        const int h = threadIdx.x & 31, w = threadIdx.x >> 5;
+        const int n_h = s_cnt[h], nsur = s_fre[32];
+        int jq[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int slot = w + 32 * u;
+            int id = -1;
+            if (slot < n_h) id = s_list[h * 64 + slot];           // (slot < 64 always)
+            else {
+                const int e = s_fre[h] + (slot - n_h);
+                if (e < nsur) id = s_ovf[e];
+            }
+            jq[u] = id;
+        }
+        double x0[D], x1[D];
+        int p0 = 0, p1 = 0;
+        if (jq[0] >= 0) p0 = load_record<D>(xs + (long long)(qb + jq[0]) * (D + 1), x0);
+        if (jq[1] >= 0) p1 = load_record<D>(xs + (long long)(qb + jq[1]) * (D + 1), x1);
+        if (jq[0] >= 0) evaluate(x0, p0);
+        if (jq[1] >= 0) evaluate(x1, p1);
+        return;
+    }
     // the coordinates (and the destination) of the NEXT round are in flight while the current one is
     // evaluated: a round's global loads would otherwise be exposed once per round
     int j = qb + threadIdx.x;
@@ -459,22 +562,7 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
         const int p = pn;
         const int jn = j + EVAL_WG;
         if (jn < qe) pn = load_record<D>(xs + (long long)jn * (D + 1), xn);
-        double b[D][4];
-        int base = 0, m = 1;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int ws = eval_table<VAL>(g, d, x[d], nd.v[d], b[d]);
-            base += (ws - a[d]) * m;
-            m *= TS::T[d];
-        }
-        const double sum = window_sum<D>(b, [&](int k1, int k2, int k3, double (&c)[4]) {
-            // four ds_read_b64 (2 LDS cycles each, 64 banks) instead of the two ds_read2_b64 the
-            // compiler would merge them into (8 cycles each, 32 banks): volatile keeps them apart
-            typedef const volatile __attribute__((address_space(3))) double *lds_cvd;
-            lds_cvd q = (lds_cvd)tile + (base + k1 * t1 + k2 * t2 + k3 * t3);
-            c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[3];
-        });
-        out[p] = (T)sum;
+        evaluate(x, p);
         j = jn;
     }
 }
@@ -736,7 +824,7 @@ eval_derivs_binned_kernel(Grid g, Regions rg, const double *__restrict__ coef, c
                           const int *__restrict__ wgoff, double *__restrict__ out, int ldout)
 {
     constexpr int NOUT = 1 + D + (ORDER == 2 ? D * (D + 1) / 2 : 0);
-    constexpr int TILE_ELEMS = tile_elems<D>();
+    constexpr int TILE_ELEMS = tile_cells<D>();          // (dense strides here: the padded ones belong to eval_binned_kernel)
     __shared__ double tile[TILE_ELEMS];
     using TS = TileShape<D>;
     const int wg = blockIdx.x;
