@@ -155,6 +155,7 @@ template <> struct TileShape<4> { static constexpr int T[4] = {8, 8, 8, 16}; };
 template <int D> struct TileStride { static constexpr int S[4] = {1, TileShape<D>::T[0], TileShape<D>::T[0] * TileShape<D>::T[1],
                                                                   TileShape<D>::T[0] * TileShape<D>::T[1] * TileShape<D>::T[2]}; };
 template <> struct TileStride<4> { static constexpr int S[4] = {1, 8, 67, 539}; };
+template <> struct TileStride<3> { static constexpr int S[4] = {1, 17, 274, 274 * 16}; };     // 13^3 starts: 67-70 per class (dense: 26 classes)
 template <int D> constexpr int tile_elems() { return TileStride<D>::S[D - 1] * TileShape<D>::T[D - 1]; }
 template <int D> constexpr int tile_cells() { return TileShape<D>::T[0] * TileShape<D>::T[1] * TileShape<D>::T[2] * TileShape<D>::T[3]; }
 constexpr int BIN_MAX = 2048;          // regions per grid handled by the LDS histograms
@@ -440,8 +441,9 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
     }
     using TT = TileStride<D>;
     __shared__ int s_cnt[32], s_off[32], s_fre[33];
-    __shared__ unsigned short s_list[D == 4 ? EVAL_QPW : 1], s_ovf[D == 4 ? EVAL_QPW : 1];
-    if (D == 4 && threadIdx.x < 32) s_cnt[threadIdx.x] = 0;
+    constexpr bool DEAL = D == 4;             // queries dealt to the lanes by LDS bank class (below; 3-D: 403 -> 476 us, the class sort costs more than the conflicts)
+    __shared__ unsigned short s_list[DEAL ? EVAL_QPW : 1], s_ovf[DEAL ? EVAL_QPW : 1];
+    if (DEAL && threadIdx.x < 32) s_cnt[threadIdx.x] = 0;
     for (int e = threadIdx.x; e < tile_cells<D>(); e += EVAL_WG) {
         int rem = e, idx = 0, te = 0;
         bool ok = true;
@@ -477,7 +479,7 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
         });
         out[p] = (T)sum;
     };
-    if constexpr (D == 4) {
+    if constexpr (DEAL) {
         // Queries dealt to the lanes by bank class: lane h of every 32-lane half takes the queries whose tile offset is
         // h mod 32 (counting sort of the workgroup's <= 2 048 queries by that class in LDS).  The 64 window rows of a query are
         // read at the same constant offsets from its base by every lane, so lanes with distinct base classes never meet on a
