@@ -620,6 +620,7 @@ struct NdState {
     hipEvent_t evR02 = nullptr;
     unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
     int nres = 0;
+    bool small_queue = false;                      // (A/B: small launches take the item queue too)
     int pinned_split = 4;                          // most waves per item of a small launch that runs beside a bulk update
     int wg4 = 0;                                   // 1: Schur launches in 4-wave workgroups, 2: the panel updates too
     int small_grid = 1024;                         // update launches of at most this many items are split over 4 waves per item, a quarter of it: 16
@@ -1060,9 +1061,14 @@ void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipS
             stats->bulk_flop += l.flop;
         }
     }
+    // A small launch (split over several waves per item) does without the item queue: its waves are gone in microseconds, so
+    // they need not keep off the reserved CUs -- and the queue costs it dearly: 2 048 placeholder workgroups plus one atomic
+    // per workgroup on ONE word made the 10-item update of the root's next diagonal block a 60-75 us launch, on the chain of
+    // every one of the root's 48 steps (round 3, tools/last_fit_trace.py).
+    const bool small_launch = (int)l.grid <= s->small_grid && !s->small_queue;
     int *queue = nullptr;
     int margin = 0;
-    if (pinned && s->nres > 0 && qnext < s->nqueues) {
+    if (pinned && s->nres > 0 && qnext < s->nqueues && !small_launch) {
         queue = s->queues + 2 * (qnext++);
         margin = 256 * s->nres;
     }
@@ -1486,6 +1492,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     if (const char *e = std::getenv("SPLPAK_ND_SMALL_GRID")) s->small_grid = atoi(e);
     if (const char *e = std::getenv("SPLPAK_ND_WG4")) s->wg4 = atoi(e);
     if (const char *e = std::getenv("SPLPAK_ND_PINNED_SPLIT")) s->pinned_split = atoi(e);
+    s->small_queue = std::getenv("SPLPAK_ND_SMALL_QUEUE") != nullptr;
     if (!nd_alloc(s, &s->queues, (size_t)2 * s->nqueues) || !nd_alloc(s, &s->resmap, (size_t)128)) return SPLPAK_E_NOMEM;
     (void)hipMemset(s->resmap, 0, 128 * sizeof(unsigned));
     // A few CUs are left to the diagonal-block factorisations of the upper tree levels: v_mfma_f64 runs on the same
