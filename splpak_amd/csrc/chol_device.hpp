@@ -45,7 +45,7 @@ constexpr int SLD = NBLK + 16;         // LDS column stride of the strip image S
 // Not inlined: its register allocation and scheduling stay apart from the latency-critical leaf / row-solve code.
 typedef const __attribute__((address_space(3))) double *lds_cptr;      // LDS pointer that survives a function boundary as ds_read
 __device__ __noinline__ void strip_trailing_update(double *__restrict__ A, long long lda, lds_cptr S,
-                                                    int c0, int wave, int l15, int q)
+                                                    int c0, int wave, int l15, int q, int nw)
 {
     const int base = c0 + SPW;
     const int nt = (NBLK - base) / 32;
@@ -72,7 +72,7 @@ __device__ __noinline__ void strip_trailing_update(double *__restrict__ A, long 
         cload(roff, coff, cur);
     }
     while (t < ntiles) {
-        const int tn = t + 4;
+        const int tn = t + nw;
         int rn = 0, cn = 0;
         if (tn < ntiles) {
             decode(tn, rn, cn);
@@ -122,9 +122,14 @@ __device__ unsigned long long g_strip_cycles[8];
 // ncols (1 .. 256): the columns from ncols on are identity padding (a front of the nested-dissection factorisation whose
 // own variables do not fill its last block): strips that hold nothing else are skipped -- their part of L is the identity
 // the assembly left there, and the leaf inverses at the end read it.
+// NW waves per workgroup (4 or 16): the leaf and the row solves are the work of waves 0 .. 3 either way; the strip copies, the
+// in-strip updates and the K = 64 update of the rest of the block are shared by all of them (round 3: 16 waves).
+template <int NW = 4>
 __device__ __forceinline__ void potrf_strip_body(double *__restrict__ A, long long lda, int k0, int *__restrict__ info,
                                                  double *__restrict__ minpiv, double *__restrict__ inv16, int ncols = NBLK)
 {
+    static_assert(NW == 4 || NW == 8 || NW == 16, "whole groups of 256 threads");
+    constexpr int NP = NW / 4;             // groups of 256 threads: the strip copies split the columns among them
     __shared__ double Ls[IB * (IB + 1)];
     __shared__ double Lrd[IB];               // reciprocals of the leaf's diagonal
     __shared__ double S[SPW * SLD];
@@ -138,15 +143,15 @@ __device__ __forceinline__ void potrf_strip_body(double *__restrict__ A, long lo
     for (int c0 = 0; c0 < cend; c0 += SPW) {
         // ---- strip -> LDS (whole rectangle rows >= c0; the part above the diagonal is never used):
         // one row per thread, 16 columns in flight at a time
-        if (c0 + tid < NBLK) {
-            const double *__restrict__ rowp = A + (c0 + tid) + (long long)c0 * lda;
+        if (c0 + (tid & 255) < NBLK) {
+            const double *__restrict__ rowp = A + (c0 + (tid & 255)) + (long long)c0 * lda;
 #pragma unroll 1
-            for (int cb = 0; cb < SPW; cb += 16) {
+            for (int cb = 16 * (tid >> 8); cb < SPW; cb += 16 * NP) {
                 double v[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = rowp[(long long)(cb + i) * lda];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) S[(cb + i) * SLD + c0 + tid] = v[i];
+                for (int i = 0; i < 16; ++i) S[(cb + i) * SLD + c0 + (tid & 255)] = v[i];
             }
         }
         __syncthreads();
@@ -223,7 +228,7 @@ __device__ __forceinline__ void potrf_strip_body(double *__restrict__ A, long lo
                 const int ntc = (SPW - ppc - IB) / 16, ntr = (NBLK - pbase) / 16;
                 int ntl = 0;                                    // tiles of the tile columns 1 .. ntc-1
                 for (int tc = 1; tc < ntc; ++tc) ntl += ntr - tc;
-                for (int t = wave - 1; t < ntl; t += 3) {
+                for (int t = wave - 1; t < ntl; t += NW - 1) {
                     int tc = 1, rem = t;
                     while (rem >= ntr - tc) { rem -= ntr - tc; ++tc; }
                     tile_update(ppc, pbase, tc, tc + rem);
@@ -255,21 +260,22 @@ __device__ __forceinline__ void potrf_strip_body(double *__restrict__ A, long lo
             // for the next leaf (above).  Every tile still receives its panels in the same order as before.
             if (pc + IB < SPW) {
                 const int ntr = mrem / 16;
-                for (int t = wave; t < ntr; t += 4) tile_update(pc, base, 0, t);
+                for (int t = wave; t < ntr; t += NW) tile_update(pc, base, 0, t);
                 __syncthreads();
             }
             STRIP_ACC(3);
         }
         // ---- the finished strip (64 columns of L) back to global: lower part only, one row per thread
-        if (c0 + tid < NBLK) {
-            double *__restrict__ rowp = A + (c0 + tid) + (long long)c0 * lda;
-            const int cmax = tid < SPW - 1 ? tid : SPW - 1;     // row c0+tid holds columns c0 .. c0+min(tid, 63)
+        if (c0 + (tid & 255) < NBLK) {
+            const int row = tid & 255;
+            double *__restrict__ rowp = A + (c0 + row) + (long long)c0 * lda;
+            const int cmax = row < SPW - 1 ? row : SPW - 1;     // row c0+row holds columns c0 .. c0+min(row, 63)
 #pragma unroll 4
-            for (int c = 0; c <= cmax; ++c) rowp[(long long)c * lda] = S[c * SLD + c0 + tid];
+            for (int c = tid >> 8; c <= cmax; c += NP) rowp[(long long)c * lda] = S[c * SLD + c0 + row];
         }
         STRIP_ACC(4);
         // ---- the block right of the strip: C -= S S^T with K = 64 (strip_trailing_update above)
-        if (c0 + SPW < cend) strip_trailing_update(A, lda, (lds_cptr)S, c0, wave, l15, q);     // (right of it: padding only)
+        if (c0 + SPW < cend) strip_trailing_update(A, lda, (lds_cptr)S, c0, wave, l15, q, NW);     // (right of it: padding only)
         __syncthreads();        // everybody is done with the strip (and its stores are issued) before it is replaced
         __threadfence_block();
         STRIP_ACC(5);
@@ -277,7 +283,7 @@ __device__ __forceinline__ void potrf_strip_body(double *__restrict__ A, long lo
     // the next strip's loads read what this workgroup stored: make the stores visible to the whole workgroup
     __syncthreads();
     // inverses of the sixteen 16x16 diagonal leaves, as in potrf_block_kernel
-    {
+    if (wave < 4) {
         const int leaf = wave * 4 + q, r = l15;
         const int d0 = leaf * IB;
         double a[IB];

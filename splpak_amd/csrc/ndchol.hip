@@ -89,11 +89,12 @@ __device__ __forceinline__ void trapezoid_decode(int it, int nr, int &tj, int &t
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
 nd_potrf_kernel(const PotrfJob *__restrict__ jobs, int *__restrict__ info, double *__restrict__ minpiv)
 {
     const PotrfJob j = jobs[blockIdx.x];
-    potrf_strip_body(j.A, j.ld, j.k0, info, minpiv, j.inv16, j.ncols);
+    potrf_strip_body<NW>(j.A, j.ld, j.k0, info, minpiv, j.inv16, j.ncols);
 }
 
 __global__ void __launch_bounds__(64)
@@ -620,6 +621,7 @@ struct NdState {
     hipEvent_t evR02 = nullptr;
     unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
     int nres = 0;
+    int potrf_waves = 8;                           // waves per diagonal-block workgroup (measured 4 / 8 / 16: C2 factor 0.813 / 0.789 / 0.839 ms, 32^3 11.53 / 11.22 / 11.67, C3 the same)
     bool small_queue = false;                      // (A/B: small launches take the item queue too)
     int pinned_split = 4;                          // most waves per item of a small launch that runs beside a bulk update
     int wg4 = 0;                                   // 1: Schur launches in 4-wave workgroups, 2: the panel updates too
@@ -1032,6 +1034,15 @@ bool nd_build_jobs(NdState *s)
     return nd_build_factor_jobs(s) && nd_build_solve_jobs(s);
 }
 
+// diagonal blocks of one step of a depth: a workgroup per front, 8 waves each (SPLPAK_ND_POTRF_WAVES = 4: the band path's form, 16)
+void launch_potrf(NdState *s, const Launch &lp, hipStream_t st, int *info_dev, double *minpiv_dev)
+{
+    const PotrfJob *jobs = s->potrf.dev + lp.first;
+    if (s->potrf_waves == 4) hipLaunchKernelGGL(nd_potrf_kernel<4>, dim3(lp.grid), dim3(256), 0, st, jobs, info_dev, minpiv_dev);
+    else if (s->potrf_waves == 8) hipLaunchKernelGGL(nd_potrf_kernel<8>, dim3(lp.grid), dim3(512), 0, st, jobs, info_dev, minpiv_dev);
+    else hipLaunchKernelGGL(nd_potrf_kernel<16>, dim3(lp.grid), dim3(1024), 0, st, jobs, info_dev, minpiv_dev);
+}
+
 // schur: the Schur-buffer passes (timed: the roofline kernel); otherwise the panel update of the chain.
 // pinned: diagonal blocks are being factored on the reserved CUs -- the waves take their items from a queue and
 // step aside there.
@@ -1219,11 +1230,11 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         if (pinned) {           // two event hops: chain -> reserved CUs -> chain
             (void)hipEventRecord(evR0p[q], sC);
             (void)hipStreamWaitEvent(sR, evR0p[q], 0);
-            hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sR, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
+            launch_potrf(s, lp, sR, info_dev, minpiv_dev);
             (void)hipEventRecord((*evIp[q])[(size_t)k], sR);
             (void)hipStreamWaitEvent(sC, (*evIp[q])[(size_t)k], 0);
         } else
-            hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sC, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
+            launch_potrf(s, lp, sC, info_dev, minpiv_dev);
         if (lt.count)
             hipLaunchKernelGGL(nd_trsm_kernel, dim3(lt.grid), dim3(64), 0, sC, (const TrsmJob *)(s->trsm.dev + lt.first), lt.count);
         if ((ls.count || lf0.count || lf1.count) && sU != sC) {
@@ -1292,11 +1303,11 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             if (pinned) {
                 (void)hipEventRecord(s->evR0, sP);
                 (void)hipStreamWaitEvent(sR, s->evR0, 0);
-                hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sR, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
+                launch_potrf(s, lp, sR, info_dev, minpiv_dev);
                 (void)hipEventRecord(s->evI[(size_t)k], sR);
                 (void)hipStreamWaitEvent(sP, s->evI[(size_t)k], 0);
             } else
-                hipLaunchKernelGGL(nd_potrf_kernel, dim3(lp.grid), dim3(256), 0, sP, (const PotrfJob *)(s->potrf.dev + lp.first), info_dev, minpiv_dev);
+                launch_potrf(s, lp, sP, info_dev, minpiv_dev);
             if (ltb.count) {            // the panel rows beyond the next diagonal block are solved beside the chain
                 if (sU != sP) {
                     if (!pinned) (void)hipEventRecord(s->evI[(size_t)k], sP);
@@ -1493,6 +1504,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     if (const char *e = std::getenv("SPLPAK_ND_WG4")) s->wg4 = atoi(e);
     if (const char *e = std::getenv("SPLPAK_ND_PINNED_SPLIT")) s->pinned_split = atoi(e);
     s->small_queue = std::getenv("SPLPAK_ND_SMALL_QUEUE") != nullptr;
+    if (const char *e = std::getenv("SPLPAK_ND_POTRF_WAVES")) s->potrf_waves = atoi(e);
     if (!nd_alloc(s, &s->queues, (size_t)2 * s->nqueues) || !nd_alloc(s, &s->resmap, (size_t)128)) return SPLPAK_E_NOMEM;
     (void)hipMemset(s->resmap, 0, 128 * sizeof(unsigned));
     // A few CUs are left to the diagonal-block factorisations of the upper tree levels: v_mfma_f64 runs on the same
