@@ -569,6 +569,186 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
     }
 }
 
+// ---- run path (3-D value / single-pattern evaluation; round 3) ----------------------------------------
+// The region sort above moves every query three times (count, place, evaluate) and spends a tenth of its time on the
+// prefixes in between.  Here the place pass stops at what it has in LDS anyway: every workgroup writes ITS 2 048 queries,
+// sorted by region, as one contiguous image (64 KB of records, fully coalesced) and leaves the starts of its runs in a row
+// of `starts`; the evaluation workgroup (region r, group k) walks the runs (w, r) of the RUN_GROUP workgroups of its
+// group.  No count pass, no prefix kernels, no global order: 24 + 32 bytes per query in the place pass, 32 + 8 in the
+// evaluation pass.  Same arithmetic per query as everywhere else: identical bits.
+// place-pass workgroups per evaluation workgroup (128 x 16.4 = 2 097 queries of a region at 64^3; 120, which keeps 96 % of the
+// evaluation workgroups within two rounds of their 1 024 threads, measured the same)
+constexpr int RUN_GROUP = 128;
+constexpr int RUN_QPW = 2048;          // queries per place-pass workgroup
+
+template <int D, typename T>
+__global__ void __launch_bounds__(256)
+run_place_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq, double *__restrict__ img,
+                 int *__restrict__ starts)
+{
+    constexpr int QPT = RUN_QPW / 256, QPW = RUN_QPW;
+    __shared__ double sx[QPW * D];
+    __shared__ int sidx[QPW];
+    extern __shared__ int lds_bins[];          // lstart[nbins + 1] | lcount[nbins]
+    int *lst = lds_bins, *lcn = lds_bins + rg.nbins + 1;
+    __shared__ int sscan[256];
+    for (int b = threadIdx.x; b < rg.nbins; b += 256) lcn[b] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * QPW;
+    int rid[QPT], rank[QPT];
+    double xr[QPT][D];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        const int i = base + j * 256 + threadIdx.x;
+        rid[j] = -1;
+        rank[j] = 0;
+        if (i < n) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) xr[j][d] = (double)xq[(long long)i * ldxq + d];
+            rid[j] = region_of<D>(g, rg, xr[j]);
+            rank[j] = atomicAdd(&lcn[rid[j]], 1);
+        }
+    }
+    __syncthreads();
+    const int per = (rg.nbins + 255) / 256;
+    const int b0 = threadIdx.x * per;
+    int q = 0;
+    for (int b = b0; b < b0 + per && b < rg.nbins; ++b) q += lcn[b];
+    sscan[threadIdx.x] = q;
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+        const int aq = threadIdx.x >= s ? sscan[threadIdx.x - s] : 0;
+        __syncthreads();
+        sscan[threadIdx.x] += aq;
+        __syncthreads();
+    }
+    q = sscan[threadIdx.x] - q;
+    for (int b = b0; b < b0 + per && b < rg.nbins; ++b) {
+        lst[b] = q;
+        q += lcn[b];
+    }
+    const int total = sscan[255];
+    if (threadIdx.x == 0) lst[rg.nbins] = total;
+    __syncthreads();
+    for (int b = threadIdx.x; b <= rg.nbins; b += 256) starts[(long long)blockIdx.x * (rg.nbins + 1) + b] = lst[b];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        if (rid[j] < 0) continue;
+        const int lp = lst[rid[j]] + rank[j];
+#pragma unroll
+        for (int d = 0; d < D; ++d) sx[d * QPW + lp] = xr[j][d];
+        sidx[lp] = base + j * 256 + threadIdx.x;
+    }
+    __syncthreads();
+    for (int lp = threadIdx.x; lp < total; lp += 256) {        // the sorted image: consecutive lanes, consecutive records
+        double x[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = sx[d * QPW + lp];
+        store_record<D>(img + ((long long)blockIdx.x * QPW + lp) * (D + 1), x, sidx[lp]);
+    }
+}
+
+template <int D, bool VAL, typename T>
+__global__ void __launch_bounds__(EVAL_WG)
+eval_runs_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef, const double *__restrict__ img,
+                 const int *__restrict__ starts, int nwg, T *__restrict__ out)
+{
+    __shared__ double tile[tile_elems<D>()];
+    static_assert(RUN_GROUP <= 128, "two workgroups per lane of one wave in the prefix");
+    __shared__ int pre[RUN_GROUP + 1], rst[RUN_GROUP];
+    using TS = TileShape<D>;
+    using TT = TileStride<D>;
+    const int r = blockIdx.x % rg.nbins, k = blockIdx.x / rg.nbins;
+    const int w0 = k * RUN_GROUP;
+    // this region's runs in the group's workgroups: start inside the workgroup's image, inclusive prefix of the lengths
+    if (threadIdx.x < 64) {
+        int c[2], st[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int wl = 2 * (int)threadIdx.x + u, w = w0 + wl;
+            c[u] = 0;
+            st[u] = 0;
+            if (wl < RUN_GROUP && w < nwg) {
+                const int *__restrict__ row = starts + (long long)w * (rg.nbins + 1) + r;
+                st[u] = row[0];
+                c[u] = row[1] - row[0];
+            }
+            if (wl < RUN_GROUP) rst[wl] = st[u];
+        }
+        int incl = c[0] + c[1];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += t;
+        }
+        if (2 * (int)threadIdx.x + 1 <= RUN_GROUP) pre[2 * threadIdx.x + 1] = incl - c[1];
+        if (2 * (int)threadIdx.x + 2 <= RUN_GROUP) pre[2 * threadIdx.x + 2] = incl;
+        if (threadIdx.x == 0) pre[0] = 0;
+    }
+    __syncthreads();
+    const int total = pre[RUN_GROUP];
+    if (total == 0) return;
+    int a[D];                                  // first node of the region's tile
+    {
+        int rr = r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            a[d] = (rr % rg.nreg[d]) * (TS::T[d] - 3);
+            rr /= rg.nreg[d];
+        }
+    }
+    for (int e = threadIdx.x; e < tile_cells<D>(); e += EVAL_WG) {
+        int rem = e, idx = 0, te = 0;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int l = rem % TS::T[d];
+            rem /= TS::T[d];
+            const int node = a[d] + l;
+            ok = ok && node < g.nodes[d];
+            idx += node * g.colstride[d];
+            te += l * TT::S[d];
+        }
+        tile[te] = ok ? (double)coef[idx] : 0.0;
+    }
+    __syncthreads();
+    constexpr int t1 = TT::S[1], t2 = TT::S[2], t3 = TT::S[3];
+    auto locate = [&](int qi) -> const double * {      // record qi of the group's queries of this region
+        int lo = 0, hi = RUN_GROUP;                    // pre[lo] <= qi < pre[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= qi) lo = mid; else hi = mid;
+        }
+        return img + ((long long)(w0 + lo) * RUN_QPW + rst[lo] + (qi - pre[lo])) * (D + 1);
+    };
+    int qi = threadIdx.x;
+    double xn[D];
+    int pn = 0;
+    if (qi < total) pn = load_record<D>(locate(qi), xn);
+    while (qi < total) {
+        double x[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = xn[d];
+        const int p = pn;
+        const int qn = qi + EVAL_WG;
+        if (qn < total) pn = load_record<D>(locate(qn), xn);
+        double b[D][4];
+        int base = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int ws = eval_table<VAL>(g, d, x[d], nd.v[d], b[d]);
+            base += (ws - a[d]) * TT::S[d];
+        }
+        const double sum = window_sum<D>(b, [&](int k1, int k2, int k3, double (&c)[4]) {
+            typedef const volatile __attribute__((address_space(3))) double *lds_cvd;
+            lds_cvd qq = (lds_cvd)tile + (base + k1 * t1 + k2 * t2 + k3 * t3);
+            c[0] = qq[0]; c[1] = qq[1]; c[2] = qq[2]; c[3] = qq[3];
+        });
+        out[p] = (T)sum;
+        qi = qn;
+    }
+}
+
 // pass C of the fused value / gradient / Hessian evaluation (defined with eval_derivs_kernel below)
 template <int D, int ORDER>
 __global__ void eval_derivs_binned_kernel(Grid g, Regions rg, const double *__restrict__ coef, const double *__restrict__ xs,
@@ -587,13 +767,31 @@ struct EvalScratch {
     hipEvent_t last = nullptr;    // end of the previous use (another stream must wait for it)
     int dev = -1;
 };
+struct RunScratch {               // run path: per-workgroup sorted images of a chunk, starts of their runs
+    double *img = nullptr;
+    int *starts = nullptr;
+    long long img_doubles = 0, start_ints = 0;
+    hipEvent_t last = nullptr;
+    int dev = -1;
+};
 thread_local EvalScratch g_scratch;
+thread_local RunScratch g_runs;
 thread_local int g_eval_mode = 0;             // 0 auto, 1 direct, 2 binned
 thread_local long long g_eval_chunk = 0;      // queries per chunk, 0 = default
 }  // namespace
 
+static void run_scratch_shutdown()
+{
+    RunScratch &s = g_runs;
+    if (s.img) (void)hipFree(s.img);
+    if (s.starts) (void)hipFree(s.starts);
+    if (s.last) (void)hipEventDestroy(s.last);
+    s = RunScratch();
+}
+
 void eval_scratch_shutdown()
 {
+    run_scratch_shutdown();
     EvalScratch &s = g_scratch;
     if (s.xs) (void)hipFree(s.xs);
     if (s.ints) (void)hipFree(s.ints);
@@ -608,12 +806,69 @@ void set_eval_mode(int mode, long long chunk)
     g_eval_chunk = chunk;
 }
 
+// run path (see run_place_kernel); hipErrorNotSupported = not for this grid / batch, take the region sort
+template <int D, typename T>
+static hipError_t eval_runs(const Grid &g, const Regions &rg, long long nq, const T *xq, int ldxq, const NDeriv &nd,
+                            const T *coef, T *out, hipStream_t st)
+{
+    // (runs of RUN_QPW / nbins records: below ~8 the evaluation pass would gather single records)
+    if (rg.nbins > 256 || std::getenv("SPLPAK_EVAL_SORT")) return hipErrorNotSupported;
+    long long chunk = g_eval_chunk > 0 ? g_eval_chunk : (1LL << 24);
+    if (chunk > (1LL << 26)) chunk = 1LL << 26;
+    if (chunk > nq) chunk = nq;
+    const long long nwg_max = (chunk + RUN_QPW - 1) / RUN_QPW;
+    const long long need_img = nwg_max * RUN_QPW * (D + 1), need_st = nwg_max * (rg.nbins + 1);
+    RunScratch &s = g_runs;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (s.dev != dev || s.img_doubles < need_img || s.start_ints < need_st) {
+        run_scratch_shutdown();
+        hipError_t e = hipMalloc(&s.img, sizeof(double) * (size_t)need_img);
+        if (e != hipSuccess && release_cached_plan_for_memory()) {
+            (void)hipGetLastError();
+            e = hipMalloc(&s.img, sizeof(double) * (size_t)need_img);
+        }
+        if (e == hipSuccess) e = hipMalloc(&s.starts, sizeof(int) * (size_t)need_st);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.last, hipEventDisableTiming);
+        if (e != hipSuccess) { run_scratch_shutdown(); (void)hipGetLastError(); return hipErrorOutOfMemory; }
+        s.img_doubles = need_img;
+        s.start_ints = need_st;
+        s.dev = dev;
+    } else {
+        (void)hipStreamWaitEvent(st, s.last, 0);
+    }
+    bool value_only = true;
+    for (int d = 0; d < D; ++d) value_only = value_only && nd.v[d] == 0;
+    for (long long c0 = 0; c0 < nq; c0 += chunk) {
+        const int n = (int)(nq - c0 < chunk ? nq - c0 : chunk);
+        const T *xc = xq + c0 * ldxq;
+        const unsigned nwg = (unsigned)((n + RUN_QPW - 1) / RUN_QPW);
+        hipLaunchKernelGGL((run_place_kernel<D, T>), dim3(nwg), dim3(256), sizeof(int) * (2 * rg.nbins + 1), st, g, rg, n, xc, ldxq,
+                           s.img, s.starts);
+        const unsigned ngroups = (nwg + RUN_GROUP - 1) / RUN_GROUP;
+        if (value_only)
+            hipLaunchKernelGGL((eval_runs_kernel<D, true, T>), dim3(ngroups * (unsigned)rg.nbins), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
+                               (const double *)s.img, (const int *)s.starts, (int)nwg, out + c0);
+        else
+            hipLaunchKernelGGL((eval_runs_kernel<D, false, T>), dim3(ngroups * (unsigned)rg.nbins), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
+                               (const double *)s.img, (const int *)s.starts, (int)nwg, out + c0);
+    }
+    (void)hipEventRecord(s.last, st);
+    return hipGetLastError();
+}
+
 // order == 0: one nderiv pattern (nd) -> out[nq]; order 1 / 2: value + gradient (+ Hessian) -> out[nq][ldout]
 template <int D, typename T = double>
 static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, const T *xq, int ldxq,
                               const NDeriv &nd, const T *coef, T *out, hipStream_t st,
                               int order = 0, int ldout = 1)
 {
+    if constexpr (D == 3) {
+        if (order == 0) {
+            const hipError_t e = eval_runs<D, T>(g, rg, nq, xq, ldxq, nd, coef, out, st);
+            if (e != hipErrorNotSupported) return e;
+        }
+    }
     // default chunk: 2^24 queries (measured best at 64^3: large enough that the ~8 000 evaluation
     // workgroups of a chunk keep every CU full to the end; chunks small enough to stay in the Infinity
     // Cache were not faster -- the passes are bound by instructions, not by HBM)

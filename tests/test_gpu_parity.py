@@ -257,6 +257,29 @@ def test_eval_binned_scratch_regrows_for_a_grid_with_more_regions():
         capi.set_eval_mode(capi.EVAL_AUTO)
 
 
+def test_eval_run_path_with_clustered_queries():
+    """The 3-D run path (round 3: every place-pass workgroup leaves its own region-sorted image and the starts of its
+    runs; the evaluation workgroups gather the runs of their region -- no global sort).  Scattered queries give runs of
+    ~16; 90 % of these sit in one small box (one region: runs of ~1 800), the rest is scattered, a few lie outside the
+    grid: every value must still be the direct kernel's, for values and a derivative pattern, over several chunks."""
+    rng = np.random.default_rng(99)
+    nodes, nq = (64, 64, 64), 300_001
+    coef = rng.standard_normal(int(np.prod(nodes)))
+    q = -0.05 + 1.1 * rng.random((nq, 3))
+    hot = rng.random(nq) < 0.9
+    q[hot] = 0.40 + 0.05 * rng.random((int(hot.sum()), 3))
+    try:
+        for pat in (None, [0, 1, 2]):
+            capi.set_eval_mode(capi.EVAL_BINNED, 1 << 17)
+            vb, rc = capi.evaluate(3, q, pat, coef, [0.0] * 3, [1.0] * 3, nodes)
+            assert rc == 0
+            capi.set_eval_mode(capi.EVAL_DIRECT)
+            vd, rc = capi.evaluate(3, q, pat, coef, [0.0] * 3, [1.0] * 3, nodes)
+            assert rc == 0 and np.array_equal(vb, vd), pat
+    finally:
+        capi.set_eval_mode(capi.EVAL_AUTO)
+
+
 @pytest.mark.parametrize("nodes", [(20, 17, 30), (12, 9, 8, 14), (70, 40)])
 def test_eval_derivs_binned_path_is_bit_identical_to_direct(nodes):
     """Value + gradient + Hessian through the region sort (LDS tiles) must return the bits of the direct
