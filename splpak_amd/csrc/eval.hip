@@ -569,16 +569,13 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
     }
 }
 
-// ---- run path (3-D value / single-pattern evaluation; round 3) ----------------------------------------
+// ---- run path (3-D / 4-D value and single-pattern evaluation; round 3) ----------------------------------------
 // The region sort above moves every query three times (count, place, evaluate) and spends a tenth of its time on the
 // prefixes in between.  Here the place pass stops at what it has in LDS anyway: every workgroup writes ITS 2 048 queries,
 // sorted by region, as one contiguous image (64 KB of records, fully coalesced) and leaves the starts of its runs in a row
-// of `starts`; the evaluation workgroup (region r, group k) walks the runs (w, r) of the RUN_GROUP workgroups of its
+// of `starts`; the evaluation workgroup (region r, group k) walks the runs (w, r) of the ~nbins workgroups of its
 // group.  No count pass, no prefix kernels, no global order: 24 + 32 bytes per query in the place pass, 32 + 8 in the
 // evaluation pass.  Same arithmetic per query as everywhere else: identical bits.
-// place-pass workgroups per evaluation workgroup (128 x 16.4 = 2 097 queries of a region at 64^3; 120, which keeps 96 % of the
-// evaluation workgroups within two rounds of their 1 024 threads, measured the same)
-constexpr int RUN_GROUP = 128;
 constexpr int RUN_QPW = 2048;          // queries per place-pass workgroup
 
 template <int D, typename T>
@@ -648,45 +645,51 @@ run_place_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq, 
     }
 }
 
+// grp = place-pass workgroups per evaluation workgroup (<= RUN_GROUP_MAX): chosen by the host so that a region's queries in a
+// group are ~2 000 (3-D 64^3: 128 x 16.4; 4-D 32^4: 615 x 3.2).
+constexpr int RUN_GROUP_MAX = 1024;
 template <int D, bool VAL, typename T>
 __global__ void __launch_bounds__(EVAL_WG)
 eval_runs_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef, const double *__restrict__ img,
-                 const int *__restrict__ starts, int nwg, T *__restrict__ out)
+                 const int *__restrict__ starts, int nwg, int grp, T *__restrict__ out)
 {
+    constexpr bool DEAL = D == 4;             // queries dealt to the lanes by LDS bank class (see eval_binned_kernel)
+    static_assert(EVAL_WG == 1024 && RUN_GROUP_MAX <= EVAL_WG, "one place-pass workgroup per thread in the prefix");
     __shared__ double tile[tile_elems<D>()];
-    static_assert(RUN_GROUP <= 128, "two workgroups per lane of one wave in the prefix");
-    __shared__ int pre[RUN_GROUP + 1], rst[RUN_GROUP];
+    __shared__ int pre[RUN_GROUP_MAX + 1];
+    __shared__ unsigned short rst[RUN_GROUP_MAX];
+    __shared__ int wsum[16];
+    __shared__ int s_cnt[32], s_sur[33], s_fre[33];
+    __shared__ unsigned short s_list[DEAL ? EVAL_QPW : 1];      // [class][64 slots] (two of these workgroups share a CU's LDS: 79 KB each)
     using TS = TileShape<D>;
     using TT = TileStride<D>;
     const int r = blockIdx.x % rg.nbins, k = blockIdx.x / rg.nbins;
-    const int w0 = k * RUN_GROUP;
+    const int w0 = k * grp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // this region's runs in the group's workgroups: start inside the workgroup's image, inclusive prefix of the lengths
-    if (threadIdx.x < 64) {
-        int c[2], st[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int wl = 2 * (int)threadIdx.x + u, w = w0 + wl;
-            c[u] = 0;
-            st[u] = 0;
-            if (wl < RUN_GROUP && w < nwg) {
-                const int *__restrict__ row = starts + (long long)w * (rg.nbins + 1) + r;
-                st[u] = row[0];
-                c[u] = row[1] - row[0];
-            }
-            if (wl < RUN_GROUP) rst[wl] = st[u];
+    {
+        int c = 0, st = 0;
+        if (tid < grp && w0 + tid < nwg) {
+            const int *__restrict__ row = starts + (long long)(w0 + tid) * (rg.nbins + 1) + r;
+            st = row[0];
+            c = row[1] - st;
         }
-        int incl = c[0] + c[1];
+        if (tid < grp) rst[tid] = (unsigned short)st;
+        int incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(incl, o, 64);
-            if ((int)threadIdx.x >= o) incl += t;
+            if (lane >= o) incl += t;
         }
-        if (2 * (int)threadIdx.x + 1 <= RUN_GROUP) pre[2 * threadIdx.x + 1] = incl - c[1];
-        if (2 * (int)threadIdx.x + 2 <= RUN_GROUP) pre[2 * threadIdx.x + 2] = incl;
-        if (threadIdx.x == 0) pre[0] = 0;
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int v = 0; v < wave; ++v) woff += wsum[v];
+        if (tid < grp) pre[tid + 1] = woff + incl;
+        if (tid == 0) pre[0] = 0;
     }
     __syncthreads();
-    const int total = pre[RUN_GROUP];
+    const int total = pre[grp];
     if (total == 0) return;
     int a[D];                                  // first node of the region's tile
     {
@@ -697,7 +700,7 @@ eval_runs_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef, cons
             rr /= rg.nreg[d];
         }
     }
-    for (int e = threadIdx.x; e < tile_cells<D>(); e += EVAL_WG) {
+    for (int e = tid; e < tile_cells<D>(); e += EVAL_WG) {
         int rem = e, idx = 0, te = 0;
         bool ok = true;
 #pragma unroll
@@ -714,24 +717,14 @@ eval_runs_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef, cons
     __syncthreads();
     constexpr int t1 = TT::S[1], t2 = TT::S[2], t3 = TT::S[3];
     auto locate = [&](int qi) -> const double * {      // record qi of the group's queries of this region
-        int lo = 0, hi = RUN_GROUP;                    // pre[lo] <= qi < pre[hi]
+        int lo = 0, hi = grp;                          // pre[lo] <= qi < pre[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (pre[mid] <= qi) lo = mid; else hi = mid;
         }
         return img + ((long long)(w0 + lo) * RUN_QPW + rst[lo] + (qi - pre[lo])) * (D + 1);
     };
-    int qi = threadIdx.x;
-    double xn[D];
-    int pn = 0;
-    if (qi < total) pn = load_record<D>(locate(qi), xn);
-    while (qi < total) {
-        double x[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) x[d] = xn[d];
-        const int p = pn;
-        const int qn = qi + EVAL_WG;
-        if (qn < total) pn = load_record<D>(locate(qn), xn);
+    auto evaluate = [&](const double (&x)[D], int p) {
         double b[D][4];
         int base = 0;
 #pragma unroll
@@ -745,7 +738,100 @@ eval_runs_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef, cons
             c[0] = qq[0]; c[1] = qq[1]; c[2] = qq[2]; c[3] = qq[3];
         });
         out[p] = (T)sum;
-        qi = qn;
+    };
+    if constexpr (DEAL) {
+        // batches of <= 2 048 queries, dealt to the lanes by the bank class of their tile offset (eval_binned_kernel has the
+        // reasoning): 64 slots per class = two rounds per lane; what a class holds beyond 64 fills the free slots of the
+        // short classes
+        for (int q0 = 0; q0 < total; q0 += EVAL_QPW) {
+            const int nqb = total - q0 < EVAL_QPW ? total - q0 : EVAL_QPW;
+            if (tid < 32) s_cnt[tid] = 0;
+            __syncthreads();
+            int key[2] = {-1, -1}, rk[2] = {0, 0};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int jj = tid + u * EVAL_WG;
+                if (jj < nqb) {
+                    double x[D];
+                    (void)load_record<D>(locate(q0 + jj), x);
+                    int base = 0;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        int lo, hi;
+                        base += (window_start(g, d, x[d], lo, hi) - a[d]) * TT::S[d];
+                    }
+                    key[u] = base & 31;
+                    rk[u] = atomicAdd(&s_cnt[key[u]], 1);
+                }
+            }
+            __syncthreads();
+            if (tid < 32) {             // exclusive scans over the 32 classes: surplus (beyond 64) and free slots
+                const int n = s_cnt[tid];
+                const int sur = n > 64 ? n - 64 : 0, fre = n < 64 ? 64 - n : 0;
+                int is = sur, ifr = fre;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    const int ts = __shfl_up(is, o, 32), tf = __shfl_up(ifr, o, 32);
+                    if (tid >= o) { is += ts; ifr += tf; }
+                }
+                s_sur[tid] = is - sur;
+                s_fre[tid] = ifr - fre;
+                if (tid == 31) { s_sur[32] = is; s_fre[32] = ifr; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (key[u] >= 0) {
+                    const unsigned short id = (unsigned short)(tid + u * EVAL_WG);
+                    if (rk[u] < 64) s_list[key[u] * 64 + rk[u]] = id;
+                    else {                               // surplus entry e takes the e-th free slot (classes in order)
+                        const int e = s_sur[key[u]] + rk[u] - 64;
+                        int lo = 0, hi = 32;             // s_fre[lo] <= e < s_fre[hi]
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_fre[mid] <= e) lo = mid; else hi = mid;
+                        }
+                        s_list[lo * 64 + s_cnt[lo] + (e - s_fre[lo])] = id;
+                    }
+                }
+            __syncthreads();
+            const int h = tid & 31, w = tid >> 5;
+            const int n_h = s_cnt[h], nsur = s_sur[32];
+            int filled = n_h < 64 ? n_h : 64;           // own entries + the surplus entries that took this class's free slots
+            if (n_h < 64) {
+                int ex = nsur - s_fre[h];
+                ex = ex < 0 ? 0 : (ex > 64 - n_h ? 64 - n_h : ex);
+                filled += ex;
+            }
+            int jq[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int slot = w + 32 * u;
+                jq[u] = slot < filled ? (int)s_list[h * 64 + slot] : -1;
+            }
+            double x0[D], x1[D];
+            int p0 = 0, p1 = 0;
+            if (jq[0] >= 0) p0 = load_record<D>(locate(q0 + jq[0]), x0);
+            if (jq[1] >= 0) p1 = load_record<D>(locate(q0 + jq[1]), x1);
+            if (jq[0] >= 0) evaluate(x0, p0);
+            if (jq[1] >= 0) evaluate(x1, p1);
+            __syncthreads();
+        }
+    } else {
+        int qi = tid;
+        double xn[D];
+        int pn = 0;
+        if (qi < total) pn = load_record<D>(locate(qi), xn);
+        while (qi < total) {
+            double x[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) x[d] = xn[d];
+            const int p = pn;
+            const int qn = qi + EVAL_WG;
+            if (qn < total) pn = load_record<D>(locate(qn), xn);
+            evaluate(x, p);
+            qi = qn;
+        }
     }
 }
 
@@ -811,8 +897,19 @@ template <int D, typename T>
 static hipError_t eval_runs(const Grid &g, const Regions &rg, long long nq, const T *xq, int ldxq, const NDeriv &nd,
                             const T *coef, T *out, hipStream_t st)
 {
-    // (runs of RUN_QPW / nbins records: below ~8 the evaluation pass would gather single records)
-    if (rg.nbins > 256 || std::getenv("SPLPAK_EVAL_SORT")) return hipErrorNotSupported;
+    // (runs of RUN_QPW / nbins records: 16 at 64^3, 3 at 4-D 32^4; with more regions than that the evaluation pass would
+    // gather single records and its groups outgrow the prefix)
+    // Measured at 4-D 32^4 (648 regions, runs of 3 records = one 128-byte line): place 0.30 ms instead of count + prefixes +
+    // place 0.70, but the evaluation pass 1.30 instead of 0.82 ms (fragments, a 10-step search per record, twice with the class
+    // dealing) -- 1.09 against 1.18e10 evals/s: the sort stays for grids of more than 256 regions.
+    static const int max_bins = std::getenv("SPLPAK_EVAL_RUNS_MAXBINS") ? atoi(std::getenv("SPLPAK_EVAL_RUNS_MAXBINS")) : 256;
+    if (rg.nbins > RUN_GROUP_MAX || rg.nbins > max_bins || std::getenv("SPLPAK_EVAL_SORT")) return hipErrorNotSupported;
+    // place-pass workgroups per evaluation workgroup: ~1 950 queries of a region (two rounds of 1 024 threads; the 4-D
+    // class dealing works in batches of 2 048)
+    int grp = (int)(0.95 * rg.nbins + 0.5);
+    if (D == 3 && grp < 128) grp = 128;
+    if (grp < 32) grp = 32;
+    if (grp > RUN_GROUP_MAX) grp = RUN_GROUP_MAX;
     long long chunk = g_eval_chunk > 0 ? g_eval_chunk : (1LL << 24);
     if (chunk > (1LL << 26)) chunk = 1LL << 26;
     if (chunk > nq) chunk = nq;
@@ -845,13 +942,13 @@ static hipError_t eval_runs(const Grid &g, const Regions &rg, long long nq, cons
         const unsigned nwg = (unsigned)((n + RUN_QPW - 1) / RUN_QPW);
         hipLaunchKernelGGL((run_place_kernel<D, T>), dim3(nwg), dim3(256), sizeof(int) * (2 * rg.nbins + 1), st, g, rg, n, xc, ldxq,
                            s.img, s.starts);
-        const unsigned ngroups = (nwg + RUN_GROUP - 1) / RUN_GROUP;
+        const unsigned ngroups = (nwg + (unsigned)grp - 1) / (unsigned)grp;
         if (value_only)
             hipLaunchKernelGGL((eval_runs_kernel<D, true, T>), dim3(ngroups * (unsigned)rg.nbins), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
-                               (const double *)s.img, (const int *)s.starts, (int)nwg, out + c0);
+                               (const double *)s.img, (const int *)s.starts, (int)nwg, grp, out + c0);
         else
             hipLaunchKernelGGL((eval_runs_kernel<D, false, T>), dim3(ngroups * (unsigned)rg.nbins), dim3(EVAL_WG), 0, st, g, rg, nd, coef,
-                               (const double *)s.img, (const int *)s.starts, (int)nwg, out + c0);
+                               (const double *)s.img, (const int *)s.starts, (int)nwg, grp, out + c0);
     }
     (void)hipEventRecord(s.last, st);
     return hipGetLastError();
@@ -863,7 +960,7 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
                               const NDeriv &nd, const T *coef, T *out, hipStream_t st,
                               int order = 0, int ldout = 1)
 {
-    if constexpr (D == 3) {
+    if constexpr (D >= 3) {
         if (order == 0) {
             const hipError_t e = eval_runs<D, T>(g, rg, nq, xq, ldxq, nd, coef, out, st);
             if (e != hipErrorNotSupported) return e;
