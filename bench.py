@@ -558,7 +558,7 @@ def main():
     eval_traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r03_eval_pmc.json")))["3d_64"]
-        eval_traffic = {"kernel": "eval_binned_kernel<3,true>", "bytes_per_launch": next(v for k, v in pm["kernels"].items() if k.startswith("eval_binned_kernel<3, true"))["hbm_bytes"],
+        eval_traffic = {"kernel": "eval_runs_kernel<3,true> (evaluation pass; all passes in bytes_per_query_all_passes)", "bytes_per_launch": next(v for k, v in pm["kernels"].items() if k.startswith(("eval_runs_kernel<3, true", "eval_binned_kernel<3, true")))["hbm_bytes"],
                         "queries_per_launch": pm["queries_per_launch"],
                         "bytes_per_query_all_passes": pm["hbm_bytes_per_query_all_passes"], "algorithmic_bytes_per_query": 8.0 * (nd + 1),
                         "source": "profiles/r03_eval_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload; not measured in this run)"}

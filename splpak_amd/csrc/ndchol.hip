@@ -520,7 +520,23 @@ nd_dot_kernel(const DotJob *__restrict__ jobs, int njobs)
     const int rend = rbeg + j.rps < j.nrows ? rbeg + j.rps : j.nrows;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const double *__restrict__ Lc = j.L + lane + (long long)c0 * j.ld;
-    for (int r = rbeg; r < rend; r += 64) {
+    // four row groups (20 loads) in flight per round: the rolled loop paid one memory round trip per 64 rows, 16 in a row
+    // for a split of 1 024 -- the launch sits on the chain of every backward step.  Same order of the sums.
+    int r = rbeg;
+    for (; r + 192 < rend; r += 256) {
+        double xr[4], l[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xr[t] = j.x[r + 64 * t + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) l[t][c] = Lc[r + 64 * t + (long long)c * j.ld];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += l[t][c] * xr[t];
+    }
+    for (; r < rend; r += 64) {
         const double xr = j.x[r + lane];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] += Lc[r + (long long)c * j.ld] * xr;
@@ -540,18 +556,35 @@ nd_bwd_kernel(const BwdJob *__restrict__ jobs)
     const BwdJob j = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * 16 + wave * 4;
-    double vv[4], s[4];
+    // the 16 matrix entries are in flight while the partial dots are summed; the four columns of a split are loaded together
+    // (the sums keep their order: split after split) -- the launch sits on the chain of every backward step
+    double vv[4], s[4], mt[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        double v = j.y[lane + 64 * u];
-        for (int sp = 0; sp < j.nsplit; ++sp) v -= j.part[(long long)sp * NBLK + lane + 64 * u];
-        vv[u] = v;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mt[i][u] = j.Mt[(r0 + i) * NBLK + lane + 64 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vv[u] = j.y[lane + 64 * u];
+    int sp = 0;
+    for (; sp + 1 < j.nsplit; sp += 2) {
+        double p0[4], p1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            p0[u] = j.part[(long long)sp * NBLK + lane + 64 * u];
+            p1[u] = j.part[(long long)(sp + 1) * NBLK + lane + 64 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vv[u] = (vv[u] - p0[u]) - p1[u];
+    }
+    if (sp < j.nsplit) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vv[u] -= j.part[(long long)sp * NBLK + lane + 64 * u];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         s[i] = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s[i] += j.Mt[(r0 + i) * NBLK + lane + 64 * u] * vv[u];
+        for (int u = 0; u < 4; ++u) s[i] += mt[i][u] * vv[u];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);

@@ -52,7 +52,7 @@ out = {
 json.dump(out, open(os.path.join(dst, "r03_fit_pmc.json"), "w"), indent=1)
 def eval_set(files, nq_launch, alg):
     ks = kernels([os.path.join(src, f) for f in files])
-    binned = {k: v for k, v in ks.items() if k.startswith("bin_") or k.startswith("eval_binned")}
+    binned = {k: v for k, v in ks.items() if k.startswith(("bin_", "eval_binned", "run_place", "eval_runs"))}
     tot = sum(v.get("hbm_bytes", 0.0) for v in binned.values())
     totu = sum(v.get("hbm_bytes_uncorrected", 0.0) for v in binned.values())
     return {"queries_per_launch": nq_launch, "hbm_bytes_per_query_all_passes": tot / nq_launch,

@@ -10,10 +10,10 @@ export C2_WARM=0 C2_REPS=1
 bash tools/pmc.sh r03/fit_fetch "FETCH_SIZE" "nd_|gram|gather|residual|scatter" python3 /root/repo/tools/c2_profile.py 3 64 10000000 > /dev/null
 bash tools/pmc.sh r03/fit_write "WRITE_SIZE" "nd_|gram|gather|residual|scatter" python3 /root/repo/tools/c2_profile.py 3 64 10000000 > /dev/null
 echo "fit pmc done"
-bash tools/pmc.sh r03/eval3_fetch "FETCH_SIZE" "eval|bin_" python3 /root/repo/tools/eval_profile.py 3 64 50000000 > /dev/null
-bash tools/pmc.sh r03/eval3_write "WRITE_SIZE" "eval|bin_" python3 /root/repo/tools/eval_profile.py 3 64 50000000 > /dev/null
-bash tools/pmc.sh r03/eval4_fetch "FETCH_SIZE" "eval|bin_" python3 /root/repo/tools/eval_profile.py 4 32 100000000 > /dev/null
-bash tools/pmc.sh r03/eval4_write "WRITE_SIZE" "eval|bin_" python3 /root/repo/tools/eval_profile.py 4 32 100000000 > /dev/null
+bash tools/pmc.sh r03/eval3_fetch "FETCH_SIZE" "eval|bin_|run_place" python3 /root/repo/tools/eval_profile.py 3 64 50000000 > /dev/null
+bash tools/pmc.sh r03/eval3_write "WRITE_SIZE" "eval|bin_|run_place" python3 /root/repo/tools/eval_profile.py 3 64 50000000 > /dev/null
+bash tools/pmc.sh r03/eval4_fetch "FETCH_SIZE" "eval|bin_|run_place" python3 /root/repo/tools/eval_profile.py 4 32 100000000 > /dev/null
+bash tools/pmc.sh r03/eval4_write "WRITE_SIZE" "eval|bin_|run_place" python3 /root/repo/tools/eval_profile.py 4 32 100000000 > /dev/null
 echo "eval pmc done"
 ls gpurun_out/r03
 python3 tools/r03_pmc_json.py gpurun_out/r03 gpurun_out/r03 > gpurun_out/r03/pmc_json.log 2>&1
