@@ -475,7 +475,17 @@ axpy_absmax_kernel(int n, double *__restrict__ x, const double *__restrict__ dx,
         mdx = fmax(mdx, __shfl_xor(mdx, o, 64));
         mx = fmax(mx, __shfl_xor(mx, o, 64));
     }
+    // one pair of atomics per workgroup (a pair per wave of 1 024 workgroups queued 8 192 atomics on two words: 96 us for a
+    // 2 MB vector, twice per fit; round 3)
+    __shared__ double red[2][4];
     if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = mdx;
+        red[1][threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mdx = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+        mx = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
         // non-negative doubles order like their bit patterns; NaN (sign clear) sorts above inf
         atomicMax(&absmax2[0], (unsigned long long)__double_as_longlong(mdx));
         atomicMax(&absmax2[1], (unsigned long long)__double_as_longlong(mx));
@@ -1329,7 +1339,7 @@ hipError_t launch_axpy_absmax(int n, double *x, const double *dx, double *absmax
     hipError_t e = hipMemsetAsync(absmax2, 0, 2 * sizeof(double), st);
     if (e != hipSuccess) return e;
     int blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(axpy_absmax_kernel, dim3(blocks), dim3(256), 0, st, n, x, dx,
                        reinterpret_cast<unsigned long long *>(absmax2));
     return hipGetLastError();
