@@ -432,7 +432,15 @@ gram_wave_kernel(Grid g, const int *__restrict__ offset, const double *__restric
     if (rel >= ncells) return;
     const int cell = cell0 + rel;
     const long long beg = offset[cell], end = offset[cell + 1];
-    if (beg == end) return;                    // the gather skips empty cells
+    if (beg == end) {                          // an empty cell leaves a zero block: the gather reads every block unconditionally
+        double *__restrict__ z = blk + (long long)rel * TRI;
+        for (int e = lane; e < (int)TRI; e += 64) z[e] = 0.0;
+        if (lane < NB) {
+            rblk[(long long)rel * NB + lane] = 0.0;
+            if (hblk) hblk[(long long)rel * NB + lane] = 0.0;
+        }
+        return;
+    }
     double *tab = s_tab[wave], *sw = s_w[wave], *swy = s_wy[wave];
     int *sslot = s_slot[wave];
     const bool hist_on = hblk != nullptr;
@@ -566,7 +574,9 @@ struct CellRange {
 // the per-cell blocks, cell after cell in CellRange order.  Entry (r, c) of a block, c <= r, belongs
 // to column offset c - r (digit-wise), i.e. stencil code sum_d (c_d - r_d + 3) 7^d; for one cell the
 // lanes c = 0..r hit distinct codes, so the wave accumulates in an LDS row without conflicts.
-template <int D>
+// ZEROED: the blocks of empty cells were written as zeros (gram_wave_kernel), so no cell's point count is looked up and the
+// rows of a batch do not wait for a first round of loads (round 3: two dependent round trips per batch of 8 cells -> one).
+template <int D, bool ZEROED = false>
 __global__ void __launch_bounds__(256)
 stencil_gather_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ blk,
                       const double *__restrict__ rblk, const double *__restrict__ hblk,
@@ -606,8 +616,11 @@ stencil_gather_kernel(Grid g, const int *__restrict__ offset, const double *__re
             const bool ok = have && cell >= cell0 && cell < cell1;
             cl[u] = ok ? cell : cell0;               // a harmless cell for the lookups below
             rr[u] = ok ? r : -1;
-            o0[u] = offset[cl[u]];
-            o1[u] = offset[cl[u] + 1];
+            if (!ZEROED) {
+                o0[u] = offset[cl[u]];
+                o1[u] = offset[cl[u] + 1];
+            } else
+                o0[u] = 0, o1[u] = 1;
         }
         double v[GB][NCH], rv[GB], hv[GB];
 #pragma unroll
@@ -1285,8 +1298,9 @@ long long gram_scratch_min_doubles(const Grid &g)
     return (long long)g.cellstride[g.ndim - 1] * (gram_tri(g.nb) + 2LL * g.nb);
 }
 
+// -> true when the blocks of empty cells were written as zeros (the gather then reads every block unconditionally)
 template <int D>
-static void gram_cells(const Grid &g, const SortScratch &s, double *blk, double *rblk, double *hblk, double *hist, int cell0,
+static bool gram_cells(const Grid &g, const SortScratch &s, double *blk, double *rblk, double *hblk, double *hist, int cell0,
                        int ncells, hipStream_t st)
 {
     static const bool old_form = std::getenv("SPLPAK_GRAM_VALU") != nullptr;       // A/B switch: the workgroup-per-cell form
@@ -1295,13 +1309,14 @@ static void gram_cells(const Grid &g, const SortScratch &s, double *blk, double 
             hipLaunchKernelGGL(gram_wave_kernel<D>, dim3((unsigned)((ncells + 3) / 4)), dim3(256), 0, st, g, (const int *)s.offset,
                                (const double *)s.xs, (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist,
                                cell0, ncells);
-            return;
+            return true;
         }
     }
     using C = GramCfg<D>;
     dim3 gr((unsigned)ncells, (unsigned)(C::NB / (C::NTX * C::TC)));
     hipLaunchKernelGGL(gram_block_kernel<D>, gr, dim3(C::NT), 0, st, g, (const int *)s.offset, (const double *)s.xs,
                        (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist, cell0);
+    return false;
 }
 
 hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, long long scratch_doubles, bool smooth,
@@ -1325,10 +1340,16 @@ hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, lon
         double *rblk = blk + (long long)ncells * gram_tri(g.nb);
         double *hblk = smooth ? rblk + (long long)ncells * g.nb : nullptr;
         DISPATCH_D(g.ndim, {
-            gram_cells<D>(g, s, blk, rblk, hblk, hist, cell0, ncells, st);
-            hipLaunchKernelGGL(stencil_gather_kernel<D>, dim3((unsigned)((node1 - node0 + 3) / 4)), dim3(256), 0, st, g,
-                               (const int *)s.offset, (const double *)blk, (const double *)rblk, (const double *)hblk,
-                               nst, rhs, hist, cell0, cell1, node0, node1);
+            const bool zeroed = gram_cells<D>(g, s, blk, rblk, hblk, hist, cell0, ncells, st) && !std::getenv("SPLPAK_GATHER_LOOKUP");
+            const dim3 gg((unsigned)((node1 - node0 + 3) / 4));
+            if (zeroed)
+                hipLaunchKernelGGL((stencil_gather_kernel<D, true>), gg, dim3(256), 0, st, g,
+                                   (const int *)s.offset, (const double *)blk, (const double *)rblk, (const double *)hblk,
+                                   nst, rhs, hist, cell0, cell1, node0, node1);
+            else
+                hipLaunchKernelGGL((stencil_gather_kernel<D, false>), gg, dim3(256), 0, st, g,
+                                   (const int *)s.offset, (const double *)blk, (const double *)rblk, (const double *)hblk,
+                                   nst, rhs, hist, cell0, cell1, node0, node1);
         });
     }
     if (smooth) hipLaunchKernelGGL(hist_total_kernel, dim3(1), dim3(1024), 0, st, (const double *)hist, g.ncol, scalH);
