@@ -977,21 +977,34 @@ constraint_rows_kernel(Grid g, const double *__restrict__ dcw, const unsigned ch
     int in[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) in[d] = (node / g.colstride[d]) % g.nodes[d];
-    // lanes look the 3^D neighbours up in parallel; most rows have no sparse neighbour and leave here
-    bool mine = false;
-    for (int ne = lane; ne < NE; ne += 64) {
-        int t = ne, col = 0;
-        bool ok = true;
+    // lanes look the 3^D neighbours up in parallel: sparse[r] = which of the neighbours 64 r .. 64 r + 63 are data sparse.  Most
+    // rows of a well-covered grid leave here; the others walk the SET bits only (the walk used to re-read the flag of every
+    // neighbour, one dependent load after the other: 27 of them for 1.6 sparse neighbours at C3)
+    unsigned long long sparse[(NE + 63) / 64];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int nd_ = in[d] + t % 3 - 1;
-            t /= 3;
-            ok = ok && nd_ >= 0 && nd_ <= g.nodes[d] - 1;
-            col += nd_ * g.colstride[d];
+    for (int r = 0; r < (NE + 63) / 64; ++r) {
+        const int ne = lane + 64 * r;
+        bool mine = false;
+        if (ne < NE) {
+            int t = ne, col = 0;
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int nd_ = in[d] + t % 3 - 1;
+                t /= 3;
+                ok = ok && nd_ >= 0 && nd_ <= g.nodes[d] - 1;
+                col += nd_ * g.colstride[d];
+            }
+            mine = ok && spf[col] != 0;
         }
-        mine = mine || (ok && spf[col] != 0);
+        sparse[r] = __builtin_amdgcn_ballot_w64(mine);
     }
-    if (__builtin_amdgcn_ballot_w64(mine) == 0) return;
+    {
+        unsigned long long anyb = 0;
+#pragma unroll
+        for (int r = 0; r < (NE + 63) / 64; ++r) anyb |= sparse[r];
+        if (anyb == 0) return;
+    }
     for (int e = lane; e < HS; e += 64) acc[e] = 0.0;
     bool any = false;
     for (int ne = 0; ne < NE; ++ne) {            // neighbour n = i + offn, offn_d in [-1,1], dim 0 fastest
@@ -1006,8 +1019,8 @@ constraint_rows_kernel(Grid g, const double *__restrict__ dcw, const unsigned ch
             ok = ok && nn[d] >= 0 && nn[d] <= g.nodes[d] - 1;
             ncol_n += nn[d] * g.colstride[d];
         }
-        if (!ok) continue;
-        if (spf[ncol_n] == 0) continue;
+        if (!((sparse[ne >> 6] >> (ne & 63)) & 1ull)) continue;        // (in the grid and data sparse)
+        (void)ok;
         SparseNode sn;
         sn.sparse = true;
         sn.dcwght = dcw[ncol_n];
