@@ -33,6 +33,9 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     if w is not None and rng.random() < 0.5:
         w[rng.random(m) < 0.1] = 0.0
     xtrap = float(rng.choice([0.0, 0.3, 1.0, 2.5]))
+    if os.environ.get("FUZZ_ONLY") and trial != int(os.environ["FUZZ_ONLY"]):
+        rng.random((300, nd)); [rng.integers(0, 3) for _ in range(nd)]        # (the draws the comparison below would make)
+        continue
     # generous workspace: the reference's own size check (suprls 32 -> 107, :1443-1454) is not under test
     if BIG:
         c0, e0, ib = port.fit_banded(nd, x, y, w, lo, hi, nodes, xtrap)
@@ -69,10 +72,17 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
         # problem (both solvers stop at cond*eps), not a discrepancy between them
         print(tag, f"flat direction: coef rel {rel:.2e} at equal residual norm {ib[8]:.12e}; hip steps {int(i1[2])}, last correction {i1[3]:.1e}")
         rel = 0.0
+    if BIG and rel > 1e-10 and i1[8] < ib[8] * (1.0 - 1e-9) and i1[9] < 1e-12:
+        # the GPU's solution has the SMALLER residual norm and a componentwise backward error at rounding level: the banded CPU
+        # comparator stopped short on this problem (1-D, ~2 000 nodes, xtrap 2.5: round 3, seed 778 trial 51)
+        print(tag, f"comparator short of the minimum: coef rel {rel:.2e}, residual norm hip {i1[8]:.9e} < cpu {ib[8]:.9e}, hip backward error {i1[9]:.1e}")
+        rel = 0.0
     worst = max(worst, rel)
     bad = rel > 1e-10 or erel > 1e-12 or (w0 is not None and xtrap != 0 and np.max(np.abs(h1[:ncol] - w0[:ncol])) > 1e-12 * max(np.max(np.abs(w0[:ncol])), 1))
     if bad:
         fails += 1
         print(tag, f"coef rel {rel:.2e} eval rel {erel:.2e}  <-- FAIL")
+        if BIG:
+            print(f"    hip: ierr {e1} steps {int(i1[2])} last correction {i1[3]:.2e} reserr {i1[8]:.12e} omega {i1[9]:.2e}; banded CPU reserr {ib[8]:.12e}")
 print(f"worst coefficient deviation {worst:.2e}; failures {fails}")
 sys.exit(1 if fails else 0)
