@@ -539,6 +539,128 @@ gram_wave_kernel(Grid g, const int *__restrict__ offset, const double *__restric
     }
 }
 
+// The 4-D blocks (256 window functions: 136 tiles of 16 x 16 in the lower triangle) on the matrix cores: one workgroup of TEN
+// waves per cell, a wave per 64 x 64 super-block (I, J), J <= I, of the 256 x 256 block -- 16 accumulator tiles with static
+// indices, as in the trailing-update kernels (the four diagonal super-blocks compute 6 tiles they do not store: 160 MFMAs per
+// 4 points for 136 useful).  Operands as in gram_wave_kernel, with the fourth dimension's factor on top:
+// B[p][c] = (((w b0[c0]) b1[c1]) b2[c2]) b3[c3], c = c0 + 4 c1 + 16 c2 + 64 c3: tile block m = (c2, c3) = (m & 3, m >> 2), so a
+// super-block (I, J) needs t[j] = u b2[j] once and t[j] b3[I], t[j] b3[J] per step.  Round 3: the workgroup-per-cell VALU form
+// took 73.8 ms at 16^4 / 10^7 points (a third of the fit) for ~11 ms of matrix-pipe time.
+template <int D>
+__global__ void __launch_bounds__(640)
+gram_mfma4_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
+                  const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
+                  double *__restrict__ blk, double *__restrict__ rblk, double *__restrict__ hblk,
+                  double *__restrict__ hist, int cell0)
+{
+    static_assert(D == 4, "256 window functions");
+    constexpr int NB = 256, PCH = 64, LDT = 4 * D + 1;
+    constexpr long long TRI = (long long)NB * (NB + 1) / 2;
+    __shared__ double tab[PCH * LDT];
+    __shared__ double sw[PCH], swy[PCH];
+    __shared__ int sslot[PCH];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int cell = cell0 + blockIdx.x;
+    const long long beg = offset[cell], end = offset[cell + 1];
+    if (beg == end) return;                    // the gather skips empty cells
+    const bool hist_on = hblk != nullptr;
+    // super-block of this wave: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) (3,0) (3,1) (3,2) (3,3)
+    int sbI = 0, sbJ = wave;
+    while (sbJ > sbI) { sbJ -= sbI + 1; ++sbI; }
+
+    d4_t acc[4][4];                            // [column tile mi of J][row tile ni of I]
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4_t{0.0, 0.0, 0.0, 0.0};
+    double racc = 0.0, hacc = 0.0;
+    for (long long p0 = beg; p0 < end; p0 += PCH) {
+        const int np = (int)((end - p0 < PCH) ? (end - p0) : PCH);
+        if (tid < PCH) {                       // lane = point: window tables, weight, w^2 y, histogram slot (zero rows beyond np)
+            double b[D][4], wv = 0.0, wyv = 0.0;
+            int sl = -2;
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b[d][k] = 0.0;
+            if (tid < np) {
+                double xv[D];
+                wv = ws[p0 + tid];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    xv[d] = xs[(long long)d * cap + p0 + tid];
+                    window_table(g, d, xv[d], 0, b[d]);
+                }
+                wyv = wv * ys[p0 + tid];
+                if (hist_on) {
+                    sl = nearest_slot<D>(g, xv);
+                    if (sl < 0) {                       // rare: far outside the grid (:899); the only atomic left
+                        double xr[MAXD] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int d = 0; d < D; ++d) xr[g.perm[d]] = xv[d];
+                        atomicAdd(&hist[nearest_node_address(g, xr)], wv);       // :905
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tab[tid * LDT + 4 * d + k] = b[d][k];
+            sw[tid] = wv;
+            swy[tid] = wyv;
+            sslot[tid] = sl;
+        }
+        __syncthreads();
+        const int nsteps = (np + 3) >> 2;
+        for (int s4 = 0; s4 < nsteps; ++s4) {
+            const int p = 4 * s4 + q;
+            const double u = (sw[p] * tab[p * LDT + (l15 & 3)]) * tab[p * LDT + 4 + (l15 >> 2)];
+            const double bI = tab[p * LDT + 12 + sbI], bJ = tab[p * LDT + 12 + sbJ];
+            double orow[4], ocol[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double t = u * tab[p * LDT + 8 + j];
+                orow[j] = t * bI;
+                ocol[j] = t * bJ;
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(orow[ni], ocol[mi], acc[mi][ni], 0, 0, 0);
+        }
+        // right-hand side and histogram shares: thread = window function, points in storage order
+        if (tid < NB) {
+            for (int p = 0; p < np; ++p) {
+                double prod = tab[p * LDT + (tid & 3)];
+#pragma unroll
+                for (int d = 1; d < D; ++d) prod *= tab[p * LDT + 4 * d + ((tid >> (2 * d)) & 3)];
+                racc += (sw[p] * prod) * swy[p];
+                if (hist_on) hacc += (sslot[p] == tid) ? sw[p] : 0.0;       // :905
+            }
+        }
+        __syncthreads();
+    }
+    // packed lower triangle: tile (m, n) = (4 J + mi, 4 I + ni), register v of lane (l15, q) = entry (r, c) = (16 n + q + 4 v, 16 m + l15)
+    double *__restrict__ out = blk + (long long)blockIdx.x * TRI;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int m = 4 * sbJ + mi, n = 4 * sbI + ni;
+            if (m > n) continue;               // (above the diagonal of a diagonal super-block)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = 16 * n + q + 4 * v, c = 16 * m + l15;
+                if (c <= r) out[(long long)r * (r + 1) / 2 + c] = acc[mi][ni][v];
+            }
+        }
+    if (tid < NB) {
+        rblk[(long long)blockIdx.x * NB + tid] = racc;
+        if (hist_on) hblk[(long long)blockIdx.x * NB + tid] = hacc;
+    }
+}
+
 // Cells whose window contains node `in`: window starts ws_d in [max(in_d - 3, 0), min(in_d, cells_d - 1)],
 // enumerated with dimension 0 fastest -- THE fixed summation order of every gather below.
 template <int D>
@@ -1323,6 +1445,13 @@ static bool gram_cells(const Grid &g, const SortScratch &s, double *blk, double 
                                (const double *)s.xs, (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist,
                                cell0, ncells);
             return true;
+        }
+    }
+    if constexpr (D == 4) {
+        if (!old_form) {
+            hipLaunchKernelGGL(gram_mfma4_kernel<D>, dim3((unsigned)ncells), dim3(640), 0, st, g, (const int *)s.offset,
+                               (const double *)s.xs, (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist, cell0);
+            return false;                      // (empty cells write nothing: a 263 KB zero block each would be too much)
         }
     }
     using C = GramCfg<D>;
