@@ -965,6 +965,84 @@ residual_wave_kernel(Grid g, const int *__restrict__ offset, const double *__res
     }
 }
 
+// The 4-D form of the same share (256 window functions), one workgroup of four waves per cell (round 3: the staged form above,
+// which builds the full 16 x 256 row image of a chunk in LDS, took 7.5 ms per pass at 16^4 / 10^7 points):
+//   phase 1  wave k3, lane = point: b3[k3] * (factorised window sum of the slab k3 of the cell's coefficients) -> 4 partials
+//   phase 2  thread = window function: racc_c += (w b)_c * e over the points
+template <int D>
+__global__ void __launch_bounds__(256)
+residual_cell4_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
+                      const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
+                      const double *__restrict__ xvec, double *__restrict__ rcell, double *__restrict__ ssq)
+{
+    static_assert(D == 4, "256 window functions");
+    constexpr int NB = 256, PCH = 64, LDT = 4 * D + 1;
+    __shared__ double tab[PCH * LDT];
+    __shared__ double sw[PCH], sy[PCH], se[PCH];
+    __shared__ double part[4][PCH];
+    __shared__ double xl[NB];
+    const int cell = blockIdx.x;
+    const long long beg = offset[cell], end = offset[cell + 1];
+    if (beg == end) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int colbase = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) colbase += ((cell / g.cellstride[d]) % g.cells[d]) * g.colstride[d];
+    xl[tid] = xvec[local_col<D>(g, colbase, tid)];
+    double racc = 0.0, e2 = 0.0;
+    for (long long p0 = beg; p0 < end; p0 += PCH) {
+        const int np = (int)((end - p0 < PCH) ? (end - p0) : PCH);
+        if (tid < np) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                double b[4];
+                window_table_value(g, d, xs[(long long)d * cap + p0 + tid], b);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tab[tid * LDT + 4 * d + k] = b[k];
+            }
+            sw[tid] = ws[p0 + tid];
+            sy[tid] = ys[p0 + tid];
+        }
+        __syncthreads();
+        if (lane < np) {                        // slab k3 = wave of the window sum of point `lane`
+            const double *__restrict__ tb = tab + lane * LDT;
+            double r3 = 0.0;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                double r2 = 0.0;
+#pragma unroll
+                for (int k1 = 0; k1 < 4; ++k1) {
+                    double r = 0.0;
+#pragma unroll
+                    for (int k0 = 0; k0 < 4; ++k0) r = fma(tb[k0], xl[k0 + 4 * k1 + 16 * k2 + 64 * wave], r);
+                    r2 = fma(tb[4 + k1], r, r2);
+                }
+                r3 = fma(tb[8 + k2], r2, r3);
+            }
+            part[wave][lane] = tb[12 + wave] * r3;
+        }
+        __syncthreads();
+        if (tid < np) {
+            const double t = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+            const double e = sw[tid] * sy[tid] - sw[tid] * t;      // row residual  w y - (w b) . x
+            se[tid] = e;
+            e2 = fma(e, e, e2);
+        }
+        __syncthreads();
+        for (int p = 0; p < np; ++p) {
+            const double *__restrict__ tb = tab + p * LDT;
+            const double prod = (((sw[p] * tb[tid & 3]) * tb[4 + ((tid >> 2) & 3)]) * tb[8 + ((tid >> 4) & 3)]) * tb[12 + (tid >> 6)];
+            racc = fma(prod, se[p], racc);
+        }
+        __syncthreads();
+    }
+    rcell[(long long)cell * NB + tid] = racc;
+    if (ssq && wave == 0) {
+        e2 = wave_sum(e2);
+        if (lane == 0) ssq[cell] = e2;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Derivative-constraint rows (:921-1046).  A data-sparse node n (histogram below spcrit = 0.75 of the
 // expected weight, :936) emits D(D+1)/2 rows, one per pair idm <= jdm, whose entries sit on the 3^D
@@ -1550,9 +1628,15 @@ static void residual_cells(const Grid &g, const SortScratch &s, const double *xv
                            (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
                            s.cap, xvec, rcell, e2c);
     } else {
-        hipLaunchKernelGGL(residual_block_kernel<D>, dim3((unsigned)g.ncell), dim3(ResCfg<D>::NT), 0, st, g,
-                           (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
-                           s.cap, xvec, rcell, e2c);
+        static const bool old_form = std::getenv("SPLPAK_RESIDUAL_STAGED") != nullptr;      // A/B switch
+        if (old_form)
+            hipLaunchKernelGGL(residual_block_kernel<D>, dim3((unsigned)g.ncell), dim3(ResCfg<D>::NT), 0, st, g,
+                               (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
+                               s.cap, xvec, rcell, e2c);
+        else
+            hipLaunchKernelGGL(residual_cell4_kernel<D>, dim3((unsigned)g.ncell), dim3(256), 0, st, g,
+                               (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
+                               s.cap, xvec, rcell, e2c);
     }
 }
 
