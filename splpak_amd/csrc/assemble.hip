@@ -465,7 +465,7 @@ gram_wave_kernel(Grid g, const int *__restrict__ offset, const double *__restric
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     xv[d] = xs[(long long)d * cap + p0 + lane];
-                    window_table(g, d, xv[d], 0, b[d]);
+                    window_table_value(g, d, xv[d], b[d]);      // (the bits of window_table(.., 0, ..), see basis.hpp)
                 }
                 wyv = wv * ys[p0 + lane];
                 if (hist_on) {
@@ -589,7 +589,7 @@ gram_mfma4_kernel(Grid g, const int *__restrict__ offset, const double *__restri
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     xv[d] = xs[(long long)d * cap + p0 + tid];
-                    window_table(g, d, xv[d], 0, b[d]);
+                    window_table(g, d, xv[d], 0, b[d]);         // (the value form costs this kernel registers it does not have: +4.7 ms at 16^4)
                 }
                 wyv = wv * ys[p0 + tid];
                 if (hist_on) {
