@@ -155,7 +155,7 @@ nd_whoami_kernel(unsigned *__restrict__ map)
 template <int SD, int WPS, bool SCHUR, int SPLIT = 1, int WGW = 1>
 __global__ void __launch_bounds__(64 * WGW, WPS)
 nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int margin, const unsigned *__restrict__ resmap,
-               int *__restrict__ queue)
+               int *__restrict__ queue, int full_diag)
 {
     // WGW = 4: four waves per workgroup take four CONSECUTIVE items -- items are stored tile column by tile column, so the
     // four share their column operand, which then comes from the CU's L1 three times out of four (less operand traffic
@@ -226,6 +226,7 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
 #pragma unroll
             for (int v = 0; v < 4; ++v)
                 acc[m][n][v] = (SCHUR && j.zinit) ? 0.0 : __builtin_nontemporal_load(&C[((n0 + n) * 16 + l15) + (long long)((m0 + m) * 16 + q + 4 * v) * ldc]);
+    const bool skipu = diag && !full_diag;
     double qa[SD][M], qb[SD][N];
     auto fetch = [&](int slot, int step) {
         const long long off = (long long)(4 * step) * ldp;
@@ -250,8 +251,12 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
 #pragma unroll
                 for (int m = 0; m < M; ++m)
 #pragma unroll
-                    for (int n = 0; n < N; ++n)
+                    for (int n = 0; n < N; ++n) {
+                        // (a diagonal item stores its lower triangle only: the 6 of its 16 tiles above the diagonal are skipped --
+                        // 1 % of the items of the root, 12 % of those of a front of 16 tile rows; wave-uniform branch)
+                        if (SPLIT == 1 && skipu && m > n) continue;
                         acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[d][m], qb[d][n], acc[m][n], 0, 0, 0);
+                    }
                 if (ks + d + SD < NSTEP) fetch(d, base + ks + d + SD);
                 else {                               // the first steps of the next block (clamped: re-reads in the last one)
                     const int nx = base + ks + d + SD;
@@ -655,6 +660,7 @@ struct NdState {
     unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
     int nres = 0;
     int potrf_waves = 8;                           // waves per diagonal-block workgroup (measured 4 / 8 / 16: C2 factor 0.813 / 0.789 / 0.839 ms, 32^3 11.53 / 11.22 / 11.67, C3 the same)
+    int full_diag = 0;                             // (A/B: diagonal items compute all 16 tiles)
     bool small_queue = false;                      // (A/B: small launches take the item queue too)
     int pinned_split = 4;                          // most waves per item of a small launch that runs beside a bulk update
     int wg4 = 0;                                   // 1: Schur launches in 4-wave workgroups, 2: the panel updates too
@@ -867,7 +873,9 @@ bool nd_build_factor_jobs(NdState *s)
                     const int kb = k - g0 + 1;
                     // (the last block of a front holds ncols real columns: the k-loop stops behind them, in chunks of 16 columns)
                     const int ksl = (k == f.nsteps - 1) ? 4 * ((ncols + 15) / 16) : 64;
-                    const double jflop = 2.0 * 64 * 64 * (256.0 * (kb - 1) + 4.0 * ksl) * (double)trapezoid_items(ns, ns);
+                    // (the ns diagonal items skip the 6 of their 16 tiles above the diagonal)
+                    const double jitems = (double)trapezoid_items(ns, ns) - (s->full_diag ? 0.0 : 0.375 * ns);
+                    const double jflop = 2.0 * 64 * 64 * (256.0 * (kb - 1) + 4.0 * ksl) * jitems;
                     if (s->fused && k == f.nsteps - 1 && f.parent >= 0) {
                         // the front's last pass carries its Schur complement into the parent itself
                         const NdFront &pf = t.fr[(size_t)f.parent];
@@ -1135,9 +1143,9 @@ void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipS
 #define ND_SYRK_GO(SCH, SPL, WW)                                                                                               \
     do {                                                                                                                       \
         if (SCH) hipExtLaunchKernelGGL((nd_syrk_kernel<ND_SD(SPL), 2, SCH, SPL, WW>), grid, dim3(64 * WW), 0, st, a, b, 0, jobs, l.count, nit, margin,  \
-                                       (const unsigned *)s->resmap, queue);                                                    \
+                                       (const unsigned *)s->resmap, queue, s->full_diag);                                      \
         else hipLaunchKernelGGL((nd_syrk_kernel<ND_SD(SPL), 2, SCH, SPL, WW>), grid, dim3(64 * WW), 0, st, jobs, l.count, nit, margin,   \
-                                (const unsigned *)s->resmap, queue);                                                           \
+                                (const unsigned *)s->resmap, queue, s->full_diag);                                             \
     } while (0)
     if (schur) {
         if (split == 16) ND_SYRK_GO(true, 16, 1); else if (split == 4) ND_SYRK_GO(true, 4, 1); else if (wg4) ND_SYRK_GO(true, 1, 4); else ND_SYRK_GO(true, 1, 1);
@@ -1511,6 +1519,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
          nd_upload(s, &s->pmap, t.pmap) && nd_upload(s, &s->rowsrc, rowsrc) && nd_upload(s, &s->padwhere, padwhere) &&
          nd_upload(s, &s->fdev, fdev);
     if (!ok) return SPLPAK_E_NOMEM;
+    s->full_diag = std::getenv("SPLPAK_ND_FULL_DIAG") != nullptr ? 1 : 0;      // (before the job tables: it enters their flop counts)
     if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
     ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->trsmb.dev, s->trsmb.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) && nd_upload(s, &s->updo.dev, s->updo.host) && nd_upload(s, &s->fin[0].dev, s->fin[0].host) &&
          nd_upload(s, &s->fin[1].dev, s->fin[1].host) &&
