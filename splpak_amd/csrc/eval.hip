@@ -611,20 +611,24 @@ run_place_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq, 
     const int b0 = threadIdx.x * per;
     int q = 0;
     for (int b = b0; b < b0 + per && b < rg.nbins; ++b) q += lcn[b];
-    sscan[threadIdx.x] = q;
-    __syncthreads();
-    for (int s = 1; s < 256; s <<= 1) {
-        const int aq = threadIdx.x >= s ? sscan[threadIdx.x - s] : 0;
-        __syncthreads();
-        sscan[threadIdx.x] += aq;
-        __syncthreads();
+    // exclusive scan over the 256 threads: within the waves by shuffles, then the four wave totals (two barriers instead of the
+    // sixteen of a Hillis-Steele scan in LDS: a third of this workgroup's time)
+    int incl = q;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) incl += t;
     }
-    q = sscan[threadIdx.x] - q;
+    if ((threadIdx.x & 63) == 63) sscan[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int v = 0; v < (int)(threadIdx.x >> 6); ++v) woff += sscan[v];
+    const int total = sscan[0] + sscan[1] + sscan[2] + sscan[3];
+    q = woff + incl - q;
     for (int b = b0; b < b0 + per && b < rg.nbins; ++b) {
         lst[b] = q;
         q += lcn[b];
     }
-    const int total = sscan[255];
     if (threadIdx.x == 0) lst[rg.nbins] = total;
     __syncthreads();
     for (int b = threadIdx.x; b <= rg.nbins; b += 256) starts[(long long)blockIdx.x * (rg.nbins + 1) + b] = lst[b];
