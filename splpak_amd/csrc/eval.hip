@@ -412,8 +412,10 @@ bin_scatter_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq
 constexpr int EVAL_WG = 1024;          // threads per workgroup in pass C (value path): 16 waves share one 32 KB tile (A/B: 256 -> 512 threads +3 %, 1024 +5 %)
 // T = storage type of the coefficients and the results (double, or float for the REAL32 entry points: widened when the
 // tile is filled / narrowed when a result is stored; the sorted coordinates are always double, the arithmetic too)
+// (8 waves per SIMD: two of these 16-wave workgroups per CU need <= 64 registers -- the 4-D instantiation came out at 65 and
+// ran ONE workgroup per CU until round 3)
 template <int D, bool VAL, typename T>
-__global__ void __launch_bounds__(EVAL_WG)
+__global__ void __launch_bounds__(EVAL_WG, 8)
 eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
                    const double *__restrict__ xs,
                    const int *__restrict__ off, const int *__restrict__ wgoff, T *__restrict__ out)
@@ -653,7 +655,7 @@ run_place_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq, 
 // group are ~2 000 (3-D 64^3: 128 x 16.4; 4-D 32^4: 615 x 3.2).
 constexpr int RUN_GROUP_MAX = 1024;
 template <int D, bool VAL, typename T>
-__global__ void __launch_bounds__(EVAL_WG)
+__global__ void __launch_bounds__(EVAL_WG, 8)
 eval_runs_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef, const double *__restrict__ img,
                  const int *__restrict__ starts, int nwg, int grp, T *__restrict__ out)
 {
