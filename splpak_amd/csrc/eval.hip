@@ -580,25 +580,28 @@ eval_binned_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef,
 // evaluation pass.  Same arithmetic per query as everywhere else: identical bits.
 constexpr int RUN_QPW = 2048;          // queries per place-pass workgroup
 
+// RUN_NT threads per workgroup: 62 KB of LDS allow two workgroups per CU, i.e. 16 waves with 512 threads each (8 with 256:
+// too few for a pass that waits on memory)
+constexpr int RUN_NT = 512;
 template <int D, typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(RUN_NT)
 run_place_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq, double *__restrict__ img,
                  int *__restrict__ starts)
 {
-    constexpr int QPT = RUN_QPW / 256, QPW = RUN_QPW;
+    constexpr int NT = RUN_NT, NW = NT / 64, QPT = RUN_QPW / NT, QPW = RUN_QPW;
     __shared__ double sx[QPW * D];
     __shared__ int sidx[QPW];
     extern __shared__ int lds_bins[];          // lstart[nbins + 1] | lcount[nbins]
     int *lst = lds_bins, *lcn = lds_bins + rg.nbins + 1;
-    __shared__ int sscan[256];
-    for (int b = threadIdx.x; b < rg.nbins; b += 256) lcn[b] = 0;
+    __shared__ int sscan[NW];
+    for (int b = threadIdx.x; b < rg.nbins; b += NT) lcn[b] = 0;
     __syncthreads();
     const int base = blockIdx.x * QPW;
     int rid[QPT], rank[QPT];
     double xr[QPT][D];
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
-        const int i = base + j * 256 + threadIdx.x;
+        const int i = base + j * NT + threadIdx.x;
         rid[j] = -1;
         rank[j] = 0;
         if (i < n) {
@@ -609,12 +612,12 @@ run_place_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq, 
         }
     }
     __syncthreads();
-    const int per = (rg.nbins + 255) / 256;
+    const int per = (rg.nbins + NT - 1) / NT;
     const int b0 = threadIdx.x * per;
     int q = 0;
     for (int b = b0; b < b0 + per && b < rg.nbins; ++b) q += lcn[b];
-    // exclusive scan over the 256 threads: within the waves by shuffles, then the four wave totals (two barriers instead of the
-    // sixteen of a Hillis-Steele scan in LDS: a third of this workgroup's time)
+    // exclusive scan over the threads: within the waves by shuffles, then the wave totals (two barriers instead of the sixteen
+    // of a Hillis-Steele scan in LDS: a third of this workgroup's time)
     int incl = q;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -625,7 +628,9 @@ run_place_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq, 
     __syncthreads();
     int woff = 0;
     for (int v = 0; v < (int)(threadIdx.x >> 6); ++v) woff += sscan[v];
-    const int total = sscan[0] + sscan[1] + sscan[2] + sscan[3];
+    int total = 0;
+#pragma unroll
+    for (int v = 0; v < NW; ++v) total += sscan[v];
     q = woff + incl - q;
     for (int b = b0; b < b0 + per && b < rg.nbins; ++b) {
         lst[b] = q;
@@ -633,17 +638,17 @@ run_place_kernel(Grid g, Regions rg, int n, const T *__restrict__ xq, int ldxq, 
     }
     if (threadIdx.x == 0) lst[rg.nbins] = total;
     __syncthreads();
-    for (int b = threadIdx.x; b <= rg.nbins; b += 256) starts[(long long)blockIdx.x * (rg.nbins + 1) + b] = lst[b];
+    for (int b = threadIdx.x; b <= rg.nbins; b += NT) starts[(long long)blockIdx.x * (rg.nbins + 1) + b] = lst[b];
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
         if (rid[j] < 0) continue;
         const int lp = lst[rid[j]] + rank[j];
 #pragma unroll
         for (int d = 0; d < D; ++d) sx[d * QPW + lp] = xr[j][d];
-        sidx[lp] = base + j * 256 + threadIdx.x;
+        sidx[lp] = base + j * NT + threadIdx.x;
     }
     __syncthreads();
-    for (int lp = threadIdx.x; lp < total; lp += 256) {        // the sorted image: consecutive lanes, consecutive records
+    for (int lp = threadIdx.x; lp < total; lp += NT) {         // the sorted image: consecutive lanes, consecutive records
         double x[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) x[d] = sx[d * QPW + lp];
@@ -946,7 +951,7 @@ static hipError_t eval_runs(const Grid &g, const Regions &rg, long long nq, cons
         const int n = (int)(nq - c0 < chunk ? nq - c0 : chunk);
         const T *xc = xq + c0 * ldxq;
         const unsigned nwg = (unsigned)((n + RUN_QPW - 1) / RUN_QPW);
-        hipLaunchKernelGGL((run_place_kernel<D, T>), dim3(nwg), dim3(256), sizeof(int) * (2 * rg.nbins + 1), st, g, rg, n, xc, ldxq,
+        hipLaunchKernelGGL((run_place_kernel<D, T>), dim3(nwg), dim3(RUN_NT), sizeof(int) * (2 * rg.nbins + 1), st, g, rg, n, xc, ldxq,
                            s.img, s.starts);
         const unsigned ngroups = (nwg + (unsigned)grp - 1) / (unsigned)grp;
         if (value_only)
