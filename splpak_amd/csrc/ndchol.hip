@@ -118,6 +118,35 @@ nd_trinv_kernel(const TrinvJob *__restrict__ jobs)
     trsm_rows<true>(j.L, j.dinv, j.ld, NBLK, j.inv16, j.dinvt, blockIdx.x * 16, xs);
 }
 
+// ints per item queue: [0] item counter, [1] waves that stepped aside, [2 .. 9] item counters of the eight XCD slices (xmode)
+constexpr int ND_QSTRIDE = 16;
+
+// Panel-major order of the n x n lower trapezoid of tiles: panels of four tile columns, row by row inside a panel -- the four
+// consecutive items of a row share their row operand, and the four column operands of a panel (2 MB at K = 1024) stay in the
+// L2 while the panel is walked.  u = index in that order -> (tj, ti).
+__device__ __forceinline__ void panel_decode(int u, int n, int &tj, int &ti)
+{
+    int c0 = 0;
+    for (;;) {
+        const int m = n - c0, w = m < 4 ? m : 4;
+        const int sz = w * (w + 1) / 2 + (m - w) * w;
+        if (u < sz) break;
+        u -= sz;
+        c0 += 4;
+    }
+    const int m = n - c0, w = m < 4 ? m : 4, tri = w * (w + 1) / 2;
+    if (u < tri) {
+        int i = 0;
+        while (u >= i + 1) { u -= i + 1; ++i; }
+        ti = c0 + i;
+        tj = c0 + u;
+    } else {
+        u -= tri;
+        ti = c0 + w + u / w;
+        tj = c0 + u % w;
+    }
+}
+
 // (XCC, shader engine, CU) of the CU this wave runs on, as a 12-bit index
 __device__ inline unsigned nd_cu_index()
 {
@@ -155,14 +184,24 @@ nd_whoami_kernel(unsigned *__restrict__ map)
 template <int SD, int WPS, bool SCHUR, int SPLIT = 1, int WGW = 1>
 __global__ void __launch_bounds__(64 * WGW, WPS)
 nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int margin, const unsigned *__restrict__ resmap,
-               int *__restrict__ queue, int full_diag)
+               int *__restrict__ queue, int full_diag, int xmode)
 {
+    // xmode (Schur passes, one wave per item): XCD-aware item map.  The launch's items are cut into eight contiguous slices,
+    // one per XCD (workgroups are dealt to the XCDs round robin: blockIdx & 7; with an item queue the XCC id register and
+    // one counter per slice, a drained XCD steals from the next), and a front's items are walked in PANEL-major order
+    // (panel_decode): operands are then fetched into ONE L2 and reused there instead of streaming through all eight.
     // WGW = 4: four waves per workgroup take four CONSECUTIVE items -- items are stored tile column by tile column, so the
     // four share their column operand, which then comes from the CU's L1 three times out of four (less operand traffic
     // = less power = a higher clock in the long power-limited Schur launches; round 2 measured +7 % for the band's bulk
     // update in sustained runs)
     constexpr int M = SPLIT == 1 ? 4 : 1, N = SPLIT == 16 ? 1 : 4;
     int b = blockIdx.x;
+    const bool xm = SCHUR && SPLIT == 1 && WGW == 1 && xmode != 0;
+    if (xm && !queue) {
+        const int chunk = (nitems + 7) >> 3, loc = b >> 3;
+        b = (b & 7) * chunk + loc;
+        if (loc >= chunk) return;
+    }
     if (queue) {
         if constexpr (WGW == 1) {
             const unsigned ci = nd_cu_index();
@@ -176,8 +215,23 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
                     return;
                 }
             }
-            if (threadIdx.x == 0) b = atomicAdd(&queue[0], 1);
-            b = __builtin_amdgcn_readfirstlane(b);
+            if (xm) {
+                const int chunk = (nitems + 7) >> 3, x0 = (int)((ci >> 8) & 7u);
+                int t = -1;
+                if (threadIdx.x == 0) {
+                    for (int k = 0; k < 8 && t < 0; ++k) {
+                        const int y = (x0 + k) & 7, lim = nitems - y * chunk < chunk ? nitems - y * chunk : chunk;
+                        if (lim <= 0) continue;
+                        const int e = atomicAdd(&queue[2 + y], 1);
+                        if (e < lim) t = y * chunk + e;
+                    }
+                }
+                b = __builtin_amdgcn_readfirstlane(t);
+                if (b < 0) return;
+            } else {
+                if (threadIdx.x == 0) b = atomicAdd(&queue[0], 1);
+                b = __builtin_amdgcn_readfirstlane(b);
+            }
         } else {
             __shared__ int s_b[2];
             if (threadIdx.x == 0) {
@@ -208,7 +262,9 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
         const int rb = -j.zinit, per = j.nr - rb, it = b - j.item0;
         tj = it / per;
         ti = rb + it - tj * per;
-    } else
+    } else if (xm && j.nc == j.nr)
+        panel_decode(b - j.item0, j.nr, tj, ti);
+    else
         trapezoid_decode(b - j.item0, j.nr, tj, ti);
     if (tj >= j.nc || ti >= j.nr) return;
     const bool diag = ti == tj;
@@ -660,6 +716,7 @@ struct NdState {
     unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
     int nres = 0;
     int potrf_waves = 8;                           // waves per diagonal-block workgroup (measured 4 / 8 / 16: C2 factor 0.813 / 0.789 / 0.839 ms, 32^3 11.53 / 11.22 / 11.67, C3 the same)
+    int xmode = 0;                                 // XCD-aware item map of the Schur passes (SPLPAK_ND_XCD=1)
     int full_diag = 0;                             // (A/B: diagonal items compute all 16 tiles)
     bool small_queue = false;                      // (A/B: small launches take the item queue too)
     int pinned_split = 4;                          // most waves per item of a small launch that runs beside a bulk update
@@ -1121,7 +1178,7 @@ void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipS
     int *queue = nullptr;
     int margin = 0;
     if (pinned && s->nres > 0 && qnext < s->nqueues && !small_launch) {
-        queue = s->queues + 2 * (qnext++);
+        queue = s->queues + ND_QSTRIDE * (qnext++);
         margin = 256 * s->nres;
     }
     const SyrkJob *jobs = tab.dev + l.first;
@@ -1136,16 +1193,18 @@ void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipS
     if (pinned && split > s->pinned_split) split = s->pinned_split;
     const int nit = (int)l.grid * split;
     const bool wg4 = split == 1 && (s->wg4 >= 2 || (s->wg4 == 1 && schur));
-    const dim3 grid((wg4 ? (l.grid + 3) / 4 : l.grid * (unsigned)split) + (unsigned)margin);
+    unsigned gx = wg4 ? (l.grid + 3) / 4 : l.grid * (unsigned)split;
+    if (s->xmode && schur && split == 1 && !wg4 && !queue) gx = (gx + 7u) / 8u * 8u;      // eight equal slices
+    const dim3 grid(gx + (unsigned)margin);
     // operand look-ahead in k-steps: a split wave issues 1 (4) MFMA per step, so 4 steps cover 256 (1 024) cycles -- less than
     // one memory round trip: 77 us per K = 256 launch of the root's look-ahead block.  32 (16) steps in flight instead.
 #define ND_SD(SPL) ((SPL) == 16 ? 32 : ((SPL) == 4 ? 16 : 4))
 #define ND_SYRK_GO(SCH, SPL, WW)                                                                                               \
     do {                                                                                                                       \
         if (SCH) hipExtLaunchKernelGGL((nd_syrk_kernel<ND_SD(SPL), 2, SCH, SPL, WW>), grid, dim3(64 * WW), 0, st, a, b, 0, jobs, l.count, nit, margin,  \
-                                       (const unsigned *)s->resmap, queue, s->full_diag);                                      \
+                                       (const unsigned *)s->resmap, queue, s->full_diag, s->xmode);                            \
         else hipLaunchKernelGGL((nd_syrk_kernel<ND_SD(SPL), 2, SCH, SPL, WW>), grid, dim3(64 * WW), 0, st, jobs, l.count, nit, margin,   \
-                                (const unsigned *)s->resmap, queue, s->full_diag);                                             \
+                                (const unsigned *)s->resmap, queue, s->full_diag, s->xmode);                                  \
     } while (0)
     if (schur) {
         if (split == 16) ND_SYRK_GO(true, 16, 1); else if (split == 4) ND_SYRK_GO(true, 4, 1); else if (wg4) ND_SYRK_GO(true, 1, 4); else ND_SYRK_GO(true, 1, 1);
@@ -1235,7 +1294,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
                 if (s->sarp_doubles[q][a] > 0) (void)hipMemsetAsync(s->sarp[q][a], 0, sizeof(double) * (size_t)s->sarp_doubles[q][a], st);
     }
     s->s_clean = false;
-    if (s->queues) (void)hipMemsetAsync(s->queues, 0, sizeof(int) * 2 * (size_t)s->nqueues, st);
+    if (s->queues) (void)hipMemsetAsync(s->queues, 0, sizeof(int) * ND_QSTRIDE * (size_t)s->nqueues, st);
     int qnext = 0;
     (void)hipEventRecord(s->ev0, st);
     for (hipStream_t q : {sPp[0], sPp[1], sU})
@@ -1520,6 +1579,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
          nd_upload(s, &s->fdev, fdev);
     if (!ok) return SPLPAK_E_NOMEM;
     s->full_diag = std::getenv("SPLPAK_ND_FULL_DIAG") != nullptr ? 1 : 0;      // (before the job tables: it enters their flop counts)
+    s->xmode = std::getenv("SPLPAK_ND_XCD") ? atoi(std::getenv("SPLPAK_ND_XCD")) : 0;
     if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
     ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->trsmb.dev, s->trsmb.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) && nd_upload(s, &s->updo.dev, s->updo.host) && nd_upload(s, &s->fin[0].dev, s->fin[0].host) &&
          nd_upload(s, &s->fin[1].dev, s->fin[1].host) &&
@@ -1547,7 +1607,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     if (const char *e = std::getenv("SPLPAK_ND_PINNED_SPLIT")) s->pinned_split = atoi(e);
     s->small_queue = std::getenv("SPLPAK_ND_SMALL_QUEUE") != nullptr;
     if (const char *e = std::getenv("SPLPAK_ND_POTRF_WAVES")) s->potrf_waves = atoi(e);
-    if (!nd_alloc(s, &s->queues, (size_t)2 * s->nqueues) || !nd_alloc(s, &s->resmap, (size_t)128)) return SPLPAK_E_NOMEM;
+    if (!nd_alloc(s, &s->queues, (size_t)ND_QSTRIDE * s->nqueues) || !nd_alloc(s, &s->resmap, (size_t)128)) return SPLPAK_E_NOMEM;
     (void)hipMemset(s->resmap, 0, 128 * sizeof(unsigned));
     // A few CUs are left to the diagonal-block factorisations of the upper tree levels: v_mfma_f64 runs on the same
     // pipes as f64 VALU code, and the latency-bound potrf workgroups ran 8x slower (1.26 ms instead of 0.16) beside

@@ -698,7 +698,7 @@ static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const
     (void)hipGetDevice(&dev);
     // switches that are read when a plan is created (they select or shape the factorisation): part of the cache key
     int nd_env = std::getenv("SPLPAK_ND") ? atoi(std::getenv("SPLPAK_ND")) : -1;
-    for (const char *v : {"SPLPAK_ND_SPLIT", "SPLPAK_ND_KB", "SPLPAK_ND_RES_CUS", "SPLPAK_NO_PANEL_CU", "SPLPAK_ND_NO_ROOT_LOOKAHEAD", "SPLPAK_ND_NO_FUSE", "SPLPAK_ND_PIPES", "SPLPAK_ND_NO_OUTER", "SPLPAK_ND_SMALL_GRID", "SPLPAK_ND_WG4", "SPLPAK_ND_NO_EARLY_CLEAR", "SPLPAK_ND_PINNED_SPLIT", "SPLPAK_ND_SMALL_QUEUE", "SPLPAK_ND_POTRF_WAVES", "SPLPAK_ND_FULL_DIAG"})
+    for (const char *v : {"SPLPAK_ND_SPLIT", "SPLPAK_ND_KB", "SPLPAK_ND_RES_CUS", "SPLPAK_NO_PANEL_CU", "SPLPAK_ND_NO_ROOT_LOOKAHEAD", "SPLPAK_ND_NO_FUSE", "SPLPAK_ND_PIPES", "SPLPAK_ND_NO_OUTER", "SPLPAK_ND_SMALL_GRID", "SPLPAK_ND_WG4", "SPLPAK_ND_NO_EARLY_CLEAR", "SPLPAK_ND_PINNED_SPLIT", "SPLPAK_ND_SMALL_QUEUE", "SPLPAK_ND_POTRF_WAVES", "SPLPAK_ND_FULL_DIAG", "SPLPAK_ND_XCD"})
         if (const char *e = std::getenv(v)) nd_env = nd_env * 31 + 7 * atoi(e) + (int)v[10];
     bool same = hc.plan && hc.dev == dev && hc.ndim == ndim && hc.xtrap == xtrap && hc.plan->max_ndata >= ndata && hc.nd_env == nd_env;
     for (int d = 0; same && d < ndim; ++d)
