@@ -603,8 +603,11 @@ def main():
             "config": {
                 "workload": workload_label(world, nd, nod, m),
                 "ncol": ncol, "points_per_gpu": m, "points_total": world * m, "host_numa_node": numa_node,
-                "parallelism": "points sharded per GPU; RCCL all-reduce of histogram, normal equations and "
-                               "refinement residuals; factorisation replicated" if world > 1 else "single GPU",
+                "parallelism": ("points sharded per GPU; RCCL all-reduce of histogram, normal equations and refinement residuals; "
+                                + ("factorisation replicated" if (fact_code != 4 or os.environ.get("SPLPAK_ND_DIST") == "0") else
+                                   "nested-dissection factorisation distributed by subtrees (a rank eliminates its own subtrees below "
+                                   "tree depth ceil(log2 ranks), their Schur complements are all-reduced, the top of the tree is "
+                                   "factored by every rank; the tree solves follow the same split)")) if world > 1 else "single GPU",
                 "factorisation": fact_name,
                 "collective_backend": (dist.get_backend() if world > 1 else None),
                 "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else 0),

@@ -103,10 +103,16 @@ int32_t splpak_eval_f32(int32_t ndim, int64_t nq, const float *xq, int32_t ldxq,
 typedef struct splpak_plan splpak_plan;
 
 /* Sum-all-reduce hook for the sharded fit.  Called by
- * splpak_plan_fit_dev with a device pointer into the plan's communication buffer;
- * must sum `count` doubles in place across all ranks ON `stream` (or synchronise
- * itself) and return 0.  With torch.distributed/RCCL this is
- * `all_reduce(tensor_view)`.  NULL => single rank. */
+ * splpak_plan_fit_dev with a device pointer; must sum `count` doubles in place
+ * across all ranks ON `stream` (or synchronise itself) and return 0.  With
+ * torch.distributed/RCCL this is `all_reduce(tensor_view)`.  NULL => single rank.
+ * The pointer lies in the plan's communication buffer for the histogram, the normal
+ * equations and the refinement residuals; since round 3 the nested-dissection
+ * factorisation of a sharded fit is distributed by subtrees (csrc/ndchol.hip,
+ * SPLPAK_ND_DIST=0 turns that off) and also sums front panels, Schur buffers and
+ * solve vectors that live in the library's own device allocations: a hook must
+ * accept ANY device pointer of the calling process (ncclAllReduce does; the Python
+ * shim wraps such a pointer through the CUDA array interface). */
 typedef int32_t (*splpak_allreduce_fn)(void *dev_buf, int64_t count, void *stream, void *user);
 
 /* Validates exactly like splcw (:716-781; 105/106 are checked at fit time) and

@@ -359,8 +359,24 @@ class Plan:
         self._L.splpak_plan_set_refine(self._h, int(max_steps), float(tol))
 
     def set_allreduce(self, fn, rank, world):
-        """fn(offset_elems, count) must sum-all-reduce self.comm[offset:offset+count] in place."""
+        """fn(offset_elems, count) must sum-all-reduce self.comm[offset:offset+count] in place; windows outside the plan's
+        buffer (the fronts the subtrees of a distributed nested-dissection factorisation report into) arrive
+        as fn(-1, count, view) with `view` a device tensor over the library's memory."""
         base = self.comm.data_ptr()
+        ncomm = self.comm.numel()
+        device = self.comm.device
+
+        class _Raw:            # a device buffer of the library as a CUDA-array-interface object
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+        def _call(ptr, count):
+            off = (int(ptr) - base) // 8
+            if 0 <= off and off + int(count) <= ncomm and (int(ptr) - base) % 8 == 0:
+                fn(off, int(count))
+            else:
+                import torch
+                fn(-1, int(count), torch.as_tensor(_Raw(ptr, count), device=device))
 
         def _cb(ptr, count, stream, user):
             # The C ABI's contract: the reduction is ordered ON `stream` (the stream the fit was
@@ -370,9 +386,9 @@ class Plan:
                 import torch
                 if torch.cuda.is_available():
                     with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0))):
-                        fn((int(ptr) - base) // 8, int(count))
+                        _call(ptr, count)
                 else:
-                    fn((int(ptr) - base) // 8, int(count))
+                    _call(ptr, count)
                 return 0
             except Exception as exc:  # pragma: no cover - surfaced as SPLPAK_E_COMM
                 print("all-reduce callback failed:", exc, flush=True)

@@ -716,6 +716,16 @@ struct NdState {
     unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
     int nres = 0;
     int potrf_waves = 8;                           // waves per diagonal-block workgroup (measured 4 / 8 / 16: C2 factor 0.813 / 0.789 / 0.839 ms, 32^3 11.53 / 11.22 / 11.67, C3 the same)
+    // Sharded fit with the factorisation DISTRIBUTED by subtrees (one process per GPU; SPLPAK_ND_DIST=0 turns it off): the 2^dcut subtrees
+    // below tree depth dcut = ceil(log2 ranks) are dealt to the ranks; a rank eliminates its own subtrees only, the Schur
+    // complements they leave in the fronts of depth dcut - 1 are summed over the ranks through the plan's all-reduce hook, and
+    // the top of the tree is factored by every rank.  The solves follow the same split.
+    bool dist = false;
+    int world = 1, rank = 0, dcut = 0;
+    std::vector<char> mine;                        // [front] this rank eliminates it
+    std::vector<int> rowsrc_host;                  // [vec_doubles] variable of every front row (-1: border / padding)
+    int *rowsrc_out = nullptr;                     // rowsrc restricted to the variables this rank reports (the rest arrive by all-reduce)
+    int ntrinv = 0;
     int xmode = 0;                                 // XCD-aware item map of the Schur passes (SPLPAK_ND_XCD=1)
     int full_diag = 0;                             // (A/B: diagonal items compute all 16 tiles)
     bool small_queue = false;                      // (A/B: small launches take the item queue too)
@@ -1035,12 +1045,16 @@ bool nd_build_factor_jobs(NdState *s)
             }
         }
     }
-    for (const NdFront &f : t.fr)
+    for (size_t id = 0; id < t.fr.size(); ++id) {
+        const NdFront &f = t.fr[id];
+        if (!s->mine.empty() && !s->mine[id]) continue;
         for (int k = 0; k < f.nsteps; ++k) {
             const double *diag = s->factor + f.panel_off + (long long)k * 256 + (long long)k * 256 * f.ld;
             s->trinv.host.push_back(TrinvJob{diag, s->inv16 + (long long)(f.blk0 + k) * 4096, s->dinv + (long long)(f.blk0 + k) * 65536,
                                              s->dinvt + (long long)(f.blk0 + k) * 65536, f.ld});
         }
+    }
+    s->ntrinv = (int)s->trinv.host.size();
     return true;
 }
 
@@ -1054,7 +1068,9 @@ bool nd_build_solve_jobs(NdState *s)
     s->l_mapall.assign((size_t)nd, Launch());
     long long part_max = 0;
     for (int d = 0; d < nd; ++d) {
-        const std::vector<int> &ids = t.by_depth[(size_t)d];
+        std::vector<int> ids;
+        for (int id : t.by_depth[(size_t)d])
+            if (s->mine.empty() || s->mine[(size_t)id]) ids.push_back(id);
         int steps = 0;
         for (int id : ids) steps = std::max(steps, t.fr[(size_t)id].nsteps);
         for (auto *L : {&s->l_mv, &s->l_fwd, &s->l_dot, &s->l_bwd}) (*L)[(size_t)d].assign((size_t)steps, Launch());
@@ -1295,6 +1311,22 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     }
     s->s_clean = false;
     if (s->queues) (void)hipMemsetAsync(s->queues, 0, sizeof(int) * ND_QSTRIDE * (size_t)s->nqueues, st);
+    if (s->dist && s->rank != 0)        // the fronts the subtrees' Schur complements are summed in: their entries of N come from rank 0 alone
+        for (int id : t.by_depth[(size_t)(s->dcut - 1)]) {
+            const NdFront &f = t.fr[(size_t)id];
+            (void)hipMemsetAsync(s->factor + f.panel_off, 0, sizeof(double) * (size_t)(f.ld * f.wp), st);
+        }
+    bool comm_failed = false;
+    // every rank has eliminated its subtrees: sum what they left in the fronts of depth dcut - 1 (panel and Schur buffer)
+    auto dist_join = [&]() {
+        for (hipStream_t q : {sPp[0], sPp[1], sU, sR})
+            if (q) (void)hipStreamSynchronize(q);
+        for (int id : t.by_depth[(size_t)(s->dcut - 1)]) {
+            const NdFront &f = t.fr[(size_t)id];
+            if (plan_allreduce(p, s->factor + f.panel_off, f.ld * (long long)f.wp, st) != 0) comm_failed = true;
+            if (f.hp > 0 && plan_allreduce(p, s_ptr(s, id), f.lds * (long long)f.hp, st) != 0) comm_failed = true;
+        }
+    };
     int qnext = 0;
     (void)hipEventRecord(s->ev0, st);
     for (hipStream_t q : {sPp[0], sPp[1], sU})
@@ -1349,6 +1381,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     };
     // ---- depths maxdepth .. 1: the pipelines step through a depth together, their Schur passes alternate on sU
     for (int d = t.maxdepth; d >= 1; --d) {
+        if (s->dist && d == s->dcut - 1) dist_join();
         int steps = 0, nfront0 = 0;
         for (int q = 0; q < np; ++q) {
             const auto &lv = s->l_potrf[(size_t)(q * nd + d)];
@@ -1388,6 +1421,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         }
     }
     // ---- the root: after both pipelines; no Schur buffer to hide its chain behind, hence the look-ahead split
+    if (s->dist && s->dcut == 1) dist_join();
     if (s->fused && t.maxdepth >= 1)
         for (int q = 0; q < np; ++q)
             if (sU != sP) (void)hipStreamWaitEvent(sP, s->evF[q][1], 0);
@@ -1434,7 +1468,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         }
     }
     // inverses of all diagonal blocks (the solves' operands)
-    hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)t.nblocks), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev);
+    hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)s->ntrinv), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev);
     (void)hipEventRecord(s->evJ, sP);
     if (sP != st) (void)hipStreamWaitEvent(st, s->evJ, 0);
     if (sU != st) {                                   // (the zero launches for the next fit may still be running: it waits for them)
@@ -1457,6 +1491,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         }
     }
     if (err != hipSuccess) s->s_clean = false;
+    if (comm_failed) return hipErrorUnknown;
     return err;
 }
 
@@ -1468,12 +1503,23 @@ hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void
     const long long n = t.vec_doubles;
     const unsigned gb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(nd_gather_kernel, dim3(gb), dim3(256), 0, st, n, (const int *)s->rowsrc, (const double *)x, s->V);
+    bool comm_failed = false;
+    if (s->dist && s->rank != 0)        // the right-hand side of the fronts the subtrees report into comes from rank 0 alone
+        for (int id : t.by_depth[(size_t)(s->dcut - 1)]) {
+            const NdFront &f = t.fr[(size_t)id];
+            (void)hipMemsetAsync(s->V + f.vofs, 0, sizeof(double) * (size_t)f.fp, st);
+        }
     // forward, bottom-up
     for (int d = t.maxdepth; d >= 0; --d) {
         if (d < t.maxdepth)
             for (int sl = 0; sl < 2; ++sl) {
                 const Launch &lm = s->l_mapslot[sl][(size_t)(d + 1)];
                 if (lm.count) hipLaunchKernelGGL(nd_map_kernel<false>, dim3(8, lm.grid), dim3(256), 0, st, (const MapJob *)(s->map.dev + lm.first));
+            }
+        if (s->dist && d == s->dcut - 1)        // the subtrees' updates of these fronts' vectors, summed over the ranks
+            for (int id : t.by_depth[(size_t)d]) {
+                const NdFront &f = t.fr[(size_t)id];
+                if (plan_allreduce(p, s->V + f.vofs, f.fp, st) != 0) comm_failed = true;
             }
         const int steps = (int)s->l_mv[(size_t)d].size();
         for (int k = 0; k < steps; ++k) {
@@ -1495,9 +1541,80 @@ hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void
             hipLaunchKernelGGL(nd_bwd_kernel, dim3(16, lb.grid), dim3(256), 0, st, (const BwdJob *)(s->bwd.dev + lb.first));
         }
     }
-    hipLaunchKernelGGL(nd_scatter_kernel, dim3(gb), dim3(256), 0, st, n, (const int *)s->rowsrc, (const double *)s->V, x);
-    (void)p;
+    if (s->dist) {
+        // every rank reports the variables of its own subtrees (rank 0 also those of the top of the tree); the sum is the solution
+        (void)hipMemsetAsync(x, 0, sizeof(double) * (size_t)p->g.ncol, st);
+        hipLaunchKernelGGL(nd_scatter_kernel, dim3(gb), dim3(256), 0, st, n, (const int *)s->rowsrc_out, (const double *)s->V, x);
+        if (plan_allreduce(p, x, p->g.ncol, st) != 0) comm_failed = true;
+    } else
+        hipLaunchKernelGGL(nd_scatter_kernel, dim3(gb), dim3(256), 0, st, n, (const int *)s->rowsrc, (const double *)s->V, x);
+    if (comm_failed) return hipErrorUnknown;
     return hipGetLastError();
+}
+
+bool nd_upload_jobs(NdState *s)
+{
+    return nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->trsmb.dev, s->trsmb.host) &&
+           nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) && nd_upload(s, &s->updo.dev, s->updo.host) &&
+           nd_upload(s, &s->fin[0].dev, s->fin[0].host) && nd_upload(s, &s->fin[1].dev, s->fin[1].host) && nd_upload(s, &s->schur.dev, s->schur.host) &&
+           nd_upload(s, &s->trinv.dev, s->trinv.host) && nd_upload(s, &s->add.dev, s->add.host) && nd_upload(s, &s->zero.dev, s->zero.host) &&
+           nd_upload(s, &s->mv.dev, s->mv.host) && nd_upload(s, &s->fwd.dev, s->fwd.host) && nd_upload(s, &s->dot.dev, s->dot.host) &&
+           nd_upload(s, &s->bwd.dev, s->bwd.host) && nd_upload(s, &s->map.dev, s->map.host);
+}
+
+// Ownership of the fronts for `world` ranks and the job tables that follow from it (see NdState::dist).  Called when the
+// sharded fit's ranks become known (splpak_plan_set_allreduce comes after the plan); SPLPAK_ND_DIST=0 opts out.
+int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
+{
+    NdState *s = static_cast<NdState *>(p->fn_user);
+    if (!s) return 0;
+    NdTree &t = s->t;
+    int dcut = 0;
+    while ((1 << dcut) < world) ++dcut;
+    const char *sw = std::getenv("SPLPAK_ND_DIST");                  // 0 = every rank factors everything (round 2's form)
+    const bool want = world > 1 && !(sw && atoi(sw) == 0) && dcut >= 1 && dcut <= t.maxdepth && s->npipe == 1;
+    if (!want && !s->dist) return 0;
+    (void)hipDeviceSynchronize();
+    s->dist = want;
+    s->world = world;
+    s->rank = rank;
+    s->dcut = want ? dcut : 0;
+    s->mine.assign(t.fr.size(), 1);
+    if (want) {
+        std::vector<int> slot_of(t.fr.size(), -1);          // index of the depth-dcut ancestor among the fronts of that depth
+        const std::vector<int> &cut = t.by_depth[(size_t)dcut];
+        for (size_t i = 0; i < cut.size(); ++i) slot_of[(size_t)cut[i]] = (int)i;
+        for (int id = (int)t.fr.size() - 1; id >= 0; --id) {   // parents have larger ids than their children (postorder)
+            const NdFront &f = t.fr[(size_t)id];
+            if (f.depth > dcut) slot_of[(size_t)id] = slot_of[(size_t)f.parent];
+            if (f.depth >= dcut) s->mine[(size_t)id] = (slot_of[(size_t)id] % world) == rank ? 1 : 0;
+        }
+    }
+    const int nd = t.maxdepth + 1, nstage = s->npipe * nd;
+    s->stage_ids.assign((size_t)nstage, {});
+    for (int d = 0; d < nd; ++d)
+        for (int id : t.by_depth[(size_t)d])
+            if (s->mine[(size_t)id]) s->stage_ids[(size_t)(s->pipe_of[(size_t)id] * nd + d)].push_back(id);
+    for (auto *h : {&s->upd, &s->updr, &s->updo, &s->schur, &s->fin[0], &s->fin[1]}) h->host.clear();
+    s->potrf.host.clear(); s->trsm.host.clear(); s->trsmb.host.clear(); s->trinv.host.clear(); s->add.host.clear(); s->zero.host.clear();
+    s->mv.host.clear(); s->fwd.host.clear(); s->dot.host.clear(); s->bwd.host.clear(); s->map.host.clear();
+    if (!nd_build_jobs(s)) { set_error("nested dissection: job tables (ranks)"); return SPLPAK_E_UNSUPPORTED; }
+    if (!nd_upload_jobs(s)) return SPLPAK_E_NOMEM;
+    std::vector<int> out(s->rowsrc_host);
+    for (size_t id = 0; id < t.fr.size(); ++id) {
+        const NdFront &f = t.fr[id];
+        const bool report = want ? (f.depth >= dcut ? s->mine[id] != 0 : rank == 0) : true;
+        if (!report)
+            for (int r = 0; r < f.fp; ++r) out[(size_t)(f.vofs + r)] = -1;
+    }
+    if (!nd_upload(s, &s->rowsrc_out, out)) return SPLPAK_E_NOMEM;
+    s->s_clean = false;
+    if (std::getenv("SPLPAK_DEBUG")) {
+        int nm = 0;
+        for (char c : s->mine) nm += c;
+        fprintf(stderr, "[splpak] nested dissection: rank %d of %d eliminates %d of %zu fronts (subtrees below depth %d)\n", rank, world, nm, t.fr.size(), dcut);
+    }
+    return 0;
 }
 
 }  // namespace
@@ -1507,6 +1624,8 @@ hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void
 // 64^2 (BASELINE config 2) 3.29 -> 2.46, 90^2 5.7 -> 4.3, 128^2 10.4 -> 5.1, 256^2 41.5 -> 13.1; 3-D 16^3 4.3 -> 3.7, 20^3 6.6 ->
 // 5.9, 24^3 11.4 -> 9.0, 32^3 26.3 -> 17.8, 40^3 67.7 -> 42.5, 48^3 166 -> 85, 64^3 831 -> 280; 4-D 8^4 10.9 -> 11.2 and 10^4
 // 19.5 -> 20.3 (band stays), 12^4 41.9 -> 41.0, 16^4 239 -> 184, 24^4 10.5 s -> 4.9 s.
+int nd_set_ranks(splpak_plan *p, int rank, int world) { return (p && p->fn_code == 4) ? nd_set_ranks_impl(p, rank, world) : 0; }
+
 bool nd_wanted(const Grid &g, const Band &band)
 {
     (void)band;
@@ -1578,14 +1697,11 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
          nd_upload(s, &s->pmap, t.pmap) && nd_upload(s, &s->rowsrc, rowsrc) && nd_upload(s, &s->padwhere, padwhere) &&
          nd_upload(s, &s->fdev, fdev);
     if (!ok) return SPLPAK_E_NOMEM;
+    s->rowsrc_host.swap(rowsrc);
     s->full_diag = std::getenv("SPLPAK_ND_FULL_DIAG") != nullptr ? 1 : 0;      // (before the job tables: it enters their flop counts)
     s->xmode = std::getenv("SPLPAK_ND_XCD") ? atoi(std::getenv("SPLPAK_ND_XCD")) : 0;
     if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
-    ok = nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->trsmb.dev, s->trsmb.host) && nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) && nd_upload(s, &s->updo.dev, s->updo.host) && nd_upload(s, &s->fin[0].dev, s->fin[0].host) &&
-         nd_upload(s, &s->fin[1].dev, s->fin[1].host) &&
-         nd_upload(s, &s->schur.dev, s->schur.host) && nd_upload(s, &s->trinv.dev, s->trinv.host) && nd_upload(s, &s->add.dev, s->add.host) && nd_upload(s, &s->zero.dev, s->zero.host) &&
-         nd_upload(s, &s->mv.dev, s->mv.host) && nd_upload(s, &s->fwd.dev, s->fwd.host) && nd_upload(s, &s->dot.dev, s->dot.host) &&
-         nd_upload(s, &s->bwd.dev, s->bwd.host) && nd_upload(s, &s->map.dev, s->map.host);
+    ok = nd_upload_jobs(s);
     if (!ok) return SPLPAK_E_NOMEM;
     // the host copies of the big index arrays are no longer needed
     std::vector<int>().swap(t.ownvar);

@@ -326,6 +326,7 @@ void splpak_plan_set_allreduce(splpak_plan *p, splpak_allreduce_fn fn, void *use
     p->ar_user = user;
     p->rank = rank;
     p->world = world < 1 ? 1 : world;
+    (void)nd_set_ranks(p, p->rank, p->world);
 }
 
 void splpak_plan_set_refine(splpak_plan *p, int32_t max_steps, double tol)
@@ -403,6 +404,10 @@ static int do_allreduce(splpak_plan *p, double *buf, long long count, hipStream_
     debug_sum(p, "after  all-reduce", buf, count, st);
     return 0;
 }
+
+}  // extern "C" (the next function has C++ linkage: it is called from ndchol.hip)
+namespace splpak { int plan_allreduce(splpak_plan *p, double *buf, long long count, hipStream_t st) { return do_allreduce(p, buf, count, st); } }
+extern "C" {
 
 int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, const double *y,
                             const double *w, int64_t ndata, double *coef_dev, void *stream,

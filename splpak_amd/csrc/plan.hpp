@@ -72,6 +72,10 @@ int plan_create_dist(int ndim, const int *nodes, const double *xmin, const doubl
 // large 3-D / 4-D grids on one GPU: nested-dissection multifrontal factorisation (ndchol.hip) instead of the band
 bool nd_wanted(const Grid &g, const Band &band);
 int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles);
+// the sharded fit's ranks are known: distribute the nested-dissection factorisation by subtrees (SPLPAK_ND_DIST=1; ndchol.hip)
+int nd_set_ranks(splpak_plan *p, int rank, int world);
+// sum over the ranks of the sharded fit through the caller's hook (plan.hip); 0 = fine (also with one rank)
+int plan_allreduce(splpak_plan *p, double *buf, long long count, hipStream_t st);
 // narrow bands on one GPU: install the two-ended factorisation (twoend.hip) when it shortens the chain
 void twoend_attach(splpak_plan *p);
 void twoend_detach(splpak_plan *p);

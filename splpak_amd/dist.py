@@ -25,11 +25,12 @@ def shard_range(n_total: int, rank: int, world: int):
 
 
 def make_allreduce(comm, dist, group=None):
-    """-> fn(offset, count) that sum-all-reduces comm[offset:offset+count] in place."""
-    def _fn(offset: int, count: int):
-        if offset < 0 or offset + count > comm.numel():
-            raise ValueError(f"all-reduce window [{offset}, {offset + count}) outside the buffer")
-        view = comm[offset:offset + count]
+    """-> fn(offset, count[, view]) that sum-all-reduces comm[offset:offset+count] (or the given device view) in place."""
+    def _fn(offset: int, count: int, view=None):
+        if view is None:
+            if offset < 0 or offset + count > comm.numel():
+                raise ValueError(f"all-reduce window [{offset}, {offset + count}) outside the buffer")
+            view = comm[offset:offset + count]
         if comm.is_cuda and dist.get_backend(group) != "nccl":
             # A host backend (gloo: the CPU tests and the one-GPU rehearsal of the multi-rank path) on a device buffer:
             # stage through host memory with explicit synchronisation.  gloo's own device-tensor path only orders its

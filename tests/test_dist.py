@@ -136,6 +136,35 @@ def test_sharded_fit_two_ranks_one_gpu(name):
     assert spec_rows == res[1][3][0]
 
 
+def _gpu_worker_nd(rank, world, port, name, q):
+    os.environ["SPLPAK_ND"] = "1"            # (the goldens' grids are below the size from which nested dissection is the default)
+    os.environ.pop("SPLPAK_ND_DIST", None)
+    _gpu_worker(rank, world, port, name, q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("3d12", 2), ("3d16", 2), ("3d16", 3), ("3d16", 4), ("2d64_c2grid", 4)])
+def test_sharded_fit_with_the_factorisation_distributed_by_subtrees(name, world):
+    """Round 3 (SPLPAK_ND_DIST=0 turns it off): the ranks of a sharded fit eliminate their own subtrees of the nested-dissection tree only;
+    the Schur complements they leave in the fronts of depth dcut - 1 are summed through the all-reduce hook, the top of the
+    tree is factored by every rank, and the tree solves exchange the same fronts' vectors and the solution.  Rehearsed
+    with 2 - 4 ranks on ONE GPU over gloo (there is no multi-GPU hardware in this pool): the reference's golden
+    coefficients at 1e-10, identical bits on every rank, repeated fits identical (in _gpu_worker)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker_nd, args=(r, world, 29631 + world, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    gold = load_golden(name)
+    for rank, ierr, coef, info in res:
+        assert ierr == 0
+        assert relmax(coef, gold["coef"]) < 1e-10
+        assert np.array_equal(coef, res[0][2])
+
+
 # ---------------------------------------------------------------------------
 # distributed band (one process, several GPUs): rehearsed with virtual GPUs on the one device
 # ---------------------------------------------------------------------------
