@@ -469,6 +469,16 @@ nd_zero_kernel(const ZeroJob *__restrict__ jobs, int njobs)
     for (int u = 0; u < 8; ++u) *reinterpret_cast<d2_t *>(S + r2 + (long long)(c0 + 8 * u) * j.lds) = (d2_t){0.0, 0.0};
 }
 
+// distributed factorisation: the pivot status is made collective (a rank must not leave the fit alone)
+__global__ void nd_flag_kernel(const int *__restrict__ info, double *__restrict__ flag, int phase)
+{
+    if (phase == 0) flag[0] = info[0] != 0 ? 1.0 : 0.0;
+}
+__global__ void nd_unflag_kernel(int *__restrict__ info, const double *__restrict__ flag)
+{
+    if (flag[0] != 0.0 && info[0] == 0) info[0] = 0x7fffffff;        // another rank's subtree failed
+}
+
 // ---- solves ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 nd_gather_kernel(long long n, const int *__restrict__ rowsrc, const double *__restrict__ b, double *__restrict__ V)
@@ -1471,6 +1481,11 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)s->ntrinv), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev);
     (void)hipEventRecord(s->evJ, sP);
     if (sP != st) (void)hipStreamWaitEvent(st, s->evJ, 0);
+    if (s->dist) {      // (a failed pivot poisons the fronts above it with NaN, so every rank fails anyway; this makes it explicit)
+        hipLaunchKernelGGL(nd_flag_kernel, dim3(1), dim3(1), 0, st, (const int *)info_dev, s->part, 0);
+        if (plan_allreduce(p, s->part, 1, st) != 0) comm_failed = true;
+        hipLaunchKernelGGL(nd_unflag_kernel, dim3(1), dim3(1), 0, st, info_dev, (const double *)s->part);
+    }
     if (sU != st) {                                   // (the zero launches for the next fit may still be running: it waits for them)
         (void)hipEventRecord(s->evZlast, sU);
         s->zlast_valid = true;

@@ -165,6 +165,47 @@ def test_sharded_fit_with_the_factorisation_distributed_by_subtrees(name, world)
         assert np.array_equal(coef, res[0][2])
 
 
+def _gpu_worker_nd_singular(rank, world, port, q):
+    os.environ["SPLPAK_ND"] = "1"
+    os.environ.pop("SPLPAK_ND_DIST", None)
+    sys.path.insert(0, ROOT)
+    from splpak_amd.dist import ShardedFit, shard_range
+    from splpak_amd.synth import synth_points
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        nd, nod = 3, 12
+        x, y, w = synth_points(nd, 3000)
+        x = x * 0.5                                  # an empty half of the box: columns without data, no smoothing rows
+        first, cnt = shard_range(x.shape[0], rank, world)
+        xs, ys, ws = (torch.tensor(a[first:first + cnt], device=dev) for a in (x, y, w))
+        coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
+        sf = ShardedFit(nd, [nod] * nd, [0.0] * nd, [1.0] * nd, 0.0, max(cnt, 1), dev, dist)
+        ierr, info = sf.fit(xs, ys, ws, coef, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        q.put((rank, ierr))
+        sf.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_distributed_subtrees_singular_system_is_107_on_every_rank():
+    """A pivot fails in ONE rank's subtree: every rank must come back with 107 (the failure reaches the top of the tree through
+    the summed Schur complements, and the pivot status is all-reduced) -- none may be left waiting in a collective."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker_nd_singular, args=(r, world, 29641, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(60)
+    assert [e for _, e in res] == [107] * world
+
+
 # ---------------------------------------------------------------------------
 # distributed band (one process, several GPUs): rehearsed with virtual GPUs on the one device
 # ---------------------------------------------------------------------------
