@@ -469,6 +469,26 @@ nd_zero_kernel(const ZeroJob *__restrict__ jobs, int njobs)
     for (int u = 0; u < 8; ++u) *reinterpret_cast<d2_t *>(S + r2 + (long long)(c0 + 8 * u) * j.lds) = (d2_t){0.0, 0.0};
 }
 
+// distributed factorisation: the lower-triangle tiles of a Schur buffer <-> a contiguous image (tile after tile, column-major
+// inside a tile), so that the join sums half the bytes of the square buffer
+template <bool PACK>
+__global__ void __launch_bounds__(256)
+nd_tripack_kernel(double *__restrict__ S, long long lds, int nt, double *__restrict__ img)
+{
+    int tj, ti;
+    trapezoid_decode(blockIdx.x, nt, tj, ti);
+    if (tj >= nt || ti >= nt) return;
+    double *__restrict__ T = S + (long long)(ti * 64) + (long long)(tj * 64) * lds;
+    double *__restrict__ I = img + (long long)blockIdx.x * 4096;
+    const int r2 = (threadIdx.x & 31) * 2, c0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int c = c0 + 8 * u;
+        if (PACK) *reinterpret_cast<d2_t *>(I + r2 + 64 * c) = *reinterpret_cast<const d2_t *>(T + r2 + (long long)c * lds);
+        else *reinterpret_cast<d2_t *>(T + r2 + (long long)c * lds) = *reinterpret_cast<const d2_t *>(I + r2 + 64 * c);
+    }
+}
+
 // distributed factorisation: the pivot status is made collective (a rank must not leave the fit alone)
 __global__ void nd_flag_kernel(const int *__restrict__ info, double *__restrict__ flag, int phase)
 {
@@ -734,6 +754,8 @@ struct NdState {
     int world = 1, rank = 0, dcut = 0;
     std::vector<char> mine;                        // [front] this rank eliminates it
     std::vector<int> rowsrc_host;                  // [vec_doubles] variable of every front row (-1: border / padding)
+    double *join_scratch = nullptr;                // packed lower triangle of the largest Schur buffer the join sums
+    long long join_scratch_doubles = 0;
     int *rowsrc_out = nullptr;                     // rowsrc restricted to the variables this rank reports (the rest arrive by all-reduce)
     int ntrinv = 0;
     int xmode = 0;                                 // XCD-aware item map of the Schur passes (SPLPAK_ND_XCD=1)
@@ -1331,11 +1353,23 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     auto dist_join = [&]() {
         for (hipStream_t q : {sPp[0], sPp[1], sU, sR})
             if (q) (void)hipStreamSynchronize(q);
+        // (Schur buffers: their lower-triangle tiles only, packed into a scratch image; the square buffer if that could not be had)
+        double *scratch = s->join_scratch;
+        const long long scap = s->join_scratch_doubles;
         for (int id : t.by_depth[(size_t)(s->dcut - 1)]) {
             const NdFront &f = t.fr[(size_t)id];
             if (plan_allreduce(p, s->factor + f.panel_off, f.ld * (long long)f.wp, st) != 0) comm_failed = true;
-            if (f.hp > 0 && plan_allreduce(p, s_ptr(s, id), f.lds * (long long)f.hp, st) != 0) comm_failed = true;
+            if (f.hp == 0) continue;
+            const int nt = f.hp / 64;
+            const long long tiles = trapezoid_items(nt, nt);
+            if (tiles * 4096 <= scap && !std::getenv("SPLPAK_ND_JOIN_SQUARE")) {
+                hipLaunchKernelGGL(nd_tripack_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, st, s_ptr(s, id), f.lds, nt, scratch);
+                if (plan_allreduce(p, scratch, tiles * 4096, st) != 0) comm_failed = true;
+                hipLaunchKernelGGL(nd_tripack_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, st, s_ptr(s, id), f.lds, nt, scratch);
+            } else if (plan_allreduce(p, s_ptr(s, id), f.lds * (long long)f.hp, st) != 0)
+                comm_failed = true;
         }
+        (void)hipStreamSynchronize(st);
     };
     int qnext = 0;
     (void)hipEventRecord(s->ev0, st);
@@ -1623,6 +1657,22 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
             for (int r = 0; r < f.fp; ++r) out[(size_t)(f.vofs + r)] = -1;
     }
     if (!nd_upload(s, &s->rowsrc_out, out)) return SPLPAK_E_NOMEM;
+    if (want) {
+        long long need = 0;
+        for (int id : t.by_depth[(size_t)(dcut - 1)]) {
+            const long long nt = t.fr[(size_t)id].hp / 64;
+            need = std::max(need, trapezoid_items(nt, nt) * 4096);
+        }
+        if (need > s->join_scratch_doubles) {
+            double *q = nullptr;
+            if (hipMalloc(&q, sizeof(double) * (size_t)need) == hipSuccess) {      // (no room: the join sums the square buffers)
+                s->owned.push_back(q);
+                s->join_scratch = q;
+                s->join_scratch_doubles = need;
+            } else
+                (void)hipGetLastError();
+        }
+    }
     s->s_clean = false;
     if (std::getenv("SPLPAK_DEBUG")) {
         int nm = 0;
