@@ -1355,7 +1355,16 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             if (q) (void)hipStreamSynchronize(q);
         // (Schur buffers: their lower-triangle tiles only, packed into a scratch image; the square buffer if that could not be had)
         double *scratch = s->join_scratch;
-        const long long scap = s->join_scratch_doubles;
+        long long scap = s->join_scratch_doubles;
+        {   // every rank must sum windows of the same size: the packed form only if ALL ranks have the scratch for it
+            const double mine_missing = scratch ? 0.0 : 1.0;
+            double any_missing = 0.0;
+            (void)hipMemcpyAsync(s->part + 1, &mine_missing, sizeof(double), hipMemcpyHostToDevice, st);
+            if (plan_allreduce(p, s->part + 1, 1, st) != 0) comm_failed = true;
+            (void)hipMemcpyAsync(&any_missing, s->part + 1, sizeof(double), hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            if (any_missing != 0.0) scap = 0;
+        }
         for (int id : t.by_depth[(size_t)(s->dcut - 1)]) {
             const NdFront &f = t.fr[(size_t)id];
             if (plan_allreduce(p, s->factor + f.panel_off, f.ld * (long long)f.wp, st) != 0) comm_failed = true;
