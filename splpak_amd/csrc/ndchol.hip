@@ -1630,7 +1630,7 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
     int dcut = 0;
     while ((1 << dcut) < world) ++dcut;
     const char *sw = std::getenv("SPLPAK_ND_DIST");                  // 0 = every rank factors everything (round 2's form)
-    const bool want = world > 1 && !(sw && atoi(sw) == 0) && dcut >= 1 && dcut <= t.maxdepth && s->npipe == 1;
+    const bool want = world > 1 && p->ar != nullptr && !(sw && atoi(sw) == 0) && dcut >= 1 && dcut <= t.maxdepth && s->npipe == 1;
     if (!want && !s->dist) return 0;
     (void)hipDeviceSynchronize();
     s->dist = want;
