@@ -107,12 +107,10 @@ typedef struct splpak_plan splpak_plan;
  * across all ranks ON `stream` (or synchronise itself) and return 0.  With
  * torch.distributed/RCCL this is `all_reduce(tensor_view)`.  NULL => single rank.
  * The pointer lies in the plan's communication buffer for the histogram, the normal
- * equations and the refinement residuals; since round 3 the nested-dissection
- * factorisation of a sharded fit is distributed by subtrees (csrc/ndchol.hip,
- * SPLPAK_ND_DIST=0 turns that off) and also sums front panels, Schur buffers and
- * solve vectors that live in the library's own device allocations: a hook must
- * accept ANY device pointer of the calling process (ncclAllReduce does; the Python
- * shim wraps such a pointer through the CUDA array interface). */
+ * equations and the refinement residuals.  A hook installed with
+ * splpak_plan_set_allreduce_ex(.., SPLPAK_AR_ANY_POINTER) is also handed front panels,
+ * Schur buffers and solve vectors that live in the library's own device allocations
+ * (the nested-dissection factorisation distributed by subtrees, csrc/ndchol.hip). */
 typedef int32_t (*splpak_allreduce_fn)(void *dev_buf, int64_t count, void *stream, void *user);
 
 /* Validates exactly like splcw (:716-781; 105/106 are checked at fit time) and
@@ -135,6 +133,17 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
 void    splpak_plan_destroy(splpak_plan *plan);
 void    splpak_plan_set_allreduce(splpak_plan *plan, splpak_allreduce_fn fn, void *user,
                                   int32_t rank, int32_t world);
+/* The same with the hook's capabilities declared (round 4).  flags = 0 is splpak_plan_set_allreduce: the hook is only
+ * ever called with windows of the plan's communication buffer (histogram, normal equations, refinement residuals) and
+ * the factorisation is replicated on every rank, as in rounds 1-2.  SPLPAK_AR_ANY_POINTER: the hook accepts ANY device
+ * pointer of the calling process (ncclAllReduce does; splpak_plan_set_rccl installs such a hook; the Python shim wraps
+ * foreign pointers through the CUDA array interface) -- the nested-dissection factorisation of a sharded fit is then
+ * distributed by subtrees (csrc/ndchol.hip; SPLPAK_ND_DIST=0 turns that off) and sums front panels, Schur buffers and
+ * solve vectors that live in the library's own allocations.  Returns 0 or a negative status (a failure while the
+ * per-rank job tables are rebuilt; the plan's next fit returns it on every rank). */
+#define SPLPAK_AR_ANY_POINTER 1
+int32_t splpak_plan_set_allreduce_ex(splpak_plan *plan, splpak_allreduce_fn fn, void *user,
+                                     int32_t rank, int32_t world, int32_t flags);
 /* tuning / test knobs: nominal refinement steps (default 4; 0 = none; a solve that still contracts goes on
  * up to max(steps, 30)) and the tolerance on the (estimated) remaining relative error |dx|/|x| after a
  * step (default 1e-11; the parity bar is 1e-10) */

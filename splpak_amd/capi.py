@@ -26,7 +26,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_voi
 SYMBOLS = [
     "splpak_fit_f64", "splpak_fit_f32", "splpak_eval_f64", "splpak_eval_f32",
     "splpak_plan_comm_len", "splpak_plan_create", "splpak_plan_destroy",
-    "splpak_plan_set_allreduce", "splpak_plan_set_refine", "splpak_plan_fit_dev",
+    "splpak_plan_set_allreduce", "splpak_plan_set_allreduce_ex", "splpak_plan_set_refine", "splpak_plan_fit_dev",
     "splpak_plan_hist_dev", "splpak_plan_factorisation", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing", "splpak_plan_stage_timing",
     "splpak_eval_dev_f64", "splpak_eval_dev_f32", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
@@ -36,6 +36,7 @@ SYMBOLS = [
 ]
 
 E_NODEVICE, E_NOMEM, E_BADARG, E_UNSUPPORTED, E_COMM = -1, -2, -3, -4, -5
+AR_ANY_POINTER = 1
 
 _lib = None
 
@@ -79,6 +80,8 @@ def lib() -> C.CDLL:
     L.splpak_plan_destroy.argtypes = [vp]
     L.splpak_plan_set_allreduce.restype = None
     L.splpak_plan_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i32, i32]
+    L.splpak_plan_set_allreduce_ex.restype = i32
+    L.splpak_plan_set_allreduce_ex.argtypes = [vp, ALLREDUCE_FN, vp, i32, i32, i32]
     L.splpak_plan_set_refine.restype = None
     L.splpak_plan_set_refine.argtypes = [vp, i32, dbl]
     L.splpak_plan_fit_dev.restype = i32
@@ -358,10 +361,19 @@ class Plan:
     def set_refine(self, max_steps, tol):
         self._L.splpak_plan_set_refine(self._h, int(max_steps), float(tol))
 
-    def set_allreduce(self, fn, rank, world):
-        """fn(offset_elems, count) must sum-all-reduce self.comm[offset:offset+count] in place; windows outside the plan's
-        buffer (the fronts the subtrees of a distributed nested-dissection factorisation report into) arrive
-        as fn(-1, count, view) with `view` a device tensor over the library's memory."""
+    def set_allreduce(self, fn, rank, world, any_pointer=None):
+        """fn(offset_elems, count) must sum-all-reduce self.comm[offset:offset+count] in place.  A hook that also takes a
+        third argument -- fn(-1, count, view) with `view` a device tensor over the library's own memory -- declares
+        SPLPAK_AR_ANY_POINTER (include/splpak_hip.h): the nested-dissection factorisation of the sharded fit is then
+        distributed by subtrees and the fronts they report into arrive that way.  A two-argument hook (rounds 1-2) keeps
+        the replicated factorisation.  `any_pointer` overrides the detection."""
+        if any_pointer is None:
+            import inspect
+            try:
+                params = list(inspect.signature(fn).parameters.values())
+                any_pointer = len(params) >= 3 or any(q.kind == q.VAR_POSITIONAL for q in params)
+            except (TypeError, ValueError):
+                any_pointer = False
         base = self.comm.data_ptr()
         ncomm = self.comm.numel()
         device = self.comm.device
@@ -395,7 +407,7 @@ class Plan:
                 return 1
 
         self._cb = ALLREDUCE_FN(_cb)
-        self._L.splpak_plan_set_allreduce(self._h, self._cb, None, int(rank), int(world))
+        _check(self._L.splpak_plan_set_allreduce_ex(self._h, self._cb, None, int(rank), int(world), AR_ANY_POINTER if any_pointer else 0))
 
     def factorisation(self):
         """-> (code, description): 0/1 band Cholesky, 2 two-ended band, 3 distributed band, 4 nested dissection."""

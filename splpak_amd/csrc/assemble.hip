@@ -175,21 +175,62 @@ scatter_kernel(Grid g, long long m, const double *__restrict__ x, int ldx,
 // Orders the points inside every cell by original index.  The scatter places them in the order in
 // which its atomic cursor was served, which differs from run to run; the per-cell sums of the Gram
 // and residual kernels are taken in storage order, so this is what makes the whole fit reproducible
-// bit for bit.  One workgroup per cell; cells with more than ORDER_CAP points (the image does not fit
-// in LDS) keep the scatter's order -- their sums are still correct, only not reproducible.
+// bit for bit.  One workgroup per cell.  Cells of up to ORDER_CAP points are permuted through an image
+// in LDS.  Larger cells (round 4; up to ORDER_BIG_CAP points): the rank of every point is counted against
+// the cell's original indices streamed through LDS in chunks of 1 024, the ordered indices are parked in
+// `ordtmp` (the key array, dead once the scatter has run) and the cell's image is rebuilt from the caller's
+// arrays.  Cells beyond ORDER_BIG_CAP (65 536 points in ONE window of the grid) keep the scatter's order:
+// their sums are correct, only not reproducible from run to run.
 constexpr int ORDER_CAP = 1024;
+constexpr int ORDER_BIG_CAP = 1 << 16;
 template <int D>
 __global__ void __launch_bounds__(256)
-cell_order_kernel(const int *__restrict__ offset, double *__restrict__ xs, double *__restrict__ ys,
-                  double *__restrict__ ws, int *__restrict__ idx, long long cap)
+cell_order_kernel(Grid g, const int *__restrict__ offset, double *__restrict__ xs, double *__restrict__ ys,
+                  double *__restrict__ ws, int *__restrict__ idx, long long cap, const double *__restrict__ x, int ldx,
+                  const double *__restrict__ y, const double *__restrict__ w, int *__restrict__ ordtmp)
 {
     __shared__ int sidx[ORDER_CAP];
     __shared__ double sv[ORDER_CAP * (D + 2)];
     const int cell = blockIdx.x;
     const long long beg = offset[cell];
     const int n = (int)(offset[cell + 1] - beg);
-    if (n < 2 || n > ORDER_CAP) return;
+    if (n < 2 || n > ORDER_BIG_CAP) return;
     const int tid = threadIdx.x;
+    if (n > ORDER_CAP) {
+        for (int t0 = 0; t0 < n; t0 += ORDER_CAP) {           // a tile of 1 024 points: four per thread
+            int me[4], rank[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = t0 + tid + 256 * u;
+                me[u] = p < n ? idx[beg + p] : 0x7fffffff;
+                rank[u] = 0;
+            }
+            for (int c0 = 0; c0 < n; c0 += ORDER_CAP) {
+                __syncthreads();
+                for (int p = tid; p < ORDER_CAP; p += 256) sidx[p] = c0 + p < n ? idx[beg + c0 + p] : 0x7fffffff;
+                __syncthreads();
+                const int cn = n - c0 < ORDER_CAP ? n - c0 : ORDER_CAP;
+                for (int q = 0; q < cn; ++q) {
+                    const int v = sidx[q];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rank[u] += v < me[u] ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + tid + 256 * u < n) ordtmp[beg + rank[u]] = me[u];
+        }
+        __syncthreads();                                      // (the workgroup's own global writes are visible to it)
+        for (int p = tid; p < n; p += 256) {
+            const int i = ordtmp[beg + p];
+            idx[beg + p] = i;
+#pragma unroll
+            for (int d = 0; d < D; ++d) xs[(long long)d * cap + beg + p] = x[(long long)i * ldx + g.perm[d]];
+            ys[beg + p] = y[i];
+            ws[beg + p] = w ? w[i] : 1.0;
+        }
+        return;
+    }
     for (int p = tid; p < n; p += 256) {
         sidx[p] = idx[beg + p];
 #pragma unroll
@@ -1500,8 +1541,8 @@ hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ld
         dim3 gr(grid_for(m, 256)), bl(256);
         DISPATCH_D(g.ndim, hipLaunchKernelGGL(scatter_kernel<D>, gr, bl, 0, st, g, m, x, ldx, y, w,
                                               s.key, s.offset, s.cursor, s.xs, s.ys, s.ws, s.idx, s.cap));
-        DISPATCH_D(g.ndim, hipLaunchKernelGGL(cell_order_kernel<D>, dim3((unsigned)g.ncell), dim3(256), 0, st,
-                                              (const int *)s.offset, s.xs, s.ys, s.ws, s.idx, s.cap));
+        DISPATCH_D(g.ndim, hipLaunchKernelGGL(cell_order_kernel<D>, dim3((unsigned)g.ncell), dim3(256), 0, st, g,
+                                              (const int *)s.offset, s.xs, s.ys, s.ws, s.idx, s.cap, x, ldx, y, w, s.key));
     }
     return hipGetLastError();
 }

@@ -1446,7 +1446,11 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         if (s->fused && d < t.maxdepth)
             for (int q = 0; q < np; ++q)
                 if (sU != sPp[q]) (void)hipStreamWaitEvent(sPp[q], s->evF[q][(size_t)(d + 1)], 0);     // the children's last passes
-        for (int k = 0; k < steps; ++k)
+        // (a rank of a distributed factorisation may hold no front at this depth -- its subtrees stop short of the tree's
+        //  depth when a split straddles split_min -- and still owes the stage's bookkeeping: the event its parents wait for
+        //  and the zeroing of the Schur buffers that use this arena half next; round-3 advice: they were skipped with
+        //  steps == 0 and the rank's later fits added onto the previous fit's Schur buffers)
+        for (int k = 0; k < std::max(steps, 1); ++k)
             for (int q = 0; q < np; ++q) {
                 const int stg = q * nd + d, sq = (int)s->l_potrf[(size_t)stg].size();
                 if (k < sq) chain_step(q, stg, k, pinned);
@@ -1610,6 +1614,26 @@ hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void
     return hipGetLastError();
 }
 
+template <typename T>
+void nd_free_dev(NdState *s, T **ptr)
+{
+    if (!*ptr) return;
+    for (size_t i = 0; i < s->owned.size(); ++i)
+        if (s->owned[i] == (void *)*ptr) { s->owned.erase(s->owned.begin() + (long)i); break; }
+    (void)hipFree(*ptr);
+    *ptr = nullptr;
+}
+
+// device copies of the job tables (before they are uploaded again for another set of ranks)
+void nd_free_jobs(NdState *s)
+{
+    nd_free_dev(s, &s->potrf.dev); nd_free_dev(s, &s->trsm.dev); nd_free_dev(s, &s->trsmb.dev); nd_free_dev(s, &s->upd.dev);
+    nd_free_dev(s, &s->updr.dev); nd_free_dev(s, &s->updo.dev); nd_free_dev(s, &s->fin[0].dev); nd_free_dev(s, &s->fin[1].dev);
+    nd_free_dev(s, &s->schur.dev); nd_free_dev(s, &s->trinv.dev); nd_free_dev(s, &s->add.dev); nd_free_dev(s, &s->zero.dev);
+    nd_free_dev(s, &s->mv.dev); nd_free_dev(s, &s->fwd.dev); nd_free_dev(s, &s->dot.dev); nd_free_dev(s, &s->bwd.dev);
+    nd_free_dev(s, &s->map.dev); nd_free_dev(s, &s->rowsrc_out);
+}
+
 bool nd_upload_jobs(NdState *s)
 {
     return nd_upload(s, &s->potrf.dev, s->potrf.host) && nd_upload(s, &s->trsm.dev, s->trsm.host) && nd_upload(s, &s->trsmb.dev, s->trsmb.host) &&
@@ -1630,7 +1654,10 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
     int dcut = 0;
     while ((1 << dcut) < world) ++dcut;
     const char *sw = std::getenv("SPLPAK_ND_DIST");                  // 0 = every rank factors everything (round 2's form)
-    const bool want = world > 1 && p->ar != nullptr && !(sw && atoi(sw) == 0) && dcut >= 1 && dcut <= t.maxdepth && s->npipe == 1;
+    // (the join sums front panels, Schur buffers and solve vectors that live outside the plan's communication buffer: only with a
+    //  hook that declared it accepts any device pointer -- SPLPAK_AR_ANY_POINTER; round-3 advice)
+    const bool want = world > 1 && p->ar != nullptr && (p->ar_flags & SPLPAK_AR_ANY_POINTER) != 0 && !(sw && atoi(sw) == 0) && dcut >= 1 &&
+                      dcut <= t.maxdepth && s->npipe == 1;
     if (!want && !s->dist) return 0;
     (void)hipDeviceSynchronize();
     s->dist = want;
@@ -1657,6 +1684,7 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
     s->potrf.host.clear(); s->trsm.host.clear(); s->trsmb.host.clear(); s->trinv.host.clear(); s->add.host.clear(); s->zero.host.clear();
     s->mv.host.clear(); s->fwd.host.clear(); s->dot.host.clear(); s->bwd.host.clear(); s->map.host.clear();
     if (!nd_build_jobs(s)) { set_error("nested dissection: job tables (ranks)"); return SPLPAK_E_UNSUPPORTED; }
+    nd_free_jobs(s);                                           // the superseded device tables
     if (!nd_upload_jobs(s)) return SPLPAK_E_NOMEM;
     std::vector<int> out(s->rowsrc_host);
     for (size_t id = 0; id < t.fr.size(); ++id) {

@@ -318,15 +318,26 @@ void splpak_plan_destroy(splpak_plan *p)
     delete p;
 }
 
-void splpak_plan_set_allreduce(splpak_plan *p, splpak_allreduce_fn fn, void *user, int32_t rank,
-                               int32_t world)
+int32_t splpak_plan_set_allreduce_ex(splpak_plan *p, splpak_allreduce_fn fn, void *user, int32_t rank,
+                                     int32_t world, int32_t flags)
 {
-    if (!p) return;
+    if (!p) { set_error("null plan"); return SPLPAK_E_BADARG; }
     p->ar = fn;
     p->ar_user = user;
     p->rank = rank;
     p->world = world < 1 ? 1 : world;
-    (void)nd_set_ranks(p, p->rank, p->world);
+    p->ar_flags = flags;
+    // (a failure here leaves the plan without usable job tables: it is remembered and every rank's next fit returns it
+    //  through the first reduction's error flag -- round-3 advice: the status used to be dropped)
+    p->setup_rc = nd_set_ranks(p, p->rank, p->world);
+    return p->setup_rc;
+}
+
+void splpak_plan_set_allreduce(splpak_plan *p, splpak_allreduce_fn fn, void *user, int32_t rank,
+                               int32_t world)
+{
+    // the hook of rounds 1-2: windows of the plan's communication buffer only -> the factorisation stays replicated
+    (void)splpak_plan_set_allreduce_ex(p, fn, user, rank, world, 0);
 }
 
 void splpak_plan_set_refine(splpak_plan *p, int32_t max_steps, double tol)
@@ -399,7 +410,7 @@ static int do_allreduce(splpak_plan *p, double *buf, long long count, hipStream_
     // 3 + refinement steps of these)
     SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
     const int r = p->ar(buf, count, (void *)st, p->ar_user);
-    if (r != 0) { set_error("all-reduce callback failed"); return SPLPAK_E_COMM; }
+    if (r != 0) { set_error("all-reduce callback failed"); p->comm_failed = true; return SPLPAK_E_COMM; }
     SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
     debug_sum(p, "after  all-reduce", buf, count, st);
     return 0;
@@ -422,8 +433,17 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     if (ndata > 0 && (!x || !y)) { set_error("null data pointer"); lerr = SPLPAK_E_BADARG; }
     else if (ndata > p->max_ndata) { set_error("ndata exceeds the plan's max_ndata"); lerr = SPLPAK_E_BADARG; }
     else if (l1xdat < p->g.ndim) { set_error("l1xdat < ndim"); lerr = SPLPAK_E_BADARG; }
+    if (lerr == 0 && p->setup_rc != 0) { set_error("the plan's rank set-up failed (splpak_plan_set_allreduce)"); lerr = p->setup_rc; }
     if (lerr != 0 && p->world <= 1) return lerr;
     if (lerr != 0) ndata = 0;
+    p->comm_failed = false;
+    // a failure inside the factorisation / solve hooks: a communication failure is not a device fault (round-3 advice)
+#define SPLPAK_HOOK_TRY(expr)                                                        \
+    do {                                                                             \
+        const hipError_t he_ = (expr);                                               \
+        if (p->comm_failed) { (void)hipGetLastError(); return SPLPAK_E_COMM; }       \
+        if (!::splpak::hip_ok(he_, #expr)) return SPLPAK_E_NODEVICE;                 \
+    } while (0)
     hipStream_t st = (hipStream_t)stream;
     const Grid &g = p->g;
     const Band &b = p->band;
@@ -493,7 +513,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     stamp(4);
     SPLPAK_HIP_TRY(p->expand_fn ? p->expand_fn(p, st, p->fn_user) : launch_expand(g, p->nst, b, p->dm, st), SPLPAK_E_NODEVICE);
     stamp(5);
-    SPLPAK_HIP_TRY(p->factor_fn ? p->factor_fn(p, p->info, p->small + 2, st, p->fn_user) : band_cholesky(b, p->info, p->small + 2, st, &p->stats), SPLPAK_E_NODEVICE);
+    SPLPAK_HOOK_TRY(p->factor_fn ? p->factor_fn(p, p->info, p->small + 2, st, p->fn_user) : band_cholesky(b, p->info, p->small + 2, st, &p->stats));
     int hinfo = 0;
     double minpiv = 0.0;
     SPLPAK_HIP_TRY(hipMemcpyAsync(&hinfo, p->info, sizeof(int), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
@@ -516,7 +536,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     SPLPAK_HIP_TRY(hipMemsetAsync(p->xvec, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
     SPLPAK_HIP_TRY(hipMemcpyAsync(p->xvec, p->rhs, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
     stamp(6);
-    SPLPAK_HIP_TRY(p->solve_fn ? p->solve_fn(p, p->xvec, p->tmp, st, p->fn_user) : band_solve(b, p->xvec, p->tmp, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HOOK_TRY(p->solve_fn ? p->solve_fn(p, p->xvec, p->tmp, st, p->fn_user) : band_solve(b, p->xvec, p->tmp, st));
     stamp(7);
     int steps = 0;
     double last_rel = 0.0, prev_rel = inf, ratio = 0.0;
@@ -532,7 +552,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, p->ctab, smooth && p->rank == 0,
                                        p->tbuf, p->rho, nullptr, nullptr, st), SPLPAK_E_NODEVICE);
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
-        SPLPAK_HIP_TRY(p->solve_fn ? p->solve_fn(p, p->rho, p->tmp, st, p->fn_user) : band_solve(b, p->rho, p->tmp, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HOOK_TRY(p->solve_fn ? p->solve_fn(p, p->rho, p->tmp, st, p->fn_user) : band_solve(b, p->rho, p->tmp, st));
         SPLPAK_HIP_TRY(launch_axpy_absmax(g.ncol, p->xvec, p->rho, p->small, st), SPLPAK_E_NODEVICE);
         double am[2];
         SPLPAK_HIP_TRY(hipMemcpyAsync(am, p->small, 2 * sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
@@ -632,6 +652,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         return 107;
     }
     return 0;
+#undef SPLPAK_HOOK_TRY
 }
 
 // ---------------------------------------------------------------------------
@@ -666,8 +687,11 @@ HostFitCache g_hostfit;
 
 // An allocation failed: give back what the one-shot entry keeps between calls (round-2 advice).  Not while a one-shot
 // fit is running (it holds the lock and has released its old plan itself).  true = something was released.
+static thread_local bool t_in_fit_host = false;      // this thread holds g_hostfit.mu (try_lock on a mutex one owns is undefined)
+
 bool splpak::release_cached_plan_for_memory()
 {
+    if (t_in_fit_host) return false;
     std::unique_lock<std::mutex> lock(g_hostfit.mu, std::try_to_lock);
     if (!lock.owns_lock() || !g_hostfit.plan) return false;
     g_hostfit.release();
@@ -699,6 +723,7 @@ static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const
 
     HostFitCache &hc = g_hostfit;
     std::lock_guard<std::mutex> lock(hc.mu);
+    struct InFit { InFit() { t_in_fit_host = true; } ~InFit() { t_in_fit_host = false; } } in_fit;
     int dev = 0;
     (void)hipGetDevice(&dev);
     // switches that are read when a plan is created (they select or shape the factorisation): part of the cache key

@@ -31,6 +31,9 @@ struct splpak_plan {
     splpak_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
     int rank = 0, world = 1;
+    int ar_flags = 0;             // SPLPAK_AR_*: what the hook accepts (splpak_plan_set_allreduce_ex)
+    int setup_rc = 0;             // a failure while the ranks were set up (nd_set_ranks): returned by the next fit, collectively
+    bool comm_failed = false;     // the hook reported a failure during the current fit (SPLPAK_E_COMM, not a device fault)
     int max_refine = 4;           // nominal number of refinement steps; a solve that is still contracting goes on (max_refine_hard)
     int max_refine_hard = 30;
     double tol = 1e-11;           // on the ESTIMATED remaining error; the parity bar is 1e-10

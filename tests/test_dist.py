@@ -165,6 +165,72 @@ def test_sharded_fit_with_the_factorisation_distributed_by_subtrees(name, world)
         assert np.array_equal(coef, res[0][2])
 
 
+def _gpu_worker_unbalanced(rank, world, port, nd, nodes, two_arg_hook, q):
+    """Sharded fit on a grid whose nested-dissection tree is UNBALANCED (a split straddles split_min: some subtrees stop one
+    level short), three fits through one plan, compared with the unsharded fit of the same points."""
+    os.environ["SPLPAK_ND"] = "1"
+    os.environ.pop("SPLPAK_ND_DIST", None)
+    sys.path.insert(0, ROOT)
+    from splpak_amd import capi
+    from splpak_amd.dist import ShardedFit, make_allreduce, shard_range
+    from splpak_amd.synth import synth_points
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        ncol = int(np.prod(nodes))
+        m = 6 * ncol
+        x, y, w = synth_points(nd, m)
+        lo, hi = [0.0] * nd, [1.0] * nd
+        first, cnt = shard_range(m, rank, world)
+        xs, ys, ws = (torch.tensor(a[first:first + cnt], device=dev) for a in (x, y, w))
+        coef = torch.zeros(ncol, dtype=torch.float64, device=dev)
+        sf = ShardedFit(nd, nodes, lo, hi, 1.0, max(cnt, 1), dev, dist)
+        if two_arg_hook:            # a hook written to the contract of rounds 1-2: windows of the plan's buffer only
+            full = make_allreduce(sf.comm, dist)
+            sf.plan.set_allreduce(lambda off, cnt_: full(off, cnt_), rank, world)
+        st = torch.cuda.current_stream().cuda_stream
+        outs = []
+        for _ in range(3):
+            ierr, info = sf.fit(xs, ys, ws, coef, st)
+            torch.cuda.synchronize()
+            outs.append((ierr, coef.cpu().numpy().copy()))
+        ref = None
+        if rank == 0:
+            ref, e1, _, _ = capi.fit(nd, x, y, w, lo, hi, nodes, 1.0)
+            assert e1 == 0
+        q.put((rank, outs, ref, info))
+        sf.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nd,nodes,world,two_arg", [(3, [18, 18, 18], 2, False), (2, [34, 34], 2, False), (3, [18, 18, 18], 3, False),
+                                                    (3, [12, 12, 12], 2, True)])
+def test_distributed_subtrees_unbalanced_tree_repeated_fits(nd, nodes, world, two_arg):
+    """Round-3 advice (high): on an unbalanced tree a rank whose subtrees stop short of the tree's depth skipped the stage
+    bookkeeping of the depths it has no front at, and its second and later fits added onto the previous fit's Schur
+    buffers.  18^3 with 2 ranks: rank 0 holds depths 1..5 of a depth-6 tree.  Every fit of the plan must give the same
+    bits, on every rank, and agree with the unsharded fit.  The two-argument hook of rounds 1-2 (no SPLPAK_AR_ANY_POINTER)
+    must keep working through the replicated factorisation."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker_unbalanced, args=(r, world, 29651 + world, nd, nodes, two_arg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    ref = res[0][2]
+    for rank, outs, _, info in res:
+        for ierr, c in outs:
+            assert ierr == 0
+            assert np.array_equal(c, res[0][1][0][1]), "fits differ between ranks or between repeated fits"
+        assert relmax(outs[0][1], ref) < 1e-11
+        assert info[9] < 1e-9
+
+
 def _gpu_worker_nd_singular(rank, world, port, q):
     os.environ["SPLPAK_ND"] = "1"
     os.environ.pop("SPLPAK_ND_DIST", None)

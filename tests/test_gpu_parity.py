@@ -840,3 +840,149 @@ def test_c3_full_size_weighted_optimality_on_the_host(port):
     c2 = c.copy()
     c2[c.size // 2] += 1e-7 * np.abs(c).max()
     assert port.rows_gradient(nd, x, y, w, lo, hi, nodes, 1.0, c2)[0] > 1e-9
+
+
+def _far_outside_case(nd, nodes, m, far_point, weighted, seed=11):
+    rng = np.random.default_rng(seed)
+    x = rng.random((m, nd))
+    x = np.vstack([x, np.asarray(far_point, dtype=np.float64).reshape(1, nd)])
+    y = np.cos(2.0 * x.sum(axis=1))
+    w = (0.5 + rng.random(m + 1)) if weighted else None
+    return x, y, w
+
+
+FAR_CASES = [
+    # SURVEY 8a3's own case (2-D 4x4: ONE window holds every node, the outlier's address 2 is a node of it)
+    ("survey_2d4", 2, [4, 4], None, (5.0, 0.5), False),
+    # grids with more than one window: the outlier's Horner address (its in-range dimensions alone, :899) is NOT a node of
+    # the window the point is binned into -> the one f64 atomicAdd left in the assembly (assemble.hip "far outside")
+    ("2d8_wave", 2, [8, 8], 600, (5.0, 0.9), True),
+    ("2d8_wave_both", 2, [8, 8], 600, (-7.0, 9.0), True),          # both dimensions skipped: address 0
+    ("3d7_wave", 3, [7, 6, 8], 2500, (0.2, -4.0, 0.95), True),
+    ("4d6_mfma4", 4, [6, 5, 6, 5], 5000, (0.9, 0.1, 7.5, 0.8), True),
+    ("1d16_block", 1, [16], 300, (5.0,), True),
+]
+
+
+@pytest.mark.parametrize("name,nd,nodes,m,far,weighted", FAR_CASES)
+def test_histogram_far_outside_point_on_gpu(port, name, nd, nodes, m, far, weighted):
+    """SURVEY 8a3 / src/splpak.F90:886-907: a coordinate so far outside the grid that its nearest-node index is out of
+    range executes the unlabelled `cycle` of the DIMENSION loop (:899) -- the point is still counted, at the Horner address
+    of its remaining dimensions, and still adds to totlwt.  Through gram_wave_kernel (2-D / 3-D), gram_mfma4_kernel (4-D)
+    and gram_block_kernel (1-D), whose only f64 atomicAdd this is; compared with the reference algorithm's work(1:ncol)."""
+    if m is None:                                   # the survey's case verbatim: 36 in-range points + (5.0, 0.5)
+        g = (np.arange(6) + 0.5) / 6.0
+        xx, yy = np.meshgrid(g, g, indexing="ij")
+        x = np.vstack([np.column_stack([xx.ravel(), yy.ravel()]), [far]])
+        y, w = x[:, 0] + x[:, 1], None
+    else:
+        x, y, w = _far_outside_case(nd, nodes, m, far, weighted)
+    lo, hi = [0.0] * nd, [1.0] * nd
+    ncol = int(np.prod(nodes))
+    c0, e0, work = port.fit(nd, x, y, w, lo, hi, nodes, 1.0)
+    c1, e1, hist, info = capi.fit(nd, x, y, w, lo, hi, nodes, 1.0, want_hist=True)
+    assert e0 == e1 == 0
+    base = capi.fit(nd, x[:-1], y[:-1], None if w is None else w[:-1], lo, hi, nodes, 1.0, want_hist=True)[2]
+    diff = hist - base
+    bump = 1.0 if w is None else w[-1]
+    print(f"{name}: outlier counted at 0-based address {int(np.argmax(np.abs(diff)))}, hist sum {hist.sum():.6f} "
+          f"(reference {work[:ncol].sum():.6f}), coef rel {relmax(c1, c0[:ncol]):.1e}")
+    assert np.count_nonzero(diff) == 1 and abs(diff.max() - bump) < 1e-12
+    assert relmax(hist, work[:ncol]) < 1e-13
+    assert int(np.argmax(diff)) == int(np.argmax(work[:ncol] - port.fit(nd, x[:-1], y[:-1], None if w is None else w[:-1],
+                                                                        lo, hi, nodes, 1.0)[2][:ncol]))
+    if m is None:
+        assert hist.sum() == 37.0 and int(np.argmax(diff)) == 2
+    assert relmax(c1, c0[:ncol]) < COEF_TOL
+
+
+def test_histogram_far_outside_point_valu_gram_kernel():
+    """The same through gram_block_kernel on 2-D / 4-D grids (SPLPAK_GRAM_VALU=1 is read once per process: a child process)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from splpak_amd import capi
+from tests.test_gpu_parity import _far_outside_case
+for nd, nodes, m, far in [(2, [8, 8], 600, (5.0, 0.9)), (4, [6, 5, 6, 5], 5000, (0.9, 0.1, 7.5, 0.8))]:
+    x, y, w = _far_outside_case(nd, nodes, m, far, True)
+    lo, hi = [0.0] * nd, [1.0] * nd
+    h = capi.fit(nd, x, y, w, lo, hi, nodes, 1.0, want_hist=True)[2]
+    np.save(sys.argv[1] + "_%%d.npy" %% nd, h)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, SPLPAK_GRAM_VALU="1")
+        subprocess.check_call([sys.executable, "-c", code % root, os.path.join(td, "h")], env=env, cwd=root)
+        for nd, nodes, m, far in [(2, [8, 8], 600, (5.0, 0.9)), (4, [6, 5, 6, 5], 5000, (0.9, 0.1, 7.5, 0.8))]:
+            x, y, w = _far_outside_case(nd, nodes, m, far, True)
+            lo, hi = [0.0] * nd, [1.0] * nd
+            h_mfma = capi.fit(nd, x, y, w, lo, hi, nodes, 1.0, want_hist=True)[2]
+            h_valu = np.load(os.path.join(td, f"h_{nd}.npy"))
+            assert relmax(h_valu, h_mfma) < 1e-13 and abs(h_valu.sum() - w.sum()) < 1e-9
+
+
+def test_cells_of_more_than_1024_points_are_ordered_too():
+    """assemble.hip cell_order_kernel: the per-cell sums follow the storage order of the binned points, and the scatter's
+    atomic cursor hands out positions in a different order every run.  Cells of up to 1 024 points are re-ordered through
+    LDS; larger ones (up to 65 536 points in one window) by the chunked rank count added in round 4.  2-D 5x5 nodes =
+    4 windows, 30 000 points = 7 500 per window: four fits must agree bit for bit, coefficients AND histogram, and hold
+    the reference algorithm's answer."""
+    import torch
+    nd, nodes, m = 2, [5, 5], 30000
+    from splpak_amd.synth import synth_points
+    x, y, w = synth_points(nd, m)
+    lo, hi = [0.0] * nd, [1.0] * nd
+    dev = torch.device("cuda", 0)
+    xt, yt, wt = (torch.tensor(a, device=dev) for a in (x, y, w))
+    coef = torch.zeros(25, dtype=torch.float64, device=dev)
+    plan = capi.Plan(nd, nodes, lo, hi, 1.0, m)
+    outs = []
+    for _ in range(4):
+        ierr, info = plan.fit(xt, yt, wt, coef, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert ierr == 0
+        outs.append((coef.cpu().numpy().copy(), info[8]))
+    plan.close()
+    for c, r in outs[1:]:
+        assert np.array_equal(c, outs[0][0]) and r == outs[0][1], "a cell of 7 500 points is summed in a run-dependent order"
+    from oracle.binding import Port
+    c0, e0, _ = Port().fit(nd, x, y, w, lo, hi, nodes, 1.0)
+    assert e0 == 0 and relmax(outs[0][0], c0[:25]) < COEF_TOL
+
+
+def test_c4_workload_on_one_gpu_weighted_optimality_on_the_host(port):
+    """BASELINE config 4's WORKLOAD -- 1e8 scattered weighted points of the seeded stream on the 64^3 grid -- on ONE GPU
+    (the config shards it over 8; the multi-GPU path is covered in tests/test_dist.py): the returned coefficients are
+    checked on the host against the reference's rows (oracle_rows_gradient over ALL 1e8 rows + the constraint rows, never
+    stored): componentwise backward error at rounding level, row counts and reserr as the GPU reports them."""
+    import torch
+    nd, nod, m = 3, 64, 100_000_000
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.empty((m, nd), dtype=torch.float64, device=dev)
+    y = torch.empty(m, dtype=torch.float64, device=dev)
+    w = torch.empty(m, dtype=torch.float64, device=dev)
+    capi.synth_points_dev(nd, 0, m, x, y, w, st)
+    lo, hi, nodes = [0.0] * nd, [1.0] * nd, [nod] * nd
+    coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
+    plan = capi.Plan(nd, nodes, lo, hi, 1.0, m)
+    try:
+        ierr, info = plan.fit(x, y, w, coef, st)
+        torch.cuda.synchronize()
+    finally:
+        plan.close()
+    assert ierr == 0
+    c = coef.cpu().numpy()
+    xh, yh, wh = x.cpu().numpy(), y.cpu().numpy(), w.cpu().numpy()
+    del x, y, w
+    torch.cuda.empty_cache()
+    omega, reserr, nrow, ncons = port.rows_gradient(nd, xh, yh, wh, lo, hi, nodes, 1.0, c)
+    print(f"C4 workload on one GPU: {info[5] + info[6] + info[7]:.3f} s, host backward error {omega:.2e} (GPU's own {info[9]:.2e}); "
+          f"rows {nrow}+{ncons}; reserr host {reserr:.9e} GPU {info[8]:.9e}")
+    assert omega < 1e-12
+    assert nrow == info[0] == m and ncons == info[1]
+    assert abs(reserr - info[8]) <= 1e-9 * reserr
