@@ -282,6 +282,17 @@ int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double 
  * Returns 0, 101/102/103 (grid checks) or a negative SPLPAK_E_* code. */
 int32_t splpak_debug_nd_tree(int32_t ndim, const int32_t *nodes, int32_t split_min, int32_t check, double *out16);
 
+/* Diagnostics (host only): how the nested-dissection factorisation of a grid is distributed over `ngpus` GPUs by the
+ * one-process multi-GPU fit (splpak_mplan_*, splpak_fit_multi_f64; csrc/ndtree.hpp NdPartition): the subtrees below tree
+ * depth ceil(log2 ngpus) belong to one rank each, the fronts above are distributed by block columns (chunk < 1: 1).
+ * out_per_rank8 (8 doubles per rank): [0] bytes of everything the factorisation keeps on that GPU = [1] panels of its
+ * subtrees + [2] its Schur arenas + [3] its block columns of the top fronts + [4] block inverses + [5] receive buffers,
+ * solve vectors and index tables; [6] padded flop of its subtrees, [7] of its share of the top fronts.
+ * out8 (optional): [0] depth of the cut, [1] top fronts, [2] their block steps, [3] bytes of the largest panel that
+ * travels, [4] bytes of the all-reduced normal equations every rank also holds, [5] fronts, [6] depth, [7] total flop. */
+int32_t splpak_debug_nd_partition(int32_t ndim, const int32_t *nodes, int32_t split_min, int32_t ngpus, int32_t chunk,
+                                  double *out_per_rank8, double *out8);
+
 /* Releases the calling thread's internal HIP streams, events, queues and evaluation scratch
  * (created lazily and kept for reuse).  Optional; plans stay valid. */
 void splpak_shutdown(void);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "splpak_eval_dev_f64", "splpak_eval_dev_f32", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
     "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
-    "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_shutdown", "splpak_set_eval_mode",
+    "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_debug_nd_partition", "splpak_shutdown", "splpak_set_eval_mode",
     "splpak_last_error_message", "splpak_device_name",
 ]
 
@@ -114,6 +114,8 @@ def lib() -> C.CDLL:
     L.splpak_debug_spd_band_solve_f64.argtypes = [i32, i32, _dp, _dp, _dp]
     L.splpak_debug_nd_tree.restype = i32
     L.splpak_debug_nd_tree.argtypes = [i32, _ip, i32, i32, _dp]
+    L.splpak_debug_nd_partition.restype = i32
+    L.splpak_debug_nd_partition.argtypes = [i32, _ip, i32, i32, i32, _dp, _dp]
     L.splpak_mplan_create.restype = i32
     L.splpak_mplan_create.argtypes = [i32, _ip, i32, i32, _ip, _dp, _dp, dbl, i64, C.POINTER(vp)]
     L.splpak_mplan_destroy.restype = None
@@ -492,6 +494,24 @@ def debug_nd_tree(nodes, split_min=0, check=True):
     if rc != 0:
         raise SplpakError(f"grid rejected: {rc}")
     return dict(zip(ND_TREE_FIELDS, out.tolist()))
+
+
+ND_RANK_FIELDS = ("bytes", "panel_bytes", "schur_bytes", "top_bytes", "inverse_bytes", "other_bytes", "flop_subtrees", "flop_top")
+
+
+def debug_nd_partition(nodes, ngpus, chunk=0, split_min=0):
+    """Host-only: how the one-process multi-GPU fit distributes the nested-dissection factorisation of a grid over
+    `ngpus` GPUs (csrc/ndtree.hpp NdPartition).  -> (list of per-rank dicts (ND_RANK_FIELDS), summary dict)."""
+    nodes = np.ascontiguousarray(np.atleast_1d(nodes), dtype=np.int32)
+    per = np.zeros(8 * int(ngpus))
+    out = np.zeros(8)
+    rc = _check(lib().splpak_debug_nd_partition(len(nodes), _p(nodes, _ip), int(split_min), int(ngpus), int(chunk), _p(per, _dp), _p(out, _dp)))
+    if rc != 0:
+        raise SplpakError(f"grid rejected: {rc}")
+    ranks = [dict(zip(ND_RANK_FIELDS, per[8 * r:8 * r + 8].tolist())) for r in range(int(ngpus))]
+    summ = dict(dcut=int(out[0]), top_fronts=int(out[1]), top_steps=int(out[2]), max_panel_bytes=out[3], normal_eq_bytes=out[4],
+                fronts=int(out[5]), depth=int(out[6]), flop=out[7])
+    return ranks, summ
 
 
 def debug_spd_band_solve(a_lower, halfbw, b):

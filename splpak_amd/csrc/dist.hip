@@ -43,28 +43,7 @@ namespace {
 constexpr int NPB = 3;      // receive buffers per rank (panels in flight)
 constexpr int NSB = 4;      // send buffers on the owner side
 
-struct Barrier {
-    std::mutex mu;
-    std::condition_variable cv;
-    int n = 1, count = 0, phase = 0;
-    // false: another rank has failed and will never arrive (abort flag) -- the caller gives up too
-    bool wait(const std::atomic<int> &abort)
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        const int ph = phase;
-        if (++count == n) {
-            count = 0;
-            ++phase;
-            cv.notify_all();
-            return true;
-        }
-        while (phase == ph) {
-            cv.wait_for(lk, std::chrono::milliseconds(20));
-            if (phase == ph && abort.load()) return false;
-        }
-        return true;
-    }
-};
+using Barrier = splpak::HostBarrier;
 
 struct MRank {
     int r = 0, dev = 0;
@@ -73,7 +52,9 @@ struct MRank {
     hipStream_t st = nullptr, sChain = nullptr, sBulk = nullptr, sCopy = nullptr;
     double *pbuf[NPB] = {nullptr, nullptr, nullptr};
     double *sbuf[NSB] = {nullptr, nullptr, nullptr, nullptr};
-    double *stage = nullptr;        // rank 0: staging of the reductions
+    double *stage = nullptr;        // staging of the reductions: a slice of the largest reduced buffer, twice (accumulator | incoming)
+    long long stage_slice = 0;      // doubles per half
+    double *red_ptr = nullptr;      // the buffer this rank brings to the current reduction (published before the first barrier)
     double *part = nullptr;         // backward sweep partial sums
     double *xs = nullptr;           // backward sweep solution / window
     double *coef = nullptr;         // this rank's copy of the coefficients (ranks > 0)
@@ -98,6 +79,7 @@ struct MRank {
 
 struct splpak_mplan {
     int R = 1, chunk = 1;
+    splpak::NdGroup *ndgrp = nullptr;       // the grid takes the nested-dissection factorisation (ndchol.hip), distributed over the ranks
     std::vector<MRank *> ranks;
     Barrier bar;
     std::atomic<int> ready_prog{-1};        // last panel whose "posted" event has been recorded
@@ -124,36 +106,56 @@ bool wait_until(splpak_mplan *mp, const std::function<bool()> &ready)
         if (e_ != hipSuccess) { me->mp->abort.store(1); return e_; } \
     } while (0)
 
-// ---- reductions (host-synchronous; deterministic: rank order) -------------------------------------
-// sum `count` doubles at offset `off` of every rank's communication buffer; result on all ranks
+// ---- reductions (host-synchronous; deterministic: every element is summed in rank order) -----------------------
+// Sum `count` doubles of the buffer every rank brings (any device buffer: the pointers are published); result on all ranks.
+// Reduce-scatter + all-gather over point-to-point copies: rank q sums slice q of the buffer -- rank 0's values, then rank
+// 1's, ... (the same order whoever owns the slice: bitwise reproducible and identical on every rank) -- and every rank then
+// fetches the finished slices from their owners.  Per rank (R-1)/R of the buffer comes in twice, spread over its R-1 links,
+// instead of everything passing through rank 0 (round 4: the 363 MB normal equations of a 64^3 grid, 10 GB at 32^4).
 hipError_t reduce_all(MRank *me, double *buf, long long count)
 {
     splpak_mplan *mp = me->mp;
-    const long long off = buf - me->p->comm;
+    const int R = mp->R;
+    me->red_ptr = buf;
     hipError_t err = hipStreamSynchronize(me->st);
     if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;
-    if (me->r == 0 && err == hipSuccess) {
-        MRank *r0 = me;
-        for (int q = 1; q < mp->R && err == hipSuccess; ++q) {
-            MRank *rq = mp->ranks[q];
-            // pieces of at most the staging size
-            const long long piece = me->p->lenG > count ? count : me->p->lenG;
-            for (long long o = 0; o < count && err == hipSuccess; o += piece) {
-                const long long n = count - o < piece ? count - o : piece;
-                err = hipMemcpyPeerAsync(r0->stage, r0->dev, rq->p->comm + off + o, rq->dev, sizeof(double) * (size_t)n, r0->st);
-                if (err == hipSuccess) err = launch_vec_add(n, buf + o, r0->stage, r0->st);
+    long long per = (count + R - 1) / R;
+    per = (per + 511) / 512 * 512;
+    const long long lo = (long long)me->r * per, hi = lo + per < count ? lo + per : count;
+    if (err == hipSuccess && hi - lo > me->stage_slice) err = hipErrorInvalidValue;       // (sized for the largest reduction of the plan)
+    if (err == hipSuccess && lo < hi) {
+        // acc = b_0 + b_1 + ... + b_{R-1} on my slice; the other ranks still read my unreduced values, so the sum is built
+        // beside them and put in place after the barrier below
+        const long long n = hi - lo;
+        double *acc = me->stage, *in = me->stage + me->stage_slice;
+        MRank *r0 = mp->ranks[0];
+        err = hipMemcpyPeerAsync(acc, me->dev, r0->red_ptr + lo, r0->dev, sizeof(double) * (size_t)n, me->st);
+        for (int q = 1; q < R && err == hipSuccess; ++q) {
+            MRank *rq = mp->ranks[(size_t)q];
+            if (q == me->r) err = launch_vec_add(n, acc, buf + lo, me->st);
+            else {
+                err = hipMemcpyPeerAsync(in, me->dev, rq->red_ptr + lo, rq->dev, sizeof(double) * (size_t)n, me->st);
+                if (err == hipSuccess) err = launch_vec_add(n, acc, in, me->st);
             }
         }
-        if (err == hipSuccess) err = hipStreamSynchronize(r0->st);
-    }
-    if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;
-    if (me->r != 0 && err == hipSuccess) {
-        MRank *r0 = mp->ranks[0];
-        err = hipMemcpyPeerAsync(buf, me->dev, r0->p->comm + off, r0->dev, sizeof(double) * (size_t)count, me->st);
         if (err == hipSuccess) err = hipStreamSynchronize(me->st);
     }
     if (err != hipSuccess) mp->abort.store(1);
-    if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;
+    if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;          // every slice is summed, nobody reads the inputs any more
+    if (lo < hi) err = hipMemcpyAsync(buf + lo, me->stage, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, me->st);
+    if (err == hipSuccess) err = hipStreamSynchronize(me->st);
+    if (err != hipSuccess) mp->abort.store(1);
+    if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;          // the finished slices are in place on their owners
+    for (int d = 1; d < R && err == hipSuccess; ++d) {               // all-gather, every rank starting at a different peer
+        const int q = (me->r + d) % R;
+        const long long qlo = (long long)q * per, qhi = qlo + per < count ? qlo + per : count;
+        if (qlo >= qhi) continue;
+        MRank *rq = mp->ranks[(size_t)q];
+        err = hipMemcpyPeerAsync(buf + qlo, me->dev, rq->red_ptr + qlo, rq->dev, sizeof(double) * (size_t)(qhi - qlo), me->st);
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(me->st);
+    if (err != hipSuccess) mp->abort.store(1);
+    if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;          // nobody reads a neighbour's buffer any more
     return mp->abort.load() ? (err != hipSuccess ? err : hipErrorUnknown) : hipSuccess;
 }
 
@@ -162,33 +164,6 @@ int32_t ar_callback(void *dev_buf, int64_t count, void *stream, void *user)
     (void)stream;       // the rank's own stream: reduce_all synchronises it
     MRank *me = static_cast<MRank *>(user);
     return reduce_all(me, static_cast<double *>(dev_buf), count) == hipSuccess ? 0 : 1;
-}
-
-// sum of a vector that is NOT in the communication buffer (the sweeps' solution): same protocol
-hipError_t reduce_vec(MRank *me, double *v, double *MRank::*member, long long count)
-{
-    splpak_mplan *mp = me->mp;
-    hipError_t err = hipStreamSynchronize(me->st);
-    if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;
-    if (me->r == 0 && err == hipSuccess) {
-        for (int q = 1; q < mp->R && err == hipSuccess; ++q) {
-            MRank *rq = mp->ranks[q];
-            double *src = member ? rq->*member : rq->p->xvec;
-            err = hipMemcpyPeerAsync(me->stage, me->dev, src, rq->dev, sizeof(double) * (size_t)count, me->st);
-            if (err == hipSuccess) err = launch_vec_add(count, v, me->stage, me->st);
-        }
-        if (err == hipSuccess) err = hipStreamSynchronize(me->st);
-    }
-    if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;
-    if (me->r != 0 && err == hipSuccess) {
-        MRank *r0 = mp->ranks[0];
-        double *src = member ? r0->*member : r0->p->xvec;
-        err = hipMemcpyPeerAsync(v, me->dev, src, r0->dev, sizeof(double) * (size_t)count, me->st);
-        if (err == hipSuccess) err = hipStreamSynchronize(me->st);
-    }
-    if (err != hipSuccess) mp->abort.store(1);
-    if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;
-    return mp->abort.load() ? (err != hipSuccess ? err : hipErrorUnknown) : hipSuccess;
 }
 
 // ---- distributed factorisation ----------------------------------------------------------------------
@@ -377,7 +352,7 @@ hipError_t dist_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, vo
     DTRY(hipStreamSynchronize(st));
     if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;                                 // nobody reads a neighbour's window any more
     DTRY(launch_mask_owned(b.npad, dm, me->xs, st));
-    DTRY(reduce_vec(me, me->xs, &MRank::xs, b.npad));
+    DTRY(reduce_all(me, me->xs, b.npad));
     DTRY(hipMemcpyAsync(x, me->xs, sizeof(double) * (size_t)b.npad, hipMemcpyDeviceToDevice, st));
     return hipSuccess;
 }
@@ -446,6 +421,13 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
     }
     mp->chunk = chunk;
     mp->bar.n = ngpus;
+    // Grids that take the nested-dissection factorisation on one GPU take it here too, distributed: subtrees per GPU, the
+    // fronts above them by block columns (round 4; SPLPAK_MPLAN_BAND=1 keeps the distributed band of round 2).
+    const bool want_nd = ngpus > 1 && !std::getenv("SPLPAK_MPLAN_BAND") && nd_wanted_for(ndim, nodes, xmin, xmax);
+    if (want_nd) {
+        const char *ck = std::getenv("SPLPAK_ND_CHUNK");
+        mp->ndgrp = nd_group_create(ngpus, ck ? atoi(ck) : 1, &mp->abort);
+    }
     int rc = 0;
     for (int r = 0; r < ngpus && rc == 0; ++r) {
         MRank *m = new MRank();
@@ -459,19 +441,24 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
             break;
         }
         (void)hipSetDevice(m->dev);
-        rc = plan_create_dist(ndim, nodes, xmin, xmax, xtrap, max_ndata_per_gpu, nullptr, 0, ngpus, r, mp->chunk, &m->p);
+        rc = plan_create_dist(ndim, nodes, xmin, xmax, xtrap, max_ndata_per_gpu, nullptr, 0, ngpus, r, mp->chunk, &m->p, mp->ndgrp != nullptr,
+                              mp->ndgrp);
         if (rc != 0) break;
         splpak_plan *p = m->p;
-        twoend_detach(p);                 // (a one-rank plan may have chosen the two-ended single-GPU factorisation)
+        const bool nd = p->fn_code == 5;    // nested dissection, distributed: the plan carries its own factorisation and solve
+        if (mp->ndgrp && !nd) { set_error("multi-GPU plan: a rank did not take the nested-dissection factorisation"); rc = SPLPAK_E_UNSUPPORTED; break; }
+        if (!nd) twoend_detach(p);        // (a one-rank plan may have chosen the two-ended single-GPU factorisation)
         p->ar = ar_callback;
         p->ar_user = m;
         p->rank = r;
         p->world = ngpus;
-        p->factor_fn = dist_factor;
-        p->solve_fn = dist_solve;
-        p->fn_user = m;
-        p->fn_name = "band Cholesky distributed over several GPUs by block columns (csrc/dist.hip)";
-        p->fn_code = 3;
+        if (!nd) {
+            p->factor_fn = dist_factor;
+            p->solve_fn = dist_solve;
+            p->fn_user = m;
+            p->fn_name = "band Cholesky distributed over several GPUs by block columns (csrc/dist.hip)";
+            p->fn_code = 3;
+        }
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         bool ok = hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) == hipSuccess &&
@@ -480,19 +467,25 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
                   hipStreamCreateWithPriority(&m->sCopy, hipStreamNonBlocking, hi) == hipSuccess &&
                   hipEventCreateWithFlags(&m->evTmp, hipEventDisableTiming) == hipSuccess;
         const Band &b = p->band;
-        const size_t panel = (size_t)(b.bw > 0 ? b.bw : 1) * NBLK * NBLK;
-        for (int i = 0; i < NPB && ok; ++i) ok = hipMalloc((void **)&m->pbuf[i], sizeof(double) * panel) == hipSuccess;
-        for (int i = 0; i < NSB && ok; ++i) ok = hipMalloc((void **)&m->sbuf[i], sizeof(double) * panel) == hipSuccess;
-        const size_t nsplit = (size_t)(b.bw * NBLK) / (4 * NBLK) + 2;
-        ok = ok && hipMalloc((void **)&m->part, sizeof(double) * nsplit * NBLK) == hipSuccess;
-        ok = ok && hipMalloc((void **)&m->xs, sizeof(double) * (size_t)(b.npad + NBLK)) == hipSuccess;
-        if (r == 0) ok = ok && hipMalloc((void **)&m->stage, sizeof(double) * (size_t)(p->lenG > b.npad ? p->lenG : b.npad)) == hipSuccess;
-        else ok = ok && hipMalloc((void **)&m->coef, sizeof(double) * (size_t)p->g.ncol) == hipSuccess;
-        if (ok) ok = hipMemset(m->xs, 0, sizeof(double) * (size_t)(b.npad + NBLK)) == hipSuccess;
-        for (auto *v : {&m->evReady, &m->evArr, &m->evBulk, &m->evCol, &m->evF, &m->evB}) {
-            v->assign((size_t)b.nblk + 1, nullptr);
-            for (auto &e : *v) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!nd) {                          // panel buffers, sweep scratch and step events of the distributed band
+            const size_t panel = (size_t)(b.bw > 0 ? b.bw : 1) * NBLK * NBLK;
+            for (int i = 0; i < NPB && ok; ++i) ok = hipMalloc((void **)&m->pbuf[i], sizeof(double) * panel) == hipSuccess;
+            for (int i = 0; i < NSB && ok; ++i) ok = hipMalloc((void **)&m->sbuf[i], sizeof(double) * panel) == hipSuccess;
+            const size_t nsplit = (size_t)(b.bw * NBLK) / (4 * NBLK) + 2;
+            ok = ok && hipMalloc((void **)&m->part, sizeof(double) * nsplit * NBLK) == hipSuccess;
+            ok = ok && hipMalloc((void **)&m->xs, sizeof(double) * (size_t)(b.npad + NBLK)) == hipSuccess;
+            if (ok) ok = hipMemset(m->xs, 0, sizeof(double) * (size_t)(b.npad + NBLK)) == hipSuccess;
+            for (auto *v : {&m->evReady, &m->evArr, &m->evBulk, &m->evCol, &m->evF, &m->evB}) {
+                v->assign((size_t)b.nblk + 1, nullptr);
+                for (auto &e : *v) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            }
         }
+        {   // staging of the reductions: one slice of the largest reduced buffer, twice (reduce_all)
+            const long long big = p->lenG > (long long)b.npad + NBLK ? p->lenG : (long long)b.npad + NBLK;
+            m->stage_slice = ((big + ngpus - 1) / ngpus + 511) / 512 * 512 + 512;
+            ok = ok && hipMalloc((void **)&m->stage, sizeof(double) * 2 * (size_t)m->stage_slice) == hipSuccess;
+        }
+        if (r != 0) ok = ok && hipMalloc((void **)&m->coef, sizeof(double) * (size_t)p->g.ncol) == hipSuccess;
         if (!ok) { set_error("device allocation of the multi-GPU plan failed"); (void)hipGetLastError(); rc = SPLPAK_E_NOMEM; }
     }
     // peer access where the ranks sit on different devices (copies fall back to staging without it)
@@ -508,6 +501,15 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
     (void)hipSetDevice(cur);
     if (rc != 0) {
         for (MRank *m : mp->ranks) free_rank(m);
+        nd_group_destroy(mp->ndgrp);
+        delete mp;
+        return rc;
+    }
+    if (rc == 0 && mp->ndgrp) rc = nd_group_finalize(mp->ndgrp);          // (the tables that hold the peers' addresses)
+    (void)hipSetDevice(cur);
+    if (rc != 0) {
+        for (MRank *m : mp->ranks) free_rank(m);
+        nd_group_destroy(mp->ndgrp);
         delete mp;
         return rc;
     }
@@ -522,6 +524,7 @@ void splpak_mplan_destroy(splpak_mplan *mp)
     int cur = 0;
     (void)hipGetDevice(&cur);
     for (MRank *m : mp->ranks) free_rank(m);
+    nd_group_destroy(mp->ndgrp);
     (void)hipSetDevice(cur);
     delete mp;
 }
@@ -547,6 +550,7 @@ int32_t splpak_mplan_fit_dev(splpak_mplan *mp, const double *const *xdata_dev, i
         mp->bar.count = 0;
         ++mp->bar.phase;
     }
+    nd_group_reset(mp->ndgrp);
     mp->coef0 = coef_dev;
     std::vector<std::thread> th;
     for (int r = 0; r < mp->R; ++r) {

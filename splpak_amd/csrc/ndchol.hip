@@ -28,9 +28,12 @@
 #include "chol_device.hpp"
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
+#include <thread>
 
 namespace splpak {
 
@@ -59,7 +62,11 @@ struct FwdJob { const double *L; const double *y; double *v; long long ld; int n
 struct DotJob { const double *L; const double *x; double *part; long long ld; int nrows; int nsplit; int rps; int wg0; };
 struct BwdJob { const double *Mt; const double *y; const double *part; double *x; int nsplit; int pad; };
 struct MapJob { double *child; double *par; const int *pm; int h; int pad; };
-struct FrontDev { long long panel_off, ld, bofs; int own0, w, wp, h; };
+struct FrontDev { long long panel_off, ld, bofs; int own0, w, wp, h; int top; int pad; };   // panel_off < 0: not stored on this rank; top >= 0: first entry of the (distributed) front in the TopColDev table
+struct TopColDev { long long off, ld; };          // block column of a top front: doubles into the arena (-1: another rank's), leading dimension
+// child's Schur complement -> the block columns of its (distributed) parent this rank owns: PULLED by the owner of the parent's
+// block column from wherever the child's columns live (another GPU's memory, read through the peer mapping)
+struct PullJob { const double *src; long long lds; const int *pm; double *dst; long long ldd; int c0, c1, h, row0, tile0, ntr, ntc, pad; };
 
 constexpr int DOT_RPS = 1024;          // rows per split of the backward sweep's column dots
 
@@ -369,7 +376,8 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
 template <int D>
 __global__ void __launch_bounds__(256)
 nd_assemble_kernel(Grid g, const double *__restrict__ nst, const int *__restrict__ pos, const int *__restrict__ front_of,
-                   const FrontDev *__restrict__ fd, const int *__restrict__ bpos, double *__restrict__ factor)
+                   const FrontDev *__restrict__ fd, const int *__restrict__ bpos, double *__restrict__ factor,
+                   const TopColDev *__restrict__ topcol)
 {
     const long long total = (long long)g.ncol * g.hstencil;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -405,7 +413,50 @@ nd_assemble_kernel(Grid g, const double *__restrict__ nst, const int *__restrict
             }
             row = f.wp + lo;
         }
-        factor[f.panel_off + row + (long long)col * f.ld] = nst[t];
+        if (f.top >= 0) {                        // a front distributed by block columns: this rank's columns only
+            const int J = col >> 8;
+            const TopColDev tc = topcol[f.top + J];
+            if (tc.off >= 0) factor[tc.off + (row - (J << 8)) + (long long)(col & 255) * tc.ld] = nst[t];
+        } else if (f.panel_off >= 0)
+            factor[f.panel_off + row + (long long)col * f.ld] = nst[t];
+    }
+}
+
+// extend-add into a distributed front (see PullJob): workgroup = 64 x 64 tile of the child's columns [c0, c1), rows >= c0
+__global__ void __launch_bounds__(256)
+nd_pull_add_kernel(const PullJob *__restrict__ jobs, int njobs)
+{
+    __shared__ int pr[64], pc[64];
+    const int b = blockIdx.x;
+    const int ji = find_job(jobs, njobs, b, [](const PullJob &t) { return t.tile0; });
+    const PullJob j = jobs[ji];
+    const int lt = b - j.tile0;
+    const int tj = lt / j.ntr, ti = lt - tj * j.ntr;
+    if (tj >= j.ntc) return;
+    const int rbase = (j.c0 >> 6) << 6;
+    const int r0 = rbase + ti * 64, cc0 = j.c0 + tj * 64;
+    if (r0 + 63 < cc0) return;                   // the tile lies above the diagonal
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int r = r0 + tid;
+        pr[tid] = r < j.h ? j.pm[r] : -1;
+    } else if (tid < 128) {
+        const int c = cc0 + tid - 64;
+        pc[tid - 64] = c < j.c1 ? j.pm[c] : -1;
+    }
+    __syncthreads();
+    const int rl = tid & 63;
+    const int prow = pr[rl];
+    if (prow < 0) return;
+    const int r = r0 + rl;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const int cl = (tid >> 6) + 4 * u;
+        const int pcol = pc[cl];
+        const int c = cc0 + cl;
+        if (pcol < 0 || r < c) continue;
+        const double v = j.src[(long long)r + (long long)c * j.lds];
+        j.dst[(long long)(prow - j.row0) + (long long)(pcol - j.row0) * j.ldd] += v;
     }
 }
 
@@ -758,6 +809,43 @@ struct NdState {
     long long join_scratch_doubles = 0;
     int *rowsrc_out = nullptr;                     // rowsrc restricted to the variables this rank reports (the rest arrive by all-reduce)
     int ntrinv = 0;
+    // ---- per-rank storage (round 4).  A plan of the one-process multi-GPU fit (mdist) keeps only ITS subtrees' panels, Schur
+    // buffers and block inverses, plus its block columns of the top fronts; everything is addressed through these tables
+    // (single GPU: poff = the tree's panel_off, lblk = blk0).
+    std::vector<long long> poff;                   // [front] doubles into this rank's arena (-1: not stored here)
+    std::vector<int> lblk;                         // [front] local index of its first 256 x 256 diagonal block (-1)
+    long long factor_doubles = 0;                  // this rank's arena: panels of its subtrees | its block columns of the top fronts
+    int nblocks = 0;                               // diagonal blocks whose inverses this rank keeps
+    bool mdist = false;                            // rank of a one-process multi-GPU fit (NdGroup)
+    NdGroup *grp = nullptr;
+    int mrank = 0;
+    NdPartition pt;
+    std::vector<long long> tbase;                  // [top index] first entry of the front in topcol
+    std::vector<TopColDev> topcol;                 // [sum of block columns of the top fronts] this rank's view
+    std::vector<int> toplblk;                      // [same] local diagonal-block index of an owned, eliminated block column (-1)
+    TopColDev *topcol_dev = nullptr;
+    double *pbuf[3] = {nullptr, nullptr, nullptr}; // receive buffers of the panels of the top steps
+    double *stagev = nullptr;                      // staging of a vector pulled from another rank (solves)
+    long long stagev_doubles = 0;
+    hipStream_t sCopy = nullptr;
+    JobTable<PotrfJob> tpotrf;
+    JobTable<TrsmJob> ttrsm;
+    JobTable<SyrkJob> tchain, tbulk;
+    JobTable<PullJob> tpull;
+    JobTable<TrinvJob> ttrinv;
+    JobTable<MvJob> tmv;
+    JobTable<FwdJob> tfwd;
+    JobTable<DotJob> tdot;
+    JobTable<BwdJob> tbwd;
+    JobTable<MapJob> tmapf, tmapb, tmaps;           // forward: children -> (F, 0); backward: parent -> (F, last); parent -> my subtree roots
+    std::vector<Launch> lt_potrf, lt_trsm, lt_chain, lt_bulk, lt_mv, lt_fwd, lt_dot, lt_bwd;     // [global top step]
+    std::vector<Launch> lt_pull[2];                // [top index] by child slot
+    std::vector<int> lt_mapf[2], lt_mapb, lt_maps; // job indices (-1: none): [top index] per slot; [top index]; [my subtree roots, in order]
+    std::vector<int> subroots;                     // my fronts of depth dcut
+    std::vector<int> rslot;                        // [global top step] receive buffer of the step's panel here (-1: own panel, in place)
+    std::vector<hipEvent_t> evReady, evArr, evCol, evBulk, evSF, evSB, evAdd;
+    hipEvent_t evSub = nullptr, evTop = nullptr;
+    int fgen = 0, sgen = 0;                        // generation of the current factorisation / solve (progress flags of the group)
     int xmode = 0;                                 // XCD-aware item map of the Schur passes (SPLPAK_ND_XCD=1)
     int full_diag = 0;                             // (A/B: diagonal items compute all 16 tiles)
     bool small_queue = false;                      // (A/B: small launches take the item queue too)
@@ -815,10 +903,12 @@ void nd_destroy(void *user)
     NdState *s = static_cast<NdState *>(user);
     if (!s) return;
     (void)hipDeviceSynchronize();
-    for (hipStream_t *q : {&s->sP, &s->sU, &s->sR, &s->sP2}) if (*q) (void)hipStreamDestroy(*q);
-    for (auto *v : {&s->evT, &s->evE, &s->evZ, &s->evA, &s->evB, &s->evI, &s->evW, &s->evT2, &s->evI2, &s->evF[0], &s->evF[1]})
+    (void)hipSetDevice(s->device);
+    for (hipStream_t *q : {&s->sP, &s->sU, &s->sR, &s->sP2, &s->sCopy}) if (*q) (void)hipStreamDestroy(*q);
+    for (auto *v : {&s->evT, &s->evE, &s->evZ, &s->evA, &s->evB, &s->evI, &s->evW, &s->evT2, &s->evI2, &s->evF[0], &s->evF[1], &s->evReady, &s->evArr,
+                    &s->evCol, &s->evBulk, &s->evSF, &s->evSB, &s->evAdd})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->evPre, s->evTail, s->f0, s->f1, s->evR0, s->evR02}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->evPre, s->evTail, s->f0, s->f1, s->evR0, s->evR02, s->evSub, s->evTop}) if (e) (void)hipEventDestroy(e);
     for (void *q : s->owned) (void)hipFree(q);
     delete s;
 }
@@ -881,11 +971,11 @@ bool nd_build_factor_jobs(NdState *s)
             for (int id : ids) {
                 const NdFront &f = t.fr[(size_t)id];
                 if (k >= f.nsteps) continue;
-                double *panel = s->factor + f.panel_off;
+                double *panel = s->factor + s->poff[(size_t)id];
                 double *diag = panel + (long long)k * 256 + (long long)k * 256 * f.ld;
                 double *below = diag + 256;
                 const int nrows = f.fp - (k + 1) * 256;
-                double *i16 = s->inv16 + (long long)(f.blk0 + k) * 4096;
+                double *i16 = s->inv16 + (long long)(s->lblk[(size_t)id] + k) * 4096;
                 const int ncols = std::max(1, std::min(256, f.w - k * 256));     // real columns of block k (w > 256 (nsteps - 1) by construction)
                 s->potrf.host.push_back(PotrfJob{diag, i16, f.ld, f.own0 + k * 256, ncols});
                 ++lp.count;
@@ -975,14 +1065,16 @@ bool nd_build_factor_jobs(NdState *s)
                     // (the ns diagonal items skip the 6 of their 16 tiles above the diagonal)
                     const double jitems = (double)trapezoid_items(ns, ns) - (s->full_diag ? 0.0 : 0.375 * ns);
                     const double jflop = 2.0 * 64 * 64 * (256.0 * (kb - 1) + 4.0 * ksl) * jitems;
-                    if (s->fused && k == f.nsteps - 1 && f.parent >= 0) {
+                    // (a subtree root of a multi-GPU fit keeps its Schur complement: the owners of the parent's block columns pull it)
+                    const bool boundary = s->mdist && f.depth == s->pt.dcut;
+                    if (s->fused && k == f.nsteps - 1 && f.parent >= 0 && !boundary) {
                         // the front's last pass carries its Schur complement into the parent itself
                         const NdFront &pf = t.fr[(size_t)f.parent];
                         const int sl = f.slot;
                         const int leaf = (f.child[0] < 0 && g0 == 0) ? 1 : 0;       // no children, one pass: the buffer is never materialised
                         s->fin[sl].host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s_ptr(s, id), f.ld,
                                                           f.lds, ns, ns, (int)fi[sl], kb, ksl, leaf, s->pmap + f.bofs,
-                                                          s->factor + pf.panel_off, s_ptr(s, f.parent), pf.ld, pf.lds, pf.wp, f.h});
+                                                          s->factor + s->poff[(size_t)f.parent], s_ptr(s, f.parent), pf.ld, pf.lds, pf.wp, f.h});
                         fi[sl] += trapezoid_items(ns, ns);
                         fflop[sl] += jflop;
                         ++lfin[sl].count;
@@ -1043,7 +1135,7 @@ bool nd_build_factor_jobs(NdState *s)
             for (int id : ids) {
                 const NdFront &f = t.fr[(size_t)id];
                 if (f.hp == 0) continue;
-                if (s->fused && f.child[0] < 0 && f.nsteps <= schur_kb) continue;       // a leaf's buffer is never materialised (fused last pass)
+                if (s->fused && f.child[0] < 0 && f.nsteps <= schur_kb && !(s->mdist && f.depth == s->pt.dcut)) continue;       // a leaf's buffer is never materialised (fused last pass)
                 const int nt = f.hp / 64;
                 s->zero.host.push_back(ZeroJob{s_ptr(s, id), f.lds, nt, (int)tiles});
                 tiles += trapezoid_items(nt, nt);
@@ -1065,7 +1157,7 @@ bool nd_build_factor_jobs(NdState *s)
                     if (f.slot != sl || f.h == 0) continue;
                     const NdFront &p = t.fr[(size_t)f.parent];
                     const int nt = f.hp / 64;
-                    s->add.host.push_back(AddJob{s_ptr(s, id), s->pmap + f.bofs, s->factor + p.panel_off, s_ptr(s, f.parent), f.lds, p.ld,
+                    s->add.host.push_back(AddJob{s_ptr(s, id), s->pmap + f.bofs, s->factor + s->poff[(size_t)f.parent], s_ptr(s, f.parent), f.lds, p.ld,
                                                  p.lds, f.h, nt, p.wp, (int)tiles});
                     tiles += trapezoid_items(nt, nt);
                     ++la2.count;
@@ -1081,9 +1173,9 @@ bool nd_build_factor_jobs(NdState *s)
         const NdFront &f = t.fr[id];
         if (!s->mine.empty() && !s->mine[id]) continue;
         for (int k = 0; k < f.nsteps; ++k) {
-            const double *diag = s->factor + f.panel_off + (long long)k * 256 + (long long)k * 256 * f.ld;
-            s->trinv.host.push_back(TrinvJob{diag, s->inv16 + (long long)(f.blk0 + k) * 4096, s->dinv + (long long)(f.blk0 + k) * 65536,
-                                             s->dinvt + (long long)(f.blk0 + k) * 65536, f.ld});
+            const double *diag = s->factor + s->poff[id] + (long long)k * 256 + (long long)k * 256 * f.ld;
+            const long long lb = s->lblk[id] + k;
+            s->trinv.host.push_back(TrinvJob{diag, s->inv16 + lb * 4096, s->dinv + lb * 65536, s->dinvt + lb * 65536, f.ld});
         }
     }
     s->ntrinv = (int)s->trinv.host.size();
@@ -1116,10 +1208,10 @@ bool nd_build_solve_jobs(NdState *s)
             for (int id : ids) {
                 const NdFront &f = t.fr[(size_t)id];
                 if (k >= f.nsteps) continue;
-                const double *below = s->factor + f.panel_off + (long long)k * 256 + (long long)k * 256 * f.ld + 256;
+                const double *below = s->factor + s->poff[(size_t)id] + (long long)k * 256 + (long long)k * 256 * f.ld + 256;
                 const int nrows = f.fp - (k + 1) * 256;
                 double *Vf = s->V + f.vofs, *Yf = s->Y + f.vofs;
-                s->mv.host.push_back(MvJob{s->dinv + (long long)(f.blk0 + k) * 65536, Vf + k * 256, Yf + k * 256});
+                s->mv.host.push_back(MvJob{s->dinv + (long long)(s->lblk[(size_t)id] + k) * 65536, Vf + k * 256, Yf + k * 256});
                 ++lm.count;
                 int nsplit = 0;
                 double *partp = s->part + partofs;
@@ -1133,7 +1225,7 @@ bool nd_build_solve_jobs(NdState *s)
                     partofs += (long long)nsplit * 256;
                     ++ld.count;
                 }
-                s->bwd.host.push_back(BwdJob{s->dinvt + (long long)(f.blk0 + k) * 65536, Yf + k * 256, partp, Vf + k * 256, nsplit, 0});
+                s->bwd.host.push_back(BwdJob{s->dinvt + (long long)(s->lblk[(size_t)id] + k) * 65536, Yf + k * 256, partp, Vf + k * 256, nsplit, 0});
                 ++lb.count;
             }
             if (fwg > 0x7fffffffLL || dwg > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
@@ -1263,6 +1355,8 @@ void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipS
 #undef ND_SD
 }
 
+#include "ndtop.inc"
+
 // The panels start from zero (14 GB at 64^3: 2.2 ms of memset).  Only the head of the arena is busy during the assembly -- the
 // per-cell Gram blocks live there until the stencil gather has read them -- so the rest is cleared on the second stream
 // while the points are binned and the blocks computed, and nd_assemble clears the head.
@@ -1272,12 +1366,12 @@ hipError_t nd_prefit(splpak_plan *p, hipStream_t st, void *user)
     s->tail_pending = false;
     if (!s->sU || !s->evPre || std::getenv("SPLPAK_ND_NO_EARLY_CLEAR")) return hipSuccess;
     long long head = 0;
-    if (p->gscratch == s->factor) head = p->gscratch_doubles < s->t.factor_doubles ? p->gscratch_doubles : s->t.factor_doubles;
-    else if (p->gscratch >= s->factor && p->gscratch < s->factor + s->t.factor_doubles) return hipSuccess;     // (not laid out that way)
-    if (head >= s->t.factor_doubles) return hipSuccess;
+    if (p->gscratch == s->factor) head = p->gscratch_doubles < s->factor_doubles ? p->gscratch_doubles : s->factor_doubles;
+    else if (p->gscratch >= s->factor && p->gscratch < s->factor + s->factor_doubles) return hipSuccess;     // (not laid out that way)
+    if (head >= s->factor_doubles) return hipSuccess;
     hipError_t e = hipEventRecord(s->evPre, st);                 // the previous fit's solves have read the factor by now
     if (e == hipSuccess) e = hipStreamWaitEvent(s->sU, s->evPre, 0);
-    if (e == hipSuccess) e = hipMemsetAsync(s->factor + head, 0, sizeof(double) * (size_t)(s->t.factor_doubles - head), s->sU);
+    if (e == hipSuccess) e = hipMemsetAsync(s->factor + head, 0, sizeof(double) * (size_t)(s->factor_doubles - head), s->sU);
     if (e == hipSuccess) e = hipEventRecord(s->evTail, s->sU);
     if (e != hipSuccess) return e;
     s->tail_pending = true;
@@ -1295,16 +1389,16 @@ hipError_t nd_assemble(splpak_plan *p, hipStream_t st, void *user)
         if (e == hipSuccess) e = hipStreamWaitEvent(st, s->evTail, 0);
         s->tail_pending = false;
     } else
-        e = hipMemsetAsync(s->factor, 0, sizeof(double) * (size_t)s->t.factor_doubles, st);
+        e = hipMemsetAsync(s->factor, 0, sizeof(double) * (size_t)s->factor_doubles, st);
     if (e != hipSuccess) return e;
     const long long total = (long long)g.ncol * g.hstencil;
     long long blocks = (total + 255) / 256;
     if (blocks > 256LL * 64) blocks = 256LL * 64;
     switch (g.ndim) {
-    case 1: hipLaunchKernelGGL(nd_assemble_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor); break;
-    case 2: hipLaunchKernelGGL(nd_assemble_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor); break;
-    case 3: hipLaunchKernelGGL(nd_assemble_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor); break;
-    default: hipLaunchKernelGGL(nd_assemble_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor); break;
+    case 1: hipLaunchKernelGGL(nd_assemble_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor, (const TopColDev *)s->topcol_dev); break;
+    case 2: hipLaunchKernelGGL(nd_assemble_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor, (const TopColDev *)s->topcol_dev); break;
+    case 3: hipLaunchKernelGGL(nd_assemble_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor, (const TopColDev *)s->topcol_dev); break;
+    default: hipLaunchKernelGGL(nd_assemble_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->front_of, (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor, (const TopColDev *)s->topcol_dev); break;
     }
     if (s->npad > 0)
         hipLaunchKernelGGL(nd_pad_diag_kernel, dim3((unsigned)((s->npad + 255) / 256)), dim3(256), 0, st, (const long long *)s->padwhere, s->npad, s->factor);
@@ -1346,7 +1440,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     if (s->dist && s->rank != 0)        // the fronts the subtrees' Schur complements are summed in: their entries of N come from rank 0 alone
         for (int id : t.by_depth[(size_t)(s->dcut - 1)]) {
             const NdFront &f = t.fr[(size_t)id];
-            (void)hipMemsetAsync(s->factor + f.panel_off, 0, sizeof(double) * (size_t)(f.ld * f.wp), st);
+            (void)hipMemsetAsync(s->factor + s->poff[(size_t)id], 0, sizeof(double) * (size_t)(f.ld * f.wp), st);
         }
     bool comm_failed = false;
     // every rank has eliminated its subtrees: sum what they left in the fronts of depth dcut - 1 (panel and Schur buffer)
@@ -1367,7 +1461,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         }
         for (int id : t.by_depth[(size_t)(s->dcut - 1)]) {
             const NdFront &f = t.fr[(size_t)id];
-            if (plan_allreduce(p, s->factor + f.panel_off, f.ld * (long long)f.wp, st) != 0) comm_failed = true;
+            if (plan_allreduce(p, s->factor + s->poff[(size_t)id], f.ld * (long long)f.wp, st) != 0) comm_failed = true;
             if (f.hp == 0) continue;
             const int nt = f.hp / 64;
             const long long tiles = trapezoid_items(nt, nt);
@@ -1433,7 +1527,10 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         launch_syrk(s, s->fin[1], lf1, sU, stats, timing, true, pinned, qnext);      // children of slot 0, then of slot 1
     };
     // ---- depths maxdepth .. 1: the pipelines step through a depth together, their Schur passes alternate on sU
-    for (int d = t.maxdepth; d >= 1; --d) {
+    // (one rank of a one-process multi-GPU fit eliminates its subtrees here -- depths maxdepth .. dcut -- and the fronts above
+    //  in the top phase, together with the other ranks: ndtop.inc)
+    const int dlow = s->mdist ? s->pt.dcut : 1;
+    for (int d = t.maxdepth; d >= dlow; --d) {
         if (s->dist && d == s->dcut - 1) dist_join();
         int steps = 0, nfront0 = 0;
         for (int q = 0; q < np; ++q) {
@@ -1458,7 +1555,9 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
                     // stage (q, d) is done on the update stream (stream order): its parents may start, and the arena half
                     // it used is free -- zero what uses it next (depth d - 2, or the deepest depth of that parity for the NEXT fit)
                     (void)hipEventRecord(s->evF[q][(size_t)d], sU);
-                    zero_stage(q, d - 2 >= 1 ? d - 2 : deepest_with_parity(d & 1));
+                    // (multi-GPU: the Schur complements of depth dcut stay in their arena half until the other ranks have pulled
+                    //  them; what shares that half is zeroed for the next fit after the top phase)
+                    if (!(s->mdist && d == dlow)) zero_stage(q, d - 2 >= dlow ? d - 2 : deepest_with_parity(d & 1));
                 }
             }
         if (!s->fused) {        // separate extend-add launches (one pipeline): the depth's passes, then slot 0, then slot 1
@@ -1479,10 +1578,15 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     }
     // ---- the root: after both pipelines; no Schur buffer to hide its chain behind, hence the look-ahead split
     if (s->dist && s->dcut == 1) dist_join();
-    if (s->fused && t.maxdepth >= 1)
+    if (s->fused && t.maxdepth >= 1 && !s->mdist)
         for (int q = 0; q < np; ++q)
             if (sU != sP) (void)hipStreamWaitEvent(sP, s->evF[q][1], 0);
-    {
+    hipError_t top_err = hipSuccess;
+    if (s->mdist) {
+        ++s->fgen;
+        top_err = nd_top_factor(s, st, info_dev, minpiv_dev, stats, timing);
+        if (top_err == hipSuccess) zero_stage(0, deepest_with_parity(dlow & 1));       // (postponed above; waited for by the next fit: evZlast)
+    } else {
         const int steps = (int)s->l_potrf[0].size();
         ensure_events(steps);
         const bool pinned = sR != nullptr && s->nres > 0 && (int)s->l_potrf[0][0].grid <= pin_rounds * s->nres;
@@ -1525,9 +1629,11 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         }
     }
     // inverses of all diagonal blocks (the solves' operands)
-    hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)s->ntrinv), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev);
+    if (s->ntrinv > 0)
+        hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)s->ntrinv), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev);
     (void)hipEventRecord(s->evJ, sP);
     if (sP != st) (void)hipStreamWaitEvent(st, s->evJ, 0);
+    if (s->mdist && top_err == hipSuccess) top_err = nd_top_pivots(s, st, info_dev, minpiv_dev);
     if (s->dist) {      // (a failed pivot poisons the fronts above it with NaN, so every rank fails anyway; this makes it explicit)
         hipLaunchKernelGGL(nd_flag_kernel, dim3(1), dim3(1), 0, st, (const int *)info_dev, s->part, 0);
         if (plan_allreduce(p, s->part, 1, st) != 0) comm_failed = true;
@@ -1552,9 +1658,9 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             else (void)hipGetLastError();
         }
     }
-    if (err != hipSuccess) s->s_clean = false;
+    if (err != hipSuccess || top_err != hipSuccess) s->s_clean = false;
     if (comm_failed) return hipErrorUnknown;
-    return err;
+    return top_err != hipSuccess ? top_err : err;
 }
 
 hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void *user)
@@ -1571,8 +1677,11 @@ hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void
             const NdFront &f = t.fr[(size_t)id];
             (void)hipMemsetAsync(s->V + f.vofs, 0, sizeof(double) * (size_t)f.fp, st);
         }
+    // (one-process multi-GPU fit: the subtrees here, the fronts above them step by step with the other ranks -- ndtop.inc)
+    const int dlow = s->mdist ? s->pt.dcut : 0;
+    if (s->mdist) ++s->sgen;
     // forward, bottom-up
-    for (int d = t.maxdepth; d >= 0; --d) {
+    for (int d = t.maxdepth; d >= dlow; --d) {
         if (d < t.maxdepth)
             for (int sl = 0; sl < 2; ++sl) {
                 const Launch &lm = s->l_mapslot[sl][(size_t)(d + 1)];
@@ -1590,9 +1699,14 @@ hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void
             if (lf.count) hipLaunchKernelGGL(nd_fwd_kernel, dim3(lf.grid), dim3(512), 0, st, (const FwdJob *)(s->fwd.dev + lf.first), lf.count);
         }
     }
+    if (s->mdist) {
+        hipError_t e = nd_top_forward(s, st);
+        if (e == hipSuccess) e = nd_top_backward(s, st);
+        if (e != hipSuccess) return e;
+    }
     // backward, top-down
-    for (int d = 0; d <= t.maxdepth; ++d) {
-        if (d >= 1) {
+    for (int d = dlow; d <= t.maxdepth; ++d) {
+        if (d >= 1 && d > dlow) {
             const Launch &lm = s->l_mapall[(size_t)d];
             if (lm.count) hipLaunchKernelGGL(nd_map_kernel<true>, dim3(8, lm.grid), dim3(256), 0, st, (const MapJob *)(s->map.dev + lm.first));
         }
@@ -1603,7 +1717,7 @@ hipError_t nd_solve(splpak_plan *p, double *x, double *tmp, hipStream_t st, void
             hipLaunchKernelGGL(nd_bwd_kernel, dim3(16, lb.grid), dim3(256), 0, st, (const BwdJob *)(s->bwd.dev + lb.first));
         }
     }
-    if (s->dist) {
+    if (s->dist || s->mdist) {
         // every rank reports the variables of its own subtrees (rank 0 also those of the top of the tree); the sum is the solution
         (void)hipMemsetAsync(x, 0, sizeof(double) * (size_t)p->g.ncol, st);
         hipLaunchKernelGGL(nd_scatter_kernel, dim3(gb), dim3(256), 0, st, n, (const int *)s->rowsrc_out, (const double *)s->V, x);
@@ -1649,7 +1763,7 @@ bool nd_upload_jobs(NdState *s)
 int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
 {
     NdState *s = static_cast<NdState *>(p->fn_user);
-    if (!s) return 0;
+    if (!s || s->mdist) return 0;
     NdTree &t = s->t;
     int dcut = 0;
     while ((1 << dcut) < world) ++dcut;
@@ -1728,6 +1842,14 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
 // 19.5 -> 20.3 (band stays), 12^4 41.9 -> 41.0, 16^4 239 -> 184, 24^4 10.5 s -> 4.9 s.
 int nd_set_ranks(splpak_plan *p, int rank, int world) { return (p && p->fn_code == 4) ? nd_set_ranks_impl(p, rank, world) : 0; }
 
+bool nd_wanted_for(int ndim, const int *nodes, const double *xmin, const double *xmax)
+{
+    Grid g;
+    if (build_grid(ndim, nodes, xmin, xmax, g, nullptr, std::getenv("SPLPAK_NO_REORDER") == nullptr) != 0) return false;
+    Band b{};
+    return nd_wanted(g, b);
+}
+
 bool nd_wanted(const Grid &g, const Band &band)
 {
     (void)band;
@@ -1739,7 +1861,7 @@ bool nd_wanted(const Grid &g, const Band &band)
 // Installs the nested-dissection factorisation on a single-GPU plan: builds the tree, allocates the arenas,
 // uploads the tables.  Returns 0, or an SPLPAK_E_* code (the plan is then unusable).  *factor_arena /
 // *factor_doubles: the factor storage, idle until the half stencil is assembled (the Gram scratch may live there).
-int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
+int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, NdGroup *grp, int rank)
 {
     NdState *s = new NdState();
     (void)hipGetDevice(&s->device);
@@ -1748,13 +1870,28 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     if (!nd_build(p->g, s->t, nd_default_split_min(p->g.ndim))) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
     NdTree &t = s->t;
     const int nd = t.maxdepth + 1;
+    // one-process multi-GPU fit: this plan is rank `rank` of the group
+    s->grp = grp;
+    s->mrank = rank;
+    s->mdist = grp != nullptr && grp->R > 1;
+    nd_partition(t, s->mdist ? grp->R : 1, s->mdist ? grp->chunk : 1, s->pt);
+    if (s->mdist && s->pt.dcut < 1) s->mdist = false;                 // (a tree of one front: nothing to distribute)
+    if (grp) {
+        if (rank < 0 || rank >= grp->R) { set_error("nested dissection: bad rank"); return SPLPAK_E_BADARG; }
+        grp->st[(size_t)rank] = s;
+    }
+    if (grp && grp->R > 1 && !s->mdist) { set_error("nested dissection: the tree of this grid has a single front; use one GPU"); return SPLPAK_E_UNSUPPORTED; }
+    const NdPartition &pt = s->pt;
+    s->mine.assign(t.fr.size(), 1);
+    if (s->mdist)
+        for (size_t id = 0; id < t.fr.size(); ++id) s->mine[id] = pt.owner[id] == rank ? 1 : 0;
     // pipelines: SPLPAK_ND_PIPES=2 eliminates the two subtrees below the root side by side (trees of depth >= 3 whose last
     // Schur passes are fused with the extend-add).  Measured at 64^3 (alternating runs, one box): 235.0 ms per factorisation
     // with two pipelines against 234.9 with one -- the 20 ms without any matrix-core kernel in flight (rocprofv3 trace) shrink,
     // but every Schur launch is half as large and the total stays at what 1.1e13 flop take at the power-limited rate.
     // One pipeline is the default.
     s->fused = std::getenv("SPLPAK_ND_NO_FUSE") == nullptr;
-    s->npipe = (t.maxdepth >= 3 && s->fused && std::getenv("SPLPAK_ND_PIPES") && atoi(std::getenv("SPLPAK_ND_PIPES")) == 2) ? 2 : 1;
+    s->npipe = (!s->mdist && t.maxdepth >= 3 && s->fused && std::getenv("SPLPAK_ND_PIPES") && atoi(std::getenv("SPLPAK_ND_PIPES")) == 2) ? 2 : 1;
     s->pipe_of.assign(t.fr.size(), 0);
     if (s->npipe == 2)
         for (int id = (int)t.fr.size() - 1; id >= 0; --id) {          // parents have larger ids than their children (postorder)
@@ -1767,37 +1904,80 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     s->stage_ids.assign((size_t)nstage, {});
     s->s_stage_doubles.assign((size_t)nstage, 0);
     s->soff.assign(t.fr.size(), 0);
+    // this rank's storage: panels and Schur buffers of the fronts it eliminates, then its block columns of the top fronts
+    s->poff.assign(t.fr.size(), -1);
+    s->lblk.assign(t.fr.size(), -1);
+    for (size_t id = 0; id < t.fr.size(); ++id) {
+        const NdFront &f = t.fr[id];
+        if (!s->mine[id]) continue;
+        s->poff[id] = s->factor_doubles;
+        s->factor_doubles += f.ld * (long long)f.wp;
+        s->lblk[id] = s->nblocks;
+        s->nblocks += f.nsteps;
+    }
     for (int d = 0; d < nd; ++d)
         for (int id : t.by_depth[(size_t)d]) {
+            if (!s->mine[(size_t)id]) continue;
             const NdFront &f = t.fr[(size_t)id];
             const int stg = s->pipe_of[(size_t)id] * nd + d;
             s->stage_ids[(size_t)stg].push_back(id);
             s->soff[(size_t)id] = s->s_stage_doubles[(size_t)stg];
             s->s_stage_doubles[(size_t)stg] += f.lds * (long long)f.hp;
         }
+    std::vector<long long> padwhere;
+    long long max_fp = 0;
+    if (s->mdist) {
+        s->tbase.assign(pt.top.size(), 0);
+        for (size_t ti = 0; ti < pt.top.size(); ++ti) {
+            const NdFront &f = t.fr[(size_t)pt.top[ti]];
+            s->tbase[ti] = (long long)s->topcol.size();
+            max_fp = std::max(max_fp, (long long)f.fp);
+            const int nb = top_nblocks(f);
+            for (int J = 0; J < nb; ++J) {
+                TopColDev tc{-1, top_block_ld(f, J)};
+                int lb = -1;
+                if (top_owner(pt, J) == rank) {
+                    tc.off = s->factor_doubles;
+                    s->factor_doubles += tc.ld * top_block_cols(f, J);
+                    if (J < f.nsteps) lb = s->nblocks++;
+                    for (int c = J * 256; c < J * 256 + top_block_cols(f, J); ++c)            // identity on the padding of the own columns
+                        if (c >= f.w && c < f.wp) padwhere.push_back(tc.off + (long long)(c - J * 256) * (tc.ld + 1));
+                }
+                s->topcol.push_back(tc);
+                s->toplblk.push_back(lb);
+            }
+        }
+    }
     for (int p = 0; p < s->npipe; ++p)
         for (int d = 0; d < nd; ++d)
             s->sarp_doubles[p][d & 1] = std::max(s->sarp_doubles[p][d & 1], s->s_stage_doubles[(size_t)(p * nd + d)]);
-    bool ok = nd_alloc(s, &s->factor, (size_t)t.factor_doubles + 64) && nd_alloc(s, &s->sarp[0][0], (size_t)s->sarp_doubles[0][0] + 64) &&
+    bool ok = nd_alloc(s, &s->factor, (size_t)s->factor_doubles + 64) && nd_alloc(s, &s->sarp[0][0], (size_t)s->sarp_doubles[0][0] + 64) &&
               nd_alloc(s, &s->sarp[0][1], (size_t)s->sarp_doubles[0][1] + 64) && nd_alloc(s, &s->sarp[1][0], (size_t)s->sarp_doubles[1][0] + 64) &&
-              nd_alloc(s, &s->sarp[1][1], (size_t)s->sarp_doubles[1][1] + 64) && nd_alloc(s, &s->dinv, (size_t)t.nblocks * 65536) &&
-              nd_alloc(s, &s->dinvt, (size_t)t.nblocks * 65536) && nd_alloc(s, &s->inv16, (size_t)t.nblocks * 4096) &&
+              nd_alloc(s, &s->sarp[1][1], (size_t)s->sarp_doubles[1][1] + 64) && nd_alloc(s, &s->dinv, (size_t)s->nblocks * 65536) &&
+              nd_alloc(s, &s->dinvt, (size_t)s->nblocks * 65536) && nd_alloc(s, &s->inv16, (size_t)s->nblocks * 4096) &&
               nd_alloc(s, &s->V, (size_t)t.vec_doubles) && nd_alloc(s, &s->Y, (size_t)t.vec_doubles) &&
               nd_alloc(s, &s->part, (size_t)(s->part_cap = t.vec_doubles / 4 + 256LL * (long long)t.fr.size() + 4096));
+    if (ok && s->mdist) {
+        for (int i = 0; i < 3 && ok; ++i) ok = nd_alloc(s, &s->pbuf[i], (size_t)pt.max_panel + 64);
+        s->stagev_doubles = max_fp + 64;
+        ok = ok && nd_alloc(s, &s->stagev, (size_t)s->stagev_doubles);
+    }
     if (!ok) return SPLPAK_E_NOMEM;
     // tables
     std::vector<int> rowsrc((size_t)t.vec_doubles, -1);
-    std::vector<long long> padwhere;
     std::vector<FrontDev> fdev;
-    for (const NdFront &f : t.fr) {
+    for (size_t id = 0; id < t.fr.size(); ++id) {
+        const NdFront &f = t.fr[id];
         for (int r = 0; r < f.w; ++r) rowsrc[(size_t)(f.vofs + r)] = t.ownvar[(size_t)(f.rofs + r)];
-        for (int r = f.w; r < f.wp; ++r) padwhere.push_back(f.panel_off + r + (long long)r * f.ld);
-        fdev.push_back(FrontDev{f.panel_off, f.ld, f.bofs, f.own0, f.w, f.wp, f.h});
+        if (s->poff[id] >= 0)
+            for (int r = f.w; r < f.wp; ++r) padwhere.push_back(s->poff[id] + r + (long long)r * f.ld);
+        const int ti = s->mdist ? pt.top_index[id] : -1;
+        fdev.push_back(FrontDev{s->poff[id], f.ld, f.bofs, f.own0, f.w, f.wp, f.h, ti >= 0 ? (int)s->tbase[(size_t)ti] : -1, 0});
     }
     s->npad = (int)padwhere.size();
     ok = nd_upload(s, &s->pos, t.pos) && nd_upload(s, &s->front_of, t.front_of) && nd_upload(s, &s->bpos, t.bpos) &&
          nd_upload(s, &s->pmap, t.pmap) && nd_upload(s, &s->rowsrc, rowsrc) && nd_upload(s, &s->padwhere, padwhere) &&
-         nd_upload(s, &s->fdev, fdev);
+         nd_upload(s, &s->fdev, fdev) && nd_upload(s, &s->topcol_dev, s->topcol);
     if (!ok) return SPLPAK_E_NOMEM;
     s->rowsrc_host.swap(rowsrc);
     s->full_diag = std::getenv("SPLPAK_ND_FULL_DIAG") != nullptr ? 1 : 0;      // (before the job tables: it enters their flop counts)
@@ -1805,6 +1985,16 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
     if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
     ok = nd_upload_jobs(s);
     if (!ok) return SPLPAK_E_NOMEM;
+    if (s->mdist) {             // what this rank reports into the solution: its subtrees' variables and the top fronts it ends the backward sweep of
+        std::vector<int> out(s->rowsrc_host);
+        for (size_t id = 0; id < t.fr.size(); ++id) {
+            const NdFront &f = t.fr[id];
+            const bool report = pt.owner[id] >= 0 ? pt.owner[id] == rank : top_owner(pt, 0) == rank;
+            if (!report)
+                for (int r = 0; r < f.fp; ++r) out[(size_t)(f.vofs + r)] = -1;
+        }
+        if (!nd_upload(s, &s->rowsrc_out, out)) return SPLPAK_E_NOMEM;
+    }
     // the host copies of the big index arrays are no longer needed
     std::vector<int>().swap(t.ownvar);
     std::vector<int>().swap(t.bvar);
@@ -1861,18 +2051,31 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles)
         (void)hipEventCreateWithFlags(&s->evE[(size_t)d], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&s->evZ[(size_t)d], hipEventDisableTiming);
     }
+    if (s->mdist) {
+        (void)hipStreamCreateWithPriority(&s->sCopy, hipStreamNonBlocking, hi);
+        for (auto *v : {&s->evReady, &s->evArr, &s->evCol, &s->evBulk, &s->evSF, &s->evSB}) {
+            v->assign((size_t)s->pt.nseq + 1, nullptr);
+            for (hipEvent_t &e : *v) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        }
+        s->evAdd.assign(s->pt.top.size() + 1, nullptr);
+        for (hipEvent_t &e : s->evAdd) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&s->evSub, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&s->evTop, hipEventDisableTiming);
+        if (!s->sCopy || !s->evSub || !s->evTop) { set_error("nested dissection: stream creation failed"); (void)hipGetLastError(); return SPLPAK_E_NODEVICE; }
+    }
     if (!s->sP || !s->sU) { set_error("nested dissection: stream creation failed"); (void)hipGetLastError(); return SPLPAK_E_NODEVICE; }
     p->expand_fn = nd_assemble;
     p->prefit_fn = nd_prefit;
     p->factor_fn = nd_factor;
     p->solve_fn = nd_solve;
-    p->fn_name = "nested-dissection multifrontal Cholesky (csrc/ndtree.hip, csrc/ndchol.hip)";
-    p->fn_code = 4;
+    p->fn_name = s->mdist ? "nested-dissection multifrontal Cholesky distributed over several GPUs: subtrees per GPU, top fronts by block columns (csrc/ndchol.hip, csrc/ndtop.inc)"
+                          : "nested-dissection multifrontal Cholesky (csrc/ndtree.hip, csrc/ndchol.hip)";
+    p->fn_code = s->mdist ? 5 : 4;
     if (factor_arena) *factor_arena = s->factor;
-    if (factor_doubles) *factor_doubles = t.factor_doubles;
+    if (factor_doubles) *factor_doubles = s->factor_doubles;
     if (std::getenv("SPLPAK_DEBUG"))
-        fprintf(stderr, "[splpak] nested dissection: %zu fronts, depth %d, factor %.2f GB, Schur arenas %.2f GB, %.3e flop, %d reserved CUs\n", t.fr.size(),
-                t.maxdepth, 8e-9 * (double)t.factor_doubles, 8e-9 * (double)(s->sarp_doubles[0][0] + s->sarp_doubles[0][1] + s->sarp_doubles[1][0] + s->sarp_doubles[1][1]), t.flop, s->nres);
+        fprintf(stderr, "[splpak] nested dissection%s: %zu fronts, depth %d, factor %.2f GB, Schur arenas %.2f GB, %.3e flop, %d reserved CUs\n",
+                s->mdist ? " (one rank of a multi-GPU fit)" : "", t.fr.size(), t.maxdepth, 8e-9 * (double)s->factor_doubles, 8e-9 * (double)(s->sarp_doubles[0][0] + s->sarp_doubles[0][1] + s->sarp_doubles[1][0] + s->sarp_doubles[1][1]), t.flop, s->nres);
     return 0;
 }
 

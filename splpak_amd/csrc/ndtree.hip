@@ -179,6 +179,78 @@ bool nd_build(const Grid &g, NdTree &t, int split_min)
     return true;
 }
 
+void nd_partition(const NdTree &t, int R, int chunk, NdPartition &pt)
+{
+    pt = NdPartition();
+    pt.R = R < 1 ? 1 : R;
+    pt.chunk = chunk < 1 ? 1 : chunk;
+    int dcut = 0;
+    while ((1 << dcut) < pt.R) ++dcut;
+    if (dcut > t.maxdepth) dcut = t.maxdepth;
+    if (pt.R == 1) dcut = 0;
+    pt.dcut = dcut;
+    const size_t nf = t.fr.size();
+    pt.owner.assign(nf, -1);
+    pt.top_index.assign(nf, -1);
+    // subtree i of the depth-dcut fronts -> rank i mod R.  A front above dcut that has no children (an unbalanced tree:
+    // a branch that stops short) is a top front like the others: it is simply eliminated in the top phase.
+    std::vector<int> slot(nf, -1);
+    const std::vector<int> &cut = t.by_depth[(size_t)dcut];
+    for (size_t i = 0; i < cut.size(); ++i) slot[(size_t)cut[i]] = (int)i;
+    for (int id = (int)nf - 1; id >= 0; --id) {            // parents have larger ids than their children (postorder)
+        const NdFront &f = t.fr[(size_t)id];
+        if (f.depth > dcut) slot[(size_t)id] = slot[(size_t)f.parent];
+        if (f.depth >= dcut) pt.owner[(size_t)id] = slot[(size_t)id] % pt.R;
+    }
+    for (int d = dcut - 1; d >= 0; --d)
+        for (int id : t.by_depth[(size_t)d]) {
+            pt.top_index[(size_t)id] = (int)pt.top.size();
+            pt.top.push_back(id);
+        }
+    pt.seq0.assign(pt.top.size(), 0);
+    for (size_t i = 0; i < pt.top.size(); ++i) {
+        pt.seq0[i] = pt.nseq;
+        pt.nseq += t.fr[(size_t)pt.top[i]].nsteps;
+    }
+    // bytes per rank
+    const size_t Rn = (size_t)pt.R;
+    for (auto *v : {&pt.b_panels, &pt.b_schur, &pt.b_top, &pt.b_inv, &pt.b_recv, &pt.b_vec, &pt.b_total, &pt.flop_sub, &pt.flop_top}) v->assign(Rn, 0.0);
+    std::vector<std::vector<double>> sdepth(Rn, std::vector<double>((size_t)t.maxdepth + 1, 0.0));
+    for (size_t id = 0; id < nf; ++id) {
+        const NdFront &f = t.fr[id];
+        const int o = pt.owner[id];
+        if (o >= 0) {
+            pt.b_panels[(size_t)o] += 8.0 * (double)f.ld * f.wp;
+            sdepth[(size_t)o][(size_t)f.depth] += 8.0 * (double)f.lds * f.hp;
+            pt.b_inv[(size_t)o] += (2.0 * 65536.0 + 4096.0) * 8.0 * f.nsteps;
+            for (int k = 0; k < f.nsteps; ++k) {
+                const long long nc = (f.wp - (k + 1) * 256) / 64, nr = (f.fp - (k + 1) * 256) / 64, ns = f.hp / 64;
+                pt.flop_sub[(size_t)o] += 2.0 * 64 * 64 * 256 * (double)(nc * nr - nc * (nc - 1) / 2 + ns * (ns + 1) / 2);
+            }
+        } else {
+            const int nb = top_nblocks(f);
+            for (int J = 0; J < nb; ++J) {
+                const int q = top_owner(pt, J);
+                pt.b_top[(size_t)q] += 8.0 * (double)top_block_ld(f, J) * top_block_cols(f, J);
+                if (J < f.nsteps) pt.b_inv[(size_t)q] += (2.0 * 65536.0 + 4096.0) * 8.0;
+                // updates this block column receives: one 64-row-tile trapezoid per eliminated block column left of it
+                const long long nr = (f.fp - J * 256) / 64, nc = (top_block_cols(f, J) + 63) / 64;
+                const long long items = nc * nr - nc * (nc - 1) / 2;
+                pt.flop_top[(size_t)q] += 2.0 * 64 * 64 * 256 * (double)items * (double)std::min(J, f.nsteps);
+            }
+            pt.max_panel = std::max(pt.max_panel, top_block_ld(f, 0) * 256);
+        }
+    }
+    for (size_t r = 0; r < Rn; ++r) {
+        double par[2] = {0.0, 0.0};
+        for (int d = 0; d <= t.maxdepth; ++d) par[d & 1] = std::max(par[d & 1], sdepth[r][(size_t)d]);
+        pt.b_schur[r] = par[0] + par[1];
+        pt.b_recv[r] = pt.top.empty() ? 0.0 : 3.0 * 8.0 * (double)pt.max_panel;
+        pt.b_vec[r] = 2.0 * 8.0 * (double)t.vec_doubles + 4.0 * ((double)t.bpos.size() * 2 + (double)t.vec_doubles * 2 + 2.0 * t.g.ncol);
+        pt.b_total[r] = pt.b_panels[r] + pt.b_schur[r] + pt.b_top[r] + pt.b_inv[r] + pt.b_recv[r] + pt.b_vec[r];
+    }
+}
+
 std::string nd_check(const NdTree &t)
 {
     const Grid &g = t.g;
@@ -252,6 +324,45 @@ std::string nd_check(const NdTree &t)
 }
 
 }  // namespace splpak
+
+extern "C" int32_t splpak_debug_nd_partition(int32_t ndim, const int32_t *nodes, int32_t split_min, int32_t ngpus, int32_t chunk,
+                                             double *out_per_rank8, double *out8)
+{
+    using namespace splpak;
+    double xmin[MAXD] = {0, 0, 0, 0}, xmax[MAXD] = {1, 1, 1, 1};
+    Grid g;
+    if (!nodes || !out_per_rank8 || ngpus < 1 || ngpus > 64) return SPLPAK_E_BADARG;
+    const int v = build_grid(ndim, nodes, xmin, xmax, g, nullptr, true);
+    if (v != 0) return v;
+    NdTree t;
+    if (!nd_build(g, t, split_min > 0 ? split_min : nd_default_split_min(ndim))) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
+    NdPartition pt;
+    nd_partition(t, ngpus, chunk, pt);
+    for (int r = 0; r < pt.R; ++r) {
+        double *o = out_per_rank8 + 8 * r;
+        o[0] = pt.b_total[(size_t)r];
+        o[1] = pt.b_panels[(size_t)r];
+        o[2] = pt.b_schur[(size_t)r];
+        o[3] = pt.b_top[(size_t)r];
+        o[4] = pt.b_inv[(size_t)r];
+        o[5] = pt.b_recv[(size_t)r] + pt.b_vec[(size_t)r];
+        o[6] = pt.flop_sub[(size_t)r];
+        o[7] = pt.flop_top[(size_t)r];
+    }
+    if (out8) {
+        out8[0] = pt.dcut;
+        out8[1] = (double)pt.top.size();
+        out8[2] = pt.nseq;
+        out8[3] = 8.0 * (double)pt.max_panel;
+        // what every rank holds besides the factorisation, for the caller's bookkeeping (doubles -> bytes): the all-reduced
+        // normal equations (half stencil + right-hand side + histogram + residual)
+        out8[4] = 8.0 * ((double)g.ncol * g.hstencil + 3.0 * g.ncol);
+        out8[5] = (double)t.fr.size();
+        out8[6] = t.maxdepth;
+        out8[7] = t.flop;
+    }
+    return 0;
+}
 
 extern "C" int32_t splpak_debug_nd_tree(int32_t ndim, const int32_t *nodes, int32_t split_min, int32_t check, double *out16)
 {

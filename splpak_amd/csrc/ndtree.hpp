@@ -68,6 +68,32 @@ struct NdTree {
     double flop_exact = 0.0;       // without the padding: w^3/3 + w^2 h + w h^2 per front
 };
 
+// Distribution of the tree over the R GPUs of a one-process multi-GPU fit (round 4; ndchol.hip "top phase"):
+//   * the subtrees below tree depth dcut = ceil(log2 R) are dealt to the ranks (subtree i of the depth-dcut fronts -> rank
+//     i mod R): a rank stores and eliminates ITS subtrees only (panels, Schur buffers, block inverses);
+//   * the fronts above (depth < dcut: "top fronts") are DISTRIBUTED BY BLOCK COLUMNS: a top front is one square lower
+//     triangular matrix of fp = wp + hp rows (own | border), cut into block columns of 256; block column J belongs to rank
+//     (J / chunk) mod R and is stored from its diagonal block down (rows J*256 .. fp-1, leading dimension fp - J*256 + 16).
+//     The first wp / 256 block columns are eliminated, the others receive the Schur complement.
+struct NdPartition {
+    int R = 1, chunk = 1, dcut = 0;
+    std::vector<int> owner;            // [front] rank of its subtree (depth >= dcut); -1: top front
+    std::vector<int> top;              // top fronts in elimination order (depth dcut-1 .. 0, ascending id inside a depth)
+    std::vector<int> top_index;        // [front] index into top, or -1
+    std::vector<int> seq0;             // [top index] first step of the front in the global sequence of top block steps
+    int nseq = 0;                      // steps of all top fronts
+    long long max_panel = 0;           // doubles of the largest solved panel that travels (receive buffers)
+    // bytes per rank
+    std::vector<double> b_panels, b_schur, b_top, b_inv, b_recv, b_vec, b_total;
+    std::vector<double> flop_sub, flop_top;      // padded flop of the rank's subtrees / of its share of the top fronts
+};
+inline int top_nblocks(const NdFront &f) { return (f.fp + 255) / 256; }
+inline int top_block_cols(const NdFront &f, int J) { const int c = f.fp - J * 256; return c < 256 ? c : 256; }
+inline long long top_block_ld(const NdFront &f, int J) { return (long long)(f.fp - J * 256) + 16; }
+inline int top_owner(const NdPartition &pt, int J) { return (J / pt.chunk) % pt.R; }
+// R >= 1; chunk < 1: 1.  dcut is clamped to the tree's depth (more ranks than subtrees: some own no subtree)
+void nd_partition(const NdTree &t, int R, int chunk, NdPartition &pt);
+
 // boxes whose largest extent reaches this are bisected (SPLPAK_ND_SPLIT overrides).  3-D / 4-D: 8 (leaves of 5 .. 7 nodes
 // per dimension: deeper trees cost flops nowhere, shallower ones +25 % at 64^3).  2-D grids are launch bound, not flop
 // bound: leaves of up to 15 x 15 nodes (one 256-column block) save two tree levels -- 64^2 / 1e6 points (BASELINE config 2)

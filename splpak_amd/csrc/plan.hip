@@ -171,7 +171,7 @@ int32_t splpak_plan_create(int32_t ndim, const int32_t *nodes, const double *xmi
 
 int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, const double *xmax, double xtrap,
                              long long max_ndata, void *comm_buf_dev, long long comm_len, int R, int r, int c,
-                             splpak_plan **plan, bool allow_nd)
+                             splpak_plan **plan, bool allow_nd, NdGroup *ndgrp)
 {
     if (!plan || !nodes || !xmin || !xmax) { set_error("null argument"); return SPLPAK_E_BADARG; }
     *plan = nullptr;
@@ -222,11 +222,13 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     if (p->dm.R > 1) p->band.bytes = (size_t)(p->nown > 0 ? p->nown : 1) * NBLK * (size_t)p->dm.ld * sizeof(double) + 4096;
     // Large 3-D / 4-D grids on one GPU: the nested-dissection multifrontal factorisation (ndchol.hip) instead of the
     // band.  It owns its storage; the factor arena stands in for the band as the home of the Gram scratch.
-    const bool use_nd = allow_nd && p->dm.R == 1 && nd_wanted(g, p->band);
+    // Several GPUs driven by one process (ndgrp): the same factorisation, distributed -- every rank keeps its own subtrees and
+    // its block columns of the fronts above them (round 4; ndchol.hip, ndtop.inc).
+    const bool use_nd = allow_nd && (p->dm.R == 1 || ndgrp != nullptr) && nd_wanted(g, p->band);
     if (use_nd && ok) {
         double *arena = nullptr;
         long long arena_doubles = 0;
-        const int rc = nd_attach(p, &arena, &arena_doubles);
+        const int rc = nd_attach(p, &arena, &arena_doubles, p->dm.R > 1 ? ndgrp : nullptr, r);
         if (rc != 0) {
             splpak_plan_destroy(p);
             return rc;
@@ -261,7 +263,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
         ok = ok && dev_alloc(p, &p->band.mbwd, nloc * NBLK * NBLK);
     } else {
         ok = ok && dev_alloc(p, &p->own_blocks, nloc);
-        if (ok && p->nown > 0)
+        if (ok && p->nown > 0 && !use_nd)
             ok = hip_ok(hipMemcpy(p->own_blocks, p->own_blocks_host.data(), sizeof(int) * (size_t)p->nown, hipMemcpyHostToDevice),
                         "hipMemcpy of the block list");
     }

@@ -2,7 +2,44 @@
 #pragma once
 #include "kernels.hpp"
 #include "../../include/splpak_hip.h"
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
+
+namespace splpak {
+// Barrier of the host threads of a one-process multi-GPU fit (one thread per GPU: dist.hip, ndchol.hip).
+struct HostBarrier {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n = 1, count = 0, phase = 0;
+    // false: another rank has failed and will never arrive (abort flag) -- the caller gives up too
+    bool wait(const std::atomic<int> &abort)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const int ph = phase;
+        if (++count == n) {
+            count = 0;
+            ++phase;
+            cv.notify_all();
+            return true;
+        }
+        while (phase == ph) {
+            cv.wait_for(lk, std::chrono::milliseconds(20));
+            if (phase == ph && abort.load()) return false;
+        }
+        return true;
+    }
+    void reset()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        count = 0;
+        ++phase;
+    }
+};
+struct NdGroup;        // the ranks of a one-process multi-GPU nested-dissection factorisation (ndchol.hip)
+}  // namespace splpak
 
 struct splpak_plan {
     splpak::Grid g{};
@@ -69,12 +106,23 @@ int build_grid(int ndim, const int *nodes, const double *xmin, const double *xma
                bool reorder = false);
 int device_ready();
 // plan for rank r of R (chunks of c block columns); R = 1 is the ordinary single-GPU plan
+// ndgrp != NULL (R > 1): the plan is rank r of a one-process multi-GPU fit whose grid takes the nested-dissection
+// factorisation -- distributed over the group's ranks by subtrees and, above them, by block columns (ndchol.hip)
 int plan_create_dist(int ndim, const int *nodes, const double *xmin, const double *xmax, double xtrap,
                      long long max_ndata, void *comm_buf_dev, long long comm_len, int R, int r, int c,
-                     splpak_plan **plan, bool allow_nd = false);
+                     splpak_plan **plan, bool allow_nd = false, NdGroup *ndgrp = nullptr);
 // large 3-D / 4-D grids on one GPU: nested-dissection multifrontal factorisation (ndchol.hip) instead of the band
 bool nd_wanted(const Grid &g, const Band &band);
-int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles);
+int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, NdGroup *grp = nullptr, int rank = 0);
+// One-process multi-GPU fit: the group its ranks' plans share (abort: the fit's abort flag, set when a rank fails).
+// nd_group_finalize: after every rank's plan has been created -- the tables that hold the peers' addresses.
+NdGroup *nd_group_create(int R, int chunk, std::atomic<int> *abort);
+int nd_group_finalize(NdGroup *g);
+void nd_group_destroy(NdGroup *g);
+// before a fit: a fit that was abandoned may have left arrivals counted in the group's barrier (all rank threads are joined)
+void nd_group_reset(NdGroup *g);
+// the whole-grid test of nd_wanted for a grid given by its nodes (no plan yet)
+bool nd_wanted_for(int ndim, const int *nodes, const double *xmin, const double *xmax);
 // the sharded fit's ranks are known: distribute the nested-dissection factorisation by subtrees (SPLPAK_ND_DIST=1; ndchol.hip)
 int nd_set_ranks(splpak_plan *p, int rank, int world);
 // sum over the ranks of the sharded fit through the caller's hook (plan.hip); 0 = fine (also with one rank)

@@ -361,3 +361,117 @@ def test_distributed_band_4d_12_property(monkeypatch):
         assert err < 1e-10 and info[9] < 1e-9
     finally:
         mp.close()
+
+
+# ---------------------------------------------------------------------------
+# nested dissection distributed over the GPUs of one process (round 4): subtrees per GPU, top fronts by block columns
+# ---------------------------------------------------------------------------
+def _mplan_fit(inp, ngpus, shard, coef_dev=None):
+    """Fit through splpak_mplan_* with every rank on the one GPU of the box.  shard=False: rank 0 holds every point (the
+    normal equations are then bit-identical to the single-GPU fit's)."""
+    from splpak_amd import capi
+    dev = torch.device("cuda", 0)
+    m = inp["xdata"].shape[0]
+    nd = inp["ndim"]
+    bounds = [(r * m) // ngpus for r in range(ngpus + 1)] if shard else [0] + [m] * ngpus
+    xs = [torch.tensor(inp["xdata"][bounds[r]:bounds[r + 1]].reshape(-1, nd), device=dev) for r in range(ngpus)]
+    ys = [torch.tensor(inp["ydata"][bounds[r]:bounds[r + 1]], device=dev) for r in range(ngpus)]
+    ws = None if inp["wdata"] is None else [torch.tensor(inp["wdata"][bounds[r]:bounds[r + 1]], device=dev) for r in range(ngpus)]
+    ncol = int(np.prod(inp["nodes"]))
+    coef = torch.zeros(ncol, dtype=torch.float64, device=dev)
+    mpl = capi.MultiPlan(ngpus, nd, inp["nodes"], inp["xmin"], inp["xmax"], inp["xtrap"], max(m, 1))
+    try:
+        outs = []
+        for _ in range(2):                      # twice through one plan: identical bits
+            ierr, info = mpl.fit(xs, ys, ws, coef)
+            outs.append(coef.cpu().numpy().copy())
+        assert np.array_equal(outs[0], outs[1]), "repeated multi-GPU fits differ"
+        return outs[0], ierr, info
+    finally:
+        mpl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,ngpus,chunk", [("3d12", 2, 1), ("3d16", 2, 1), ("3d16", 3, 1), ("3d16", 4, 2), ("3d16", 8, 1),
+                                              ("2d64_c2grid", 4, 1), ("2d64_c2grid", 8, 1), ("3d8_cc_clust", 2, 1)])
+def test_multi_gpu_nested_dissection_is_bitwise_the_single_gpu_fit(name, ngpus, chunk, monkeypatch):
+    """splpak_mplan_* (what Fortran's set_gpus reaches) factor through the nested-dissection tree -- every rank
+    stores and eliminates only its subtrees, the fronts above are distributed by block columns with peer-copied panels and
+    pulled Schur complements.  With every point on rank 0 the normal equations are those of the single-GPU fit, and so must
+    be every bit of the coefficients (same operations per element in the same order); with the points sharded the sums of
+    the normal equations are ordered differently: 1e-12.  Goldens at 1e-10 either way."""
+    from splpak_amd import capi
+    from tests.cases import CASES, make_inputs
+    monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
+    monkeypatch.setenv("SPLPAK_ND", "1")
+    monkeypatch.setenv("SPLPAK_ND_CHUNK", str(chunk))
+    inp = make_inputs(CASES[name])
+    gold = load_golden(name)
+    args = (inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"], inp["nodes"], inp["xtrap"])
+    c1, e1, h1, i1 = capi.fit(*args, want_hist=True)
+    assert e1 == 0
+    c0, e0, info0 = _mplan_fit(inp, ngpus, shard=False)
+    cs, es, infos = _mplan_fit(inp, ngpus, shard=True)
+    print(f"{name} x{ngpus} (chunk {chunk}): golden rel {relmax(c0, gold['coef']):.2e}; all points on rank 0 vs single GPU: "
+          f"{'identical bits' if np.array_equal(c0, c1) else 'rel %.2e' % relmax(c0, c1)}; sharded vs single {relmax(cs, c1):.2e}")
+    assert e0 == es == 0
+    assert relmax(c0, gold["coef"]) < 1e-10 and relmax(cs, gold["coef"]) < 1e-10
+    assert np.array_equal(c0, c1)
+    assert relmax(cs, c1) < 1e-12
+    assert infos[0] == i1[0] and infos[1] == i1[1] and infos[9] < 1e-9
+
+
+@pytest.mark.gpu
+def test_multi_gpu_nested_dissection_fortran_entry_and_errors(monkeypatch):
+    """splpak_fit_multi_f64 (the entry Fortran's set_gpus binds) through the distributed nested dissection: golden + histogram;
+    a rank-deficient problem is 107 on every rank; the grid checks come first."""
+    from splpak_amd import capi
+    from tests.cases import CASES, make_inputs
+    monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
+    monkeypatch.setenv("SPLPAK_ND", "1")
+    inp = make_inputs(CASES["3d12"])
+    gold = load_golden("3d12")
+    args = (inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"], inp["nodes"], inp["xtrap"])
+    cm, em, hm, im = capi.fit_multi(4, *args, want_hist=True)
+    assert em == 0 and relmax(cm, gold["coef"]) < 1e-10 and relmax(hm, gold["hist"]) < 1e-12 and im[9] < 1e-9
+    from splpak_amd.synth import synth_points
+    x, y, w = synth_points(3, 3000)
+    assert capi.fit_multi(3, 3, x * 0.5, y, w, [0.0] * 3, [1.0] * 3, [12] * 3, 0.0)[1] == 107        # an empty half of the box
+    assert capi.fit_multi(2, 0, x, y, w, [0.0] * 3, [1.0] * 3, [12] * 3, 0.0)[1] == 101
+
+
+@pytest.mark.gpu
+def test_multi_gpu_nested_dissection_4d_12_property(monkeypatch):
+    """BASELINE config 5's shape at a size one test can afford: 4-D 12^4 (20 736 columns) on 4 virtual GPUs through the
+    distributed nested dissection -- data sampled from a spline of the grid with random coefficients gives them back."""
+    from splpak_amd import capi
+    monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
+    monkeypatch.setenv("SPLPAK_ND", "1")
+    nd, nod, m, R = 4, 12, 400000, 4
+    nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    ctrue = torch.randn(nod ** nd, dtype=torch.float64, device=dev, generator=gen)
+    per = m // R
+    xs, ys = [], []
+    for r in range(R):
+        x = torch.empty((per, nd), dtype=torch.float64, device=dev)
+        capi.synth_points_dev(nd, r * per, per, x, None, None, st)
+        y = torch.empty(per, dtype=torch.float64, device=dev)
+        capi.evaluate_dev(nd, x, None, ctrue, lo, hi, nodes, y, st)
+        xs.append(x)
+        ys.append(y)
+    torch.cuda.synchronize()
+    mpl = capi.MultiPlan(R, nd, nodes, lo, hi, 0.0, per)
+    try:
+        coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
+        ierr, info = mpl.fit(xs, ys, None, coef)
+        err = float((coef - ctrue).abs().max() / ctrue.abs().max())
+        print(f"4-D 12^4 x{R} virtual GPUs, nested dissection: coefficient error {err:.2e}, steps {info[2]:.0f}, optimality {info[9]:.1e}, "
+              f"phases {info[5]:.3f} / {info[6]:.3f} / {info[7]:.3f} s")
+        assert ierr == 0 and info[0] == m
+        assert err < 1e-10 and info[9] < 1e-9
+    finally:
+        mpl.close()
