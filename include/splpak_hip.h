@@ -160,10 +160,13 @@ int32_t splpak_plan_fit_dev(splpak_plan *plan, const double *xdata_dev, int32_t 
                             int64_t ndata, double *coef_dev, void *stream, double *info);
 /* device pointer to the (all-reduced) sparse-area histogram of the last fit */
 const double *splpak_plan_hist_dev(const splpak_plan *plan);
+/* device memory the plan holds (bytes) */
+int64_t splpak_plan_device_bytes(const splpak_plan *plan);
 /* Which factorisation of the normal equations the plan uses in place of suprls' triangularisation
  * (src/splpak.F90:1516-1619): returns 0 band Cholesky (four-stream pipeline), 1 its narrow form, 2 two-ended band,
- * 3 band distributed over several GPUs, 4 nested-dissection multifrontal (2-D .. 4-D grids of >= 8192 columns);
- * a description is copied into buf. */
+ * 3 band distributed over several GPUs, 4 nested-dissection multifrontal (2-D / 3-D grids of >= 4 096 columns, 4-D grids of
+ * >= 20 000), 5 the same distributed over the GPUs of a one-process multi-GPU plan (subtrees per GPU, the fronts above them by
+ * block columns); a description is copied into buf. */
 int32_t splpak_plan_factorisation(const splpak_plan *plan, char *buf, int32_t buflen);
 
 /* Per-kernel accounting of the last splpak_plan_fit_dev call, measured with HIP
@@ -206,6 +209,11 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
 void    splpak_mplan_destroy(splpak_mplan *mplan);
 /* device of a rank (for placing its shard) */
 int32_t splpak_mplan_device(const splpak_mplan *mplan, int32_t rank);
+/* which factorisation the plan's ranks use (codes of splpak_plan_factorisation: 3 distributed band, 5 distributed nested dissection) */
+int32_t splpak_mplan_factorisation(const splpak_mplan *mplan, char *buf, int32_t buflen);
+/* device memory a rank of the plan holds (bytes): its plan (binning scratch, normal equations, its part of the factor)
+ * and its panel / staging buffers */
+int64_t splpak_mplan_rank_bytes(const splpak_mplan *mplan, int32_t rank);
 /* xdata_dev[r] / ydata_dev[r] / wdata_dev[r] (wdata_dev may be NULL = unweighted) are device pointers
  * on rank r's GPU holding ndata[r] points (0 allowed); coef_dev (ncol doubles) is on rank 0's GPU.
  * Blocks until the fit is complete.  Status and `info` as splpak_plan_fit_dev. */

@@ -30,7 +30,8 @@ SYMBOLS = [
     "splpak_plan_hist_dev", "splpak_plan_factorisation", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing", "splpak_plan_stage_timing",
     "splpak_eval_dev_f64", "splpak_eval_dev_f32", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
-    "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
+    "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_rank_bytes", "splpak_mplan_factorisation", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
+    "splpak_plan_device_bytes",
     "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_debug_nd_partition", "splpak_shutdown", "splpak_set_eval_mode",
     "splpak_last_error_message", "splpak_device_name",
 ]
@@ -122,6 +123,12 @@ def lib() -> C.CDLL:
     L.splpak_mplan_destroy.argtypes = [vp]
     L.splpak_mplan_device.restype = i32
     L.splpak_mplan_device.argtypes = [vp, i32]
+    L.splpak_mplan_factorisation.restype = i32
+    L.splpak_mplan_factorisation.argtypes = [vp, C.c_char_p, i32]
+    L.splpak_mplan_rank_bytes.restype = i64
+    L.splpak_mplan_rank_bytes.argtypes = [vp, i32]
+    L.splpak_plan_device_bytes.restype = i64
+    L.splpak_plan_device_bytes.argtypes = [vp]
     L.splpak_mplan_fit_dev.restype = i32
     L.splpak_mplan_fit_dev.argtypes = [vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp, _dp]
     L.splpak_fit_multi_f64.restype = i32
@@ -247,6 +254,16 @@ class MultiPlan:
 
     def device(self, rank):
         return int(self._L.splpak_mplan_device(self._h, int(rank)))
+
+    def factorisation(self):
+        """-> (code, description): 3 distributed band, 5 distributed nested dissection (one rank: the single-GPU codes)."""
+        buf = C.create_string_buffer(320)
+        code = self._L.splpak_mplan_factorisation(self._h, buf, 320)
+        return int(code), buf.value.decode()
+
+    def rank_bytes(self, rank):
+        """Device memory rank `rank` of the plan holds (bytes)."""
+        return int(self._L.splpak_mplan_rank_bytes(self._h, int(rank)))
 
     def fit(self, xs, ys, ws, coef):
         """xs/ys/ws: lists (one entry per rank) of float64 device tensors on that rank's GPU (ws may be
@@ -410,6 +427,9 @@ class Plan:
 
         self._cb = ALLREDUCE_FN(_cb)
         _check(self._L.splpak_plan_set_allreduce_ex(self._h, self._cb, None, int(rank), int(world), AR_ANY_POINTER if any_pointer else 0))
+
+    def device_bytes(self):
+        return int(self._L.splpak_plan_device_bytes(self._h))
 
     def factorisation(self):
         """-> (code, description): 0/1 band Cholesky, 2 two-ended band, 3 distributed band, 4 nested dissection."""

@@ -54,6 +54,7 @@ struct MRank {
     double *sbuf[NSB] = {nullptr, nullptr, nullptr, nullptr};
     double *stage = nullptr;        // staging of the reductions: a slice of the largest reduced buffer, twice (accumulator | incoming)
     long long stage_slice = 0;      // doubles per half
+    size_t extra_bytes = 0;         // device bytes this rank holds beside its plan (panel / staging buffers)
     double *red_ptr = nullptr;      // the buffer this rank brings to the current reduction (published before the first barrier)
     double *part = nullptr;         // backward sweep partial sums
     double *xs = nullptr;           // backward sweep solution / window
@@ -474,6 +475,7 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
             const size_t nsplit = (size_t)(b.bw * NBLK) / (4 * NBLK) + 2;
             ok = ok && hipMalloc((void **)&m->part, sizeof(double) * nsplit * NBLK) == hipSuccess;
             ok = ok && hipMalloc((void **)&m->xs, sizeof(double) * (size_t)(b.npad + NBLK)) == hipSuccess;
+            m->extra_bytes += sizeof(double) * ((NPB + NSB) * panel + nsplit * NBLK + (size_t)(b.npad + NBLK));
             if (ok) ok = hipMemset(m->xs, 0, sizeof(double) * (size_t)(b.npad + NBLK)) == hipSuccess;
             for (auto *v : {&m->evReady, &m->evArr, &m->evBulk, &m->evCol, &m->evF, &m->evB}) {
                 v->assign((size_t)b.nblk + 1, nullptr);
@@ -484,6 +486,7 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
             const long long big = p->lenG > (long long)b.npad + NBLK ? p->lenG : (long long)b.npad + NBLK;
             m->stage_slice = ((big + ngpus - 1) / ngpus + 511) / 512 * 512 + 512;
             ok = ok && hipMalloc((void **)&m->stage, sizeof(double) * 2 * (size_t)m->stage_slice) == hipSuccess;
+            m->extra_bytes += sizeof(double) * 2 * (size_t)m->stage_slice;
         }
         if (r != 0) ok = ok && hipMalloc((void **)&m->coef, sizeof(double) * (size_t)p->g.ncol) == hipSuccess;
         if (!ok) { set_error("device allocation of the multi-GPU plan failed"); (void)hipGetLastError(); rc = SPLPAK_E_NOMEM; }
@@ -527,6 +530,19 @@ void splpak_mplan_destroy(splpak_mplan *mp)
     nd_group_destroy(mp->ndgrp);
     (void)hipSetDevice(cur);
     delete mp;
+}
+
+int32_t splpak_mplan_factorisation(const splpak_mplan *mp, char *buf, int32_t buflen)
+{
+    if (!mp || mp->ranks.empty()) return SPLPAK_E_BADARG;
+    return splpak_plan_factorisation(mp->ranks[0]->p, buf, buflen);
+}
+
+int64_t splpak_mplan_rank_bytes(const splpak_mplan *mp, int32_t rank)
+{
+    if (!mp || rank < 0 || rank >= mp->R) return -1;
+    const MRank *m = mp->ranks[(size_t)rank];
+    return splpak_plan_device_bytes(m->p) + (int64_t)m->extra_bytes;
 }
 
 int32_t splpak_mplan_device(const splpak_mplan *mp, int32_t rank)

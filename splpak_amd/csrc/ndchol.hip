@@ -866,6 +866,7 @@ struct NdState {
     std::vector<hipEvent_t> evA, evB;              // start / stop of the timed update launches
     hipEvent_t f0 = nullptr, f1 = nullptr;
     std::vector<void *> owned;
+    size_t owned_bytes = 0;
 };
 
 template <typename T>
@@ -886,9 +887,12 @@ bool nd_alloc(NdState *s, T **ptr, size_t count)
         return false;
     }
     s->owned.push_back(q);
+    s->owned_bytes += count * sizeof(T);
     *ptr = static_cast<T *>(q);
     return true;
 }
+
+size_t nd_bytes(void *user) { return user ? static_cast<NdState *>(user)->owned_bytes : 0; }
 
 template <typename T>
 bool nd_upload(NdState *s, T **dev, const std::vector<T> &host)
@@ -1867,6 +1871,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     (void)hipGetDevice(&s->device);
     p->fn_user = s;
     p->fn_destroy = nd_destroy;
+    p->fn_bytes = nd_bytes;
     if (!nd_build(p->g, s->t, nd_default_split_min(p->g.ndim))) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
     NdTree &t = s->t;
     const int nd = t.maxdepth + 1;

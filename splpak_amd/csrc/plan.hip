@@ -132,6 +132,7 @@ static bool dev_alloc(splpak_plan *p, T **ptr, size_t count)
         return false;
     }
     p->owned.push_back(q);
+    p->owned_bytes += count * sizeof(T);
     *ptr = static_cast<T *>(q);
     return true;
 }
@@ -374,6 +375,12 @@ void splpak_plan_stage_timing(const splpak_plan *p, double *out6)
 }
 
 const double *splpak_plan_hist_dev(const splpak_plan *p) { return p ? p->hist : nullptr; }
+
+int64_t splpak_plan_device_bytes(const splpak_plan *p)
+{
+    if (!p) return 0;
+    return (int64_t)(p->owned_bytes + (p->fn_bytes ? p->fn_bytes(p->fn_user) : 0));
+}
 
 int32_t splpak_plan_factorisation(const splpak_plan *p, char *buf, int32_t buflen)
 {

@@ -79,6 +79,8 @@ struct splpak_plan {
     hipEvent_t evStage[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [8], [9]: the diagnostic residual pass
     double stage_ms[6] = {0, 0, 0, 0, 0, 0};    // bin, gram blocks + gather, constraint rows, expand (+ band memset), residual pass, solve
     std::vector<void *> owned;
+    size_t owned_bytes = 0;       // device bytes of `owned` (+ what the factorisation hooks report: fn_bytes)
+    size_t (*fn_bytes)(void *user) = nullptr;
     // distributed band (dist.hip): this plan holds the block columns DistMap deals to rank dm.r
     splpak::DistMap dm{1, 0, 1, 0};
     int nown = 0;                 // block columns stored here

@@ -475,3 +475,151 @@ def test_multi_gpu_nested_dissection_4d_12_property(monkeypatch):
         assert err < 1e-10 and info[9] < 1e-9
     finally:
         mpl.close()
+
+
+def _single_and_multi(nd, nodes, m, R, weighted=True, xtrap=1.0, shard=False):
+    """The same points through a single-GPU plan and through splpak_mplan_* on R virtual GPUs (all points on rank 0 unless
+    shard).  -> (single coefficients, multi coefficients, multi info, MultiPlan factorisation code, per-rank bytes, single plan bytes)"""
+    from splpak_amd import capi
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    lo, hi = [0.0] * nd, [1.0] * nd
+    ncol = int(np.prod(nodes))
+    x = torch.empty((m, nd), dtype=torch.float64, device=dev)
+    y = torch.empty(m, dtype=torch.float64, device=dev)
+    w = torch.empty(m, dtype=torch.float64, device=dev)
+    capi.synth_points_dev(nd, 0, m, x, y, w, st)
+    torch.cuda.synchronize()
+    c1 = torch.zeros(ncol, dtype=torch.float64, device=dev)
+    plan = capi.Plan(nd, nodes, lo, hi, xtrap, m)
+    try:
+        e1, i1 = plan.fit(x, y, w if weighted else None, c1, st)
+        torch.cuda.synchronize()
+        single_bytes = plan.device_bytes()
+    finally:
+        plan.close()
+    assert e1 == 0
+    bounds = [(r * m) // R for r in range(R + 1)] if shard else [0] + [m] * R
+    xs = [x[bounds[r]:bounds[r + 1]] for r in range(R)]
+    ys = [y[bounds[r]:bounds[r + 1]] for r in range(R)]
+    ws = [w[bounds[r]:bounds[r + 1]] for r in range(R)] if weighted else None
+    cm = torch.zeros(ncol, dtype=torch.float64, device=dev)
+    mpl = capi.MultiPlan(R, nd, nodes, lo, hi, xtrap, max(bounds[r + 1] - bounds[r] for r in range(R)))
+    try:
+        code, what = mpl.factorisation()
+        rb = [mpl.rank_bytes(r) for r in range(R)]
+        em, im = mpl.fit(xs, ys, ws, cm)
+        first = cm.clone()
+        em2, _ = mpl.fit(xs, ys, ws, cm)
+        assert em == em2 == 0 and torch.equal(first, cm), "repeated multi-GPU fits differ"
+    finally:
+        mpl.close()
+    return c1.cpu().numpy(), cm.cpu().numpy(), im, i1, code, rb, single_bytes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nd,nodes,m,R", [(3, [32] * 3, 300000, 4), (3, [24, 40, 24], 200000, 3), (2, [150, 130], 200000, 8)])
+def test_multi_gpu_nested_dissection_medium_grids_bitwise(nd, nodes, m, R, monkeypatch):
+    """Grids whose top fronts take many block steps (32^3: root of 12 steps, borders of several blocks; an anisotropic box on
+    THREE ranks; a 2-D grid on eight): nested dissection is the default from 4 096 columns on, also for the multi-GPU plan."""
+    monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
+    c1, cm, im, i1, code, rb, sb = _single_and_multi(nd, nodes, m, R)
+    print(f"{nodes} x{R}: factorisation code {code}; per-rank bytes {[round(b / 1e9, 2) for b in rb]} GB (single-GPU plan {sb / 1e9:.2f} GB); "
+          f"{'identical bits' if np.array_equal(c1, cm) else 'rel %.2e' % relmax(cm, c1)}")
+    assert code == 5
+    assert np.array_equal(c1, cm)
+    assert im[0] == i1[0] and im[1] == i1[1] and im[9] < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [2, 4])
+def test_multi_gpu_nested_dissection_c3_full_size(R, monkeypatch):
+    """BASELINE config 3 at full size (64^3 nodes, 1e7 weighted points of the seeded stream, xtrap = 1) through the multi-GPU
+    plan on R virtual GPUs: every bit of the single-GPU fit's coefficients, and every rank holds only its share of the factor
+    (the byte counts the host-only partition promises)."""
+    from splpak_amd import capi
+    monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
+    nodes = [64] * 3
+    c1, cm, im, i1, code, rb, sb = _single_and_multi(3, nodes, 10_000_000, R)
+    ranks, summ = capi.debug_nd_partition(nodes, R)
+    print(f"C3 x{R} virtual GPUs: {'identical bits' if np.array_equal(c1, cm) else 'rel %.2e' % relmax(cm, c1)}; per-rank bytes "
+          f"{[round(b / 1e9, 1) for b in rb]} GB, of which factorisation {[round(r['bytes'] / 1e9, 1) for r in ranks]} GB; single-GPU plan "
+          f"{sb / 1e9:.1f} GB; phases {im[5]:.3f} / {im[6]:.3f} / {im[7]:.3f} s; backward error {im[9]:.1e}")
+    assert code == 5 and np.array_equal(c1, cm)
+    assert im[9] < 1e-9
+    for r in range(R):
+        # what the rank holds = its share of the factorisation + normal equations, binning scratch for its points, Gram scratch, staging
+        assert rb[r] > ranks[r]["bytes"] * 0.98
+        assert rb[r] < ranks[r]["bytes"] + 2.2 * summ["normal_eq_bytes"] + 4.5e9 + 10_000_000 * 60
+    assert max(rb) < 0.75 * sb
+
+
+@pytest.mark.gpu
+def test_multi_gpu_nested_dissection_4d_24_on_four_virtual_gpus(monkeypatch):
+    """4-D 24^4 nodes (331 776 columns; 208 GB of panels + Schur arenas on one GPU) on FOUR virtual GPUs,
+    memory PARTITIONED: every rank's device bytes stay below a cap derived from the host-only partition (its subtrees + its
+    block columns of the top fronts + the replicated normal equations), far below the single-GPU plan's.  Data sampled from
+    a spline of the grid with random coefficients (xtrap = 0) gives the coefficients back."""
+    from splpak_amd import capi
+    monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
+    capi.shutdown()
+    torch.cuda.empty_cache()
+    nd, nod, m, R = 4, 24, 2_000_000, 4
+    nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    ctrue = torch.randn(nod ** nd, dtype=torch.float64, device=dev, generator=gen)
+    per = m // R
+    xs, ys = [], []
+    for r in range(R):
+        x = torch.empty((per, nd), dtype=torch.float64, device=dev)
+        capi.synth_points_dev(nd, r * per, per, x, None, None, st)
+        y = torch.empty(per, dtype=torch.float64, device=dev)
+        capi.evaluate_dev(nd, x, None, ctrue, lo, hi, nodes, y, st)
+        xs.append(x)
+        ys.append(y)
+    torch.cuda.synchronize()
+    ranks, summ = capi.debug_nd_partition(nodes, R)
+    tree = capi.debug_nd_tree(nodes, check=False)
+    mpl = capi.MultiPlan(R, nd, nodes, lo, hi, 0.0, per)
+    try:
+        code, _ = mpl.factorisation()
+        rb = [mpl.rank_bytes(r) for r in range(R)]
+        coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
+        ierr, info = mpl.fit(xs, ys, None, coef)
+        err = float((coef - ctrue).abs().max() / ctrue.abs().max())
+        print(f"4-D 24^4 x{R} virtual GPUs: per-rank bytes {[round(b / 1e9, 1) for b in rb]} GB (factorisation "
+              f"{[round(r['bytes'] / 1e9, 1) for r in ranks]} GB; one GPU would hold {(tree['factor_bytes'] + tree['arena_bytes']) / 1e9:.0f} GB); "
+              f"coefficient error {err:.2e}, steps {info[2]:.0f}, optimality {info[9]:.1e}, phases {info[5]:.2f} / {info[6]:.2f} / {info[7]:.2f} s")
+        assert code == 5 and ierr == 0 and info[0] == m
+        assert err < 1e-10 and info[9] < 1e-9
+        for r in range(R):
+            cap = ranks[r]["bytes"] + 2.2 * summ["normal_eq_bytes"] + 3e9
+            assert rb[r] < cap, f"rank {r} holds {rb[r] / 1e9:.1f} GB, cap {cap / 1e9:.1f} GB"
+        assert max(rb) < 0.4 * (tree["factor_bytes"] + tree["arena_bytes"])
+    finally:
+        mpl.close()
+        capi.shutdown()
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_c4_full_size_rehearsed_on_eight_virtual_gpus(monkeypatch):
+    """BASELINE config 4 at full size -- 1e8 weighted points of the seeded stream on the 64^3 grid, sharded
+    over EIGHT ranks (1.25e7 each) of the one-process multi-GPU plan, nested dissection distributed (subtree per rank, top
+    fronts by block columns) -- rehearsed on the one GPU of the test box.  Held to the single-GPU fit of the same 1e8 points."""
+    from splpak_amd import capi
+    monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
+    capi.shutdown()
+    torch.cuda.empty_cache()
+    c1, cm, im, i1, code, rb, sb = _single_and_multi(3, [64] * 3, 100_000_000, 8, shard=True)
+    print(f"C4 (1e8 points, 64^3) on 8 virtual GPUs: rel to the single-GPU fit {relmax(cm, c1):.2e}; per-rank bytes "
+          f"{[round(b / 1e9, 1) for b in rb]} GB (single-GPU plan {sb / 1e9:.1f} GB); rows {im[0]:.0f}+{im[1]:.0f}; backward error {im[9]:.1e}; "
+          f"phases {im[5]:.3f} / {im[6]:.3f} / {im[7]:.3f} s")
+    assert code == 5
+    assert relmax(cm, c1) < 1e-10
+    assert im[0] == i1[0] == 100_000_000 and im[1] == i1[1]
+    assert im[9] < 1e-9 and abs(im[8] - i1[8]) <= 1e-9 * i1[8]
+    assert max(rb) < 0.5 * sb

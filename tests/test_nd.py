@@ -204,3 +204,43 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
                 {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_RES_CUS": "3", "SPLPAK_ND_PIN_ROUNDS": "8"}):
         c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1"))
         assert e == 0 and np.array_equal(c, ref), env
+
+
+def test_multi_gpu_partition_of_the_4d_32_grid_fits_eight_gpus():
+    """BASELINE config 5's 4-D 32^4 grid does not fit one 288 GB GPU by any route (476 GB of panels); the
+    one-process multi-GPU fit distributes the nested-dissection factorisation -- subtrees per GPU, the fronts above them by
+    block columns (csrc/ndtree.hpp NdPartition).  Host-only: per rank, everything the factorisation keeps + the all-reduced
+    normal equations + the Gram scratch + the binned points of its shard must stay below the GPU's memory."""
+    ranks, summ = capi.debug_nd_partition([32] * 4, 8)
+    assert summ["dcut"] == 3 and summ["top_fronts"] == 7
+    hbm = 288e9
+    points = 1.25e6 * (8 * 5 + 8 * 6 + 8)          # a shard of config 5's 1e7 points: caller's arrays + sorted copies + keys
+    gram_scratch = 8.6e9                           # slabs of per-cell Gram blocks (plan.hip: at most 8 GiB)
+    worst = 0.0
+    for r in ranks:
+        assert abs(r["bytes"] - (r["panel_bytes"] + r["schur_bytes"] + r["top_bytes"] + r["inverse_bytes"] + r["other_bytes"])) < 1.0
+        total = r["bytes"] + summ["normal_eq_bytes"] * 1.3 + gram_scratch + points      # (x 1.3: reduction staging, residual shares)
+        worst = max(worst, total)
+    print(f"32^4 on 8 GPUs: {min(r['bytes'] for r in ranks) / 1e9:.0f} - {max(r['bytes'] for r in ranks) / 1e9:.0f} GB of factorisation "
+          f"per GPU, {worst / 1e9:.0f} GB in all on the fullest; flop per GPU {max(r['flop_subtrees'] + r['flop_top'] for r in ranks):.2e}")
+    assert worst < 0.9 * hbm
+    # the work is spread: no rank does more than 1.3 x the mean
+    fl = [r["flop_subtrees"] + r["flop_top"] for r in ranks]
+    assert max(fl) < 1.3 * sum(fl) / len(fl)
+    # on FOUR GPUs it does not fit (the test has teeth), on one rank the partition is the whole tree
+    ranks4, _ = capi.debug_nd_partition([32] * 4, 4)
+    assert max(r["bytes"] for r in ranks4) > hbm
+    one, s1 = capi.debug_nd_partition([24] * 4, 1)
+    tree = capi.debug_nd_tree([24] * 4, check=False)
+    assert s1["dcut"] == 0 and s1["top_fronts"] == 0
+    assert one[0]["panel_bytes"] == tree["factor_bytes"] and one[0]["schur_bytes"] == tree["arena_bytes"]
+
+
+@pytest.mark.parametrize("nodes,R", [([64] * 3, 8), ([64] * 3, 3), ([24] * 4, 4), ([90, 90], 8)])
+def test_multi_gpu_partition_memory_shrinks_with_the_ranks(nodes, R):
+    ranks, summ = capi.debug_nd_partition(nodes, R)
+    tree = capi.debug_nd_tree(nodes, check=False)
+    whole = tree["factor_bytes"] + tree["arena_bytes"]
+    fullest = max(r["panel_bytes"] + r["schur_bytes"] + r["top_bytes"] for r in ranks)
+    assert fullest < 1.6 * whole / R + 3 * summ["max_panel_bytes"]
+    assert abs(sum(r["flop_subtrees"] + r["flop_top"] for r in ranks) / tree["flop"] - 1.0) < 0.02
