@@ -23,7 +23,7 @@ Extra objects on the line:
                 64^3 grid at all (550 GB workspace)
   eval          batched evaluation throughput (one thread per query) + its HBM roofline
   strong        (N > 1) config 3's 1e7 points in all, sharded: the fixed-total line beside the weak headline
-  c2, grid32, c5_eval, c5_fit, fit_incl_h2d, dist_band   guarded side legs (N = 1)
+  c2, grid32, c5_eval, c5_fit, fit_incl_h2d, multi_gpu_one_process   guarded side legs (N = 1; the last one also at N > 1)
 """
 import argparse
 import json
@@ -261,10 +261,11 @@ def bench_c2(capi, dev, stream, steps):
 
 
 def bench_dist_band(capi, ngpus, nd, nod, m_total, virtual, steps):
-    """The fit with the band factor DISTRIBUTED over `ngpus` GPUs, driven from this one process
-    (splpak_mplan_*: block columns dealt to the GPUs, panels handed over by peer copies).  Strong
-    scaling: the point count is fixed.  virtual=True places every rank on this GPU (a rehearsal of the
-    protocol, not a speed-up)."""
+    """The fit with the FACTORISATION DISTRIBUTED over `ngpus` GPUs, driven from this one process (splpak_mplan_*, what a
+    Fortran caller reaches through set_gpus): the points sharded, the nested-dissection factorisation distributed -- a subtree
+    per GPU, the fronts above them by block columns with peer-copied panels (round 4; grids below the nested-dissection
+    threshold: the distributed band of round 2).  m_total points in all.  virtual=True places every rank on this GPU (a
+    rehearsal of the protocol, not a speed-up)."""
     import torch
     nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
     if virtual:
@@ -286,6 +287,8 @@ def bench_dist_band(capi, ngpus, nd, nod, m_total, virtual, steps):
             xs.append(x); ys.append(y); ws.append(w)
         torch.cuda.set_device(cur)
         coef = torch.zeros(nod ** nd, dtype=torch.float64, device=torch.device("cuda", mp.device(0)))
+        code, what = mp.factorisation()
+        rank_gb = [round(mp.rank_bytes(r) / 1e9, 2) for r in range(ngpus)]
         ierr, info = mp.fit(xs, ys, ws, coef)                      # warm-up
         assert ierr == 0, f"distributed fit failed with ierror {ierr}"
         n = max(1, min(steps, 3))
@@ -295,8 +298,9 @@ def bench_dist_band(capi, ngpus, nd, nod, m_total, virtual, steps):
         dt = (time.perf_counter() - t0) / n
         mp.close()
         assert ierr == 0 and info[9] < 1e-9, f"distributed fit: ierror {ierr}, optimality residual {info[9]:.2e}"
-        return {"workload": f"{nd}-D splcw fit, {m_total} points in all (strong scaling), {nod}^{nd} nodes, band factor distributed over "
+        return {"workload": f"{nd}-D splcw fit, {m_total} points in all, {nod}^{nd} nodes, factorisation distributed over "
                             f"{ngpus} {'virtual GPUs (all ranks on this device: protocol rehearsal)' if virtual else 'GPUs, one process, peer copies over xGMI'}",
+                "factorisation": {"code": code, "what": what}, "device_gb_per_rank": rank_gb,
                 "value": m_total / dt, "unit": "points/s", "ms_per_fit": 1e3 * dt, "n_gpus": ngpus, "virtual": bool(virtual),
                 "phase_seconds": {"assembly": float(info[5]), "factor": float(info[6]), "solve_refine": float(info[7])},
                 "refine_steps": int(info[2]), "optimality_residual": float(info[9])}
@@ -578,7 +582,8 @@ def main():
         store = dist.distributed_c10d._get_default_store()
         if rank == 0:
             try:
-                dist_leg = dist_band_in_child(world, nd, nod, m, bool(os.environ.get("SPLPAK_BENCH_SINGLE_DEVICE")),
+                # the headline's workload (every rank's m points: m * world in all) through the one-process route
+                dist_leg = dist_band_in_child(world, nd, nod, m * world, bool(os.environ.get("SPLPAK_BENCH_SINGLE_DEVICE")),
                                               args.steps, 150)
             finally:
                 store.set("splpak_dist_leg_done", "1")
@@ -699,8 +704,9 @@ def main():
         if world == 1 and not args.no_side_legs:
             plan.close()                      # the side legs have the GPU to themselves
             # every side leg is guarded: a failure becomes {"error": ...} inside the line, the headline survives
-            # rehearsal of the distributed-band path on this one GPU (2 virtual ranks, reduced size)
-            line["dist_band"] = guarded(dist_band_in_child, 2, nd, min(nod, 32), 1_000_000, True, args.steps, 180)
+            # rehearsal of the one-process multi-GPU route on this one GPU: the headline workload on 2 virtual ranks
+            # (nested dissection distributed: a subtree per rank, the root by block columns)
+            line["multi_gpu_one_process"] = guarded(dist_band_in_child, 2, nd, nod, m, True, args.steps, 180)
             line["c2"] = guarded(bench_c2, capi, dev, stream, args.steps)
             line["grid32"] = guarded(bench_small, capi, dev, stream, args.steps, 3, 32, 1_000_000, True,
                                      "3-D splcw fit, 1e6 weighted scattered points, 32x32x32 nodes, xtrap=1, real64, resident data")
@@ -714,7 +720,7 @@ def main():
             torch.cuda.empty_cache()
             line["c5_fit"] = guarded(bench_c5_fit, capi, dev, stream)
         if dist_leg is not None:
-            line["dist_band"] = dist_leg
+            line["multi_gpu_one_process"] = dist_leg
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = guarded(cpu_baseline, nd)
         print(json.dumps(line), flush=True)

@@ -142,11 +142,25 @@ void    splpak_plan_set_allreduce(splpak_plan *plan, splpak_allreduce_fn fn, voi
  * solve vectors that live in the library's own allocations.  Returns 0 or a negative status (a failure while the
  * per-rank job tables are rebuilt; the plan's next fit returns it on every rank). */
 #define SPLPAK_AR_ANY_POINTER 1
+#define SPLPAK_AR_ALWAYS      2   /* call the hook with one rank too (smoke tests of a one-rank communicator) */
 int32_t splpak_plan_set_allreduce_ex(splpak_plan *plan, splpak_allreduce_fn fn, void *user,
                                      int32_t rank, int32_t world, int32_t flags);
 /* tuning / test knobs: nominal refinement steps (default 4; 0 = none; a solve that still contracts goes on
  * up to max(steps, 30)) and the tolerance on the (estimated) remaining relative error |dx|/|x| after a
  * step (default 1e-11; the parity bar is 1e-10) */
+/* A native RCCL hook (round 4): the plan's sum-all-reduce becomes ncclAllReduce(.., ncclDouble, ncclSum, comm, stream) on the
+ * fit's stream, with SPLPAK_AR_ANY_POINTER declared -- what a C / Fortran process-per-GPU caller uses instead of the Python
+ * callback.  `nccl_comm` is the caller's ncclComm_t (one per process, made on the GPU the plan lives on).  librccl is opened at
+ * run time (an RCCL the process already carries is reused; SPLPAK_RCCL_LIB names another); SPLPAK_E_COMM if it cannot be.
+ * For callers without RCCL headers the communicator can be made here: rank 0 draws the 128-byte ncclUniqueId
+ * (splpak_rccl_unique_id) and passes it to the other processes by any means -- splpak_rccl_comm_create_from_file does it
+ * through a file (rank 0 writes `path` atomically, the others wait for it up to timeout_s seconds; no MPI needed on one
+ * node) -- and every process calls splpak_rccl_comm_create with the CURRENT device set to its GPU. */
+int32_t splpak_plan_set_rccl(splpak_plan *plan, void *nccl_comm, int32_t rank, int32_t world);
+int32_t splpak_rccl_unique_id(char *id128);
+int32_t splpak_rccl_comm_create(const char *id128, int32_t rank, int32_t world, void **nccl_comm);
+int32_t splpak_rccl_comm_create_from_file(const char *path, int32_t rank, int32_t world, double timeout_s, void **nccl_comm);
+void    splpak_rccl_comm_destroy(void *nccl_comm);
 void    splpak_plan_set_refine(splpak_plan *plan, int32_t max_steps, double tol);
 
 /* The fit on resident data.  xdata_dev/ydata_dev/wdata_dev (wdata_dev may be

@@ -26,7 +26,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_voi
 SYMBOLS = [
     "splpak_fit_f64", "splpak_fit_f32", "splpak_eval_f64", "splpak_eval_f32",
     "splpak_plan_comm_len", "splpak_plan_create", "splpak_plan_destroy",
-    "splpak_plan_set_allreduce", "splpak_plan_set_allreduce_ex", "splpak_plan_set_refine", "splpak_plan_fit_dev",
+    "splpak_plan_set_allreduce", "splpak_plan_set_allreduce_ex", "splpak_plan_set_rccl", "splpak_rccl_unique_id", "splpak_rccl_comm_create",
+    "splpak_rccl_comm_create_from_file", "splpak_rccl_comm_destroy", "splpak_plan_set_refine", "splpak_plan_fit_dev",
     "splpak_plan_hist_dev", "splpak_plan_factorisation", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing", "splpak_plan_stage_timing",
     "splpak_eval_dev_f64", "splpak_eval_dev_f32", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
@@ -83,6 +84,16 @@ def lib() -> C.CDLL:
     L.splpak_plan_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i32, i32]
     L.splpak_plan_set_allreduce_ex.restype = i32
     L.splpak_plan_set_allreduce_ex.argtypes = [vp, ALLREDUCE_FN, vp, i32, i32, i32]
+    L.splpak_plan_set_rccl.restype = i32
+    L.splpak_plan_set_rccl.argtypes = [vp, vp, i32, i32]
+    L.splpak_rccl_unique_id.restype = i32
+    L.splpak_rccl_unique_id.argtypes = [C.c_char_p]
+    L.splpak_rccl_comm_create.restype = i32
+    L.splpak_rccl_comm_create.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
+    L.splpak_rccl_comm_create_from_file.restype = i32
+    L.splpak_rccl_comm_create_from_file.argtypes = [C.c_char_p, i32, i32, dbl, C.POINTER(vp)]
+    L.splpak_rccl_comm_destroy.restype = None
+    L.splpak_rccl_comm_destroy.argtypes = [vp]
     L.splpak_plan_set_refine.restype = None
     L.splpak_plan_set_refine.argtypes = [vp, i32, dbl]
     L.splpak_plan_fit_dev.restype = i32
@@ -431,6 +442,10 @@ class Plan:
     def device_bytes(self):
         return int(self._L.splpak_plan_device_bytes(self._h))
 
+    def set_rccl(self, comm, rank, world):
+        """The library's own RCCL hook (no Python in the reductions): `comm` is an ncclComm_t as an integer / c_void_p."""
+        _check(self._L.splpak_plan_set_rccl(self._h, C.c_void_p(comm if isinstance(comm, int) else comm.value), int(rank), int(world)))
+
     def factorisation(self):
         """-> (code, description): 0/1 band Cholesky, 2 two-ended band, 3 distributed band, 4 nested dissection."""
         buf = C.create_string_buffer(256)
@@ -499,6 +514,17 @@ def synth_points_dev(ndim, first_point, ndata, xdata, ydata, wdata, stream=0):
 def synth_queries_dev(ndim, ndata_before, first_query, nq, xq, stream=0):
     return _check(lib().splpak_synth_queries_f64(ndim, int(ndata_before), int(first_query), int(nq),
                                                  xq.data_ptr(), C.c_void_p(stream)))
+
+
+def rccl_comm_create_from_file(path, rank, world, timeout_s=60.0):
+    """ncclComm_t (as an int) made by the library: rank 0 draws the id and publishes it through `path`."""
+    comm = C.c_void_p()
+    _check(lib().splpak_rccl_comm_create_from_file(str(path).encode(), int(rank), int(world), float(timeout_s), C.byref(comm)))
+    return comm.value
+
+
+def rccl_comm_destroy(comm):
+    lib().splpak_rccl_comm_destroy(C.c_void_p(comm))
 
 
 ND_TREE_FIELDS = ("fronts", "depth", "factor_bytes", "arena_bytes", "schur_bytes_per_fit", "flop", "flop_exact",

@@ -318,6 +318,7 @@ void splpak_plan_destroy(splpak_plan *p)
     band_pipeline_destroy(p->band.pipe);
     for (hipEvent_t e : p->evStage) if (e) (void)hipEventDestroy(e);
     for (void *q : p->owned) (void)hipFree(q);
+    std::free(p->ar_owned);
     delete p;
 }
 
@@ -411,7 +412,7 @@ static void debug_sum(const splpak_plan *p, const char *what, const double *buf,
 
 static int do_allreduce(splpak_plan *p, double *buf, long long count, hipStream_t st)
 {
-    if (!p->ar || p->world <= 1) return 0;
+    if (!p->ar || (p->world <= 1 && !(p->ar_flags & SPLPAK_AR_ALWAYS))) return 0;
     debug_sum(p, "before all-reduce", buf, count, st);
     // The buffer is complete before the hook sees it and the reduced values are in place before the fit goes on,
     // whatever the hook's own ordering is worth: the rehearsal of `bench.py --gpus 2` on ONE device over gloo summed

@@ -68,6 +68,7 @@ struct splpak_plan {
     splpak_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
     int rank = 0, world = 1;
+    void *ar_owned = nullptr;     // hook state the plan owns (splpak_plan_set_rccl): free()d with the plan
     int ar_flags = 0;             // SPLPAK_AR_*: what the hook accepts (splpak_plan_set_allreduce_ex)
     int setup_rc = 0;             // a failure while the ranks were set up (nd_set_ranks): returned by the next fit, collectively
     bool comm_failed = false;     // the hook reported a failure during the current fit (SPLPAK_E_COMM, not a device fault)

@@ -1,0 +1,173 @@
+// Native RCCL hook for the sharded fit (one process per GPU; round 4).
+//
+// north_star: "the fit is partitioned across the 8 GPUs of one node by sharding data points and RCCL-reducing the normal
+// equations over xGMI", with the host code in Fortran.  splpak_plan_set_allreduce takes ANY sum-all-reduce; until round 3 the
+// only one in the repository was a ctypes callback into torch.distributed, so a C / Fortran multi-process caller had no way to
+// reach RCCL.  This file gives the library its own: librccl is opened at run time (dlopen: the library does not link against
+// it, and a process that already carries an RCCL -- PyTorch ships one -- keeps using that one), the plan's hook becomes
+// ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, stream) on the fit's stream, and it declares SPLPAK_AR_ANY_POINTER
+// (ncclAllReduce takes any device pointer), so the nested-dissection factorisation is distributed by subtrees.
+//
+// A caller without RCCL headers (Fortran) can also have the communicator made here: rank 0 draws the ncclUniqueId and hands
+// it to the other processes through a file (no MPI needed on one node), see INTEGRATION.md.
+#include "plan.hpp"
+
+#include <dlfcn.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+using namespace splpak;
+
+namespace {
+
+struct UniqueId { char internal[128]; };          // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+using GetUniqueId_t = int (*)(UniqueId *);
+using CommInitRank_t = int (*)(void **, int, UniqueId, int);
+using CommDestroy_t = int (*)(void *);
+using AllReduce_t = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
+using GetErrorString_t = const char *(*)(int);
+
+struct Rccl {
+    void *handle = nullptr;
+    GetUniqueId_t get_unique_id = nullptr;
+    CommInitRank_t comm_init_rank = nullptr;
+    CommDestroy_t comm_destroy = nullptr;
+    AllReduce_t all_reduce = nullptr;
+    GetErrorString_t error_string = nullptr;
+    bool tried = false;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0;    // rccl.h: ncclFloat64 = ncclDouble = 8, ncclSum = 0
+
+bool rccl_load()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.tried) return g_rccl.all_reduce != nullptr;
+    g_rccl.tried = true;
+    void *h = nullptr;
+    if (const char *e = std::getenv("SPLPAK_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+    // an RCCL the process already carries (PyTorch's) first: two RCCLs in one process would not share their state
+    for (const char *name : {"librccl.so.1", "librccl.so"})
+        if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+        if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+        set_error(std::string("RCCL: librccl.so could not be opened (") + (dlerror() ? dlerror() : "not found") + "); set SPLPAK_RCCL_LIB");
+        return false;
+    }
+    g_rccl.handle = h;
+    g_rccl.get_unique_id = (GetUniqueId_t)dlsym(h, "ncclGetUniqueId");
+    g_rccl.comm_init_rank = (CommInitRank_t)dlsym(h, "ncclCommInitRank");
+    g_rccl.comm_destroy = (CommDestroy_t)dlsym(h, "ncclCommDestroy");
+    g_rccl.all_reduce = (AllReduce_t)dlsym(h, "ncclAllReduce");
+    g_rccl.error_string = (GetErrorString_t)dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce) {
+        set_error("RCCL: librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
+        g_rccl.all_reduce = nullptr;
+        return false;
+    }
+    return true;
+}
+
+void rccl_fail(const char *what, int rc)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "RCCL: %s failed: %s (%d)", what, g_rccl.error_string ? g_rccl.error_string(rc) : "?", rc);
+    set_error(buf);
+}
+
+struct RcclHook { void *comm; };
+
+// the plan's sum-all-reduce: in place, on the fit's stream (plan.hip synchronises the stream around every call of a hook)
+int32_t rccl_allreduce(void *buf, int64_t count, void *stream, void *user)
+{
+    RcclHook *h = static_cast<RcclHook *>(user);
+    const int rc = g_rccl.all_reduce(buf, buf, (size_t)count, NCCL_FLOAT64, NCCL_SUM, h->comm, (hipStream_t)stream);
+    if (rc != 0) { rccl_fail("ncclAllReduce", rc); return 1; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t splpak_plan_set_rccl(splpak_plan *plan, void *nccl_comm, int32_t rank, int32_t world)
+{
+    if (!plan || !nccl_comm || world < 1 || rank < 0 || rank >= world) { set_error("splpak_plan_set_rccl: bad argument"); return SPLPAK_E_BADARG; }
+    if (!rccl_load()) return SPLPAK_E_COMM;
+    RcclHook *h = static_cast<RcclHook *>(std::malloc(sizeof(RcclHook)));
+    if (!h) return SPLPAK_E_NOMEM;
+    h->comm = nccl_comm;
+    std::free(plan->ar_owned);
+    plan->ar_owned = h;
+    // SPLPAK_RCCL_ONE_RANK_CALLS=1 (smoke tests on a one-GPU box): the reductions of a one-rank fit go through RCCL too
+    const int always = std::getenv("SPLPAK_RCCL_ONE_RANK_CALLS") ? SPLPAK_AR_ALWAYS : 0;
+    return splpak_plan_set_allreduce_ex(plan, rccl_allreduce, h, rank, world, SPLPAK_AR_ANY_POINTER | always);
+}
+
+int32_t splpak_rccl_unique_id(char *id128)
+{
+    if (!id128) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    if (!rccl_load()) return SPLPAK_E_COMM;
+    UniqueId id;
+    const int rc = g_rccl.get_unique_id(&id);
+    if (rc != 0) { rccl_fail("ncclGetUniqueId", rc); return SPLPAK_E_COMM; }
+    std::memcpy(id128, id.internal, sizeof id.internal);
+    return 0;
+}
+
+int32_t splpak_rccl_comm_create(const char *id128, int32_t rank, int32_t world, void **comm)
+{
+    if (!id128 || !comm || world < 1 || rank < 0 || rank >= world) { set_error("splpak_rccl_comm_create: bad argument"); return SPLPAK_E_BADARG; }
+    *comm = nullptr;
+    if (int r = device_ready()) return r;
+    if (!rccl_load()) return SPLPAK_E_COMM;
+    UniqueId id;
+    std::memcpy(id.internal, id128, sizeof id.internal);
+    const int rc = g_rccl.comm_init_rank(comm, world, id, rank);          // the communicator lives on the CURRENT device
+    if (rc != 0) { rccl_fail("ncclCommInitRank", rc); *comm = nullptr; return SPLPAK_E_COMM; }
+    return 0;
+}
+
+int32_t splpak_rccl_comm_create_from_file(const char *path, int32_t rank, int32_t world, double timeout_s, void **comm)
+{
+    if (!path || !comm) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    char id[128];
+    if (rank == 0) {
+        if (int r = splpak_rccl_unique_id(id)) return r;
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE *f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) { if (f) std::fclose(f); set_error("RCCL: cannot write the id file"); return SPLPAK_E_COMM; }
+        std::fclose(f);
+        if (std::rename(tmp.c_str(), path) != 0) { set_error("RCCL: cannot publish the id file"); return SPLPAK_E_COMM; }     // (atomic: readers never see half an id)
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            FILE *f = std::fopen(path, "rb");
+            if (f) {
+                const size_t n = std::fread(id, 1, sizeof id, f);
+                std::fclose(f);
+                if (n == sizeof id) break;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (timeout_s > 0 ? timeout_s : 60.0)) {
+                set_error("RCCL: timed out waiting for rank 0's id file");
+                return SPLPAK_E_COMM;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    return splpak_rccl_comm_create(id, rank, world, comm);
+}
+
+void splpak_rccl_comm_destroy(void *comm)
+{
+    if (comm && rccl_load()) (void)g_rccl.comm_destroy(comm);
+}
+
+}  // extern "C"

@@ -623,3 +623,37 @@ def test_c4_full_size_rehearsed_on_eight_virtual_gpus(monkeypatch):
     assert im[0] == i1[0] == 100_000_000 and im[1] == i1[1]
     assert im[9] < 1e-9 and abs(im[8] - i1[8]) <= 1e-9 * i1[8]
     assert max(rb) < 0.5 * sb
+
+
+@pytest.mark.gpu
+def test_native_rccl_hook_one_rank_smoke(tmp_path, monkeypatch):
+    """the library's own RCCL hook (csrc/rccl.hip: librccl opened at run time, ncclAllReduce on the fit's
+    stream) through the C ABI -- no Python in the reductions.  This pool has ONE GPU, so the communicator has one rank;
+    SPLPAK_RCCL_ONE_RANK_CALLS=1 makes the fit route its reductions (histogram, normal equations, every refinement residual)
+    through ncclAllReduce anyway.  The communicator is made by the library from an id file, as a Fortran caller would."""
+    from splpak_amd import capi
+    from tests.cases import CASES, make_inputs
+    monkeypatch.setenv("SPLPAK_RCCL_ONE_RANK_CALLS", "1")
+    monkeypatch.setenv("SPLPAK_DEBUG_SUMS", "1")            # prints "before / after all-reduce" lines: the hook really ran
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    comm = capi.rccl_comm_create_from_file(tmp_path / "splpak_nccl_id", 0, 1)
+    assert comm
+    try:
+        for name in ("3d8", "2d16_zero_w"):
+            inp = make_inputs(CASES[name])
+            gold = load_golden(name)
+            x = torch.tensor(inp["xdata"], device=dev)
+            y = torch.tensor(inp["ydata"], device=dev)
+            w = None if inp["wdata"] is None else torch.tensor(inp["wdata"], device=dev)
+            coef = torch.zeros(int(np.prod(inp["nodes"])), dtype=torch.float64, device=dev)
+            plan = capi.Plan(inp["ndim"], inp["nodes"], inp["xmin"], inp["xmax"], inp["xtrap"], x.shape[0])
+            try:
+                plan.set_rccl(comm, 0, 1)
+                ierr, info = plan.fit(x, y, w, coef, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+            finally:
+                plan.close()
+            assert ierr == 0 and relmax(coef.cpu().numpy(), gold["coef"]) < 1e-10 and info[9] < 1e-9
+    finally:
+        capi.rccl_comm_destroy(comm)
