@@ -38,6 +38,15 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
+def committed_profile(*names):
+    """The newest of the committed rocprofv3 summaries under profiles/ (the counters are collected in runs of their own)."""
+    for n in names:
+        q = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(q):
+            return q
+    return None
+
+
 F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix peak (AMD datasheet; = 256 CU * 4 SIMD * 32 flop/clk * 2.4 GHz)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
@@ -243,6 +252,7 @@ def bench_c5_fit(capi, dev, stream):
     assert ierr == 0 and info[9] < 1e-9, f"4-D fit: ierror {ierr}, optimality residual {info[9]:.2e}"
     tree = capi.debug_nd_tree(nodes, check=False)
     big = capi.debug_nd_tree([32] * 4, check=False)
+    ranks8, summ8 = capi.debug_nd_partition([32] * 4, 8)
     return {"workload": "C5 (fit half) on the largest 4-D grid one GPU holds: 4-D splcw fit, 1e7 weighted scattered points, 24^4 nodes "
                         "(331 776 columns), xtrap=1, real64, resident data",
             "value": m / dt, "unit": "points/s", "seconds_per_fit": dt, "plan_seconds": t_plan, "factorisation": fact,
@@ -251,7 +261,14 @@ def bench_c5_fit(capi, dev, stream):
             "refine_steps": int(info[2]), "optimality_residual": float(info[9]),
             "fronts": int(tree["fronts"]), "factor_GB": tree["factor_bytes"] / 1e9, "schur_arenas_GB": tree["arena_bytes"] / 1e9,
             "config5_32^4_needs": {"factor_GB": big["factor_bytes"] / 1e9, "schur_arenas_GB": big["arena_bytes"] / 1e9,
-                                   "flop": big["flop"], "note": "does not fit one 288 GB GPU; the plan is refused with SPLPAK_E_NOMEM"}}
+                                   "flop": big["flop"], "note": "does not fit one 288 GB GPU; the single-GPU plan is refused with SPLPAK_E_NOMEM",
+                                   "on_8_gpus_one_process": {
+                                       "factorisation_GB_per_gpu": [round(r["bytes"] / 1e9, 1) for r in ranks8],
+                                       "normal_equations_GB_per_gpu": round(summ8["normal_eq_bytes"] / 1e9, 1),
+                                       "flop_per_gpu": [r["flop_subtrees"] + r["flop_top"] for r in ranks8],
+                                       "note": "splpak_mplan_* distribute the nested-dissection factorisation: a subtree per GPU, the 7 fronts above "
+                                               "them by block columns (host-only partition, splpak_debug_nd_partition; this pool has one GPU per box: "
+                                               "rehearsed at 24^4 on 4 virtual GPUs in tests/test_dist.py, never run at 32^4)"}}}
 
 
 def bench_c2(capi, dev, stream, steps):
@@ -560,12 +577,13 @@ def main():
     # fabric bytes of the evaluation passes: PMC passes of an earlier run of the same workload, kept under profiles/ --
     # NOT measured in this run
     eval_traffic = None
+    eval_pmc = committed_profile("r04_eval_pmc.json", "r03_eval_pmc.json")
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_eval_pmc.json")))["3d_64"]
+        pm = json.load(open(eval_pmc))["3d_64"]
         eval_traffic = {"kernel": "eval_runs_kernel<3,true> (evaluation pass; all passes in bytes_per_query_all_passes)", "bytes_per_launch": next(v for k, v in pm["kernels"].items() if k.startswith(("eval_runs_kernel<3, true", "eval_binned_kernel<3, true")))["hbm_bytes"],
                         "queries_per_launch": pm["queries_per_launch"],
                         "bytes_per_query_all_passes": pm["hbm_bytes_per_query_all_passes"], "algorithmic_bytes_per_query": 8.0 * (nd + 1),
-                        "source": "profiles/r03_eval_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload; not measured in this run)"}
+                        "source": os.path.relpath(eval_pmc, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload; not measured in this run)"}
     except Exception:
         pass
     dist_leg = None
@@ -629,8 +647,15 @@ def main():
                 "direct_path_evals_per_s": world * nq / (ev_direct_ms * 1e-3),
                 "roofline": {"bound": "hbm", "achieved": ev_bytes / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": ev_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": eval_traffic},
+                             # scalars (the driver's parser keeps scalars only): HBM bytes per query over ALL passes, by the counters
+                             "traffic": (eval_traffic or {}).get("bytes_per_query_all_passes"),
+                             "algorithmic_bytes_per_query": 8.0 * (nd + 1),
+                             "traffic_source": (eval_traffic or {}).get("source"),
+                             "traffic_detail": eval_traffic},
             },
+            # the evaluation half of the headline metric as scalars of the line itself
+            "eval_roofline_frac": ev_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "eval_hbm_bytes_per_query": (eval_traffic or {}).get("bytes_per_query_all_passes"),
         }
         if stages["bin_ms"] > 0:
             # the HBM-bound stages around the factorisation: algorithmic bytes (8*(d+1+[weighted]) per point
@@ -652,7 +677,11 @@ def main():
             }
             if fact_code == 4:
                 fbytes = capi.debug_nd_tree(nodes, check=False)["factor_bytes"]
-                line["assembly"]["factor-arena memset + front assembly"] = hbm(8.0 * ncol * hst + fbytes, stages["expand_ms"])
+                # (no bandwidth figure for this stage: most of the arena is cleared on a second stream BESIDE the binning and the
+                #  Gram stage -- nd_prefit -- so the stamped interval holds only the head of the arena and the scatter of the
+                #  half stencil into the fronts; round 3 divided the whole arena's bytes by it and reported 1.07 of the HBM peak)
+                line["assembly"]["front assembly (+ clearing the head of the factor arena)"] = {
+                    "ms": stages["expand_ms"], "stencil_GB": 8.0 * ncol * hst / 1e9, "arena_GB_cleared_beside_the_assembly": fbytes / 1e9}
                 line["assembly"]["one solve (forward + backward tree sweep)"] = hbm(2 * fbytes, stages["solve_ms"])
             else:
                 line["assembly"]["band memset + expansion"] = hbm(8.0 * ncol * hst + 8.0 * ncol * ldband, stages["expand_ms"])
@@ -663,8 +692,8 @@ def main():
             # fabric bytes per launch of the roofline kernel: PMC passes of an earlier run of the same workload, kept
             # under profiles/ -- NOT measured in this run (counters and kernel timing do not share a run)
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r03_fit_pmc.json" if nd_path else "r02_fit_pmc.json")
-            if nd == 3 and nod == 64 and os.path.exists(pmc):
+            pmc = committed_profile("r04_fit_pmc.json", "r03_fit_pmc.json") if nd_path else committed_profile("r02_fit_pmc.json")
+            if nd == 3 and nod == 64 and pmc:
                 try:
                     pj = json.load(open(pmc))
                     traffic = {"hbm_bytes_per_launch": pj.get("schur_hbm_bytes_per_launch" if nd_path else "bulk_hbm_bytes_per_launch"),
@@ -678,7 +707,12 @@ def main():
                            "v_mfma_f64_16x16x4_f64; one launch at a time per tree depth and block group)") if nd_path else
                           "syrk64_kernel<16,1,4,256> (bulk trailing update C -= P P^T of the band Cholesky, v_mfma_f64_16x16x4_f64; one launch per block step)",
                 "bound": "mfma", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "frac": ach / F64_MFMA_PEAK_TFLOPS,
+                # scalars (the driver's parser keeps scalars only): HBM / fabric bytes per launch by the PMC counters of a
+                # separate run of the same workload, beside the algorithmic bytes of the tiles
+                "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+                "algorithmic_bytes_per_launch": (traffic or {}).get("algorithmic_bytes_per_launch"),
+                "traffic_source": (traffic or {}).get("source"),
                 "timed_launches": kt_sum["syrk_launches"], "launches": kt_sum["bulk_launches"],
                 "timing": "HIP start/stop event pair carried by every launch of this kernel inside the timed region (hipExtLaunchKernelGGL, on the launch stream)",
                 "avg_launch_ms": kt_sum["syrk_ms"] / max(kt_sum["syrk_launches"], 1),
@@ -690,11 +724,11 @@ def main():
             }
             if kt_alone is not None and kt_alone["syrk_ms"] > 0:
                 al = kt_alone["syrk_flop"] / (kt_alone["syrk_ms"] * 1e-3) / 1e12
-                line["roofline"]["kernel_alone"] = {
-                    "achieved": al, "frac": al / F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": kt_alone["syrk_launches"],
-                    "factor_ms": kt_alone["factor_ms"],
-                    "what": "the same launches in one extra fit outside the timed region with the whole factorisation on ONE stream "
-                            "(SPLPAK_NO_LOOKAHEAD=1): every launch has the chip to itself"}
+                line["roofline"]["kernel_alone_tflops"] = al
+                line["roofline"]["kernel_alone_frac"] = al / F64_MFMA_PEAK_TFLOPS
+                line["roofline"]["kernel_alone_factor_ms"] = kt_alone["factor_ms"]
+                line["roofline"]["kernel_alone_what"] = ("the same launches in one extra fit outside the timed region, whole factorisation on "
+                                                         "ONE stream (SPLPAK_NO_LOOKAHEAD=1): every launch has the chip to itself")
             if nd_path:
                 line["roofline"]["note"] = ("the panel updates of the chain (nd_syrk_kernel<4,2,false>, K = 256) and the diagonal-block / panel-solve "
                                             "kernels run beside these launches on other streams and share the CUs with them; "

@@ -181,6 +181,42 @@ __host__ __device__ inline int window_start_value(const Grid &g, int d, double x
     return a < nod - 4 ? a : nod - 4;
 }
 
+// The four values of an INTERIOR window in closed form (round 4).  With t = dxin (x - xmin), it = trunc(t) and u = t - it in
+// [0, 1) the window functions are those of the nodes it-1 .. it+2 at distances 1+u, u, 1-u, 2-u (in units of dx), and the
+// chapeau function (:253-270) is (2-z)^3/4 on [1, 2) and (2-z)^3/4 - (1-z)^3 on [0, 1):
+//     b0 = (1-u)^3/4,   b1 = (2-u)^3/4 - (1-u)^3,   b2 = (1+u)^3/4 - u^3,   b3 = u^3/4
+// 16 operations instead of the 56 of four separate evaluations (each with its own node coordinate, distance, two clamps and
+// two cubes).  The values differ from those by rounding only (both carry the ~1e-14 that dxin (x - x_node) loses at 64 nodes);
+// which form a query gets depends on the query alone (interior window in this dimension or not), never on the wave it is
+// evaluated in, so every evaluation path still returns the same bits for the same query.
+__host__ __device__ inline void window_values_interior(double u, double b[4])
+{
+    const double v = 1.0 - u, p = 2.0 - u, q = 1.0 + u;
+    const double v3 = v * v * v, u3 = u * u * u, p3 = p * p * p, q3 = q * q * q;
+    b[0] = 0.25 * v3;
+    b[1] = fma(0.25, p3, -v3);
+    b[2] = fma(0.25, q3, -u3);
+    b[3] = 0.25 * u3;
+}
+
+// window start, whether the window is an interior one, and the fractional position u of x in its cell (interior windows)
+__host__ __device__ inline int window_start_frac(const Grid &g, int d, double x, int &lo, int &hi, bool &interior, double &u)
+{
+#pragma clang fp contract(off)
+    const int nod = g.nodes[d];
+    const double t = g.dxin[d] * (x - g.xmin[d]);
+    int it = (t >= 2.0e9) ? 2000000000 : (t <= -2.0e9 ? -2000000000 : (int)t);
+    u = t - (double)it;
+    int a = it - 1;
+    if (a < 0) a = 0;
+    lo = a < nod - 2 ? a : nod - 2;
+    int h = it + 2;
+    if (h > nod - 1) h = nod - 1;
+    hi = h > 1 ? h : 1;
+    interior = it >= 3 && it <= nod - 5;
+    return a < nod - 4 ? a : nod - 4;
+}
+
 template <bool INTERIOR>
 __host__ __device__ inline void window_values(const Grid &g, int d, double x, int ws, int lo, int hi, double b[4])
 {

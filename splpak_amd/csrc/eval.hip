@@ -79,12 +79,18 @@ __device__ inline int eval_table(const Grid &g, int d, double x, int nder, doubl
     if constexpr (VAL) {
         int lo, hi;
         bool interior;
-        const int ws = window_start_value(g, d, x, lo, hi, interior);
-        // wave-uniform choice: the short interior form when EVERY lane's window is an interior one
-        // (queries sorted by region: most waves), the general form for all lanes otherwise -- no
-        // wave ever executes both
-        if (__builtin_amdgcn_ballot_w64(!interior) == 0) window_values<true>(g, d, x, ws, lo, hi, b);
-        else window_values<false>(g, d, x, ws, lo, hi, b);
+        double u;
+        const int ws = window_start_frac(g, d, x, lo, hi, interior, u);
+        // every lane computes the closed form of an interior window (16 operations); a wave that holds queries whose window
+        // in this dimension is NOT interior (end functions, clipped windows: the first / last three cells) also computes the
+        // general form and those lanes take it.  Which form a query gets depends on the query alone.
+        window_values_interior(u, b);
+        if (__builtin_amdgcn_ballot_w64(!interior) != 0) {
+            double bg[4];
+            window_values<false>(g, d, x, ws, lo, hi, bg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[k] = interior ? b[k] : bg[k];
+        }
         return ws;
     } else {
         return window_table(g, d, x, nder, b);
@@ -846,6 +852,346 @@ eval_runs_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef, cons
     }
 }
 
+// ---- persistent region path (round 4) ---------------------------------------------------------------------------------
+// The run path above moves every query twice through HBM as a 32-byte record and writes its 8-byte result into a sector that
+// other regions' workgroups fill at other times: 149 B per query by the counters for 32 algorithmic ones.  Here:
+//
+//   pr_place_kernel   a workgroup reads 8 192 queries, bins them by (region, interior or not) in LDS and writes their
+//                     coordinates as D planes in that order (staged through LDS: consecutive stores), their LOCAL indices
+//                     (16 bit) and the starts of the runs.  24 B read, 26 B written per 3-D query.
+//   pr_eval_kernel    PERSISTENT: 8 x nbins workgroups, each claims one (XCD, region) pair, loads the region's coefficient
+//                     tile into LDS ONCE and walks the place-pass workgroups dealt to it.  Every wave is an independent worker
+//                     over its own stream of runs (four in flight, so the lanes the tail of one run leaves idle start the
+//                     next ones: no barrier after the tile load, no prefix, no search), first the interior runs -- every lane
+//                     takes the 16-operation closed form of the basis table -- then the others.  The coordinates of element
+//                     i + 1 are requested before the window of element i is read.  Results go to the SAME sorted places:
+//                     consecutive lanes, consecutive words.  24 B read, 8 B written.
+//   pr_unsort_kernel  per place-pass workgroup: sorted results + local indices -> the caller's order, through LDS.  10 B read,
+//                     8 B written.
+//
+// By construction 100 B of HBM traffic per 3-D query, every byte of it in consecutive runs of at least 200 B.  (The first
+// form of this path sorted only the 16-bit indices and let the evaluation pass gather the coordinates and scatter the results
+// through the L2 of "its" XCD: 60 B by construction, but the windows of 8 192 workers do not stay in a 4 MB L2 -- 108 B
+// fetched and 124 B written per query by the counters, every 8-byte result a read-for-ownership and an eviction of a line.)
+// Arithmetic per query: eval_table + window_sum as everywhere else -- identical bits.  Used for 3-D grids of at most 64 regions
+// of 16 (or 8) window starts per dimension: 64^3 nodes give 4 x 4 x 4 regions with tiles of 19^3 coefficients (55 KB).
+struct PRegions { int nreg[MAXD]; int sper[MAXD]; int text[MAXD]; int tstr[MAXD]; int nbins; int telems; int tcells; };
+
+constexpr int PR_Q = 8192;         // queries per place-pass workgroup (16-bit local indices; half a coordinate plane of them = 32 KB of LDS)
+constexpr int PR_NT = 1024;        // threads of a place-pass workgroup
+constexpr int PR_EW = 640;         // threads of an evaluation workgroup: 10 waves, two workgroups per CU
+constexpr int PR_WPE = 5;          // waves per SIMD the evaluation kernel is compiled for (96 registers; it takes 90)
+constexpr int PR_MAXBINS = 64;
+
+template <int D, typename T>
+__global__ void __launch_bounds__(PR_NT)
+pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int ldxq, unsigned short *__restrict__ sidx,
+                int *__restrict__ starts, T *__restrict__ xs)
+{
+    // bins: 2 per region -- [2 r] the queries whose windows are interior ones in every dimension (closed-form basis table,
+    // eval_table), [2 r + 1] the others (end functions / clipped windows in some dimension): the evaluation pass walks the
+    // interior runs first and the others afterwards, so that its waves are homogeneous (a wave with one non-interior lane
+    // pays the general table for that dimension)
+    constexpr int QPT = PR_Q / PR_NT, NB2 = 2 * PR_MAXBINS, HALF = PR_Q / 2;
+    __shared__ unsigned short ssort[PR_Q];
+    __shared__ T splane[HALF];
+    __shared__ int lcn[NB2], lst[NB2 + 1];
+    __shared__ int wsum[2];
+    __shared__ unsigned char rtab[D][256];         // region index of a window start, per dimension (window starts < 256: host check)
+    const int tid = threadIdx.x;
+    const int nb2 = 2 * rg.nbins;
+    for (int e = tid; e < D * 256; e += PR_NT) {
+        const int d = e >> 8, ws = e & 255;
+        const int rd = ws / rg.sper[d];
+        rtab[d][ws] = (unsigned char)(rd < rg.nreg[d] - 1 ? rd : rg.nreg[d] - 1);
+    }
+    if (tid < NB2) lcn[tid] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * PR_Q;
+    int rid[QPT], rank[QPT];
+    T xr[QPT][D];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        const long long i = base + j * PR_NT + tid;
+        rid[j] = -1;
+        rank[j] = 0;
+        if (i < nq) {
+            int r = 0, m = 1;
+            bool inter = true;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                int lo, hi;
+                bool in_d;
+                xr[j][d] = xq[i * ldxq + d];
+                const int ws = window_start_value(g, d, (double)xr[j][d], lo, hi, in_d);
+                inter = inter && in_d;
+                r += (int)rtab[d][ws] * m;
+                m *= rg.nreg[d];
+            }
+            rid[j] = 2 * r + (inter ? 0 : 1);
+            rank[j] = atomicAdd(&lcn[rid[j]], 1);
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {                               // exclusive scan of the (at most 128) bin counts by two waves
+        const int c = tid < nb2 ? lcn[tid] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if ((tid & 63) >= o) incl += t;
+        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        lcn[tid] = incl - c;                       // (exclusive within the wave; the first wave's total is added below)
+    }
+    __syncthreads();
+    if (tid < 128) lst[tid] = lcn[tid] + (tid >= 64 ? wsum[0] : 0);
+    if (tid == 0) lst[128] = wsum[0] + wsum[1];
+    __syncthreads();
+    // the coordinates go to their sorted places in the workgroup's image (D planes of PR_Q entries: the evaluation pass reads
+    // them with consecutive lanes on consecutive entries), half a plane at a time through LDS so that the stores are
+    // consecutive (straight scattered 8-byte stores into the image: 1.03 ms per 5e7 queries instead of 0.25 without them)
+    int lp[QPT];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        lp[j] = -1;
+        if (rid[j] >= 0) {
+            lp[j] = lst[rid[j]] + rank[j];
+            ssort[lp[j]] = (unsigned short)(j * PR_NT + tid);
+        }
+    }
+    const int total = lst[nb2 < 128 ? nb2 : 128];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        T *__restrict__ dstp = xs + ((long long)blockIdx.x * D + d) * PR_Q;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (d + hf > 0) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) {
+                const int l = lp[j] - hf * HALF;
+                if (lp[j] >= 0 && l >= 0 && l < HALF) splane[l] = xr[j][d];
+            }
+            __syncthreads();
+            for (int e = tid; e < HALF && hf * HALF + e < total; e += PR_NT) dstp[hf * HALF + e] = splane[e];
+        }
+    }
+    if (tid <= nb2) starts[(long long)blockIdx.x * (nb2 + 1) + tid] = lst[tid];
+    unsigned *__restrict__ dst = reinterpret_cast<unsigned *>(sidx + base);
+    for (int e = tid; 2 * e < total; e += PR_NT) {
+        const unsigned lo = ssort[2 * e], hi = 2 * e + 1 < total ? ssort[2 * e + 1] : 0u;
+        dst[e] = lo | (hi << 16);
+    }
+}
+
+template <int D, int SPER> struct PTile {            // tile of a region: SPER window starts + 3 per dimension, compile-time LDS strides
+    static constexpr int TE = SPER + 3;
+    static constexpr int S1 = TE | 1;                // odd row stride: the window rows of a lane spread over the LDS banks
+    static constexpr int S2 = S1 * TE + 1;
+    static constexpr int S3 = S2 * TE + 1;
+    static constexpr int stride(int d) { return d == 0 ? 1 : (d == 1 ? S1 : (d == 2 ? S2 : S3)); }
+    static constexpr int ELEMS = (D == 1 ? TE : (D == 2 ? S1 * TE : (D == 3 ? S2 * TE : S3 * TE))) + 8;
+};
+
+template <int D, int SPER, bool VAL, typename T>
+__global__ void __launch_bounds__(PR_EW, PR_WPE)
+pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const T *__restrict__ xs,
+               const int *__restrict__ starts, int nwg, int *__restrict__ claim, T *__restrict__ outs)
+{
+    using PT = PTile<D, SPER>;
+    __shared__ double pr_tile[PT::ELEMS];
+    __shared__ int s_claim[2];
+    constexpr int NW = PR_EW / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const int x0 = (int)(xcc & 7u);
+        int r = -1, xx = x0;
+        for (int y = 0; y < 8 && r < 0; ++y) {       // the next unclaimed region of my XCD; of another one if mine are all taken
+            xx = (x0 + y) & 7;
+            const int sl = atomicAdd(&claim[xx], 1);
+            if (sl < rg.nbins) r = sl;
+        }
+        s_claim[0] = xx;
+        s_claim[1] = r;
+    }
+    __syncthreads();
+    const int xcd = __builtin_amdgcn_readfirstlane(s_claim[0]), r = __builtin_amdgcn_readfirstlane(s_claim[1]);
+    if (r < 0) return;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int a[D];                                        // first node of the region's tile
+    {
+        int rr = r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            a[d] = (rr % rg.nreg[d]) * rg.sper[d];
+            rr /= rg.nreg[d];
+        }
+    }
+    for (int e = tid; e < rg.tcells; e += PR_EW) {
+        int rem = e, idx = 0, te = 0;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int l = rem % rg.text[d];
+            rem /= rg.text[d];
+            const int node = a[d] + l;
+            ok = ok && node < g.nodes[d];
+            idx += node * g.colstride[d];
+            te += l * PT::stride(d);
+        }
+        pr_tile[te] = ok ? (double)coef[idx] : 0.0;
+    }
+    __syncthreads();
+    constexpr int t1 = D > 1 ? PT::S1 : 0, t2 = D > 2 ? PT::S2 : 0, t3 = D > 3 ? PT::S3 : 0;
+    // This wave's stream: the region's runs of the place-pass workgroups w = xcd NW + wave, + 8 NW, ...  -- first their
+    // INTERIOR runs (every lane takes the closed form of the basis table), then the others.  NR runs are in flight, so that
+    // the lanes the tail of one run leaves idle start the next ones (the runs of the second phase hold ~24 queries each).
+    constexpr int NR = 4;
+    const int nb1 = 2 * rg.nbins + 1, wstep = 8 * NW;
+    for (int phase = 0; phase < 2; ++phase) {
+        const int col = 2 * r + phase;
+        int wf = xcd * NW + wave;                    // place-pass workgroup of run 0
+        int rst[NR], rlen[NR];
+        int qa = 0, qb = 0;                          // the run after the last one in flight, as loaded (made uniform when it moves up)
+        auto fetch_run = [&](int w, int &fa, int &fb) {
+            fa = 0;
+            fb = 0;
+            if (w < nwg) {
+                const int *__restrict__ row = starts + (long long)w * nb1 + col;
+                fa = row[0];
+                fb = row[1];
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            int fa, fb;
+            fetch_run(wf + j * wstep, fa, fb);
+            rst[j] = __builtin_amdgcn_readfirstlane(fa);
+            rlen[j] = __builtin_amdgcn_readfirstlane(fb) - rst[j];
+        }
+        fetch_run(wf + NR * wstep, qa, qb);
+        int pos = lane;                              // this lane's next element of the stream, relative to the start of run 0
+        // locates the lane's next element (drops the runs every lane has passed) and requests its coordinates
+        auto next_element = [&](bool &act, long long &oq, T (&xn)[D]) {
+            while (wf < nwg && __builtin_amdgcn_ballot_w64(pos < rlen[0]) == 0) {
+                pos -= rlen[0];
+#pragma unroll
+                for (int j = 0; j + 1 < NR; ++j) { rst[j] = rst[j + 1]; rlen[j] = rlen[j + 1]; }
+                rst[NR - 1] = __builtin_amdgcn_readfirstlane(qa);
+                rlen[NR - 1] = __builtin_amdgcn_readfirstlane(qb) - rst[NR - 1];
+                wf += wstep;
+                fetch_run(wf + NR * wstep, qa, qb);
+            }
+            act = false;
+            int off = 0, wsel = 0, rel = pos;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const bool here = !act && rel < rlen[j];
+                if (here) { off = rst[j] + rel; wsel = j; }
+                act = act || here;
+                rel -= rlen[j];
+            }
+            if (act) {
+                const int wa = wf + wsel * wstep;
+                oq = (long long)wa * PR_Q + off;
+#pragma unroll
+                for (int d = 0; d < D; ++d) xn[d] = xs[((long long)wa * D + d) * PR_Q + off];
+                pos += 64;
+            }
+        };
+        // the coordinates of element i + 1 are requested between the basis tables and the window sum of element i: they
+        // arrive while the window is read from LDS (without this the two memory round trips and the LDS phase of a wave simply
+        // added up: 0.5 + 0.5 ms of a 1.2 ms pass per 5e7 queries, measured by leaving either out)
+        bool act = false;
+        long long oq = 0;
+        T xc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xc[d] = (T)0;
+        next_element(act, oq, xc);
+        while (__builtin_amdgcn_ballot_w64(act) != 0) {
+            double b[D][4];
+            int base = 0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int ws = eval_table<VAL>(g, d, (double)xc[d], nd.v[d], b[d]);
+                base += (ws - a[d]) * PT::stride(d);
+            }
+            if (!act) base = 0;
+            const bool act_c = act;
+            const long long oq_c = oq;
+            next_element(act, oq, xc);
+            double sum;
+            if constexpr (D == 3) {
+                // window_sum<3> with the LDS reads written as inline assembly, one k2 plane (16 reads, 32 registers) at a time:
+                // left to the compiler, all 64 reads of a window are issued up front (128 registers: 2 waves per SIMD, or
+                // spills), and behind a function call the coordinates requested above would be waited for at the call (the
+                // compiler drains every counter there).  Same operations in the same order as window_sum<3>: identical bits.
+                const unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) double *)pr_tile + (unsigned)base * 8u;
+                sum = 0.0;
+                // (the reads need the window starts only and would move above the basis tables, which then spill: the first
+                //  read names the tables as operands it does not use)
+                asm volatile("; tables ready %0 %1 %2 %3 %4 %5" :: "v"(b[0][0]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][3]));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    double c[4][4];
+                    // (the first read of a plane names the running sum as an operand it does not use: the multiply-adds of the
+                    //  plane before stay in front of it)
+                    asm volatile("ds_read_b64 %0, %1 offset:%2 ; after %3" : "=v"(c[0][0]) : "v"(la), "n"((k2 * t2) * 8), "v"(sum));
+#pragma unroll
+                    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+                        for (int k0 = (k1 == 0 ? 1 : 0); k0 < 4; ++k0)
+                            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c[k1][k0]) : "v"(la), "n"((k1 * t1 + k2 * t2 + k0) * 8));
+                    // (the sixteen values pass through the wait as in/out operands: what uses them stays behind it)
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[0][2]), "+v"(c[0][3]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[1][2]), "+v"(c[1][3]),
+                                   "+v"(c[2][0]), "+v"(c[2][1]), "+v"(c[2][2]), "+v"(c[2][3]), "+v"(c[3][0]), "+v"(c[3][1]), "+v"(c[3][2]), "+v"(c[3][3])
+                                 :: "memory");
+                    double rr = 0.0;
+#pragma unroll
+                    for (int k1 = 0; k1 < 4; ++k1) {
+                        double t = c[k1][0] * b[0][0];
+                        t = fma(c[k1][1], b[0][1], t);
+                        t = fma(c[k1][2], b[0][2], t);
+                        t = fma(c[k1][3], b[0][3], t);
+                        rr = fma(t, b[1][k1], rr);
+                    }
+                    sum = fma(rr, b[2][k2], sum);
+                    __builtin_amdgcn_sched_barrier(0);          // (the multiply-adds of a plane stay in front of the next plane's reads)
+                }
+            } else {
+                sum = window_sum<D>(b, [&](int k1, int k2, int k3, double (&c)[4]) {
+                    typedef const volatile __attribute__((address_space(3))) double *lds_cvd;
+                    lds_cvd qq = (lds_cvd)pr_tile + (base + k1 * t1 + k2 * t2 + k3 * t3);
+                    c[0] = qq[0]; c[1] = qq[1]; c[2] = qq[2]; c[3] = qq[3];
+                });
+            }
+            if (act_c) outs[oq_c] = (T)sum;
+        }
+    }
+}
+
+// results of a place-pass workgroup's queries, from the sorted order of its image back to the caller's order: staged through
+// LDS, so that both the read and the write are consecutive
+template <typename T>
+__global__ void __launch_bounds__(PR_NT)
+pr_unsort_kernel(long long nq, const unsigned short *__restrict__ sidx, const int *__restrict__ starts, int nb1, const T *__restrict__ outs,
+                 T *__restrict__ out)
+{
+    __shared__ T lv[PR_Q];
+    const long long base = (long long)blockIdx.x * PR_Q;
+    const int total = starts[(long long)blockIdx.x * nb1 + nb1 - 1];
+    for (int p = threadIdx.x; p < total; p += PR_NT) lv[sidx[base + p]] = outs[base + p];
+    __syncthreads();
+    const long long left = nq - base;
+    const int n = left < PR_Q ? (int)left : PR_Q;
+    // (every query of the workgroup has a region: total == n)
+    for (int j = threadIdx.x; j < n; j += PR_NT) out[base + j] = lv[j];
+}
+
 // pass C of the fused value / gradient / Hessian evaluation (defined with eval_derivs_kernel below)
 template <int D, int ORDER>
 __global__ void eval_derivs_binned_kernel(Grid g, Regions rg, const double *__restrict__ coef, const double *__restrict__ xs,
@@ -886,9 +1232,12 @@ static void run_scratch_shutdown()
     s = RunScratch();
 }
 
+static void pscratch_shutdown();
+
 void eval_scratch_shutdown()
 {
     run_scratch_shutdown();
+    pscratch_shutdown();
     EvalScratch &s = g_scratch;
     if (s.xs) (void)hipFree(s.xs);
     if (s.ints) (void)hipFree(s.ints);
@@ -901,6 +1250,104 @@ void set_eval_mode(int mode, long long chunk)
 {
     g_eval_mode = mode;
     g_eval_chunk = chunk;
+}
+
+// persistent region path: regions of the grid, or false when it does not apply (more than 64 regions / tiles beyond 64 KB)
+template <int D>
+static bool make_pregions(const Grid &g, PRegions &rg, int sper)
+{
+    rg.nbins = 1;
+    rg.tcells = 1;
+    for (int d = 0; d < MAXD; ++d) { rg.nreg[d] = 1; rg.sper[d] = 1; rg.text[d] = 1; rg.tstr[d] = 0; }
+    for (int d = 0; d < D; ++d) {
+        const int S = g.nodes[d] - 3;                // window starts 0 .. nodes - 4
+        if (g.nodes[d] < 8 || S > 256) return false;
+        rg.sper[d] = sper;
+        rg.nreg[d] = (S + sper - 1) / sper;
+        rg.text[d] = sper + 3;
+        rg.nbins *= rg.nreg[d];
+        rg.tcells *= rg.text[d];
+    }
+    rg.telems = 0;
+    return rg.nbins >= 8 && rg.nbins <= PR_MAXBINS;
+}
+
+namespace {
+struct PScratch {
+    unsigned short *sidx = nullptr;
+    int *starts = nullptr, *claim = nullptr;
+    void *xs = nullptr, *outs = nullptr;          // sorted coordinate planes [workgroup][D][PR_Q], sorted results
+    long long cap_q = 0, cap_st = 0, cap_xs = 0;
+    hipEvent_t last = nullptr;
+    int dev = -1;
+};
+thread_local PScratch g_pscratch;
+}  // namespace
+
+static void pscratch_shutdown()
+{
+    PScratch &s = g_pscratch;
+    if (s.sidx) (void)hipFree(s.sidx);
+    if (s.starts) (void)hipFree(s.starts);
+    if (s.claim) (void)hipFree(s.claim);
+    if (s.xs) (void)hipFree(s.xs);
+    if (s.outs) (void)hipFree(s.outs);
+    if (s.last) (void)hipEventDestroy(s.last);
+    s = PScratch();
+}
+
+// persistent region path (see pr_place_kernel); hipErrorNotSupported = not for this grid: take the run path
+template <int D, typename T>
+static hipError_t eval_persistent(const Grid &g, long long nq, const T *xq, int ldxq, const NDeriv &nd, const T *coef, T *out, hipStream_t st)
+{
+    if (std::getenv("SPLPAK_EVAL_NO_PERSISTENT")) return hipErrorNotSupported;
+    // regions of 16 window starts per dimension (tiles of 19^3 = 55 KB: 64^3 nodes give 4 x 4 x 4 regions), of 8 for smaller grids
+    PRegions rg;
+    int sper = 16;
+    if (!make_pregions<D>(g, rg, sper)) {
+        sper = 8;
+        if (!make_pregions<D>(g, rg, sper)) return hipErrorNotSupported;
+    }
+    const long long nwg_ll = (nq + PR_Q - 1) / PR_Q;
+    if (nwg_ll > 0x3fffffffLL / (2 * rg.nbins + 1)) return hipErrorNotSupported;
+    const int nwg = (int)nwg_ll;
+    if (nwg_ll * PR_Q > 0xffffffffLL) return hipErrorNotSupported;          // (32-bit query indices in the evaluation kernel)
+    const long long need_q = nwg_ll * PR_Q, need_st = nwg_ll * (2 * rg.nbins + 1);
+    PScratch &s = g_pscratch;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const long long need_xs = need_q * (D + 1) * (long long)sizeof(T);
+    if (s.dev != dev || s.cap_q < need_q || s.cap_st < need_st || s.cap_xs < need_xs) {
+        pscratch_shutdown();
+        hipError_t e = hipMalloc(&s.sidx, sizeof(unsigned short) * (size_t)need_q);
+        if (e == hipSuccess) e = hipMalloc(&s.starts, sizeof(int) * (size_t)need_st);
+        if (e == hipSuccess) e = hipMalloc(&s.xs, sizeof(T) * (size_t)need_q * D);
+        if (e == hipSuccess) e = hipMalloc(&s.outs, sizeof(T) * (size_t)need_q);
+        if (e == hipSuccess) e = hipMalloc(&s.claim, sizeof(int) * 8);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.last, hipEventDisableTiming);
+        if (e != hipSuccess) { pscratch_shutdown(); (void)hipGetLastError(); return hipErrorNotSupported; }      // (no room: the other paths need less)
+        s.cap_q = need_q;
+        s.cap_st = need_st;
+        s.cap_xs = need_xs;
+        s.dev = dev;
+    } else
+        (void)hipStreamWaitEvent(st, s.last, 0);
+    bool value_only = true;
+    for (int d = 0; d < D; ++d) value_only = value_only && nd.v[d] == 0;
+    hipError_t e = hipMemsetAsync(s.claim, 0, sizeof(int) * 8, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((pr_place_kernel<D, T>), dim3((unsigned)nwg), dim3(PR_NT), 0, st, g, rg, nq, xq, ldxq, s.sidx, s.starts, (T *)s.xs);
+    const dim3 grid(8u * (unsigned)rg.nbins);
+#define PR_GO(SP, VL)                                                                                                                        \
+    hipLaunchKernelGGL((pr_eval_kernel<D, SP, VL, T>), grid, dim3(PR_EW), 0, st, g, rg, nd, coef, (const T *)s.xs, (const int *)s.starts, nwg, \
+                       s.claim, (T *)s.outs)
+    if (sper == 16) { if (value_only) PR_GO(16, true); else PR_GO(16, false); }
+    else { if (value_only) PR_GO(8, true); else PR_GO(8, false); }
+#undef PR_GO
+    hipLaunchKernelGGL((pr_unsort_kernel<T>), dim3((unsigned)nwg), dim3(PR_NT), 0, st, nq, (const unsigned short *)s.sidx, (const int *)s.starts,
+                       2 * rg.nbins + 1, (const T *)s.outs, out);
+    (void)hipEventRecord(s.last, st);
+    return hipGetLastError();
 }
 
 // run path (see run_place_kernel); hipErrorNotSupported = not for this grid / batch, take the region sort
@@ -971,6 +1418,12 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
                               const NDeriv &nd, const T *coef, T *out, hipStream_t st,
                               int order = 0, int ldout = 1)
 {
+    if constexpr (D == 3) {
+        if (order == 0) {
+            const hipError_t e = eval_persistent<D, T>(g, nq, xq, ldxq, nd, coef, out, st);
+            if (e != hipErrorNotSupported) return e;
+        }
+    }
     if constexpr (D >= 3) {
         if (order == 0) {
             const hipError_t e = eval_runs<D, T>(g, rg, nq, xq, ldxq, nd, coef, out, st);
