@@ -580,7 +580,7 @@ def main():
     eval_pmc = committed_profile("r04_eval_pmc.json", "r03_eval_pmc.json")
     try:
         pm = json.load(open(eval_pmc))["3d_64"]
-        eval_traffic = {"kernel": "eval_runs_kernel<3,true> (evaluation pass; all passes in bytes_per_query_all_passes)", "bytes_per_launch": next(v for k, v in pm["kernels"].items() if k.startswith(("eval_runs_kernel<3, true", "eval_binned_kernel<3, true")))["hbm_bytes"],
+        eval_traffic = {"kernel": "pr_eval_kernel<3,16,true,double> (evaluation pass of the persistent region path; all three passes in bytes_per_query_all_passes)", "bytes_per_launch": next(v for k, v in pm["kernels"].items() if k.startswith(("pr_eval_kernel<3", "eval_runs_kernel<3, true", "eval_binned_kernel<3, true")))["hbm_bytes"],
                         "queries_per_launch": pm["queries_per_launch"],
                         "bytes_per_query_all_passes": pm["hbm_bytes_per_query_all_passes"], "algorithmic_bytes_per_query": 8.0 * (nd + 1),
                         "source": os.path.relpath(eval_pmc, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload; not measured in this run)"}
@@ -643,7 +643,7 @@ def main():
             "evals_per_s": evals_per_s,
             "eval": {
                 "value": evals_per_s, "unit": "evals/s", "queries_per_gpu": nq, "ms_per_batch": ev_ms,
-                "path": "auto (LDS-binned: queries sorted by grid region -- count, place, evaluate from LDS tiles)",
+                "path": "auto (3-D: persistent region path -- place pass, persistent per-region workers with the tile in LDS, unsort pass)",
                 "direct_path_evals_per_s": world * nq / (ev_direct_ms * 1e-3),
                 "roofline": {"bound": "hbm", "achieved": ev_bytes / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": ev_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
