@@ -996,7 +996,7 @@ template <int D, int SPER> struct PTile {            // tile of a region: SPER w
 template <int D, int SPER, bool VAL, typename T>
 __global__ void __launch_bounds__(PR_EW, PR_WPE)
 pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const T *__restrict__ xs,
-               const int *__restrict__ starts, int nwg, int *__restrict__ claim, T *__restrict__ outs)
+               const int *__restrict__ starts, int nwg_all, int *__restrict__ claim, T *__restrict__ outs)
 {
     using PT = PTile<D, SPER>;
     __shared__ double pr_tile[PT::ELEMS];
@@ -1049,20 +1049,24 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
     // INTERIOR runs (every lane takes the closed form of the basis table), then the others.  NR runs are in flight, so that
     // the lanes the tail of one run leaves idle start the next ones (the runs of the second phase hold ~24 queries each).
     constexpr int NR = 4;
-    const int nb1 = 2 * rg.nbins + 1, wstep = 8 * NW;
+    const int nb1 = 2 * rg.nbins + 1, wstep = 1;
+    // (a wave walks a CONTIGUOUS range of place-pass workgroups: its next run lies 196 KB further in the coordinate planes,
+    //  not 25 MB as with the ranges interleaved over the waves)
+    const int wper = (nwg_all + 8 * NW - 1) / (8 * NW);
+    const int wbeg = (xcd * NW + wave) * wper;
+    const int nwg = wbeg + wper < nwg_all ? wbeg + wper : nwg_all;
     for (int phase = 0; phase < 2; ++phase) {
         const int col = 2 * r + phase;
-        int wf = xcd * NW + wave;                    // place-pass workgroup of run 0
+        int wf = wbeg;                               // place-pass workgroup of run 0
         int rst[NR], rlen[NR];
         int qa = 0, qb = 0;                          // the run after the last one in flight, as loaded (made uniform when it moves up)
+        // (a VECTOR load, lanes 0 and 1 fetching the two words: as a scalar load -- the address is uniform -- it counts on
+        //  lgkmcnt, and the lgkmcnt(0) waits of the window reads then wait for IT: a trip to L2 in front of every window)
         auto fetch_run = [&](int w, int &fa, int &fb) {
-            fa = 0;
-            fb = 0;
-            if (w < nwg) {
-                const int *__restrict__ row = starts + (long long)w * nb1 + col;
-                fa = row[0];
-                fb = row[1];
-            }
+            int v = 0;
+            if (w < nwg) v = starts[(long long)w * nb1 + col + (lane & 1)];
+            fa = __builtin_amdgcn_readlane(v, 0);
+            fb = __builtin_amdgcn_readlane(v, 1);
         };
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
@@ -1338,6 +1342,11 @@ static hipError_t eval_persistent(const Grid &g, long long nq, const T *xq, int 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((pr_place_kernel<D, T>), dim3((unsigned)nwg), dim3(PR_NT), 0, st, g, rg, nq, xq, ldxq, s.sidx, s.starts, (T *)s.xs);
     const dim3 grid(8u * (unsigned)rg.nbins);
+    if (std::getenv("SPLPAK_DEBUG")) {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)pr_eval_kernel<D, 16, true, T>, PR_EW, 0);
+        fprintf(stderr, "[splpak] persistent evaluation: %d regions, %u workgroups of %d threads, %d resident per CU\n", rg.nbins, grid.x, PR_EW, nb);
+    }
 #define PR_GO(SP, VL)                                                                                                                        \
     hipLaunchKernelGGL((pr_eval_kernel<D, SP, VL, T>), grid, dim3(PR_EW), 0, st, g, rg, nd, coef, (const T *)s.xs, (const int *)s.starts, nwg, \
                        s.claim, (T *)s.outs)
