@@ -185,12 +185,15 @@ int32_t splpak_plan_factorisation(const splpak_plan *plan, char *buf, int32_t bu
 
 /* Per-kernel accounting of the last splpak_plan_fit_dev call, measured with HIP
  * events on the stream the kernels ran on (bench.py's roofline object).  Every BULK
- * trailing-update launch (syrk64_kernel, f64 MFMA; one bulk launch per block step carries
- * ~96 % of the factorisation's flops, the small block-column pieces are a separate
- * instantiation) carries a start/stop event pair in its dispatch (hipExtLaunchKernelGGL):
+ * trailing-update launch carries a start/stop event pair in its dispatch (hipExtLaunchKernelGGL).
+ * "Bulk" is, for the nested-dissection factorisation, every Schur-buffer pass of the fronts
+ * (nd_syrk_kernel<4,2,true,..>, f64 MFMA, K up to 1024 per pass: ~73 % of the factorisation's flops at
+ * 64^3; the panel updates of the chain are the instantiation <..,false,..>); for the band factorisation
+ * the one launch per block step that updates the block columns beyond the next one (syrk64_kernel,
+ * ~96 % of the flops):
  *   out[0] = number of timed bulk launches
  *   out[1] = total milliseconds in them
- *   out[2] = floating-point operations they performed (algorithmic: 2*64*64*256 per 64x64 item)
+ *   out[2] = floating-point operations they performed (algorithmic: 2*64*64*K per 64x64 item)
  *   out[3] = milliseconds in the whole factorisation
  *   out[4] = floating-point operations of ALL trailing-update launches
  *   out[5] = number of bulk launches, out[6] = their floating-point operations

@@ -3,8 +3,13 @@
 SURVEY.md section 8e: data points are independent rows, so the fit shards by points.
 Every rank bins and assembles ITS points; the nearest-node histogram, then the normal
 equations (half-stencil + right-hand side), then each refinement residual are
-sum-all-reduced (RCCL over xGMI = torch.distributed backend "nccl" on ROCm); the band
-Cholesky is replicated.  Evaluation shards the queries and needs no collective.
+sum-all-reduced (RCCL over xGMI = torch.distributed backend "nccl" on ROCm).  The Cholesky of
+the normal equations: with a hook that accepts any device pointer (make_allreduce's does) the
+nested-dissection factorisation is distributed by subtrees -- a rank eliminates its own, their
+Schur complements are summed through the same hook, the top of the tree and all memory are
+replicated (route (a)); band-path grids and two-argument hooks: the
+factorisation is replicated.  The route whose MEMORY is partitioned is the one-process multi-GPU
+plan (capi.MultiPlan).  Evaluation shards the queries and needs no collective.
 
 The reduction buffers live in ONE torch tensor (`comm`) that is handed to the plan at
 creation; the HIP library calls back with a pointer into it and this module all-reduces

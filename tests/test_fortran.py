@@ -140,3 +140,18 @@ def test_fortran_program_on_gpu(prog):
         got = float(re.search(r"reserr =\s*(\S+)", r.stdout).group(1))
         assert e0 == 0 and abs(got - P.last_reserr) <= 1e-9 * P.last_reserr, (got, P.last_reserr)
         assert "2-GPU vs 1-GPU coefficients" in r.stdout
+
+
+@pytest.mark.gpu
+def test_fortran_set_gpus_reaches_the_distributed_nested_dissection():
+    """what a Fortran caller reaches through `call solver%set_gpus(n)` (splpak_fit_multi_f64) factors through
+    the nested-dissection tree, distributed over the GPUs, whenever the single-GPU fit of the grid would (forced here with
+    SPLPAK_ND=1 on test_info's 16 x 16 grid; by default from 4 096 columns on).  The program itself checks the 2-GPU fit
+    against the 1-GPU fit at 1e-12; the library's debug line shows which factorisation ran."""
+    _ensure_built()
+    env = dict(os.environ, SPLPAK_VIRTUAL_GPUS="1", SPLPAK_ND="1", SPLPAK_DEBUG="1")
+    r = subprocess.run([os.path.join(BUILD, "test_info")], capture_output=True, text=True, timeout=300, env=env)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0 and "PASS test_info" in r.stdout
+    assert "one rank of a multi-GPU fit" in r.stderr
+    assert "2-GPU vs 1-GPU coefficients" in r.stdout
