@@ -393,7 +393,8 @@ def _mplan_fit(inp, ngpus, shard, coef_dev=None):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,ngpus,chunk", [("3d12", 2, 1), ("3d16", 2, 1), ("3d16", 3, 1), ("3d16", 4, 2), ("3d16", 8, 1),
-                                              ("2d64_c2grid", 4, 1), ("2d64_c2grid", 8, 1), ("3d8_cc_clust", 2, 1)])
+                                              ("2d64_c2grid", 4, 1), ("2d64_c2grid", 8, 1), ("3d8_cc_clust", 2, 1),
+                                              ("2d16", 8, 1), ("2d16_sparse", 3, 1), ("3d_aniso", 6, 1)])     # more ranks than subtrees (a tree of 4 leaves on 8 ranks), odd rank counts
 def test_multi_gpu_nested_dissection_is_bitwise_the_single_gpu_fit(name, ngpus, chunk, monkeypatch):
     """splpak_mplan_* (what Fortran's set_gpus reaches) factor through the nested-dissection tree -- every rank
     stores and eliminates only its subtrees, the fronts above are distributed by block columns with peer-copied panels and
@@ -518,10 +519,12 @@ def _single_and_multi(nd, nodes, m, R, weighted=True, xtrap=1.0, shard=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nd,nodes,m,R", [(3, [32] * 3, 300000, 4), (3, [24, 40, 24], 200000, 3), (2, [150, 130], 200000, 8)])
+@pytest.mark.parametrize("nd,nodes,m,R", [(3, [32] * 3, 300000, 4), (3, [24, 40, 24], 200000, 3), (2, [150, 130], 200000, 8),
+                                          (3, [18] * 3, 60000, 2), (3, [18] * 3, 60000, 3), (2, [66, 70], 50000, 8), (3, [16, 16, 17], 40000, 5)])
 def test_multi_gpu_nested_dissection_medium_grids_bitwise(nd, nodes, m, R, monkeypatch):
     """Grids whose top fronts take many block steps (32^3: root of 12 steps, borders of several blocks; an anisotropic box on
-    THREE ranks; a 2-D grid on eight): nested dissection is the default from 4 096 columns on, also for the multi-GPU plan."""
+    THREE ranks; a 2-D grid on eight; UNBALANCED trees -- 18^3, 66 x 70 -- whose subtrees stop at different depths; five ranks):
+    nested dissection is the default from 4 096 columns on, also for the multi-GPU plan."""
     monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
     c1, cm, im, i1, code, rb, sb = _single_and_multi(nd, nodes, m, R)
     print(f"{nodes} x{R}: factorisation code {code}; per-rank bytes {[round(b / 1e9, 2) for b in rb]} GB (single-GPU plan {sb / 1e9:.2f} GB); "
