@@ -77,19 +77,29 @@ template <bool VAL>
 __device__ inline int eval_table(const Grid &g, int d, double x, int nder, double (&b)[4])
 {
     if constexpr (VAL) {
-        int lo, hi;
+        int lo, hi, it;
         bool interior;
-        double u;
-        const int ws = window_start_frac(g, d, x, lo, hi, interior, u);
+        double u, t;
+        const int ws = window_start_frac(g, d, x, lo, hi, interior, u, t, it);
         // every lane computes the closed form of an interior window (16 operations); a wave that holds queries whose window
-        // in this dimension is NOT interior (end functions, clipped windows: the first / last three cells) also computes the
-        // general form and those lanes take it.  Which form a query gets depends on the query alone.
+        // in this dimension is NOT interior also computes, for those lanes, the form of a window next to an end of the grid
+        // (the first / last three cells: end functions put into the closed form, window_values_near) and, if it holds
+        // queries OUTSIDE the grid (or the grid has fewer than 8 nodes), the general form for these.  Which form a query
+        // gets depends on the query alone.
         window_values_interior(u, b);
         if (__builtin_amdgcn_ballot_w64(!interior) != 0) {
-            double bg[4];
-            window_values<false>(g, d, x, ws, lo, hi, bg);
+            const int nod = g.nodes[d];
+            const bool near = !interior && nod >= 8 && t >= 0.0 && it <= nod - 2;
+            double bn[4];
+            window_values_near(t, it, nod, b, bn);
+            if (__builtin_amdgcn_ballot_w64(!interior && !near) != 0) {
+                double bg[4];
+                window_values<false>(g, d, x, ws, lo, hi, bg);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) b[k] = interior ? b[k] : bg[k];
+                for (int k = 0; k < 4; ++k) bn[k] = near ? bn[k] : bg[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[k] = interior ? b[k] : bn[k];
         }
         return ws;
     } else {
@@ -859,13 +869,15 @@ eval_runs_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef, cons
 //   pr_place_kernel   a workgroup reads 8 192 queries, bins them by (region, interior or not) in LDS and writes their
 //                     coordinates as D planes in that order (staged through LDS: consecutive stores), their LOCAL indices
 //                     (16 bit) and the starts of the runs.  24 B read, 26 B written per 3-D query.
-//   pr_eval_kernel    PERSISTENT: 8 x nbins workgroups, each claims one (XCD, region) pair, loads the region's coefficient
-//                     tile into LDS ONCE and walks the place-pass workgroups dealt to it.  Every wave is an independent worker
-//                     over its own stream of runs (four in flight, so the lanes the tail of one run leaves idle start the
-//                     next ones: no barrier after the tile load, no prefix, no search), first the interior runs -- every lane
-//                     takes the 16-operation closed form of the basis table -- then the others.  The coordinates of element
-//                     i + 1 are requested before the window of element i is read.  Results go to the SAME sorted places:
-//                     consecutive lanes, consecutive words.  24 B read, 8 B written.
+//   pr_eval_kernel    PERSISTENT: one workgroup of 16 waves per CU.  A workgroup holds the coefficient tile of ONE region in
+//                     LDS; its waves, each an independent worker, take chunks of that region's runs (two levels: the
+//                     workgroup takes superchunks from the region's counter in global memory, its waves take chunks from
+//                     a counter in LDS) and walk them as one stream (four runs in flight, so the lanes the tail of one run
+//                     leaves idle start the next ones: no barrier, no prefix, no search), the boundary runs first, then
+//                     the interior ones, whose lanes all take the 16-operation closed form of the basis table.  When a
+//                     region is used up the workgroup moves to the one with the most work left per workgroup there.
+//                     The coordinates of element i + 1 are requested before the window of element i is read.  Results go
+//                     to the SAME sorted places: consecutive lanes, consecutive words.  24 B read, 8 B written.
 //   pr_unsort_kernel  per place-pass workgroup: sorted results + local indices -> the caller's order, through LDS.  10 B read,
 //                     8 B written.
 //
@@ -879,8 +891,10 @@ struct PRegions { int nreg[MAXD]; int sper[MAXD]; int text[MAXD]; int tstr[MAXD]
 
 constexpr int PR_Q = 8192;         // queries per place-pass workgroup (16-bit local indices; half a coordinate plane of them = 32 KB of LDS)
 constexpr int PR_NT = 1024;        // threads of a place-pass workgroup
-constexpr int PR_EW = 640;         // threads of an evaluation workgroup: 10 waves, two workgroups per CU
-constexpr int PR_WPE = 5;          // waves per SIMD the evaluation kernel is compiled for (96 registers; it takes 90)
+constexpr int PR_EW = 1024;        // threads of an evaluation workgroup: 16 waves = 4 per SIMD, ONE workgroup per CU (two of 640 threads
+                                   // never shared a CU: 10 waves go to the SIMDs as 3,3,2,2 and two such sets can need 6 x 88 registers
+                                   // on one SIMD -- the second workgroup of every CU only started when the first had ended)
+constexpr int PR_WPE = 4;          // waves per SIMD the evaluation kernel is compiled for (128 registers; it takes 88)
 constexpr int PR_MAXBINS = 64;
 
 template <int D, typename T>
@@ -996,31 +1010,67 @@ template <int D, int SPER> struct PTile {            // tile of a region: SPER w
 template <int D, int SPER, bool VAL, typename T>
 __global__ void __launch_bounds__(PR_EW, PR_WPE)
 pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const T *__restrict__ xs,
-               const int *__restrict__ starts, int nwg_all, int *__restrict__ claim, T *__restrict__ outs)
+               const int *__restrict__ starts, int nwg_all, int c0, int *__restrict__ queue, T *__restrict__ outs)
 {
     using PT = PTile<D, SPER>;
     __shared__ double pr_tile[PT::ELEMS];
-    __shared__ int s_claim[2];
-    constexpr int NW = PR_EW / 64;
+    __shared__ int s_region, s_next, s_done, s_base[8], s_ready[8];
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const int x0 = (int)(xcc & 7u);
-        int r = -1, xx = x0;
-        for (int y = 0; y < 8 && r < 0; ++y) {       // the next unclaimed region of my XCD; of another one if mine are all taken
-            xx = (x0 + y) & 7;
-            const int sl = atomicAdd(&claim[xx], 1);
-            if (sl < rg.nbins) r = sl;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int t1 = D > 1 ? PT::S1 : 0, t2 = D > 2 ? PT::S2 : 0, t3 = D > 3 ? PT::S3 : 0;
+    // Work distribution (round 4, third form).  A workgroup holds the tile of ONE region; its waves, each on its own, take
+    // chunks of that region's runs (c0 place-pass workgroups of interior runs, 4 c0 of the others) from the region's counter
+    // until it is used up, then the workgroup moves to the region with the most chunks left per workgroup already there.
+    // Why per wave: the SIMD issues from its oldest wave first, so the waves of a workgroup given equal shares finish one
+    // after the other -- with a workgroup-wide barrier per work item the first wave waited 28-42 % of its life at barriers
+    // (in-kernel clocks) while the last ones ran alone on their SIMDs with nothing to hide their latencies behind.
+    //   queue[r]          chunks of region r taken (may overshoot by one per wave)
+    //   queue[nbins + r]  workgroups at region r
+    const int nbins = rg.nbins;
+    const int c1 = 4 * c0;
+    const int nch0 = (nwg_all + c0 - 1) / c0, nch1 = (nwg_all + c1 - 1) / c1;
+    // lane L of a wave: cost of region L (window starts it covers, those with a boundary window in some dimension 2.5-fold)
+    // and whether it has boundary windows at all (regions without them have no chunks of the second kind)
+    double cost_l = 0.0;
+    bool edge_l = false;
+    if (lane < nbins) {
+        double vol = 1.0, inter = 1.0;
+        int rr = lane;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int rd = rr % rg.nreg[d], S = g.nodes[d] - 3;
+            rr /= rg.nreg[d];
+            const int lo = rd * rg.sper[d], hi = min(S, lo + rg.sper[d]);
+            const int ilo = max(lo, 2), ihi = min(hi, g.nodes[d] - 5);
+            vol *= hi - lo;
+            inter *= max(0, ihi - ilo);
         }
-        s_claim[0] = xx;
-        s_claim[1] = r;
+        cost_l = vol + 1.5 * (vol - inter);
+        edge_l = inter < vol;
+    }
+    const unsigned long long edge_mask = __builtin_amdgcn_ballot_w64(edge_l);
+    if (wave == 0) {
+        // the first region of this workgroup: workgroups are dealt to the regions in proportion to the costs
+        double cum = cost_l;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const double up = __shfl_up(cum, sft);
+            if (lane >= sft) cum += up;
+        }
+        const double total = __shfl(cum, 63);
+        const double target = ((double)blockIdx.x + 0.5) * total / (double)gridDim.x;
+        int r0 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(cum <= target));
+        if (r0 > nbins - 1) r0 = nbins - 1;
+        if (lane == 0) {
+            atomicAdd(queue + nbins + r0, 1);
+            s_region = r0;
+        }
     }
     __syncthreads();
-    const int xcd = __builtin_amdgcn_readfirstlane(s_claim[0]), r = __builtin_amdgcn_readfirstlane(s_claim[1]);
-    if (r < 0) return;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int a[D];                                        // first node of the region's tile
+    int a[D];                                        // first node of the current region's tile
+    for (;;) {
+    const int r = __builtin_amdgcn_readfirstlane(s_region);
+    if (r < 0) break;
     {
         int rr = r;
 #pragma unroll
@@ -1028,77 +1078,135 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
             a[d] = (rr % rg.nreg[d]) * rg.sper[d];
             rr /= rg.nreg[d];
         }
-    }
-    for (int e = tid; e < rg.tcells; e += PR_EW) {
-        int rem = e, idx = 0, te = 0;
-        bool ok = true;
+        for (int e = tid; e < rg.tcells; e += PR_EW) {
+            int rem = e, idx = 0, te = 0;
+            bool ok = true;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int l = rem % rg.text[d];
-            rem /= rg.text[d];
-            const int node = a[d] + l;
-            ok = ok && node < g.nodes[d];
-            idx += node * g.colstride[d];
-            te += l * PT::stride(d);
+            for (int d = 0; d < D; ++d) {
+                const int l = rem % rg.text[d];
+                rem /= rg.text[d];
+                const int node = a[d] + l;
+                ok = ok && node < g.nodes[d];
+                idx += node * g.colstride[d];
+                te += l * PT::stride(d);
+            }
+            pr_tile[te] = ok ? (double)coef[idx] : 0.0;
         }
-        pr_tile[te] = ok ? (double)coef[idx] : 0.0;
+    }
+    constexpr int SC = 16;                           // chunks of a superchunk
+    const int nedge = ((edge_mask >> r) & 1ull) ? nch1 : 0;      // chunks of boundary runs come first
+    const int ntot = nedge + nch0, nsc = (ntot + SC - 1) / SC;
+    if (tid == 0) {
+        const int b0 = atomicAdd(queue + r, 1);
+        s_next = 0;
+        s_done = b0 >= nsc ? 1 : 0;
+        s_base[0] = b0 < nsc ? b0 : -1;
+        s_ready[0] = 1;
+        for (int k = 1; k < 8; ++k) s_ready[k] = 0;
     }
     __syncthreads();
-    constexpr int t1 = D > 1 ? PT::S1 : 0, t2 = D > 2 ? PT::S2 : 0, t3 = D > 3 ? PT::S3 : 0;
-    // This wave's stream: the region's runs of the place-pass workgroups w = xcd NW + wave, + 8 NW, ...  -- first their
-    // INTERIOR runs (every lane takes the closed form of the basis table), then the others.  NR runs are in flight, so that
-    // the lanes the tail of one run leaves idle start the next ones (the runs of the second phase hold ~24 queries each).
     constexpr int NR = 4;
-    const int nb1 = 2 * rg.nbins + 1, wstep = 1;
-    // (a wave walks a CONTIGUOUS range of place-pass workgroups: its next run lies 196 KB further in the coordinate planes,
-    //  not 25 MB as with the ranges interleaved over the waves)
-    const int wper = (nwg_all + 8 * NW - 1) / (8 * NW);
-    const int wbeg = (xcd * NW + wave) * wper;
-    const int nwg = wbeg + wper < nwg_all ? wbeg + wper : nwg_all;
-    for (int phase = 0; phase < 2; ++phase) {
-        const int col = 2 * r + phase;
-        int wf = wbeg;                               // place-pass workgroup of run 0
-        int rst[NR], rlen[NR];
-        int qa = 0, qb = 0;                          // the run after the last one in flight, as loaded (made uniform when it moves up)
-        // (a VECTOR load, lanes 0 and 1 fetching the two words: as a scalar load -- the address is uniform -- it counts on
-        //  lgkmcnt, and the lgkmcnt(0) waits of the window reads then wait for IT: a trip to L2 in front of every window)
-        auto fetch_run = [&](int w, int &fa, int &fb) {
-            int v = 0;
-            if (w < nwg) v = starts[(long long)w * nb1 + col + (lane & 1)];
-            fa = __builtin_amdgcn_readlane(v, 0);
-            fb = __builtin_amdgcn_readlane(v, 1);
-        };
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            int fa, fb;
-            fetch_run(wf + j * wstep, fa, fb);
-            rst[j] = __builtin_amdgcn_readfirstlane(fa);
-            rlen[j] = __builtin_amdgcn_readfirstlane(fb) - rst[j];
+    const int nb1 = 2 * nbins + 1;
+    // A wave's stream of runs goes on across its chunks (the first form drained the lanes and paid two memory round trips
+    // at the start of every chunk: a sixth of a wave's life by the in-kernel clocks).
+    // Chunks are handed out in two levels: the region's counter in global memory counts SUPERCHUNKS of SC chunks (an atomic
+    // add on one address from all XCDs took ~0.4 us of that address's time: with one per chunk and wave the 64 counters were
+    // the bottleneck at 2 place-pass workgroups per chunk and cost 10 us per chunk at 8); inside the workgroup the waves
+    // take chunk numbers from a counter in LDS.  Superchunk k of the workgroup is published (s_base, s_ready = k + 1) by the
+    // wave that took its chunk SC/2 of superchunk k - 1: half a superchunk ahead of its first use.
+    auto take_chunk = [&]() -> int {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&s_next, 1);
+        v = __builtin_amdgcn_readfirstlane(v);
+        const int k = v / SC, o = v % SC;
+        for (;;) {
+            if (__hip_atomic_load(&s_ready[k & 7], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == k + 1) break;
+            if (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return -1;       // (set after every valid superchunk was published)
+            __builtin_amdgcn_s_sleep(4);
         }
-        fetch_run(wf + NR * wstep, qa, qb);
+        const int b = __hip_atomic_load(&s_base[k & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (o == SC / 2) {
+            // this wave publishes superchunk k + 1, whatever happens to its own chunk: the waves that hold numbers of it wait for that
+            int nb = -1;
+            if (b >= 0) {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(queue + r, 1);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t < nsc) nb = t;
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&s_base[(k + 1) & 7], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (nb < 0) __hip_atomic_store(&s_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&s_ready[(k + 1) & 7], k + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (b < 0) return -1;
+        const int c = b * SC + o;
+        return c < ntot ? c : -1;
+    };
+    {
+        bool more = true;
+        int pw = 0, pend = 0, pcol = 0;              // the run whose descriptor is asked for next, the end of its chunk, its column
+        int rst[NR], rlen[NR], rwa[NR];              // runs in flight: first element, length, place-pass workgroup (< 0: none)
+        int qv = 0, qw = -1;                         // the run after them, as loaded (lanes 0 and 1; made uniform when it moves up)
+        // (a VECTOR load, lanes 0 and 1 fetching the two words: as a scalar load -- the address is uniform -- it counts on
+        //  lgkmcnt, and the lgkmcnt(0) waits of the window reads then wait for IT: a trip to L2 in front of every window.
+        //  The loaded register is only looked at when the run moves up, several runs later: reading it into scalars at once
+        //  was a full memory round trip at every run boundary)
+        auto fetch_run = [&](int &v, int &w) {
+            if (pw == pend && more) {
+                const int c = take_chunk();
+                if (c < 0)
+                    more = false;
+                else {
+                    const int ph = c < nedge ? 1 : 0;
+                    pw = ph ? c * c1 : (c - nedge) * c0;
+                    pend = pw + (ph ? c1 : c0);
+                    pend = pend < nwg_all ? pend : nwg_all;
+                    pcol = 2 * r + ph;
+                }
+            }
+            v = 0;
+            w = -1;
+            if (pw < pend) {
+                v = starts[(long long)pw * nb1 + pcol + (lane & 1)];
+                w = pw;
+                ++pw;
+            }
+        };
+        {
+            int fv[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) fetch_run(fv[j], rwa[j]);
+            fetch_run(qv, qw);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                rst[j] = __builtin_amdgcn_readlane(fv[j], 0);
+                rlen[j] = __builtin_amdgcn_readlane(fv[j], 1) - rst[j];
+            }
+        }
         int pos = lane;                              // this lane's next element of the stream, relative to the start of run 0
         // locates the lane's next element (drops the runs every lane has passed) and requests its coordinates
         auto next_element = [&](bool &act, long long &oq, T (&xn)[D]) {
-            while (wf < nwg && __builtin_amdgcn_ballot_w64(pos < rlen[0]) == 0) {
+            while (rwa[0] >= 0 && __builtin_amdgcn_ballot_w64(pos < rlen[0]) == 0) {
                 pos -= rlen[0];
 #pragma unroll
-                for (int j = 0; j + 1 < NR; ++j) { rst[j] = rst[j + 1]; rlen[j] = rlen[j + 1]; }
-                rst[NR - 1] = __builtin_amdgcn_readfirstlane(qa);
-                rlen[NR - 1] = __builtin_amdgcn_readfirstlane(qb) - rst[NR - 1];
-                wf += wstep;
-                fetch_run(wf + NR * wstep, qa, qb);
+                for (int j = 0; j + 1 < NR; ++j) { rst[j] = rst[j + 1]; rlen[j] = rlen[j + 1]; rwa[j] = rwa[j + 1]; }
+                rst[NR - 1] = __builtin_amdgcn_readlane(qv, 0);
+                rlen[NR - 1] = __builtin_amdgcn_readlane(qv, 1) - rst[NR - 1];
+                rwa[NR - 1] = qw;
+                fetch_run(qv, qw);
             }
             act = false;
-            int off = 0, wsel = 0, rel = pos;
+            int off = 0, wa = 0, rel = pos;
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 const bool here = !act && rel < rlen[j];
-                if (here) { off = rst[j] + rel; wsel = j; }
+                if (here) { off = rst[j] + rel; wa = rwa[j]; }
                 act = act || here;
                 rel -= rlen[j];
             }
             if (act) {
-                const int wa = wf + wsel * wstep;
                 oq = (long long)wa * PR_Q + off;
 #pragma unroll
                 for (int d = 0; d < D; ++d) xn[d] = xs[((long long)wa * D + d) * PR_Q + off];
@@ -1175,7 +1283,32 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
             }
             if (act_c) outs[oq_c] = (T)sum;
         }
+    }      // chunks
+    __syncthreads();                                 // every wave is done with the tile
+    if (wave == 0) {
+        // the next region: the one with the most chunks left per workgroup that would then be there
+        int left = 0, there = 0;
+        if (lane < nbins) {
+            const int taken = __hip_atomic_load(queue + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            there = __hip_atomic_load(queue + nbins + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            left = (nch0 + (((edge_mask >> lane) & 1ull) ? nch1 : 0) + SC - 1) / SC - taken;
+        }
+        const float score = left > 0 ? (float)left / (float)(there + 1) : 0.0f;
+        unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned)lane;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const unsigned long long o = __shfl_xor(key, sft);
+            key = o > key ? o : key;
+        }
+        if (lane == 0) {
+            const int rn = (key >> 32) != 0 ? (int)(key & 63u) : -1;
+            atomicSub(queue + nbins + r, 1);
+            if (rn >= 0) atomicAdd(queue + nbins + rn, 1);
+            s_region = rn;
+        }
     }
+    __syncthreads();
+    }      // regions
 }
 
 // results of a place-pass workgroup's queries, from the sorted order of its image back to the caller's order: staged through
@@ -1273,7 +1406,8 @@ static bool make_pregions(const Grid &g, PRegions &rg, int sper)
         rg.tcells *= rg.text[d];
     }
     rg.telems = 0;
-    return rg.nbins >= 8 && rg.nbins <= PR_MAXBINS;
+    if (rg.nbins < 8 || rg.nbins > PR_MAXBINS) return false;
+    return true;
 }
 
 namespace {
@@ -1283,7 +1417,7 @@ struct PScratch {
     void *xs = nullptr, *outs = nullptr;          // sorted coordinate planes [workgroup][D][PR_Q], sorted results
     long long cap_q = 0, cap_st = 0, cap_xs = 0;
     hipEvent_t last = nullptr;
-    int dev = -1;
+    int dev = -1, ncu = 0;
 };
 thread_local PScratch g_pscratch;
 }  // namespace
@@ -1327,7 +1461,7 @@ static hipError_t eval_persistent(const Grid &g, long long nq, const T *xq, int 
         if (e == hipSuccess) e = hipMalloc(&s.starts, sizeof(int) * (size_t)need_st);
         if (e == hipSuccess) e = hipMalloc(&s.xs, sizeof(T) * (size_t)need_q * D);
         if (e == hipSuccess) e = hipMalloc(&s.outs, sizeof(T) * (size_t)need_q);
-        if (e == hipSuccess) e = hipMalloc(&s.claim, sizeof(int) * 8);
+        if (e == hipSuccess) e = hipMalloc(&s.claim, sizeof(int) * 2 * PR_MAXBINS);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.last, hipEventDisableTiming);
         if (e != hipSuccess) { pscratch_shutdown(); (void)hipGetLastError(); return hipErrorNotSupported; }      // (no room: the other paths need less)
         s.cap_q = need_q;
@@ -1338,18 +1472,24 @@ static hipError_t eval_persistent(const Grid &g, long long nq, const T *xq, int 
         (void)hipStreamWaitEvent(st, s.last, 0);
     bool value_only = true;
     for (int d = 0; d < D; ++d) value_only = value_only && nd.v[d] == 0;
-    hipError_t e = hipMemsetAsync(s.claim, 0, sizeof(int) * 8, st);
+    hipError_t e = hipMemsetAsync(s.claim, 0, sizeof(int) * 2 * PR_MAXBINS, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((pr_place_kernel<D, T>), dim3((unsigned)nwg), dim3(PR_NT), 0, st, g, rg, nq, xq, ldxq, s.sidx, s.starts, (T *)s.xs);
-    const dim3 grid(8u * (unsigned)rg.nbins);
-    if (std::getenv("SPLPAK_DEBUG")) {
-        int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)pr_eval_kernel<D, 16, true, T>, PR_EW, 0);
-        fprintf(stderr, "[splpak] persistent evaluation: %d regions, %u workgroups of %d threads, %d resident per CU\n", rg.nbins, grid.x, PR_EW, nb);
+    // persistent workers: one workgroup per CU
+    if (s.ncu <= 0) {
+        int v = 0;
+        s.ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     }
+    const int ncu = s.ncu;
+    const unsigned nworkers = (unsigned)ncu;
+    // (chunks of 4 place-pass workgroups of interior runs, 16 of boundary runs: ~400 queries; the waves of a workgroup take
+    //  them from a counter in LDS, so small chunks cost nothing and keep the tails short)
+    static const int c0_env = std::getenv("SPLPAK_PR_C0") ? atoi(std::getenv("SPLPAK_PR_C0")) : 0;
+    const int c0 = c0_env > 0 ? c0_env : 4;
+    const dim3 grid(nworkers);
 #define PR_GO(SP, VL)                                                                                                                        \
     hipLaunchKernelGGL((pr_eval_kernel<D, SP, VL, T>), grid, dim3(PR_EW), 0, st, g, rg, nd, coef, (const T *)s.xs, (const int *)s.starts, nwg, \
-                       s.claim, (T *)s.outs)
+                       c0, s.claim, (T *)s.outs)
     if (sper == 16) { if (value_only) PR_GO(16, true); else PR_GO(16, false); }
     else { if (value_only) PR_GO(8, true); else PR_GO(8, false); }
 #undef PR_GO

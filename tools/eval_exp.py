@@ -14,14 +14,14 @@ xq = torch.empty((nq, nd), dtype=torch.float64, device=dev)
 out = torch.empty(nq, dtype=torch.float64, device=dev)
 capi.synth_queries_dev(nd, 0, 0, nq, xq, 0)
 capi.set_eval_mode(capi.EVAL_BINNED, 0)
-for _ in range(2):
+for _ in range(20):
     capi.evaluate_dev(nd, xq, None, coef, lo, hi, nodes, out, 0)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(5):
+for _ in range(40):
     capi.evaluate_dev(nd, xq, None, coef, lo, hi, nodes, out, 0)
 e1.record()
 torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 5
+ms = e0.elapsed_time(e1) / 40
 print(f"exp={os.environ.get('SPLPAK_PR_EXP', '0')}: {ms:.3f} ms per {nq} queries = {nq / ms / 1e6:.2f} Gevals/s", flush=True)
