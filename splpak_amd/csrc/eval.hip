@@ -887,7 +887,7 @@ eval_runs_kernel(Grid g, Regions rg, NDeriv nd, const T *__restrict__ coef, cons
 // fetched and 124 B written per query by the counters, every 8-byte result a read-for-ownership and an eviction of a line.)
 // Arithmetic per query: eval_table + window_sum as everywhere else -- identical bits.  Used for 3-D grids of at most 64 regions
 // of 16 (or 8) window starts per dimension: 64^3 nodes give 4 x 4 x 4 regions with tiles of 19^3 coefficients (55 KB).
-struct PRegions { int nreg[MAXD]; int sper[MAXD]; int text[MAXD]; int tstr[MAXD]; int nbins; int telems; int tcells; };
+struct PRegions { int nreg[MAXD]; int sper[MAXD]; int text[MAXD]; int tstr[MAXD]; int nbins; int telems; int tcells; int deal; };
 
 constexpr int PR_Q = 8192;         // queries per place-pass workgroup (16-bit local indices; half a coordinate plane of them = 32 KB of LDS)
 constexpr int PR_NT = 1024;        // threads of a place-pass workgroup
@@ -906,11 +906,27 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
     // eval_table), [2 r + 1] the others (end functions / clipped windows in some dimension): the evaluation pass walks the
     // interior runs first and the others afterwards, so that its waves are homogeneous (a wave with one non-interior lane
     // pays the general table for that dimension)
-    constexpr int QPT = PR_Q / PR_NT, NB2 = 2 * PR_MAXBINS, HALF = PR_Q / 2;
+    // Inside a bin the queries are DEALT by the LDS slot class of their window (the 16-byte slot, mod 16, of the address the
+    // evaluation pass reads the window from: ds_read_b128 serves 16 lanes per cycle from 16 slots): first the first query of
+    // every class, then the second of every class, ... -- neighbouring lanes of the evaluation pass then read from
+    // different slots where a random order has ~3 of 16 lanes on the busiest one (SQ_LDS_BANK_CONFLICT was 70 % of that
+    // pass's LDS cycles, and the LDS its bottleneck).  A query's rank within its (bin, class) is its ROUND; it marks its
+    // class in the round's mask, the rounds' populations (popcounts) are prefixed over bins x rounds, and its place is the
+    // start of its round + the number of classes below its own in that round (class order inside a round: 16 consecutive
+    // queries then straddle two rounds with fewer repeats than in the order the counters would give, 8.4 against 9.8 LDS
+    // cycles per read in a simulation of 64^3).  Ranks beyond JMAX - 1 (clustered queries) share the last round, in counter order.
+    constexpr int QPT = PR_Q / PR_NT, NB2 = 2 * PR_MAXBINS, HALF = PR_Q / 2, NCLS = 16, JMAX = 16, NKEY = NB2 * JMAX;
+    static_assert(NKEY == 2 * PR_NT, "the prefix below gives every thread two (bin, round) counters");
+    constexpr int TAB_BYTES = NB2 * NCLS * 4 + 2 * NKEY * 4;
+    constexpr int SB_BYTES = HALF * (int)sizeof(T) > TAB_BYTES ? HALF * (int)sizeof(T) : TAB_BYTES;
     __shared__ unsigned short ssort[PR_Q];
-    __shared__ T splane[HALF];
-    __shared__ int lcn[NB2], lst[NB2 + 1];
-    __shared__ int wsum[2];
+    __shared__ __attribute__((aligned(16))) unsigned char sbuf[SB_BYTES];      // the counters, then the staging half plane
+    T *splane = reinterpret_cast<T *>(sbuf);
+    int *ccnt = reinterpret_cast<int *>(sbuf);                                   // [bin][class]: queries so far
+    unsigned *dmask = reinterpret_cast<unsigned *>(sbuf + NB2 * NCLS * 4);       // [bin][round]: the classes present (last round: a counter)
+    int *rstart = reinterpret_cast<int *>(sbuf + NB2 * NCLS * 4 + NKEY * 4);     // [bin][round]: where the round starts in the image
+    __shared__ int lst[NB2 + 1];
+    __shared__ int wsum[PR_NT / 64];
     __shared__ unsigned char rtab[D][256];         // region index of a window start, per dimension (window starts < 256: host check)
     const int tid = threadIdx.x;
     const int nb2 = 2 * rg.nbins;
@@ -919,10 +935,10 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
         const int rd = ws / rg.sper[d];
         rtab[d][ws] = (unsigned char)(rd < rg.nreg[d] - 1 ? rd : rg.nreg[d] - 1);
     }
-    if (tid < NB2) lcn[tid] = 0;
+    for (int e = tid; e < TAB_BYTES / 4; e += PR_NT) reinterpret_cast<int *>(sbuf)[e] = 0;
     __syncthreads();
     const long long base = (long long)blockIdx.x * PR_Q;
-    int rid[QPT], rank[QPT];
+    int rid[QPT], rank[QPT];                       // rid: bin * JMAX + round; rank: within the last round, or -1 - class
     T xr[QPT][D];
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
@@ -930,7 +946,7 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
         rid[j] = -1;
         rank[j] = 0;
         if (i < nq) {
-            int r = 0, m = 1;
+            int r = 0, m = 1, tb = 0;
             bool inter = true;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -939,42 +955,64 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
                 xr[j][d] = xq[i * ldxq + d];
                 const int ws = window_start_value(g, d, (double)xr[j][d], lo, hi, in_d);
                 inter = inter && in_d;
-                r += (int)rtab[d][ws] * m;
+                const int rd = (int)rtab[d][ws];
+                r += rd * m;
                 m *= rg.nreg[d];
+                tb += (ws - rd * rg.sper[d]) * rg.tstr[d];          // the window's first entry in the region's tile
             }
-            rid[j] = 2 * r + (inter ? 0 : 1);
-            rank[j] = atomicAdd(&lcn[rid[j]], 1);
+            // (3-D tiles: an odd start reads the second copy of the tile, rg.telems entries further and one entry down)
+            const int ta = (rg.telems > 0 && (tb & 1)) ? rg.telems + tb - 1 : tb;
+            const int cls = rg.telems > 0 ? (ta >> 1) & (NCLS - 1) : tb & (NCLS - 1);
+            const int bin = 2 * r + (inter ? 0 : 1);
+            int round = atomicAdd(&ccnt[bin * NCLS + cls], 1);
+            if (!rg.deal) round = JMAX - 1;
+            if (round < JMAX - 1) {
+                atomicOr(&dmask[bin * JMAX + round], 1u << cls);
+                rid[j] = bin * JMAX + round;
+                rank[j] = -1 - cls;                                  // (place: by the mask)
+            } else {
+                rid[j] = bin * JMAX + JMAX - 1;
+                rank[j] = (int)atomicAdd(&dmask[rid[j]], 1u);        // (place: by this counter)
+            }
         }
     }
     __syncthreads();
-    if (tid < 128) {                               // exclusive scan of the (at most 128) bin counts by two waves
-        const int c = tid < nb2 ? lcn[tid] : 0;
-        int incl = c;
+    {
+        // exclusive prefix over the NKEY = 2 PR_NT (bin, round) counters, in place
+        // (two neighbouring rounds of one bin: the odd one may be the bin's last round, which holds a count, not a mask)
+        const unsigned m0 = dmask[2 * tid], m1 = dmask[2 * tid + 1];
+        const int c0 = __builtin_popcount(m0), c1 = ((2 * tid + 1) % JMAX == JMAX - 1) ? (int)m1 : __builtin_popcount(m1);
+        int incl = c0 + c1;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(incl, o, 64);
             if ((tid & 63) >= o) incl += t;
         }
         if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-        lcn[tid] = incl - c;                       // (exclusive within the wave; the first wave's total is added below)
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < (tid >> 6); ++w) before += wsum[w];
+        const int excl = before + incl - (c0 + c1);
+        rstart[2 * tid] = excl;
+        rstart[2 * tid + 1] = excl + c0;
+        if (tid == PR_NT - 1) lst[NB2] = excl + c0 + c1;
     }
     __syncthreads();
-    if (tid < 128) lst[tid] = lcn[tid] + (tid >= 64 ? wsum[0] : 0);
-    if (tid == 0) lst[128] = wsum[0] + wsum[1];
-    __syncthreads();
-    // the coordinates go to their sorted places in the workgroup's image (D planes of PR_Q entries: the evaluation pass reads
-    // them with consecutive lanes on consecutive entries), half a plane at a time through LDS so that the stores are
-    // consecutive (straight scattered 8-byte stores into the image: 1.03 ms per 5e7 queries instead of 0.25 without them)
+    if (tid < NB2) lst[tid] = rstart[tid * JMAX];
     int lp[QPT];
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
         lp[j] = -1;
         if (rid[j] >= 0) {
-            lp[j] = lst[rid[j]] + rank[j];
+            lp[j] = rstart[rid[j]] + (rank[j] >= 0 ? rank[j] : __builtin_popcount(dmask[rid[j]] & ((1u << (-1 - rank[j])) - 1u)));
             ssort[lp[j]] = (unsigned short)(j * PR_NT + tid);
         }
     }
-    const int total = lst[nb2 < 128 ? nb2 : 128];
+    __syncthreads();                               // (the counters give way to the staging buffer; lst is complete)
+    const int total = lst[NB2];
+    // the coordinates go to their sorted places in the workgroup's image (D planes of PR_Q entries: the evaluation pass reads
+    // them with consecutive lanes on consecutive entries), half a plane at a time through LDS so that the stores are
+    // consecutive (straight scattered 8-byte stores into the image: 1.03 ms per 5e7 queries instead of 0.25 without them)
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         T *__restrict__ dstp = xs + ((long long)blockIdx.x * D + d) * PR_Q;
@@ -1000,11 +1038,16 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
 
 template <int D, int SPER> struct PTile {            // tile of a region: SPER window starts + 3 per dimension, compile-time LDS strides
     static constexpr int TE = SPER + 3;
-    static constexpr int S1 = TE | 1;                // odd row stride: the window rows of a lane spread over the LDS banks
-    static constexpr int S2 = S1 * TE + 1;
+    // 3-D: the rows of a window are read as two 16-byte halves (ds_read_b128: 16 lanes per LDS cycle, 16-byte slots -- a
+    // random set of 16 slots out of 16 collides less than 32 out of 32, and half as many instructions), which must be
+    // 16-byte aligned: even strides, and a SECOND copy of the tile one entry further for the windows with an odd start
+    static constexpr bool W128 = D == 3;
+    static constexpr int S1 = W128 ? ((TE + 1) & ~1) : (TE | 1);      // (else) odd row stride: the window rows of a lane spread over the LDS banks
+    static constexpr int S2 = W128 ? S1 * TE : S1 * TE + 1;
     static constexpr int S3 = S2 * TE + 1;
     static constexpr int stride(int d) { return d == 0 ? 1 : (d == 1 ? S1 : (d == 2 ? S2 : S3)); }
-    static constexpr int ELEMS = (D == 1 ? TE : (D == 2 ? S1 * TE : (D == 3 ? S2 * TE : S3 * TE))) + 8;
+    static constexpr int COPY = ((D == 1 ? TE : (D == 2 ? S1 * TE : (D == 3 ? S2 * TE : S3 * TE))) + 8 + 1) & ~1;
+    static constexpr int ELEMS = W128 ? 2 * COPY : COPY;
 };
 
 template <int D, int SPER, bool VAL, typename T>
@@ -1013,7 +1056,7 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
                const int *__restrict__ starts, int nwg_all, int c0, int *__restrict__ queue, T *__restrict__ outs)
 {
     using PT = PTile<D, SPER>;
-    __shared__ double pr_tile[PT::ELEMS];
+    __shared__ __attribute__((aligned(16))) double pr_tile[PT::ELEMS];
     __shared__ int s_region, s_next, s_done, s_base[8], s_ready[8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1090,7 +1133,9 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
                 idx += node * g.colstride[d];
                 te += l * PT::stride(d);
             }
-            pr_tile[te] = ok ? (double)coef[idx] : 0.0;
+            const double cv = ok ? (double)coef[idx] : 0.0;
+            pr_tile[te] = cv;
+            if (PT::W128 && te > 0) pr_tile[PT::COPY + te - 1] = cv;      // the copy for odd window starts: entry i holds tile entry i + 1
         }
     }
     constexpr int SC = 16;                           // chunks of a superchunk
@@ -1185,7 +1230,14 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
                 rlen[j] = __builtin_amdgcn_readlane(fv[j], 1) - rst[j];
             }
         }
-        int pos = lane;                              // this lane's next element of the stream, relative to the start of run 0
+        // this lane's next element of the stream, relative to the start of run 0.  Not simply the lane number: ds_read_b128
+        // serves the lanes in four fixed sets of 16 per half wave ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}); each set takes 16
+        // CONSECUTIVE elements of the stream, which the place pass dealt so that neighbours read different LDS slots
+        int pos;
+        {
+            const int m = lane & 31;
+            pos = (lane & 32) + (m < 4 ? m : (m < 12 ? m + 12 : (m < 16 ? m - 8 : (m < 20 ? m + 8 : (m < 28 ? m - 12 : m)))));
+        }
         // locates the lane's next element (drops the runs every lane has passed) and requests its coordinates
         auto next_element = [&](bool &act, long long &oq, T (&xn)[D]) {
             while (rwa[0] >= 0 && __builtin_amdgcn_ballot_w64(pos < rlen[0]) == 0) {
@@ -1240,35 +1292,37 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
                 // left to the compiler, all 64 reads of a window are issued up front (128 registers: 2 waves per SIMD, or
                 // spills), and behind a function call the coordinates requested above would be waited for at the call (the
                 // compiler drains every counter there).  Same operations in the same order as window_sum<3>: identical bits.
-                const unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) double *)pr_tile + (unsigned)base * 8u;
+                // an odd window start reads the second copy of the tile, one entry down: every address is 16-byte aligned
+                const unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) double *)pr_tile +
+                                    (unsigned)((base & 1) ? PT::COPY + base - 1 : base) * 8u;
                 sum = 0.0;
                 // (the reads need the window starts only and would move above the basis tables, which then spill: the first
                 //  read names the tables as operands it does not use)
                 asm volatile("; tables ready %0 %1 %2 %3 %4 %5" :: "v"(b[0][0]), "v"(b[0][3]), "v"(b[1][0]), "v"(b[1][3]), "v"(b[2][0]), "v"(b[2][3]));
                 __builtin_amdgcn_sched_barrier(0);
+                typedef double d2v __attribute__((ext_vector_type(2)));
 #pragma unroll
                 for (int k2 = 0; k2 < 4; ++k2) {
-                    double c[4][4];
+                    d2v c[4][2];
                     // (the first read of a plane names the running sum as an operand it does not use: the multiply-adds of the
                     //  plane before stay in front of it)
-                    asm volatile("ds_read_b64 %0, %1 offset:%2 ; after %3" : "=v"(c[0][0]) : "v"(la), "n"((k2 * t2) * 8), "v"(sum));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2 ; after %3" : "=v"(c[0][0]) : "v"(la), "n"((k2 * t2) * 8), "v"(sum));
 #pragma unroll
                     for (int k1 = 0; k1 < 4; ++k1)
 #pragma unroll
-                        for (int k0 = (k1 == 0 ? 1 : 0); k0 < 4; ++k0)
-                            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c[k1][k0]) : "v"(la), "n"((k1 * t1 + k2 * t2 + k0) * 8));
-                    // (the sixteen values pass through the wait as in/out operands: what uses them stays behind it)
+                        for (int h = (k1 == 0 ? 1 : 0); h < 2; ++h)
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c[k1][h]) : "v"(la), "n"((k1 * t1 + k2 * t2 + 2 * h) * 8));
+                    // (the values pass through the wait as in/out operands: what uses them stays behind it)
                     asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[0][2]), "+v"(c[0][3]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[1][2]), "+v"(c[1][3]),
-                                   "+v"(c[2][0]), "+v"(c[2][1]), "+v"(c[2][2]), "+v"(c[2][3]), "+v"(c[3][0]), "+v"(c[3][1]), "+v"(c[3][2]), "+v"(c[3][3])
+                                 : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[2][0]), "+v"(c[2][1]), "+v"(c[3][0]), "+v"(c[3][1])
                                  :: "memory");
                     double rr = 0.0;
 #pragma unroll
                     for (int k1 = 0; k1 < 4; ++k1) {
-                        double t = c[k1][0] * b[0][0];
-                        t = fma(c[k1][1], b[0][1], t);
-                        t = fma(c[k1][2], b[0][2], t);
-                        t = fma(c[k1][3], b[0][3], t);
+                        double t = c[k1][0].x * b[0][0];
+                        t = fma(c[k1][0].y, b[0][1], t);
+                        t = fma(c[k1][1].x, b[0][2], t);
+                        t = fma(c[k1][1].y, b[0][3], t);
                         rr = fma(t, b[1][k1], rr);
                     }
                     sum = fma(rr, b[2][k2], sum);
@@ -1405,8 +1459,11 @@ static bool make_pregions(const Grid &g, PRegions &rg, int sper)
         rg.nbins *= rg.nreg[d];
         rg.tcells *= rg.text[d];
     }
-    rg.telems = 0;
     if (rg.nbins < 8 || rg.nbins > PR_MAXBINS) return false;
+    rg.deal = std::getenv("SPLPAK_PR_NODEAL") ? 0 : 1;
+    // what the place pass needs to know of the evaluation pass's LDS tile: its strides and the distance of its second copy
+    if (sper == 16) { using PT = PTile<D, 16>; for (int d = 0; d < D; ++d) rg.tstr[d] = PT::stride(d); rg.telems = PT::W128 ? PT::COPY : 0; }
+    else { using PT = PTile<D, 8>; for (int d = 0; d < D; ++d) rg.tstr[d] = PT::stride(d); rg.telems = PT::W128 ? PT::COPY : 0; }
     return true;
 }
 

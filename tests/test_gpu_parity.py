@@ -257,6 +257,51 @@ def test_eval_binned_scratch_regrows_for_a_grid_with_more_regions():
         capi.set_eval_mode(capi.EVAL_AUTO)
 
 
+@pytest.mark.parametrize("nodes", [(64, 64, 64), (40, 33, 52), (20, 20, 20)])
+def test_eval_persistent_path_clusters_ends_and_small_batches(port, nodes):
+    """The persistent 3-D path of round 4 (place pass that DEALS the queries of a bin by LDS slot class / evaluation waves
+    that take chunks from two-level counters / windows next to an end of the grid in the semi-closed form): batches that
+    stress its bookkeeping -- every query in ONE cell (all in one (bin, class): the overflow round of the dealing), every
+    query in the first / last three cells of some dimension (boundary runs only), queries outside the grid and on the
+    nodes, and batches smaller than one place-pass workgroup -- return the bits of the direct kernel and the values of the
+    reference algorithm (oracle)."""
+    nd = 3
+    rng = np.random.default_rng(nodes[0] * 7 + nodes[2])
+    coef = rng.standard_normal(int(np.prod(nodes)))
+    lo = np.array([-0.5, 1.0, 2.0])
+    hi = lo + np.array([1.0, 2.5, 0.75])
+    dx = (hi - lo) / (np.array(nodes) - 1)
+    batches = {}
+    n = 70_001
+    one_cell = lo + dx * (np.array([5, 2, nodes[2] - 3]) + rng.random((n, 3)))                 # one cell, next to two ends
+    batches["one cell"] = one_cell
+    ends = lo + (hi - lo) * rng.random((n, 3))
+    k = rng.integers(0, 3, n)
+    side = rng.integers(0, 2, n)
+    cell = rng.integers(0, 3, n) + rng.random(n)
+    ends[np.arange(n), k] = np.where(side == 0, lo[k] + dx[k] * cell, hi[k] - dx[k] * cell)  # first / last three cells
+    batches["ends"] = ends
+    mixed = lo + (hi - lo) * (-0.3 + 1.6 * rng.random((n, 3)))                                 # ~60 % outside the grid
+    mixed[:4000] = lo + dx * rng.integers(-1, np.array(nodes) + 1, (4000, 3))                 # on the nodes (and one step outside)
+    batches["outside + nodes"] = mixed
+    batches["tiny"] = lo + (hi - lo) * rng.random((37, 3))
+    batches["one workgroup"] = lo + (hi - lo) * rng.random((8192, 3))
+    try:
+        for name, q in batches.items():
+            capi.set_eval_mode(capi.EVAL_DIRECT)
+            vd, rc = capi.evaluate(nd, q, None, coef, lo, hi, nodes)
+            assert rc == 0
+            capi.set_eval_mode(capi.EVAL_BINNED, 0)
+            vb, rc = capi.evaluate(nd, q, None, coef, lo, hi, nodes)
+            assert rc == 0
+            assert np.array_equal(vd, vb), (nodes, name)
+            m = min(len(q), 3000)
+            vo, _ = port.evaluate(nd, q[:m], None, coef, lo, hi, nodes)
+            assert np.max(np.abs(vb[:m] - vo)) <= EVAL_TOL * max(np.max(np.abs(vo)), np.max(np.abs(coef))), (nodes, name)
+    finally:
+        capi.set_eval_mode(capi.EVAL_AUTO)
+
+
 def test_eval_run_path_with_clustered_queries():
     """The 3-D run path (round 3: every place-pass workgroup leaves its own region-sorted image and the starts of its
     runs; the evaluation workgroups gather the runs of their region -- no global sort).  Scattered queries give runs of
