@@ -555,7 +555,7 @@ def main():
         capi.evaluate_dev(nd, xq, None, coef, lo, hi, nodes, out, stream)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
+        reps = 20
         barrier()
         e0.record()
         for _ in range(reps):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One binned and one direct evaluation batch, for rocprofv3 --kernel-trace --stats."""
+"""Binned and direct evaluation batches (EVAL_PROFILE_REPS of each, default 3), for rocprofv3 --kernel-trace --stats / --pmc."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,6 +17,6 @@ out = torch.empty(nq, dtype=torch.float64, device=dev)
 capi.synth_queries_dev(nd, 0, 0, nq, xq, 0)
 for mode in (capi.EVAL_BINNED, capi.EVAL_DIRECT):
     capi.set_eval_mode(mode, chunk)
-    for _ in range(3):
+    for _ in range(int(os.environ.get("EVAL_PROFILE_REPS", "3"))):
         capi.evaluate_dev(nd, xq, None, coef, lo, hi, nodes, out, 0)
     torch.cuda.synchronize()

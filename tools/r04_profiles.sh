@@ -15,7 +15,7 @@ bash tools/pmc.sh r04/eval3_write "WRITE_SIZE" "eval|bin_|run_place|pr_" python3
 bash tools/pmc.sh r04/eval3_valu "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "eval|bin_|run_place|pr_" python3 /root/repo/tools/eval_profile.py 3 64 50000000 > /dev/null
 bash tools/pmc.sh r04/eval4_fetch "FETCH_SIZE" "eval|bin_|run_place|pr_" python3 /root/repo/tools/eval_profile.py 4 32 100000000 > /dev/null
 bash tools/pmc.sh r04/eval4_write "WRITE_SIZE" "eval|bin_|run_place|pr_" python3 /root/repo/tools/eval_profile.py 4 32 100000000 > /dev/null
-bash tools/prof.sh r04/eval3_stats python3 /root/repo/tools/eval_profile.py 3 64 50000000 > /dev/null
-bash tools/prof.sh r04/eval4_stats python3 /root/repo/tools/eval_profile.py 4 32 100000000 > /dev/null
+EVAL_PROFILE_REPS=20 bash tools/prof.sh r04/eval3_stats python3 /root/repo/tools/eval_profile.py 3 64 50000000 > /dev/null
+EVAL_PROFILE_REPS=6 bash tools/prof.sh r04/eval4_stats python3 /root/repo/tools/eval_profile.py 4 32 100000000 > /dev/null
 echo "eval pmc done"
 ls gpurun_out/r04
