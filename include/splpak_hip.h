@@ -318,6 +318,14 @@ int32_t splpak_debug_nd_tree(int32_t ndim, const int32_t *nodes, int32_t split_m
 int32_t splpak_debug_nd_partition(int32_t ndim, const int32_t *nodes, int32_t split_min, int32_t ngpus, int32_t chunk,
                                   double *out_per_rank8, double *out8);
 
+/* Diagnostics (host only): the four basis values of the window of x (1-D grid of `nodes` nodes on [xmin, xmax];
+ * src/splpak.F90:206-389, window rule :1201-1209) for n points, (a) as the evaluation kernels compute them -- the closed
+ * form of an interior window, the closed form with the end functions put in next to an end of the grid, the general
+ * form elsewhere (csrc/basis.hpp; form_out: 0 / 1 / 2) -- and (b) in the general form throughout.  ws_out: first node of
+ * the window.  used4 / general4: 4 values per point.  Returns 0, 102/103 (grid checks) or a negative SPLPAK_E_* code. */
+int32_t splpak_debug_window_values(int32_t nodes, double xmin, double xmax, int64_t n, const double *x, int32_t *ws_out,
+                                   double *used4, double *general4, int32_t *form_out);
+
 /* Releases the calling thread's internal HIP streams, events, queues and evaluation scratch
  * (created lazily and kept for reuse).  Optional; plans stay valid. */
 void splpak_shutdown(void);

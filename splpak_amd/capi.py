@@ -33,7 +33,7 @@ SYMBOLS = [
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
     "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_rank_bytes", "splpak_mplan_factorisation", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
     "splpak_plan_device_bytes",
-    "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_debug_nd_partition", "splpak_shutdown", "splpak_set_eval_mode",
+    "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_debug_nd_partition", "splpak_debug_window_values", "splpak_shutdown", "splpak_set_eval_mode",
     "splpak_last_error_message", "splpak_device_name",
 ]
 
@@ -128,6 +128,8 @@ def lib() -> C.CDLL:
     L.splpak_debug_nd_tree.argtypes = [i32, _ip, i32, i32, _dp]
     L.splpak_debug_nd_partition.restype = i32
     L.splpak_debug_nd_partition.argtypes = [i32, _ip, i32, i32, i32, _dp, _dp]
+    L.splpak_debug_window_values.restype = i32
+    L.splpak_debug_window_values.argtypes = [i32, dbl, dbl, i64, _dp, _ip, _dp, _dp, _ip]
     L.splpak_mplan_create.restype = i32
     L.splpak_mplan_create.argtypes = [i32, _ip, i32, i32, _ip, _dp, _dp, dbl, i64, C.POINTER(vp)]
     L.splpak_mplan_destroy.restype = None
@@ -558,6 +560,22 @@ def debug_nd_partition(nodes, ngpus, chunk=0, split_min=0):
     summ = dict(dcut=int(out[0]), top_fronts=int(out[1]), top_steps=int(out[2]), max_panel_bytes=out[3], normal_eq_bytes=out[4],
                 fronts=int(out[5]), depth=int(out[6]), flop=out[7])
     return ranks, summ
+
+
+def debug_window_values(nodes, xmin, xmax, x):
+    """Host-only: the 4 basis values of the window of every x on a 1-D grid, as the evaluation kernels select the form
+    (0 interior closed form / 1 next to an end / 2 general) and in the general form.  -> (ws, used[n,4], general[n,4], form)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = x.size
+    ws = np.zeros(n, dtype=np.int32)
+    form = np.zeros(n, dtype=np.int32)
+    used = np.zeros((n, 4))
+    gen = np.zeros((n, 4))
+    rc = _check(lib().splpak_debug_window_values(int(nodes), float(xmin), float(xmax), int(n), _p(x, _dp),
+                                                 _p(ws, _ip), _p(used, _dp), _p(gen, _dp), _p(form, _ip)))
+    if rc != 0:
+        raise SplpakError(f"grid rejected: {rc}")
+    return ws, used, gen, form
 
 
 def debug_spd_band_solve(a_lower, halfbw, b):

@@ -274,6 +274,30 @@ __host__ __device__ inline void window_values(const Grid &g, int d, double x, in
     }
 }
 
+// The value table as the evaluation kernels compute it, per query (eval.hip's eval_table does the same with wave-uniform
+// branches around the rarer forms): form 0 = interior closed form, 1 = next to an end of the grid, 2 = general.
+__host__ __device__ inline int window_table_selected(const Grid &g, int d, double x, double b[4], int &form)
+{
+    int lo, hi, it;
+    bool interior;
+    double u, t;
+    const int ws = window_start_frac(g, d, x, lo, hi, interior, u, t, it);
+    const int nod = g.nodes[d];
+    double c[4];
+    window_values_interior(u, c);
+    if (interior) {
+        form = 0;
+        for (int k = 0; k < 4; ++k) b[k] = c[k];
+    } else if (nod >= 8 && t >= 0.0 && it <= nod - 2) {
+        form = 1;
+        window_values_near(t, it, nod, c, b);
+    } else {
+        form = 2;
+        window_values<false>(g, d, x, ws, lo, hi, b);
+    }
+    return ws;
+}
+
 __host__ __device__ inline int window_table_value(const Grid &g, int d, double x, double b[4])
 {
     int lo, hi;

@@ -16,6 +16,7 @@
 // before the reduction so all ranks hold bit-identical normal equations; 4-5 are
 // replicated.
 #include "plan.hpp"
+#include "basis.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -833,6 +834,24 @@ static int eval_validate(int32_t ndim, const int32_t *nderiv, const double *xmin
         for (int d = 0; d < ndim; ++d)
             if (nderiv[d] < 0 || nderiv[d] > 2) v = 104;
     return v;
+}
+
+// host only: the 4-entry value table of a 1-D grid at n points, as the evaluation kernels select it and in the general form
+int32_t splpak_debug_window_values(int32_t nodes, double xmin, double xmax, int64_t n, const double *x, int32_t *ws_out,
+                                   double *used4, double *general4, int32_t *form_out)
+{
+    if (!x || !ws_out || !used4 || !general4 || !form_out || n < 0) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    Grid g;
+    const int v = build_grid(1, &nodes, &xmin, &xmax, g, nullptr);
+    if (v != 0) return v;
+    for (int64_t i = 0; i < n; ++i) {
+        int form = 0;
+        ws_out[i] = window_table_selected(g, 0, x[i], used4 + 4 * i, form);
+        form_out[i] = form;
+        const int wg = window_table_value(g, 0, x[i], general4 + 4 * i);
+        if (wg != ws_out[i]) { set_error("window starts of the two forms differ"); return SPLPAK_E_BADARG; }
+    }
+    return 0;
 }
 
 int32_t splpak_eval_dev_f64(int32_t ndim, int64_t nq, const double *xq_dev, int32_t ldxq,

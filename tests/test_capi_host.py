@@ -92,3 +92,47 @@ def test_comm_len_formula():
     n = 512
     npad = 512
     assert capi.lib().splpak_plan_comm_len(3, capi._p(nodes, capi._ip)) == n * 172 + n + 8 + n + 8 + npad + 8
+
+
+@pytest.mark.parametrize("nodes", [4, 7, 8, 9, 16, 64, 301])
+def test_basis_table_forms_match_the_reference_basis(port, nodes):
+    """The value table of the evaluation kernels (csrc/basis.hpp: closed form of an interior window, closed form with
+    the end functions put in next to an end of the grid, general form elsewhere and on grids of fewer than 8 nodes)
+    against the reference's bascmp (oracle, :206-389) entry by entry: inside, on the nodes, one ulp either side of them,
+    in the end cells and outside the grid.  Host code only -- the same functions the kernels compile."""
+    import ctypes as C
+    rng = np.random.default_rng(nodes)
+    xmin, xmax = -1.25, 3.5
+    dx = (xmax - xmin) / (nodes - 1)
+    grid = xmin + dx * np.arange(-2, nodes + 2)
+    x = np.concatenate([rng.uniform(xmin - 2 * dx, xmax + 2 * dx, 20000), grid, np.nextafter(grid, 1e9), np.nextafter(grid, -1e9),
+                        xmin + dx * rng.uniform(0, 3, 3000), xmax - dx * rng.uniform(0, 3, 3000), [xmin, xmax, xmin - 40.0, xmax + 1e6]])
+    ws, used, gen, form = capi.debug_window_values(nodes, xmin, xmax, x)
+    if nodes >= 8:
+        assert set(np.unique(form)) == {0, 1, 2}
+        assert np.all(form[x < xmin] == 2) and np.all(form[x > xmax] == 2)
+        assert np.all(form[(x >= xmin) & (x < xmax - 1e-9)] <= 1)
+    else:
+        assert np.all(form == 2)
+    # the forms among themselves: rounding of dxin (x - x_node) only
+    assert np.max(np.abs(used - gen)) <= 1e-12 * max(1.0, np.max(np.abs(gen)))
+    # against the reference's basis function of every window node
+    L = port.lib if hasattr(port, "lib") else port._lib
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    nd0 = (C.c_int * 1)(0)
+    nodes_c = (C.c_int * 1)(nodes)
+    xmin_c, dx_c = (C.c_double * 1)(xmin), (C.c_double * 1)(dx)
+    icol = (C.c_int * 1)(0)
+    worst = 0.0
+    for i in range(0, x.size, 7):
+        # window rule :1201-1209: entries outside [ibmn, ibmx] do not enter the sum (value 0 in the table)
+        it = int(np.trunc((1.0 / dx) * (x[i] - xmin))) if abs((x[i] - xmin) / dx) < 2e9 else 0
+        ibmn = min(max(it - 1, 0), nodes - 2)
+        ibmx = max(min(it + 2, nodes - 1), 1)
+        for k in range(4):
+            ib = int(ws[i]) + k
+            xi = (C.c_double * 1)(x[i])
+            ibc = (C.c_int * 1)(ib)
+            ref = L.oracle_bascmp(1, xi, nd0, ibc, xmin_c, dx_c, nodes_c, icol) if ibmn <= ib <= ibmx else 0.0
+            worst = max(worst, abs(used[i, k] - ref) / max(1.0, abs(ref)))
+    assert worst <= 1e-12, worst
