@@ -952,7 +952,7 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
             for (int d = 0; d < D; ++d) {
                 int lo, hi;
                 bool in_d;
-                xr[j][d] = xq[i * ldxq + d];
+                xr[j][d] = __builtin_nontemporal_load(xq + i * ldxq + d);
                 const int ws = window_start_value(g, d, (double)xr[j][d], lo, hi, in_d);
                 inter = inter && in_d;
                 const int rd = (int)rtab[d][ws];
@@ -1025,7 +1025,7 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
                 if (lp[j] >= 0 && l >= 0 && l < HALF) splane[l] = xr[j][d];
             }
             __syncthreads();
-            for (int e = tid; e < HALF && hf * HALF + e < total; e += PR_NT) dstp[hf * HALF + e] = splane[e];
+            for (int e = tid; e < HALF && hf * HALF + e < total; e += PR_NT) __builtin_nontemporal_store(splane[e], dstp + hf * HALF + e);
         }
     }
     if (tid <= nb2) starts[(long long)blockIdx.x * (nb2 + 1) + tid] = lst[tid];
@@ -1261,7 +1261,7 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
             if (act) {
                 oq = (long long)wa * PR_Q + off;
 #pragma unroll
-                for (int d = 0; d < D; ++d) xn[d] = xs[((long long)wa * D + d) * PR_Q + off];
+                for (int d = 0; d < D; ++d) xn[d] = __builtin_nontemporal_load(xs + ((long long)wa * D + d) * PR_Q + off);
                 pos += 64;
             }
         };
@@ -1335,7 +1335,7 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
                     c[0] = qq[0]; c[1] = qq[1]; c[2] = qq[2]; c[3] = qq[3];
                 });
             }
-            if (act_c) outs[oq_c] = (T)sum;
+            if (act_c) __builtin_nontemporal_store((T)sum, outs + oq_c);
         }
     }      // chunks
     __syncthreads();                                 // every wave is done with the tile
@@ -1375,12 +1375,12 @@ pr_unsort_kernel(long long nq, const unsigned short *__restrict__ sidx, const in
     __shared__ T lv[PR_Q];
     const long long base = (long long)blockIdx.x * PR_Q;
     const int total = starts[(long long)blockIdx.x * nb1 + nb1 - 1];
-    for (int p = threadIdx.x; p < total; p += PR_NT) lv[sidx[base + p]] = outs[base + p];
+    for (int p = threadIdx.x; p < total; p += PR_NT) lv[sidx[base + p]] = __builtin_nontemporal_load(outs + base + p);
     __syncthreads();
     const long long left = nq - base;
     const int n = left < PR_Q ? (int)left : PR_Q;
     // (every query of the workgroup has a region: total == n)
-    for (int j = threadIdx.x; j < n; j += PR_NT) out[base + j] = lv[j];
+    for (int j = threadIdx.x; j < n; j += PR_NT) __builtin_nontemporal_store(lv[j], out + base + j);
 }
 
 // pass C of the fused value / gradient / Hessian evaluation (defined with eval_derivs_kernel below)
