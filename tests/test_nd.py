@@ -199,7 +199,7 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
     ref, e, _, info = _fit_env(inp, {"SPLPAK_ND": "1"})
     assert e == 0 and info[9] < 1e-9
     for env in ({"SPLPAK_NO_PANEL_CU": "1"}, {"SPLPAK_ND_NO_ROOT_LOOKAHEAD": "1"}, {"SPLPAK_ND_KB": "1"}, {"SPLPAK_ND_NO_FUSE": "1"},
-                {"SPLPAK_ND_PIPES": "2"}, {"SPLPAK_ND_PIPES": "2", "SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_NO_OUTER": "1"}, {"SPLPAK_ND_SMALL_GRID": "0"}, {"SPLPAK_ND_WG4": "2"}, {"SPLPAK_ND_POTRF_WAVES": "4"}, {"SPLPAK_ND_POTRF_WAVES": "16"}, {"SPLPAK_ND_SMALL_QUEUE": "1"}, {"SPLPAK_ND_FULL_DIAG": "1"}, {"SPLPAK_ND_XCD": "1"},
+                {"SPLPAK_ND_PIPES": "2"}, {"SPLPAK_ND_PIPES": "2", "SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_NO_OUTER": "1"}, {"SPLPAK_ND_SMALL_GRID": "0"}, {"SPLPAK_ND_WG4": "2"}, {"SPLPAK_ND_POTRF_WAVES": "4"}, {"SPLPAK_ND_POTRF_WAVES": "16"}, {"SPLPAK_ND_SMALL_QUEUE": "1"}, {"SPLPAK_ND_FULL_DIAG": "1"}, {"SPLPAK_ND_XCD": "0"},
                 {"SPLPAK_ND_NO_FUSE": "1", "SPLPAK_ND_MEMSET": "1", "SPLPAK_ND_KB": "2"},
                 {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_RES_CUS": "3", "SPLPAK_ND_PIN_ROUNDS": "8"}):
         c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1"))
