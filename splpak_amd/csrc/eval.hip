@@ -1061,13 +1061,13 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int t1 = D > 1 ? PT::S1 : 0, t2 = D > 2 ? PT::S2 : 0, t3 = D > 3 ? PT::S3 : 0;
-    // Work distribution (round 4, third form).  A workgroup holds the tile of ONE region; its waves, each on its own, take
-    // chunks of that region's runs (c0 place-pass workgroups of interior runs, 4 c0 of the others) from the region's counter
-    // until it is used up, then the workgroup moves to the region with the most chunks left per workgroup already there.
+    // Work distribution.  A workgroup holds the tile of ONE region; its waves, each on its own, take chunks of that region's
+    // runs (c0 place-pass workgroups of interior runs, 4 c0 of the others; take_chunk below) until the region is used up, then
+    // the workgroup moves to the region with the most work left per workgroup already there.
     // Why per wave: the SIMD issues from its oldest wave first, so the waves of a workgroup given equal shares finish one
     // after the other -- with a workgroup-wide barrier per work item the first wave waited 28-42 % of its life at barriers
     // (in-kernel clocks) while the last ones ran alone on their SIMDs with nothing to hide their latencies behind.
-    //   queue[r]          chunks of region r taken (may overshoot by one per wave)
+    //   queue[r]          SUPERCHUNKS (SC chunks) of region r taken (may overshoot by one per workgroup)
     //   queue[nbins + r]  workgroups at region r
     const int nbins = rg.nbins;
     const int c1 = 4 * c0;
