@@ -143,6 +143,8 @@ void    splpak_plan_set_allreduce(splpak_plan *plan, splpak_allreduce_fn fn, voi
  * per-rank job tables are rebuilt; the plan's next fit returns it on every rank). */
 #define SPLPAK_AR_ANY_POINTER 1
 #define SPLPAK_AR_ALWAYS      2   /* call the hook with one rank too (smoke tests of a one-rank communicator) */
+#define SPLPAK_AR_STREAM_ORDERED 4 /* the hook only ENQUEUES its work on the stream it is handed (ncclAllReduce): the library then
+                                     does not synchronise the stream before and after the call */
 int32_t splpak_plan_set_allreduce_ex(splpak_plan *plan, splpak_allreduce_fn fn, void *user,
                                      int32_t rank, int32_t world, int32_t flags);
 /* tuning / test knobs: nominal refinement steps (default 4; 0 = none; a solve that still contracts goes on

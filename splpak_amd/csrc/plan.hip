@@ -419,10 +419,13 @@ static int do_allreduce(splpak_plan *p, double *buf, long long count, hipStream_
     // whatever the hook's own ordering is worth: the rehearsal of `bench.py --gpus 2` on ONE device over gloo summed
     // buffers the fit's kernels were still writing (round 3; a host synchronisation costs ~10 us, a fit issues
     // 3 + refinement steps of these)
-    SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+    // (a hook that declares SPLPAK_AR_STREAM_ORDERED -- the native RCCL one: ncclAllReduce is enqueued on the stream it is
+    //  handed -- is ordered with the fit's kernels by the stream itself: no host synchronisation on either side)
+    const bool ordered = (p->ar_flags & SPLPAK_AR_STREAM_ORDERED) != 0;
+    if (!ordered) SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
     const int r = p->ar(buf, count, (void *)st, p->ar_user);
     if (r != 0) { set_error("all-reduce callback failed"); p->comm_failed = true; return SPLPAK_E_COMM; }
-    SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+    if (!ordered) SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
     debug_sum(p, "after  all-reduce", buf, count, st);
     return 0;
 }

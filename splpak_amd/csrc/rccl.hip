@@ -84,7 +84,8 @@ void rccl_fail(const char *what, int rc)
 
 struct RcclHook { void *comm; };
 
-// the plan's sum-all-reduce: in place, on the fit's stream (plan.hip synchronises the stream around every call of a hook)
+// the plan's sum-all-reduce: in place, enqueued on the fit's stream (SPLPAK_AR_STREAM_ORDERED: plan.hip does not synchronise
+// the stream around it)
 int32_t rccl_allreduce(void *buf, int64_t count, void *stream, void *user)
 {
     RcclHook *h = static_cast<RcclHook *>(user);
@@ -108,7 +109,7 @@ int32_t splpak_plan_set_rccl(splpak_plan *plan, void *nccl_comm, int32_t rank, i
     plan->ar_owned = h;
     // SPLPAK_RCCL_ONE_RANK_CALLS=1 (smoke tests on a one-GPU box): the reductions of a one-rank fit go through RCCL too
     const int always = std::getenv("SPLPAK_RCCL_ONE_RANK_CALLS") ? SPLPAK_AR_ALWAYS : 0;
-    return splpak_plan_set_allreduce_ex(plan, rccl_allreduce, h, rank, world, SPLPAK_AR_ANY_POINTER | always);
+    return splpak_plan_set_allreduce_ex(plan, rccl_allreduce, h, rank, world, SPLPAK_AR_ANY_POINTER | SPLPAK_AR_STREAM_ORDERED | always);
 }
 
 int32_t splpak_rccl_unique_id(char *id128)
