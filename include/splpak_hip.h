@@ -155,13 +155,19 @@ int32_t splpak_plan_set_allreduce_ex(splpak_plan *plan, splpak_allreduce_fn fn, 
  * callback.  `nccl_comm` is the caller's ncclComm_t (one per process, made on the GPU the plan lives on).  librccl is opened at
  * run time (an RCCL the process already carries is reused; SPLPAK_RCCL_LIB names another); SPLPAK_E_COMM if it cannot be.
  * For callers without RCCL headers the communicator can be made here: rank 0 draws the 128-byte ncclUniqueId
- * (splpak_rccl_unique_id) and passes it to the other processes by any means -- splpak_rccl_comm_create_from_file does it
- * through a file (rank 0 writes `path` atomically, the others wait for it up to timeout_s seconds; no MPI needed on one
- * node) -- and every process calls splpak_rccl_comm_create with the CURRENT device set to its GPU. */
+ * (splpak_rccl_unique_id) and passes it to the other processes by any means -- splpak_rccl_comm_create_from_file[_ex] does it
+ * through a file (no MPI needed on one node) -- and every process calls splpak_rccl_comm_create with the CURRENT device set
+ * to its GPU.  The id file (round 5): { "SPLPAKID", job tag, publish time, id } = 152 bytes.  Rank 0 removes whatever lies at
+ * `path`, writes its file atomically and removes it again once ncclCommInitRank has returned (collective: every rank has the
+ * id by then); the others wait up to timeout_s seconds (<= 0: 60) for a file that carries THEIR job's tag and is no older than
+ * that wait -- a file left by another run is ignored (a stale id would hang ncclCommInitRank), and the call times out with
+ * SPLPAK_E_COMM.  `job` names the run (any string all ranks of ONE run share and other runs do not); NULL / "" = the environment
+ * variable SPLPAK_RCCL_JOB, else what the launcher exports (TORCHELASTIC_RUN_ID, MASTER_ADDR, MASTER_PORT, SLURM_JOB_ID, ...). */
 int32_t splpak_plan_set_rccl(splpak_plan *plan, void *nccl_comm, int32_t rank, int32_t world);
 int32_t splpak_rccl_unique_id(char *id128);
 int32_t splpak_rccl_comm_create(const char *id128, int32_t rank, int32_t world, void **nccl_comm);
 int32_t splpak_rccl_comm_create_from_file(const char *path, int32_t rank, int32_t world, double timeout_s, void **nccl_comm);
+int32_t splpak_rccl_comm_create_from_file_ex(const char *path, const char *job, int32_t rank, int32_t world, double timeout_s, void **nccl_comm);
 void    splpak_rccl_comm_destroy(void *nccl_comm);
 void    splpak_plan_set_refine(splpak_plan *plan, int32_t max_steps, double tol);
 
@@ -209,14 +215,26 @@ void    splpak_plan_stage_timing(const splpak_plan *plan, double *out6);
 
 /* ---------------------------------------------------------------------------
  * Several GPUs of one node, driven from ONE process: what a Fortran caller reaches
- * through `splpak_type%set_gpus(n)`.  The points are sharded over the GPUs, the band of the normal
- * equations is DISTRIBUTED: its 256-column blocks are dealt to the GPUs in chunks of `chunk` blocks,
- * every GPU stores and updates only its own block columns, the solved panel of every block step
- * travels GPU-to-GPU with hipMemcpyPeerAsync over xGMI, and the triangular sweeps hand the active
- * window from owner to owner.  Memory per GPU is 1/ngpus of the band (26.9 GB at 64^3; the 852 GB of
- * the 4-D 32^4 grid of BASELINE config 5 fit a node of 8 x 288 GB only this way).  Results are those
- * of the single-GPU fit (same kernels per tile; reductions in rank order: bitwise reproducible).
- * `chunk` < 1 chooses it automatically: about one chunk per GPU inside the band window, at most 8 blocks.
+ * through `splpak_type%set_gpus(n)`.  The points are sharded over the GPUs and the factorisation of the
+ * normal equations is DISTRIBUTED WITH ITS MEMORY PARTITIONED:
+ *   - grids that take the nested-dissection factorisation (2-D / 3-D grids of >= 4 096 columns, 4-D grids of
+ *     >= 20 000; since round 4): the subtrees below tree depth ceil(log2 ngpus) are dealt to the GPUs, the
+ *     fronts above them are cut into 256-column blocks dealt to the GPUs in chunks of `chunk` blocks; a solved
+ *     panel is copied GPU-to-GPU (hipMemcpyPeerAsync over xGMI) by the owners of the columns it updates, a
+ *     child's Schur complement is pulled by the owners of the parent's columns through the peer mapping
+ *     (csrc/ndtop.inc).  64^3: 4.4-4.6 GB of factorisation per GPU on eight instead of 30 GB; the 4-D 32^4 grid
+ *     of BASELINE config 5: 159-190 GB per GPU on eight (476 GB of panels do not fit one GPU).  This form needs
+ *     peer access between every pair of distinct devices (kernels read the other GPUs' memory): without it the
+ *     plan falls back to the distributed band below, or returns SPLPAK_E_UNSUPPORTED when that cannot hold the grid;
+ *   - smaller grids (or SPLPAK_MPLAN_BAND=1): the BAND of the normal equations dealt by block columns (round 2),
+ *     every GPU stores and updates only its own block columns, the solved panel of every block step travels
+ *     GPU-to-GPU, the triangular sweeps hand the active window from owner to owner (copies only: no peer mapping needed).
+ * The sums over the ranks (histogram, normal equations, residuals) are reduce-scatter + all-gather over point-to-point
+ * copies in rank order (bitwise reproducible), or -- SPLPAK_MPLAN_RCCL=1, round 5 -- grouped ncclAllReduce calls of a
+ * communicator the plan makes over its devices (ncclCommInitAll; distinct devices only).
+ * Results are those of the single-GPU fit (same kernels per tile: with all points on rank 0 the coefficients are
+ * bit-identical to it).
+ * `chunk` < 1 chooses it automatically (nested dissection: 1; band: about one chunk per GPU inside the band window, at most 8).
  * `devices`: NULL = devices 0..ngpus-1; entries may repeat -- with SPLPAK_VIRTUAL_GPUS=1 in the
  * environment every rank is placed on the current device, which runs the whole protocol on one GPU
  * (the 1-GPU test tier does that).
@@ -308,6 +326,13 @@ int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double 
  *   [12] border rows (padded)  [13] bytes of the diagonal-block inverses.
  * Returns 0, 101/102/103 (grid checks) or a negative SPLPAK_E_* code. */
 int32_t splpak_debug_nd_tree(int32_t ndim, const int32_t *nodes, int32_t split_min, int32_t check, double *out16);
+
+/* Diagnostics (host only): the elimination schedule of the nested-dissection factorisation (csrc/ndtree.hpp NdSchedule, round 5)
+ * and the Schur-buffer arena it needs.  cut = 0: one stage per tree depth (rounds 3-4); cut > 0: the fronts above depth `cut` one
+ * by one in postorder, the subtrees below it one after the other.  packed != 0: Schur buffers as packed lower triangles.  The
+ * schedule's invariants are verified (children before parents, live buffers disjoint).  out8: [0] stages, [1] bytes of the
+ * arena (peak of the allocation), [2] bytes of all Schur buffers of one fit, [3] bytes of the factor panels, [4] cut, [5] depth. */
+int32_t splpak_debug_nd_schedule(int32_t ndim, const int32_t *nodes, int32_t split_min, int32_t cut, int32_t packed, double *out8);
 
 /* Diagnostics (host only): how the nested-dissection factorisation of a grid is distributed over `ngpus` GPUs by the
  * one-process multi-GPU fit (splpak_mplan_*, splpak_fit_multi_f64; csrc/ndtree.hpp NdPartition): the subtrees below tree

@@ -27,13 +27,13 @@ SYMBOLS = [
     "splpak_fit_f64", "splpak_fit_f32", "splpak_eval_f64", "splpak_eval_f32",
     "splpak_plan_comm_len", "splpak_plan_create", "splpak_plan_destroy",
     "splpak_plan_set_allreduce", "splpak_plan_set_allreduce_ex", "splpak_plan_set_rccl", "splpak_rccl_unique_id", "splpak_rccl_comm_create",
-    "splpak_rccl_comm_create_from_file", "splpak_rccl_comm_destroy", "splpak_plan_set_refine", "splpak_plan_fit_dev",
+    "splpak_rccl_comm_create_from_file", "splpak_rccl_comm_create_from_file_ex", "splpak_rccl_comm_destroy", "splpak_plan_set_refine", "splpak_plan_fit_dev",
     "splpak_plan_hist_dev", "splpak_plan_factorisation", "splpak_plan_enable_kernel_timing", "splpak_plan_kernel_timing", "splpak_plan_stage_timing",
     "splpak_eval_dev_f64", "splpak_eval_dev_f32", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
     "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_rank_bytes", "splpak_mplan_factorisation", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
     "splpak_plan_device_bytes",
-    "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_debug_nd_partition", "splpak_debug_window_values", "splpak_shutdown", "splpak_set_eval_mode",
+    "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_debug_nd_partition", "splpak_debug_nd_schedule", "splpak_debug_window_values", "splpak_shutdown", "splpak_set_eval_mode",
     "splpak_last_error_message", "splpak_device_name",
 ]
 
@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
     L.splpak_rccl_comm_create.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
     L.splpak_rccl_comm_create_from_file.restype = i32
     L.splpak_rccl_comm_create_from_file.argtypes = [C.c_char_p, i32, i32, dbl, C.POINTER(vp)]
+    L.splpak_rccl_comm_create_from_file_ex.restype = i32
+    L.splpak_rccl_comm_create_from_file_ex.argtypes = [C.c_char_p, C.c_char_p, i32, i32, dbl, C.POINTER(vp)]
     L.splpak_rccl_comm_destroy.restype = None
     L.splpak_rccl_comm_destroy.argtypes = [vp]
     L.splpak_plan_set_refine.restype = None
@@ -126,6 +128,8 @@ def lib() -> C.CDLL:
     L.splpak_debug_spd_band_solve_f64.argtypes = [i32, i32, _dp, _dp, _dp]
     L.splpak_debug_nd_tree.restype = i32
     L.splpak_debug_nd_tree.argtypes = [i32, _ip, i32, i32, _dp]
+    L.splpak_debug_nd_schedule.restype = i32
+    L.splpak_debug_nd_schedule.argtypes = [i32, _ip, i32, i32, i32, _dp]
     L.splpak_debug_nd_partition.restype = i32
     L.splpak_debug_nd_partition.argtypes = [i32, _ip, i32, i32, i32, _dp, _dp]
     L.splpak_debug_window_values.restype = i32
@@ -518,10 +522,33 @@ def synth_queries_dev(ndim, ndata_before, first_query, nq, xq, stream=0):
                                                  xq.data_ptr(), C.c_void_p(stream)))
 
 
-def rccl_comm_create_from_file(path, rank, world, timeout_s=60.0):
-    """ncclComm_t (as an int) made by the library: rank 0 draws the id and publishes it through `path`."""
+def rccl_comm_create_from_file(path, rank, world, timeout_s=60.0, job=None):
+    """ncclComm_t (as an int) made by the library: rank 0 draws the id and publishes it through `path` together with the
+    job's tag (`job`: any string the ranks of ONE run share; None = SPLPAK_RCCL_JOB or what the launcher exports), the others
+    wait for a file of THEIR job -- a file left by another run is ignored (include/splpak_hip.h)."""
     comm = C.c_void_p()
-    _check(lib().splpak_rccl_comm_create_from_file(str(path).encode(), int(rank), int(world), float(timeout_s), C.byref(comm)))
+    rc = lib().splpak_rccl_comm_create_from_file_ex(str(path).encode(), None if job is None else str(job).encode(), int(rank), int(world),
+                                                    float(timeout_s), C.byref(comm))
+    if rc != 0:
+        raise SplpakError(f"splpak_rccl_comm_create_from_file: {rc}: {last_error()}")
+    return comm.value
+
+
+def rccl_unique_id():
+    """128-byte ncclUniqueId drawn by the library's RCCL (rank 0; hand it to the other ranks by any means)."""
+    buf = C.create_string_buffer(128)
+    rc = lib().splpak_rccl_unique_id(buf)
+    if rc != 0:
+        raise SplpakError(f"splpak_rccl_unique_id: {rc}: {last_error()}")
+    return buf.raw
+
+
+def rccl_comm_create(id128, rank, world):
+    """ncclComm_t (as an int) on the CURRENT device from an id all ranks share."""
+    comm = C.c_void_p()
+    rc = lib().splpak_rccl_comm_create(bytes(id128), int(rank), int(world), C.byref(comm))
+    if rc != 0:
+        raise SplpakError(f"splpak_rccl_comm_create: {rc}: {last_error()}")
     return comm.value
 
 
@@ -542,6 +569,17 @@ def debug_nd_tree(nodes, split_min=0, check=True):
     if rc != 0:
         raise SplpakError(f"grid rejected: {rc}")
     return dict(zip(ND_TREE_FIELDS, out.tolist()))
+
+
+def debug_nd_schedule(nodes, cut=0, packed=True, split_min=0):
+    """Host-only: the elimination schedule of the nested-dissection factorisation for a given cut depth (csrc/ndtree.hpp
+    NdSchedule), its invariants verified.  -> dict(stages, arena_bytes, schur_bytes_per_fit, factor_bytes, cut, depth)."""
+    nodes = np.ascontiguousarray(np.atleast_1d(nodes), dtype=np.int32)
+    out = np.zeros(8)
+    rc = _check(lib().splpak_debug_nd_schedule(len(nodes), _p(nodes, _ip), int(split_min), int(cut), 1 if packed else 0, _p(out, _dp)))
+    if rc != 0:
+        raise SplpakError(f"schedule rejected: {rc}: {last_error()}")
+    return dict(stages=int(out[0]), arena_bytes=out[1], schur_bytes_per_fit=out[2], factor_bytes=out[3], cut=int(out[4]), depth=int(out[5]))
 
 
 ND_RANK_FIELDS = ("bytes", "panel_bytes", "schur_bytes", "top_bytes", "inverse_bytes", "other_bytes", "flop_subtrees", "flop_top")

@@ -83,6 +83,29 @@ __device__ __forceinline__ int find_job(const J *__restrict__ jobs, int njobs, i
     return lo;
 }
 
+// Schur buffers come in two forms (round 5).  Square (lds > 0): element (r, c) at S[r + c lds].  PACKED (lds < 0, L = -lds =
+// hp + 16): only the 64-column tile columns of the lower triangle, tile column c stored from its diagonal tile down with the
+// leading dimension L - 64 c -- half the bytes; a tile is still an ordinary column-major 64 x 64 matrix.
+// tile (ti, tj), ti >= tj -> its first element; ld: leading dimension inside its tile column
+__device__ __forceinline__ double *schur_tile(double *S, long long lds, int ti, int tj, long long &ld)
+{
+    if (lds >= 0) {
+        ld = lds;
+        return S + (long long)(ti * 64) + (long long)(tj * 64) * lds;
+    }
+    const long long L = -lds;
+    ld = L - 64 * tj;
+    return S + 64 * L * tj - 2048LL * tj * (tj - 1) + (long long)(ti - tj) * 64;
+}
+// column c -> p with p[r] = element (r, c), r >= 64 (c / 64)
+__device__ __forceinline__ double *schur_col(double *S, long long lds, int c)
+{
+    if (lds >= 0) return S + (long long)c * lds;
+    const long long L = -lds;
+    const int tj = c >> 6;
+    return S + 64 * L * tj - 2048LL * tj * (tj - 1) + (long long)(c & 63) * (L - 64 * tj) - 64 * tj;
+}
+
 // item -> (tj, ti) of a trapezoid of 64-row tiles stored column by column: column tj holds ti = tj .. nr-1
 __device__ __forceinline__ void trapezoid_decode(int it, int nr, int &tj, int &ti)
 {
@@ -279,8 +302,9 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
     const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
     const double *__restrict__ pJ = j.P + (long long)(tj * 64 + 16 * m0 + l15) + (long long)q * j.ldp;
     const double *__restrict__ pI = j.P + (long long)(ti * 64 + 16 * n0 + l15) + (long long)q * j.ldp;
-    double *__restrict__ C = j.C + (long long)(ti * 64) + (long long)(tj * 64) * j.ldc;
-    const long long ldp = j.ldp, ldc = j.ldc;
+    long long ldc;
+    double *__restrict__ C = schur_tile(j.C, j.ldc, ti, tj, ldc);
+    const long long ldp = j.ldp;
     d4_t acc[M][N];
 #pragma unroll
     for (int m = 0; m < M; ++m)
@@ -346,8 +370,7 @@ nd_syrk_kernel(const SyrkJob *__restrict__ jobs, int njobs, int nitems, int marg
                 const int cc = (m0 + m) * 16 + q + 4 * v, c = tj * 64 + cc;
                 const int pcol = c < j.h ? j.pm[c] : -1;
                 if (pcol < 0) continue;
-                double *__restrict__ colp = pcol < j.wpp ? j.Pp + (long long)pcol * j.ldpp
-                                                         : j.Sp + (long long)(pcol - j.wpp) * j.ldsp - j.wpp;
+                double *__restrict__ colp = pcol < j.wpp ? j.Pp + (long long)pcol * j.ldpp : schur_col(j.Sp, j.ldsp, pcol - j.wpp) - j.wpp;
 #pragma unroll
                 for (int n = 0; n < N; ++n) {
                     const int rr = (n0 + n) * 16 + l15;
@@ -490,15 +513,15 @@ nd_extend_add_kernel(const AddJob *__restrict__ jobs, int njobs)
     const int r = tid & 63;
     const int prow = pr[r];
     if (prow < 0) return;
-    const double *__restrict__ S = j.S + (long long)(ti * 64 + r) + (long long)(tj * 64) * j.lds;
+    long long lds;
+    const double *__restrict__ S = schur_tile(const_cast<double *>(j.S), j.lds, ti, tj, lds) + r;
 #pragma unroll 4
     for (int u = 0; u < 16; ++u) {
         const int c = (tid >> 6) + 4 * u;
         const int pcol = pc[c];
         if (pcol < 0 || (ti == tj && r < c)) continue;
-        const double v = S[(long long)c * j.lds];
-        double *dst = pcol < j.wpp ? j.P + prow + (long long)pcol * j.ldp
-                                   : j.Sp + (prow - j.wpp) + (long long)(pcol - j.wpp) * j.ldsp;
+        const double v = S[(long long)c * lds];
+        double *dst = pcol < j.wpp ? j.P + prow + (long long)pcol * j.ldp : schur_col(j.Sp, j.ldsp, pcol - j.wpp) + (prow - j.wpp);
         *dst += v;
     }
 }
@@ -514,10 +537,11 @@ nd_zero_kernel(const ZeroJob *__restrict__ jobs, int njobs)
     int tj, ti;
     trapezoid_decode(b - j.tile0, j.nt, tj, ti);
     if (tj >= j.nt || ti >= j.nt) return;
-    double *__restrict__ S = j.S + (long long)(ti * 64) + (long long)(tj * 64) * j.lds;
+    long long lds;
+    double *__restrict__ S = schur_tile(j.S, j.lds, ti, tj, lds);
     const int r2 = (threadIdx.x & 31) * 2, c0 = threadIdx.x >> 5;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) *reinterpret_cast<d2_t *>(S + r2 + (long long)(c0 + 8 * u) * j.lds) = (d2_t){0.0, 0.0};
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<d2_t *>(S + r2 + (long long)(c0 + 8 * u) * lds) = (d2_t){0.0, 0.0};
 }
 
 // distributed factorisation: the lower-triangle tiles of a Schur buffer <-> a contiguous image (tile after tile, column-major
@@ -751,16 +775,17 @@ struct NdState {
     int device = 0;
     // arenas
     double *factor = nullptr, *dinv = nullptr, *dinvt = nullptr, *inv16 = nullptr;
-    // Two PIPELINES = the two subtrees below the root, eliminated side by side: each has its own chain stream, their
-    // Schur passes alternate on one stream, so the chain of one runs beside the passes of the other (npipe = 1: small
-    // trees, separate extend-add launches).  Schur arenas per pipeline and depth parity; stage = pipeline * depths + depth.
-    int npipe = 1;
-    std::vector<int> pipe_of;                      // [front] (the root: 0)
-    std::vector<long long> soff;                   // [front] doubles into its pipeline's arena of its depth parity
-    double *sarp[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    long long sarp_doubles[2][2] = {{0, 0}, {0, 0}};
-    std::vector<long long> s_stage_doubles;        // [stage] extent of its Schur buffers (a prefix of its arena)
-    std::vector<std::vector<int>> stage_ids;       // [stage] its fronts
+    // Elimination schedule (round 5, ndtree.hpp NdSchedule): the stages in execution order -- one per tree depth (cut = 0), or
+    // the fronts above depth `cut` one by one in postorder and the subtrees below one after the other -- and ONE Schur arena
+    // whose blocks are reused along the schedule; Schur buffers as packed lower triangles (not on a rank of a one-process
+    // multi-GPU fit, whose subtree roots are read by the other GPUs' pull kernels in the square form).
+    NdSchedule sc;
+    double *sarena = nullptr;
+    long long sarena_doubles = 0;
+    std::vector<char> needs;                       // [front] its Schur buffer is materialised (a leaf whose only pass is fused with the extend-add has none)
+    std::vector<std::vector<int>> starts;          // [stage] the stages whose buffers come alive (are zeroed) at its start
+    int root_stage = -1;                           // stage of the root (single-GPU plans; -1 otherwise)
+    int schur_kb = 4;                              // panel blocks per Schur pass (SPLPAK_ND_KB: 1 .. 4)
     double *V = nullptr, *Y = nullptr, *part = nullptr;
     long long part_cap = 0;                        // doubles of the backward sweep's partial sums (one launch at a time)
     int *pos = nullptr, *front_of = nullptr, *bpos = nullptr, *pmap = nullptr, *rowsrc = nullptr;
@@ -785,15 +810,14 @@ struct NdState {
     JobTable<SyrkJob> updo;                        // outer panel passes: K = 1024 update of the panel columns right of a group of blocks
     JobTable<SyrkJob> fin[2];                      // final Schur passes fused with the extend-add, by child slot
     std::vector<std::vector<Launch>> l_fin[2];
+    std::vector<Launch> l_add[2];                  // [stage] separate extend-add launches of its fronts, by child slot (SPLPAK_ND_NO_FUSE)
+    std::vector<Launch> l_zero;                    // [stage] zero the lower-triangle tiles of its Schur buffers
     bool fused = true;                             // SPLPAK_ND_NO_FUSE (read when the plan is created): separate extend-add launches
     std::vector<hipEvent_t> evW;                   // rest of the panel update of step k done
-    std::vector<Launch> l_add[2], l_mapslot[2], l_mapall;     // per depth (of the children)
-    std::vector<Launch> l_zero;                    // per depth: zero the lower-triangle tiles of its Schur buffers
+    std::vector<Launch> l_mapslot[2], l_mapall;     // per depth (of the children)
     // streams / events
     hipStream_t sP = nullptr, sU = nullptr, sR = nullptr;   // chain, Schur updates (+ their memsets), CU-masked: diagonal blocks
-    hipStream_t sP2 = nullptr;                     // chain of the second pipeline
-    std::vector<hipEvent_t> evT2, evI2, evF[2];    // second pipeline's step events; evF[p][d]: the fused last passes of stage (p, d) are done
-    hipEvent_t evR02 = nullptr;
+    std::vector<hipEvent_t> evF;                   // [stage] its last Schur passes (fused with the extend-add) are done
     unsigned *resmap = nullptr;                    // bitmap (nd_cu_index) of the CUs of sR; nres of them
     int nres = 0;
     int potrf_waves = 8;                           // waves per diagonal-block workgroup (measured 4 / 8 / 16: C2 factor 0.813 / 0.789 / 0.839 ms, 32^3 11.53 / 11.22 / 11.67, C3 the same)
@@ -857,12 +881,12 @@ struct NdState {
     hipEvent_t evR0 = nullptr;
     std::vector<hipEvent_t> evI;                   // potrf of step k done (per step of the current depth)
     std::vector<hipEvent_t> evT;                   // panel of step k solved (per step of the current depth)
-    std::vector<hipEvent_t> evE, evZ;              // depth consumed / depth zeroed
+    std::vector<hipEvent_t> evE;                   // [stage] its separate extend-add launches are done (SPLPAK_ND_NO_FUSE)
     hipEvent_t ev0 = nullptr, evJ = nullptr, evU = nullptr, evZlast = nullptr, evDone = nullptr, evPre = nullptr, evTail = nullptr;
     bool zlast_valid = false, used = false;
     bool tail_pending = false;                     // nd_prefit is clearing factor[head_doubles ..) on sU (evTail)
     long long head_doubles = 0;
-    bool s_clean = false;                          // the Schur buffers of the two deepest levels are zero
+    bool s_clean = false;                          // the Schur buffers that are alive when the first stage starts are zero
     std::vector<hipEvent_t> evA, evB;              // start / stop of the timed update launches
     hipEvent_t f0 = nullptr, f1 = nullptr;
     std::vector<void *> owned;
@@ -908,30 +932,31 @@ void nd_destroy(void *user)
     if (!s) return;
     (void)hipDeviceSynchronize();
     (void)hipSetDevice(s->device);
-    for (hipStream_t *q : {&s->sP, &s->sU, &s->sR, &s->sP2, &s->sCopy}) if (*q) (void)hipStreamDestroy(*q);
-    for (auto *v : {&s->evT, &s->evE, &s->evZ, &s->evA, &s->evB, &s->evI, &s->evW, &s->evT2, &s->evI2, &s->evF[0], &s->evF[1], &s->evReady, &s->evArr,
+    for (hipStream_t *q : {&s->sP, &s->sU, &s->sR, &s->sCopy}) if (*q) (void)hipStreamDestroy(*q);
+    for (auto *v : {&s->evT, &s->evE, &s->evA, &s->evB, &s->evI, &s->evW, &s->evF, &s->evReady, &s->evArr,
                     &s->evCol, &s->evBulk, &s->evSF, &s->evSB, &s->evAdd})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->evPre, s->evTail, s->f0, s->f1, s->evR0, s->evR02, s->evSub, s->evTop}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->evPre, s->evTail, s->f0, s->f1, s->evR0, s->evSub, s->evTop}) if (e) (void)hipEventDestroy(e);
     for (void *q : s->owned) (void)hipFree(q);
     delete s;
 }
 
 long long trapezoid_items(long long nc, long long nr) { return nc * nr - nc * (nc - 1) / 2; }
 
-// builds every job table from the tree and the arena pointers
-// Schur buffer of front `id`: its pipeline's arena of its depth parity
+// Schur buffer of front `id` (NULL: none is materialised) and the leading-dimension argument the kernels take for it
+// (negative: the packed form, see schur_tile / schur_col)
 inline double *s_ptr(NdState *s, int id)
 {
-    const NdFront &f = s->t.fr[(size_t)id];
-    return f.hp > 0 ? s->sarp[s->pipe_of[(size_t)id]][f.depth & 1] + s->soff[(size_t)id] : nullptr;
+    const long long o = s->sc.soff[(size_t)id];
+    return o >= 0 ? s->sarena + o : nullptr;
 }
+inline long long s_ld(NdState *s, int id) { return nd_schur_ld(s->t.fr[(size_t)id], s->sc.packed); }
 
-// Job tables of the FACTORISATION: one set of launches per stage = (pipeline, tree depth) and block step.
+// Job tables of the FACTORISATION: one set of launches per stage of the schedule and block step.
 bool nd_build_factor_jobs(NdState *s)
 {
     NdTree &t = s->t;
-    const int nd = t.maxdepth + 1, nstage = s->npipe * nd;
+    const int nstage = (int)s->sc.st.size();
     for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_updo, &s->l_schur}) L->assign((size_t)nstage, {});
     const bool two_level = std::getenv("SPLPAK_ND_NO_OUTER") == nullptr;
     s->lookahead.assign((size_t)nstage, 0);
@@ -940,16 +965,15 @@ bool nd_build_factor_jobs(NdState *s)
     // Schur buffer passes: groups of up to schur_kb panel blocks (K = 1024: the C tiles are read and written once per
     // group; measured at 64^3: 257.6 ms per factorisation against 262.4 with K = 512 and 270.9 with K = 256; groups that
     // ramp up 1, 2, 4, 4, .. so that the first pass of a depth starts earlier made no difference)
-    int schur_kb = 4;                                   // SPLPAK_ND_KB: 1 .. 4
-    if (const char *e = std::getenv("SPLPAK_ND_KB")) schur_kb = std::max(1, std::min(4, atoi(e)));
+    const int schur_kb = s->schur_kb;
     auto group_of = [&](int k, int nsteps, int &g0, int &gend) {
         g0 = (k / schur_kb) * schur_kb;
         gend = std::min(g0 + schur_kb, nsteps) - 1;
     };
     const SyrkJob syrk_end{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     for (int stg = 0; stg < nstage; ++stg) {
-        const std::vector<int> &ids = s->stage_ids[(size_t)stg];
-        const int d = stg % nd;
+        const std::vector<int> &ids = s->sc.st[(size_t)stg].ids;
+        const int d = s->sc.st[(size_t)stg].depth;
         int steps = 0;
         for (int id : ids) steps = std::max(steps, t.fr[(size_t)id].nsteps);
         for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_updo, &s->l_schur}) (*L)[(size_t)stg].assign((size_t)steps, Launch());
@@ -1075,16 +1099,16 @@ bool nd_build_factor_jobs(NdState *s)
                         // the front's last pass carries its Schur complement into the parent itself
                         const NdFront &pf = t.fr[(size_t)f.parent];
                         const int sl = f.slot;
-                        const int leaf = (f.child[0] < 0 && g0 == 0) ? 1 : 0;       // no children, one pass: the buffer is never materialised
+                        const int leaf = s->needs[(size_t)id] ? 0 : 1;       // no children, one pass: the buffer is never materialised
                         s->fin[sl].host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s_ptr(s, id), f.ld,
-                                                          f.lds, ns, ns, (int)fi[sl], kb, ksl, leaf, s->pmap + f.bofs,
-                                                          s->factor + s->poff[(size_t)f.parent], s_ptr(s, f.parent), pf.ld, pf.lds, pf.wp, f.h});
+                                                          s_ld(s, id), ns, ns, (int)fi[sl], kb, ksl, leaf, s->pmap + f.bofs,
+                                                          s->factor + s->poff[(size_t)f.parent], s_ptr(s, f.parent), pf.ld, s_ld(s, f.parent), pf.wp, f.h});
                         fi[sl] += trapezoid_items(ns, ns);
                         fflop[sl] += jflop;
                         ++lfin[sl].count;
                     } else {
                         s->schur.host.push_back(SyrkJob{panel + f.wp + (long long)g0 * 256 * f.ld, s_ptr(s, id), f.ld,
-                                                        f.lds, ns, ns, (int)si, kb, ksl, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
+                                                        s_ld(s, id), ns, ns, (int)si, kb, ksl, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0});
                         si += trapezoid_items(ns, ns);
                         sflop += jflop;
                         ++ls.count;
@@ -1138,10 +1162,9 @@ bool nd_build_factor_jobs(NdState *s)
             long long tiles = 0;
             for (int id : ids) {
                 const NdFront &f = t.fr[(size_t)id];
-                if (f.hp == 0) continue;
-                if (s->fused && f.child[0] < 0 && f.nsteps <= schur_kb && !(s->mdist && f.depth == s->pt.dcut)) continue;       // a leaf's buffer is never materialised (fused last pass)
+                if (f.hp == 0 || !s->needs[(size_t)id]) continue;       // (a leaf's buffer is never materialised: fused last pass)
                 const int nt = f.hp / 64;
-                s->zero.host.push_back(ZeroJob{s_ptr(s, id), f.lds, nt, (int)tiles});
+                s->zero.host.push_back(ZeroJob{s_ptr(s, id), s_ld(s, id), nt, (int)tiles});
                 tiles += trapezoid_items(nt, nt);
                 ++lz.count;
             }
@@ -1161,8 +1184,8 @@ bool nd_build_factor_jobs(NdState *s)
                     if (f.slot != sl || f.h == 0) continue;
                     const NdFront &p = t.fr[(size_t)f.parent];
                     const int nt = f.hp / 64;
-                    s->add.host.push_back(AddJob{s_ptr(s, id), s->pmap + f.bofs, s->factor + s->poff[(size_t)f.parent], s_ptr(s, f.parent), f.lds, p.ld,
-                                                 p.lds, f.h, nt, p.wp, (int)tiles});
+                    s->add.host.push_back(AddJob{s_ptr(s, id), s->pmap + f.bofs, s->factor + s->poff[(size_t)f.parent], s_ptr(s, f.parent), s_ld(s, id), p.ld,
+                                                 s_ld(s, f.parent), f.h, nt, p.wp, (int)tiles});
                     tiles += trapezoid_items(nt, nt);
                     ++la2.count;
                 }
@@ -1418,15 +1441,12 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     const bool enabled = stats->enabled;
     *stats = CholStats{};
     stats->enabled = enabled;
-    const int nd = t.maxdepth + 1, np = s->npipe;
+    const int ns = (int)s->sc.st.size();
     const bool serial = std::getenv("SPLPAK_NO_LOOKAHEAD") != nullptr;
-    hipStream_t sPp[2] = {s->sP, s->sP2 ? s->sP2 : s->sP}, sU = s->sU, sR = s->sR;
-    if (serial) sPp[0] = sPp[1] = sU = st;
+    hipStream_t sP = s->sP, sU = s->sU, sR = s->sR;
+    if (serial) sP = sU = st;
     if (serial || !sR || std::getenv("SPLPAK_NO_PANEL_CU")) sR = nullptr;
-    hipStream_t sP = sPp[0];
-    std::vector<hipEvent_t> *evTp[2] = {&s->evT, &s->evT2}, *evIp[2] = {&s->evI, &s->evI2};
-    hipEvent_t evR0p[2] = {s->evR0, s->evR02};
-    // potrf goes to the reserved CUs while a depth has at most this many diagonal blocks per step per reserved CU
+    // potrf goes to the reserved CUs while a stage has at most this many diagonal blocks per step per reserved CU
     const int pin_rounds = std::getenv("SPLPAK_ND_PIN_ROUNDS") ? atoi(std::getenv("SPLPAK_ND_PIN_ROUNDS")) : 2;
     if (timing) {
         if (!s->f0) { (void)hipEventCreate(&s->f0); (void)hipEventCreate(&s->f1); }
@@ -1434,11 +1454,14 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     }
     if (s->used && s->evDone) (void)hipStreamWaitEvent(st, s->evDone, 0);
     if (s->zlast_valid) (void)hipStreamWaitEvent(st, s->evZlast, 0);
-    if (!s->s_clean) {          // first fit, or the previous one was abandoned: zero every arena
-        for (int q = 0; q < 2; ++q)
-            for (int a = 0; a < 2; ++a)
-                if (s->sarp_doubles[q][a] > 0) (void)hipMemsetAsync(s->sarp[q][a], 0, sizeof(double) * (size_t)s->sarp_doubles[q][a], st);
-    }
+    // the Schur buffers of stage x are zeroed (lower-triangle tiles) when they come alive: at the start of the first stage
+    // that adds into them, on the update stream -- whatever used their place in the arena before was last touched there
+    auto zero_block = [&](int x, hipStream_t q) {
+        const Launch &lz = s->l_zero[(size_t)x];
+        if (lz.count) hipLaunchKernelGGL(nd_zero_kernel, dim3(lz.grid), dim3(256), 0, q, (const ZeroJob *)(s->zero.dev + lz.first), lz.count);
+    };
+    if (!s->s_clean && ns > 0)  // first fit, or the previous one was abandoned (otherwise the previous fit left them zeroed: evZlast)
+        for (int x : s->starts[0]) zero_block(x, st);
     s->s_clean = false;
     if (s->queues) (void)hipMemsetAsync(s->queues, 0, sizeof(int) * ND_QSTRIDE * (size_t)s->nqueues, st);
     if (s->dist && s->rank != 0)        // the fronts the subtrees' Schur complements are summed in: their entries of N come from rank 0 alone
@@ -1449,12 +1472,13 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     bool comm_failed = false;
     // every rank has eliminated its subtrees: sum what they left in the fronts of depth dcut - 1 (panel and Schur buffer)
     auto dist_join = [&]() {
-        for (hipStream_t q : {sPp[0], sPp[1], sU, sR})
+        for (hipStream_t q : {sP, sU, sR})
             if (q) (void)hipStreamSynchronize(q);
-        // (Schur buffers: their lower-triangle tiles only, packed into a scratch image; the square buffer if that could not be had)
+        // (square Schur buffers: their lower-triangle tiles only, packed into a scratch image; the square buffer if that could
+        //  not be had.  Buffers in the packed form are summed where they lie.)
         double *scratch = s->join_scratch;
         long long scap = s->join_scratch_doubles;
-        {   // every rank must sum windows of the same size: the packed form only if ALL ranks have the scratch for it
+        if (!s->sc.packed) {   // every rank must sum windows of the same size: the scratch image only if ALL ranks have the scratch for it
             const double mine_missing = scratch ? 0.0 : 1.0;
             double any_missing = 0.0;
             (void)hipMemcpyAsync(s->part + 1, &mine_missing, sizeof(double), hipMemcpyHostToDevice, st);
@@ -1469,7 +1493,9 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             if (f.hp == 0) continue;
             const int nt = f.hp / 64;
             const long long tiles = trapezoid_items(nt, nt);
-            if (tiles * 4096 <= scap && !std::getenv("SPLPAK_ND_JOIN_SQUARE")) {
+            if (s->sc.packed) {
+                if (plan_allreduce(p, s_ptr(s, id), nd_schur_doubles(f, true), st) != 0) comm_failed = true;
+            } else if (tiles * 4096 <= scap && !std::getenv("SPLPAK_ND_JOIN_SQUARE")) {
                 hipLaunchKernelGGL(nd_tripack_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, st, s_ptr(s, id), f.lds, nt, scratch);
                 if (plan_allreduce(p, scratch, tiles * 4096, st) != 0) comm_failed = true;
                 hipLaunchKernelGGL(nd_tripack_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, st, s_ptr(s, id), f.lds, nt, scratch);
@@ -1480,49 +1506,37 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     };
     int qnext = 0;
     (void)hipEventRecord(s->ev0, st);
-    for (hipStream_t q : {sPp[0], sPp[1], sU})
+    for (hipStream_t q : {sP, sU})
         if (q != st) (void)hipStreamWaitEvent(q, s->ev0, 0);
     if (sR) (void)hipStreamWaitEvent(sR, s->ev0, 0);
     auto ensure_events = [&](int steps) {
-        for (auto *v : {&s->evT, &s->evI, &s->evW, &s->evT2, &s->evI2})
+        for (auto *v : {&s->evT, &s->evI, &s->evW})
             while ((int)v->size() < steps) {
                 hipEvent_t e;
                 (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
                 v->push_back(e);
             }
     };
-    // the Schur buffers of stage (q, target) are zeroed on the update stream (their arena half is free there: stream order)
-    auto zero_stage = [&](int q, int target) {
-        if (target < 1) return;
-        const int stg = q * nd + target;
-        if (s->s_stage_doubles[(size_t)stg] <= 0) return;
-        const Launch &lz = s->l_zero[(size_t)stg];
-        if (std::getenv("SPLPAK_ND_MEMSET"))
-            (void)hipMemsetAsync(s->sarp[q][target & 1], 0, sizeof(double) * (size_t)s->s_stage_doubles[(size_t)stg], sU);
-        else if (lz.count)
-            hipLaunchKernelGGL(nd_zero_kernel, dim3(lz.grid), dim3(256), 0, sU, (const ZeroJob *)(s->zero.dev + lz.first), lz.count);
-    };
-    auto deepest_with_parity = [&](int par) { int d = t.maxdepth; if ((d & 1) != par) --d; return d; };
     // one block step of a stage's chain: potrf (on the reserved CUs when pinned) -> panel solve -> panel update, on the
-    // pipeline's chain stream; the Schur passes that become ready go to the update stream
-    auto chain_step = [&](int q, int stg, int k, bool pinned) {
-        hipStream_t sC = sPp[q];
+    // chain stream; the Schur passes that become ready go to the update stream
+    auto chain_step = [&](int stg, int k, bool pinned) {
+        hipStream_t sC = sP;
         const Launch &lp = s->l_potrf[(size_t)stg][(size_t)k], &lt = s->l_trsm[(size_t)stg][(size_t)k];
         const Launch &lu = s->l_upd[(size_t)stg][(size_t)k], &ls = s->l_schur[(size_t)stg][(size_t)k];
         const Launch &lf0 = s->l_fin[0][(size_t)stg][(size_t)k], &lf1 = s->l_fin[1][(size_t)stg][(size_t)k];
         if (pinned) {           // two event hops: chain -> reserved CUs -> chain
-            (void)hipEventRecord(evR0p[q], sC);
-            (void)hipStreamWaitEvent(sR, evR0p[q], 0);
+            (void)hipEventRecord(s->evR0, sC);
+            (void)hipStreamWaitEvent(sR, s->evR0, 0);
             launch_potrf(s, lp, sR, info_dev, minpiv_dev);
-            (void)hipEventRecord((*evIp[q])[(size_t)k], sR);
-            (void)hipStreamWaitEvent(sC, (*evIp[q])[(size_t)k], 0);
+            (void)hipEventRecord(s->evI[(size_t)k], sR);
+            (void)hipStreamWaitEvent(sC, s->evI[(size_t)k], 0);
         } else
             launch_potrf(s, lp, sC, info_dev, minpiv_dev);
         if (lt.count)
             hipLaunchKernelGGL(nd_trsm_kernel, dim3(lt.grid), dim3(64), 0, sC, (const TrsmJob *)(s->trsm.dev + lt.first), lt.count);
         if ((ls.count || lf0.count || lf1.count) && sU != sC) {
-            (void)hipEventRecord((*evTp[q])[(size_t)k], sC);
-            (void)hipStreamWaitEvent(sU, (*evTp[q])[(size_t)k], 0);
+            (void)hipEventRecord(s->evT[(size_t)k], sC);
+            (void)hipStreamWaitEvent(sU, s->evT[(size_t)k], 0);
         }
         launch_syrk(s, s->upd, lu, sC, stats, timing, false, pinned, qnext);
         launch_syrk(s, s->updo, s->l_updo[(size_t)stg][(size_t)k], sC, stats, timing, false, pinned, qnext);     // the group's outer panel pass
@@ -1530,75 +1544,16 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         launch_syrk(s, s->fin[0], lf0, sU, stats, timing, true, pinned, qnext);      // final passes, fused with the extend-add:
         launch_syrk(s, s->fin[1], lf1, sU, stats, timing, true, pinned, qnext);      // children of slot 0, then of slot 1
     };
-    // ---- depths maxdepth .. 1: the pipelines step through a depth together, their Schur passes alternate on sU
-    // (one rank of a one-process multi-GPU fit eliminates its subtrees here -- depths maxdepth .. dcut -- and the fronts above
-    //  in the top phase, together with the other ranks: ndtop.inc)
-    const int dlow = s->mdist ? s->pt.dcut : 1;
-    for (int d = t.maxdepth; d >= dlow; --d) {
-        if (s->dist && d == s->dcut - 1) dist_join();
-        int steps = 0, nfront0 = 0;
-        for (int q = 0; q < np; ++q) {
-            const auto &lv = s->l_potrf[(size_t)(q * nd + d)];
-            steps = std::max(steps, (int)lv.size());
-            if (!lv.empty()) nfront0 += (int)lv[0].grid;
-        }
+    // the root: no Schur buffer to hide its chain behind, hence the look-ahead split
+    auto root_stage = [&](int stg) {
+        const int steps = (int)s->l_potrf[(size_t)stg].size();
         ensure_events(steps);
-        const bool pinned = sR != nullptr && s->nres > 0 && nfront0 <= pin_rounds * s->nres;
-        if (s->fused && d < t.maxdepth)
-            for (int q = 0; q < np; ++q)
-                if (sU != sPp[q]) (void)hipStreamWaitEvent(sPp[q], s->evF[q][(size_t)(d + 1)], 0);     // the children's last passes
-        // (a rank of a distributed factorisation may hold no front at this depth -- its subtrees stop short of the tree's
-        //  depth when a split straddles split_min -- and still owes the stage's bookkeeping: the event its parents wait for
-        //  and the zeroing of the Schur buffers that use this arena half next; round-3 advice: they were skipped with
-        //  steps == 0 and the rank's later fits added onto the previous fit's Schur buffers)
-        for (int k = 0; k < std::max(steps, 1); ++k)
-            for (int q = 0; q < np; ++q) {
-                const int stg = q * nd + d, sq = (int)s->l_potrf[(size_t)stg].size();
-                if (k < sq) chain_step(q, stg, k, pinned);
-                if (s->fused && k == std::max(sq, 1) - 1) {
-                    // stage (q, d) is done on the update stream (stream order): its parents may start, and the arena half
-                    // it used is free -- zero what uses it next (depth d - 2, or the deepest depth of that parity for the NEXT fit)
-                    (void)hipEventRecord(s->evF[q][(size_t)d], sU);
-                    // (multi-GPU: the Schur complements of depth dcut stay in their arena half until the other ranks have pulled
-                    //  them; what shares that half is zeroed for the next fit after the top phase)
-                    if (!(s->mdist && d == dlow)) zero_stage(q, d - 2 >= dlow ? d - 2 : deepest_with_parity(d & 1));
-                }
-            }
-        if (!s->fused) {        // separate extend-add launches (one pipeline): the depth's passes, then slot 0, then slot 1
-            if (sU != sP) {
-                (void)hipEventRecord(s->evU, sU);
-                (void)hipStreamWaitEvent(sP, s->evU, 0);
-            }
-            for (int sl = 0; sl < 2; ++sl) {
-                const Launch &la = s->l_add[sl][(size_t)d];
-                if (la.count)
-                    hipLaunchKernelGGL(nd_extend_add_kernel, dim3(la.grid), dim3(256), 0, sP, (const AddJob *)(s->add.dev + la.first), la.count);
-            }
-            (void)hipEventRecord(s->evE[(size_t)d], sP);
-            if (sU != sP) (void)hipStreamWaitEvent(sU, s->evE[(size_t)d], 0);
-            zero_stage(0, d - 2 >= 1 ? d - 2 : deepest_with_parity(d & 1));
-            // (the zero launches of a depth precede its children's extend-add: sU -> evU -> sP at the end of the next depth)
-        }
-    }
-    // ---- the root: after both pipelines; no Schur buffer to hide its chain behind, hence the look-ahead split
-    if (s->dist && s->dcut == 1) dist_join();
-    if (s->fused && t.maxdepth >= 1 && !s->mdist)
-        for (int q = 0; q < np; ++q)
-            if (sU != sP) (void)hipStreamWaitEvent(sP, s->evF[q][1], 0);
-    hipError_t top_err = hipSuccess;
-    if (s->mdist) {
-        ++s->fgen;
-        top_err = nd_top_factor(s, st, info_dev, minpiv_dev, stats, timing);
-        if (top_err == hipSuccess) zero_stage(0, deepest_with_parity(dlow & 1));       // (postponed above; waited for by the next fit: evZlast)
-    } else {
-        const int steps = (int)s->l_potrf[0].size();
-        ensure_events(steps);
-        const bool pinned = sR != nullptr && s->nres > 0 && (int)s->l_potrf[0][0].grid <= pin_rounds * s->nres;
-        const bool la = s->lookahead[0] != 0;
+        const bool pinned = sR != nullptr && s->nres > 0 && steps > 0 && (int)s->l_potrf[(size_t)stg][0].grid <= pin_rounds * s->nres;
+        const bool la = s->lookahead[(size_t)stg] != 0;
         for (int k = 0; k < steps; ++k) {
-            if (!la) { chain_step(0, 0, k, pinned); continue; }
-            const Launch &lp = s->l_potrf[0][(size_t)k], &lt = s->l_trsm[0][(size_t)k], &ltb = s->l_trsmb[0][(size_t)k];
-            const Launch &lu = s->l_upd[0][(size_t)k], &lur = s->l_updr[0][(size_t)k];
+            if (!la) { chain_step(stg, k, pinned); continue; }
+            const Launch &lp = s->l_potrf[(size_t)stg][(size_t)k], &lt = s->l_trsm[(size_t)stg][(size_t)k], &ltb = s->l_trsmb[(size_t)stg][(size_t)k];
+            const Launch &lu = s->l_upd[(size_t)stg][(size_t)k], &lur = s->l_updr[(size_t)stg][(size_t)k];
             if (pinned) {
                 (void)hipEventRecord(s->evR0, sP);
                 (void)hipStreamWaitEvent(sR, s->evR0, 0);
@@ -1631,7 +1586,50 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             (void)hipEventRecord(s->evU, sU);
             (void)hipStreamWaitEvent(sP, s->evU, 0);
         }
+    };
+    // ---- the stages in schedule order (children before parents).  A rank of a one-process multi-GPU fit eliminates its
+    // subtrees here and the fronts above them in the top phase, together with the other ranks (ndtop.inc).
+    bool joined = false;
+    for (int i = 0; i < ns; ++i) {
+        const NdStage &S = s->sc.st[(size_t)i];
+        if (s->dist && !joined && S.depth <= s->dcut - 1) { dist_join(); joined = true; }
+        if (i > 0)
+            for (int x : s->starts[(size_t)i]) zero_block(x, sU);
+        // the fronts' children have added their Schur complements (their last passes run on the update stream)
+        if (s->fused && S.dep >= 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evF[(size_t)S.dep], 0);
+        if (i == s->root_stage) {
+            root_stage(i);
+            continue;
+        }
+        const int steps = (int)s->l_potrf[(size_t)i].size();
+        ensure_events(steps);
+        const bool pinned = sR != nullptr && s->nres > 0 && steps > 0 && (int)s->l_potrf[(size_t)i][0].grid <= pin_rounds * s->nres;
+        for (int k = 0; k < steps; ++k) chain_step(i, k, pinned);
+        if (s->fused) (void)hipEventRecord(s->evF[(size_t)i], sU);     // (stream order: the stage's last passes are behind it)
+        else {                  // separate extend-add launches: the stage's passes, then slot 0, then slot 1
+            if (sU != sP) {
+                (void)hipEventRecord(s->evU, sU);
+                (void)hipStreamWaitEvent(sP, s->evU, 0);
+            }
+            for (int sl = 0; sl < 2; ++sl) {
+                const Launch &la = s->l_add[sl][(size_t)i];
+                if (la.count)
+                    hipLaunchKernelGGL(nd_extend_add_kernel, dim3(la.grid), dim3(256), 0, sP, (const AddJob *)(s->add.dev + la.first), la.count);
+            }
+            (void)hipEventRecord(s->evE[(size_t)i], sP);       // (the arena blocks of this stage are reused on the update stream)
+            if (sU != sP) (void)hipStreamWaitEvent(sU, s->evE[(size_t)i], 0);
+        }
     }
+    if (s->dist && !joined && s->dcut >= 1) dist_join();
+    hipError_t top_err = hipSuccess;
+    if (s->mdist) {
+        ++s->fgen;
+        top_err = nd_top_factor(s, st, info_dev, minpiv_dev, stats, timing);
+    }
+    // what is alive when the first stage starts is zeroed for the NEXT fit here, beside the tail of this one (waited for
+    // through evZlast; multi-GPU: after the top phase, the other ranks have pulled the subtree roots' Schur complements)
+    if (top_err == hipSuccess && ns > 0)
+        for (int x : s->starts[0]) zero_block(x, sU);
     // inverses of all diagonal blocks (the solves' operands)
     if (s->ntrinv > 0)
         hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)s->ntrinv), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev);
@@ -1762,6 +1760,65 @@ bool nd_upload_jobs(NdState *s)
            nd_upload(s, &s->bwd.dev, s->bwd.host) && nd_upload(s, &s->map.dev, s->map.host);
 }
 
+// (Re)builds the elimination schedule for the fronts in s->mine and sizes the Schur arena for it.  cut < 0: chosen here --
+// the level-by-level order (cut = 0: the largest batches) if its arena fits beside `other_bytes` of further allocations in the
+// free device memory, otherwise the smallest cut that does (SPLPAK_ND_CUT overrides).
+bool nd_make_schedule(NdState *s, int cut, size_t other_bytes)
+{
+    NdTree &t = s->t;
+    const bool packed = !s->mdist && std::getenv("SPLPAK_ND_SQUARE") == nullptr;
+    const int dlow = s->mdist ? s->pt.dcut : 0;
+    s->needs.assign(t.fr.size(), 0);
+    for (size_t id = 0; id < t.fr.size(); ++id) {
+        const NdFront &f = t.fr[id];
+        const bool boundary = s->mdist && f.depth == s->pt.dcut;
+        s->needs[id] = f.hp > 0 && !(s->fused && f.child[0] < 0 && f.nsteps <= s->schur_kb && !boundary) ? 1 : 0;
+    }
+    if (cut < 0) {
+        cut = 0;
+        if (const char *e = std::getenv("SPLPAK_ND_CUT")) cut = std::max(0, std::min(t.maxdepth, atoi(e)));
+        else if (!s->mdist) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 0; }
+            const double room = (double)fr - (double)other_bytes - 1.0e9;
+            long long best = -1;
+            int best_cut = 0;
+            for (int c = 0; c <= std::min(t.maxdepth, 6); ++c) {
+                nd_schedule(t, c, packed, &s->mine, &s->needs, dlow, s->sc);
+                if (best < 0 || s->sc.arena < best) { best = s->sc.arena; best_cut = c; }
+                if (fr == 0 || 8.0 * (double)s->sc.arena <= room) { best_cut = c; break; }
+            }
+            cut = best_cut;         // (nothing fits: the smallest arena -- the allocation then fails with the byte counts in the message)
+        }
+    }
+    nd_schedule(t, cut, packed, &s->mine, &s->needs, dlow, s->sc);
+    const int ns = (int)s->sc.st.size();
+    s->starts.assign((size_t)std::max(ns, 1), {});
+    s->root_stage = -1;
+    for (int i = 0; i < ns; ++i) {
+        const NdStage &S = s->sc.st[(size_t)i];
+        s->starts[(size_t)S.first].push_back(i);
+        if (S.ids.size() == 1 && t.fr[(size_t)S.ids[0]].parent < 0 && !s->mdist) s->root_stage = i;
+    }
+    for (auto *v : {&s->evF, &s->evE})
+        while ((int)v->size() < ns + 1) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            v->push_back(e);
+        }
+    if (s->sc.arena + 64 > s->sarena_doubles) {
+        if (s->sarena) {
+            (void)hipDeviceSynchronize();
+            nd_free_dev(s, &s->sarena);
+            s->owned_bytes -= sizeof(double) * (size_t)s->sarena_doubles;
+        }
+        s->sarena_doubles = 0;
+        if (!nd_alloc(s, &s->sarena, (size_t)s->sc.arena + 64)) return false;
+        s->sarena_doubles = s->sc.arena + 64;
+    }
+    return true;
+}
+
 // Ownership of the fronts for `world` ranks and the job tables that follow from it (see NdState::dist).  Called when the
 // sharded fit's ranks become known (splpak_plan_set_allreduce comes after the plan); SPLPAK_ND_DIST=0 opts out.
 int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
@@ -1775,7 +1832,7 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
     // (the join sums front panels, Schur buffers and solve vectors that live outside the plan's communication buffer: only with a
     //  hook that declared it accepts any device pointer -- SPLPAK_AR_ANY_POINTER; round-3 advice)
     const bool want = world > 1 && p->ar != nullptr && (p->ar_flags & SPLPAK_AR_ANY_POINTER) != 0 && !(sw && atoi(sw) == 0) && dcut >= 1 &&
-                      dcut <= t.maxdepth && s->npipe == 1;
+                      dcut <= t.maxdepth && (s->sc.cut == 0 || s->dist);
     if (!want && !s->dist) return 0;
     (void)hipDeviceSynchronize();
     s->dist = want;
@@ -1793,11 +1850,7 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
             if (f.depth >= dcut) s->mine[(size_t)id] = (slot_of[(size_t)id] % world) == rank ? 1 : 0;
         }
     }
-    const int nd = t.maxdepth + 1, nstage = s->npipe * nd;
-    s->stage_ids.assign((size_t)nstage, {});
-    for (int d = 0; d < nd; ++d)
-        for (int id : t.by_depth[(size_t)d])
-            if (s->mine[(size_t)id]) s->stage_ids[(size_t)(s->pipe_of[(size_t)id] * nd + d)].push_back(id);
+    if (!nd_make_schedule(s, want ? 0 : -1, 0)) return SPLPAK_E_NOMEM;
     for (auto *h : {&s->upd, &s->updr, &s->updo, &s->schur, &s->fin[0], &s->fin[1]}) h->host.clear();
     s->potrf.host.clear(); s->trsm.host.clear(); s->trsmb.host.clear(); s->trinv.host.clear(); s->add.host.clear(); s->zero.host.clear();
     s->mv.host.clear(); s->fwd.host.clear(); s->dot.host.clear(); s->bwd.host.clear(); s->map.host.clear();
@@ -1812,7 +1865,7 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
             for (int r = 0; r < f.fp; ++r) out[(size_t)(f.vofs + r)] = -1;
     }
     if (!nd_upload(s, &s->rowsrc_out, out)) return SPLPAK_E_NOMEM;
-    if (want) {
+    if (want && !s->sc.packed) {
         long long need = 0;
         for (int id : t.by_depth[(size_t)(dcut - 1)]) {
             const long long nt = t.fr[(size_t)id].hp / 64;
@@ -1874,7 +1927,6 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     p->fn_bytes = nd_bytes;
     if (!nd_build(p->g, s->t, nd_default_split_min(p->g.ndim))) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
     NdTree &t = s->t;
-    const int nd = t.maxdepth + 1;
     // one-process multi-GPU fit: this plan is rank `rank` of the group
     s->grp = grp;
     s->mrank = rank;
@@ -1890,25 +1942,10 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     s->mine.assign(t.fr.size(), 1);
     if (s->mdist)
         for (size_t id = 0; id < t.fr.size(); ++id) s->mine[id] = pt.owner[id] == rank ? 1 : 0;
-    // pipelines: SPLPAK_ND_PIPES=2 eliminates the two subtrees below the root side by side (trees of depth >= 3 whose last
-    // Schur passes are fused with the extend-add).  Measured at 64^3 (alternating runs, one box): 235.0 ms per factorisation
-    // with two pipelines against 234.9 with one -- the 20 ms without any matrix-core kernel in flight (rocprofv3 trace) shrink,
-    // but every Schur launch is half as large and the total stays at what 1.1e13 flop take at the power-limited rate.
-    // One pipeline is the default.
+    // (round 3 also knew two PIPELINES -- the two subtrees below the root side by side on two chain streams, SPLPAK_ND_PIPES=2:
+    //  235.0 against 234.9 ms per factorisation at 64^3; removed in round 5, the postorder schedule gives the same overlap)
     s->fused = std::getenv("SPLPAK_ND_NO_FUSE") == nullptr;
-    s->npipe = (!s->mdist && t.maxdepth >= 3 && s->fused && std::getenv("SPLPAK_ND_PIPES") && atoi(std::getenv("SPLPAK_ND_PIPES")) == 2) ? 2 : 1;
-    s->pipe_of.assign(t.fr.size(), 0);
-    if (s->npipe == 2)
-        for (int id = (int)t.fr.size() - 1; id >= 0; --id) {          // parents have larger ids than their children (postorder)
-            const NdFront &f = t.fr[(size_t)id];
-            if (f.parent < 0) s->pipe_of[(size_t)id] = 0;
-            else if (t.fr[(size_t)f.parent].parent < 0) s->pipe_of[(size_t)id] = f.slot;
-            else s->pipe_of[(size_t)id] = s->pipe_of[(size_t)f.parent];
-        }
-    const int nstage = s->npipe * nd;
-    s->stage_ids.assign((size_t)nstage, {});
-    s->s_stage_doubles.assign((size_t)nstage, 0);
-    s->soff.assign(t.fr.size(), 0);
+    if (const char *e = std::getenv("SPLPAK_ND_KB")) s->schur_kb = std::max(1, std::min(4, atoi(e)));
     // this rank's storage: panels and Schur buffers of the fronts it eliminates, then its block columns of the top fronts
     s->poff.assign(t.fr.size(), -1);
     s->lblk.assign(t.fr.size(), -1);
@@ -1920,15 +1957,6 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
         s->lblk[id] = s->nblocks;
         s->nblocks += f.nsteps;
     }
-    for (int d = 0; d < nd; ++d)
-        for (int id : t.by_depth[(size_t)d]) {
-            if (!s->mine[(size_t)id]) continue;
-            const NdFront &f = t.fr[(size_t)id];
-            const int stg = s->pipe_of[(size_t)id] * nd + d;
-            s->stage_ids[(size_t)stg].push_back(id);
-            s->soff[(size_t)id] = s->s_stage_doubles[(size_t)stg];
-            s->s_stage_doubles[(size_t)stg] += f.lds * (long long)f.hp;
-        }
     std::vector<long long> padwhere;
     long long max_fp = 0;
     if (s->mdist) {
@@ -1953,15 +1981,22 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
             }
         }
     }
-    for (int p = 0; p < s->npipe; ++p)
-        for (int d = 0; d < nd; ++d)
-            s->sarp_doubles[p][d & 1] = std::max(s->sarp_doubles[p][d & 1], s->s_stage_doubles[(size_t)(p * nd + d)]);
-    bool ok = nd_alloc(s, &s->factor, (size_t)s->factor_doubles + 64) && nd_alloc(s, &s->sarp[0][0], (size_t)s->sarp_doubles[0][0] + 64) &&
-              nd_alloc(s, &s->sarp[0][1], (size_t)s->sarp_doubles[0][1] + 64) && nd_alloc(s, &s->sarp[1][0], (size_t)s->sarp_doubles[1][0] + 64) &&
-              nd_alloc(s, &s->sarp[1][1], (size_t)s->sarp_doubles[1][1] + 64) && nd_alloc(s, &s->dinv, (size_t)s->nblocks * 65536) &&
+    // Everything but the Schur arena first; the schedule is then chosen for the device memory that is left (the plan still
+    // allocates its communication buffer -- half stencil, right-hand side, histogram, residual -- and two vectors after this)
+    bool ok = nd_alloc(s, &s->factor, (size_t)s->factor_doubles + 64) && nd_alloc(s, &s->dinv, (size_t)s->nblocks * 65536) &&
               nd_alloc(s, &s->dinvt, (size_t)s->nblocks * 65536) && nd_alloc(s, &s->inv16, (size_t)s->nblocks * 4096) &&
               nd_alloc(s, &s->V, (size_t)t.vec_doubles) && nd_alloc(s, &s->Y, (size_t)t.vec_doubles) &&
               nd_alloc(s, &s->part, (size_t)(s->part_cap = t.vec_doubles / 4 + 256LL * (long long)t.fr.size() + 4096));
+    if (ok) {
+        const size_t later = sizeof(double) * ((size_t)p->g.ncol * (size_t)(p->g.hstencil + 8)) + sizeof(int) * 8 * (size_t)t.vec_doubles;
+        ok = nd_make_schedule(s, -1, later);
+        if (!ok) {
+            char buf[320];
+            snprintf(buf, sizeof buf, "nested dissection: the Schur arena of %.1f GB (packed lower triangles, schedule cut %d) does not fit beside %.1f GB of factor panels",
+                     8e-9 * (double)s->sc.arena, s->sc.cut, 8e-9 * (double)s->factor_doubles);
+            set_error(buf);
+        }
+    }
     if (ok && s->mdist) {
         for (int i = 0; i < 3 && ok; ++i) ok = nd_alloc(s, &s->pbuf[i], (size_t)pt.max_panel + 64);
         s->stagev_doubles = max_fp + 64;
@@ -2009,12 +2044,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     (void)hipStreamCreateWithPriority(&s->sP, hipStreamNonBlocking, hi);
     (void)hipStreamCreateWithFlags(&s->sU, hipStreamNonBlocking);
-    if (s->npipe == 2) (void)hipStreamCreateWithPriority(&s->sP2, hipStreamNonBlocking, hi);
-    for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone, &s->evPre, &s->evTail, &s->evR0, &s->evR02}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
-    for (int p = 0; p < 2; ++p) {
-        s->evF[p].assign((size_t)nd + 1, nullptr);
-        for (int d = 0; d <= nd; ++d) (void)hipEventCreateWithFlags(&s->evF[p][(size_t)d], hipEventDisableTiming);
-    }
+    for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone, &s->evPre, &s->evTail, &s->evR0}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
     // item queues of the update launches (two per step at most)
     s->nqueues = 8 * t.nblocks + 64;
     if (const char *e = std::getenv("SPLPAK_ND_SMALL_GRID")) s->small_grid = atoi(e);
@@ -2052,12 +2082,6 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
             s->sR = nullptr;
         }
     }
-    s->evE.assign((size_t)nd + 1, nullptr);
-    s->evZ.assign((size_t)nd + 1, nullptr);
-    for (int d = 0; d <= nd; ++d) {
-        (void)hipEventCreateWithFlags(&s->evE[(size_t)d], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&s->evZ[(size_t)d], hipEventDisableTiming);
-    }
     if (s->mdist) {
         (void)hipStreamCreateWithPriority(&s->sCopy, hipStreamNonBlocking, hi);
         for (auto *v : {&s->evReady, &s->evArr, &s->evCol, &s->evBulk, &s->evSF, &s->evSB}) {
@@ -2081,8 +2105,9 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     if (factor_arena) *factor_arena = s->factor;
     if (factor_doubles) *factor_doubles = s->factor_doubles;
     if (std::getenv("SPLPAK_DEBUG"))
-        fprintf(stderr, "[splpak] nested dissection%s: %zu fronts, depth %d, factor %.2f GB, Schur arenas %.2f GB, %.3e flop, %d reserved CUs\n",
-                s->mdist ? " (one rank of a multi-GPU fit)" : "", t.fr.size(), t.maxdepth, 8e-9 * (double)s->factor_doubles, 8e-9 * (double)(s->sarp_doubles[0][0] + s->sarp_doubles[0][1] + s->sarp_doubles[1][0] + s->sarp_doubles[1][1]), t.flop, s->nres);
+        fprintf(stderr, "[splpak] nested dissection%s: %zu fronts, depth %d, factor %.2f GB, Schur arena %.2f GB (%s, %zu stages, cut %d), %.3e flop, %d reserved CUs\n",
+                s->mdist ? " (one rank of a multi-GPU fit)" : "", t.fr.size(), t.maxdepth, 8e-9 * (double)s->factor_doubles, 8e-9 * (double)s->sarena_doubles,
+                s->sc.packed ? "packed" : "square", s->sc.st.size(), s->sc.cut, t.flop, s->nres);
     return 0;
 }
 

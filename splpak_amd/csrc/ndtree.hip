@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstring>
+#include <functional>
 
 namespace splpak {
 
@@ -177,6 +178,140 @@ bool nd_build(const Grid &g, NdTree &t, int split_min)
         }
     }
     return true;
+}
+
+void nd_schedule(const NdTree &t, int cut, bool packed, const std::vector<char> *mine, const std::vector<char> *needs, int dlow, NdSchedule &sc)
+{
+    sc = NdSchedule();
+    sc.cut = cut < 0 ? 0 : cut;
+    sc.packed = packed;
+    const size_t nf = t.fr.size();
+    sc.stage_of.assign(nf, -1);
+    sc.soff.assign(nf, -1);
+    auto is_mine = [&](int id) { return t.fr[(size_t)id].depth >= dlow && (!mine || (*mine)[(size_t)id]); };
+    auto add_stage = [&](std::vector<int> &ids, int depth) {
+        if (ids.empty()) return;
+        std::sort(ids.begin(), ids.end());
+        NdStage st;
+        st.depth = depth;
+        st.ids.swap(ids);
+        for (int id : st.ids) sc.stage_of[(size_t)id] = (int)sc.st.size();
+        sc.st.push_back(std::move(st));
+    };
+    // level by level through the subtree of `r` (children before parents; ids ascend in postorder, so a front's descendants
+    // are the contiguous range of ids before it -- walked explicitly here to stay independent of that)
+    auto emit_subtree = [&](int r) {
+        std::vector<std::vector<int>> lev((size_t)t.maxdepth + 1);
+        std::vector<int> stack{r};
+        while (!stack.empty()) {
+            const int id = stack.back();
+            stack.pop_back();
+            const NdFront &f = t.fr[(size_t)id];
+            if (is_mine(id)) lev[(size_t)f.depth].push_back(id);
+            for (int c : f.child) if (c >= 0) stack.push_back(c);
+        }
+        for (int d = t.maxdepth; d >= 0; --d) add_stage(lev[(size_t)d], d);
+    };
+    struct Rec { static void go(const NdTree &t, int id, int cut, const std::function<void(int)> &sub, const std::function<void(int)> &one) {
+        const NdFront &f = t.fr[(size_t)id];
+        if (f.depth >= cut) { sub(id); return; }
+        for (int c : f.child) if (c >= 0) go(t, c, cut, sub, one);
+        one(id);
+    } };
+    if (t.root >= 0)
+        Rec::go(t, t.root, sc.cut, emit_subtree, [&](int id) { std::vector<int> one; if (is_mine(id)) one.push_back(id); add_stage(one, t.fr[(size_t)id].depth); });
+    const int ns = (int)sc.st.size();
+    for (int i = 0; i < ns; ++i) {
+        NdStage &st = sc.st[(size_t)i];
+        st.first = i;
+        for (int id : st.ids)
+            for (int c : t.fr[(size_t)id].child) {
+                const int cs = c >= 0 ? sc.stage_of[(size_t)c] : -1;
+                if (cs < 0) continue;
+                st.dep = std::max(st.dep, cs);
+                st.first = std::min(st.first, cs);
+            }
+        st.keep = dlow > 0 && st.depth == dlow;
+        for (int id : st.ids) {
+            const NdFront &f = t.fr[(size_t)id];
+            if (f.hp <= 0 || (needs && !(*needs)[(size_t)id])) continue;
+            sc.soff[(size_t)id] = st.doubles;               // relative to the block, for now
+            st.doubles += (nd_schur_doubles(f, packed) + 63) / 64 * 64;
+        }
+        sc.total += st.doubles;
+    }
+    // Interval allocation over the stage sequence (offline: the lifetimes are known).  Three placements are tried and the
+    // smallest arena kept: first fit from the bottom; best fit; and "two-ended" -- blocks of even tree depth from the bottom,
+    // of odd depth from the top of a trial arena -- which is exact for the level-by-level order (the two arenas of rounds 3-4).
+    std::vector<std::vector<int>> starts((size_t)ns);
+    for (int i = 0; i < ns; ++i) starts[(size_t)sc.st[(size_t)i].first].push_back(i);
+    for (int i = 0; i < ns; ++i) std::stable_sort(starts[(size_t)i].begin(), starts[(size_t)i].end(), [&](int a, int b) { return a > b; });   // (longest-lived first)
+    auto place = [&](int mode, long long cap, std::vector<long long> &off) -> long long {
+        std::vector<std::pair<long long, long long>> freel{{0, cap}};      // (offset, length), ascending offsets
+        auto take = [&](long long n, bool high) {
+            long long best = -1;
+            size_t bk = 0;
+            for (size_t k = 0; k < freel.size(); ++k) {
+                if (freel[k].second < n) continue;
+                if (mode == 1) { if (best < 0 || freel[k].second < freel[bk].second) { best = 0; bk = k; } continue; }
+                best = 0; bk = k;
+                if (!high) break;                                       // first fit from the bottom; `high`: the last fit
+            }
+            if (best < 0) return (long long)-1;
+            long long o;
+            if (high) { o = freel[bk].first + freel[bk].second - n; freel[bk].second -= n; }
+            else { o = freel[bk].first; freel[bk].first += n; freel[bk].second -= n; }
+            if (freel[bk].second == 0) freel.erase(freel.begin() + (long)bk);
+            return o;
+        };
+        auto give = [&](long long o, long long n) {
+            size_t k = 0;
+            while (k < freel.size() && freel[k].first < o) ++k;
+            freel.insert(freel.begin() + (long)k, {o, n});
+            if (k + 1 < freel.size() && freel[k].first + freel[k].second == freel[k + 1].first) { freel[k].second += freel[k + 1].second; freel.erase(freel.begin() + (long)k + 1); }
+            if (k > 0 && freel[k - 1].first + freel[k - 1].second == freel[k].first) { freel[k - 1].second += freel[k].second; freel.erase(freel.begin() + (long)k); }
+        };
+        long long lo_end = 0, hi_beg = cap;
+        for (int i = 0; i < ns; ++i) {
+            for (int x : starts[(size_t)i]) {
+                const NdStage &st = sc.st[(size_t)x];
+                if (st.doubles <= 0) continue;
+                const bool high = mode == 2 && (st.depth & 1) != 0;
+                const long long o = take(st.doubles, high);
+                if (o < 0) return -1;
+                off[(size_t)x] = o;
+                if (high) hi_beg = std::min(hi_beg, o); else lo_end = std::max(lo_end, o + st.doubles);
+            }
+            const NdStage &me = sc.st[(size_t)i];
+            if (me.doubles > 0 && !me.keep) give(off[(size_t)i], me.doubles);
+        }
+        if (mode != 2) return lo_end;
+        return hi_beg >= lo_end ? lo_end + (cap - hi_beg) : -1;        // (the two ends must not have met)
+    };
+    std::vector<long long> off((size_t)ns, 0), best_off;
+    long long best = -1;
+    for (int mode = 0; mode < 2; ++mode) {
+        const long long a = place(mode, (long long)1 << 60, off);
+        if (a >= 0 && (best < 0 || a < best)) { best = a; best_off = off; }
+    }
+    if (best > 0) {
+        // two-ended: bisect the smallest trial arena in which the two ends do not collide
+        long long lo = 0, hi = best;
+        std::vector<long long> o2((size_t)ns, 0);
+        if (place(2, hi, o2) >= 0) {
+            while (hi - lo > 4096) {
+                const long long mid = (lo + (hi - lo) / 2 + 63) / 64 * 64;
+                if (place(2, mid, off) >= 0) { hi = mid; o2 = off; }
+                else lo = mid;
+            }
+            if (hi < best) { best = hi; best_off = o2; }
+        }
+    }
+    sc.arena = best < 0 ? 0 : best;
+    for (int i = 0; i < ns; ++i) sc.st[(size_t)i].off = best_off.empty() ? 0 : best_off[(size_t)i];
+    for (int i = 0; i < ns; ++i)
+        for (int id : sc.st[(size_t)i].ids)
+            if (sc.soff[(size_t)id] >= 0) sc.soff[(size_t)id] += sc.st[(size_t)i].off;
 }
 
 void nd_partition(const NdTree &t, int R, int chunk, NdPartition &pt)
@@ -417,5 +552,45 @@ extern "C" int32_t splpak_debug_nd_tree(int32_t ndim, const int32_t *nodes, int3
     out16[12] = (double)t.border_rows;
     out16[13] = 2.0 * 8.0 * 65536.0 * t.nblocks + 8.0 * 4096.0 * t.nblocks;   // bytes of the block inverses
     out16[14] = out16[15] = 0;
+    return 0;
+}
+
+extern "C" int32_t splpak_debug_nd_schedule(int32_t ndim, const int32_t *nodes, int32_t split_min, int32_t cut, int32_t packed, double *out8)
+{
+    using namespace splpak;
+    double xmin[MAXD] = {0, 0, 0, 0}, xmax[MAXD] = {1, 1, 1, 1};
+    Grid g;
+    if (!nodes || !out8) return SPLPAK_E_BADARG;
+    const int v = build_grid(ndim, nodes, xmin, xmax, g, nullptr, true);
+    if (v != 0) return v;
+    NdTree t;
+    if (!nd_build(g, t, split_min > 0 ? split_min : nd_default_split_min(ndim))) { set_error("nested dissection: inconsistent tree"); return SPLPAK_E_BADARG; }
+    NdSchedule sc;
+    nd_schedule(t, cut, packed != 0, nullptr, nullptr, 0, sc);
+    // every front in exactly one stage, children in earlier stages, no two live blocks overlap
+    std::string bad;
+    for (size_t id = 0; id < t.fr.size() && bad.empty(); ++id) {
+        const int st = sc.stage_of[id];
+        if (st < 0) { bad = "a front is in no stage"; break; }
+        for (int c : t.fr[id].child)
+            if (c >= 0 && sc.stage_of[(size_t)c] >= st) bad = "a child is not eliminated before its parent";
+    }
+    const int ns = (int)sc.st.size();
+    for (int a = 0; a < ns && bad.empty(); ++a)
+        for (int b = a + 1; b < ns && bad.empty(); ++b) {
+            const NdStage &A = sc.st[(size_t)a], &B = sc.st[(size_t)b];
+            if (A.doubles <= 0 || B.doubles <= 0) continue;
+            const bool time_overlap = B.first <= a;                      // A lives over stages [A.first, a], B over [B.first, b], a < b
+            const bool mem_overlap = A.off < B.off + B.doubles && B.off < A.off + A.doubles;
+            if (time_overlap && mem_overlap) bad = "two live Schur blocks overlap";
+        }
+    if (!bad.empty()) { set_error("nested dissection schedule: " + bad); return SPLPAK_E_BADARG; }
+    out8[0] = ns;
+    out8[1] = 8.0 * (double)sc.arena;
+    out8[2] = 8.0 * (double)sc.total;
+    out8[3] = 8.0 * (double)t.factor_doubles;
+    out8[4] = sc.cut;
+    out8[5] = t.maxdepth;
+    out8[6] = out8[7] = 0;
     return 0;
 }

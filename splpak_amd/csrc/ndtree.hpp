@@ -68,6 +68,52 @@ struct NdTree {
     double flop_exact = 0.0;       // without the padding: w^3/3 + w^2 h + w h^2 per front
 };
 
+// ELIMINATION SCHEDULE and the Schur-buffer arena (round 5).
+//
+// A STAGE is a set of fronts of one tree depth that are eliminated together (every launch of the factorisation is a batch over
+// the fronts of a stage).  Rounds 3-4 knew one schedule: a stage per tree depth, deepest first, and two Schur arenas by depth
+// parity, each as large as the largest depth of its parity -- at a 4-D grid every depth of the tree holds 50-70 % of all the
+// border x border buffers of the top of the tree at once (24^4: 132 GB of arenas for 76 GB of factor; 32^4: 714 GB).
+// Now the fronts of depth < cut are stages of their own, visited in POSTORDER, and the subtrees below depth cut are
+// eliminated one after the other, each level by level as before: at any time only the buffers of ONE root-to-leaf path of the
+// top of the tree plus two levels of one subtree are alive.  cut = 0 is the old order.
+//
+// A front's Schur buffer is alive from the start of the first stage that adds into it (its first child's stage: the
+// extend-add is fused into the child's last pass) to the end of its own stage; the arena offsets come from a first-fit
+// interval allocation over the stage sequence, done once per plan on the host.  All accesses to the arena are ordered by the
+// update stream (Schur passes, fused extend-adds, zeroing), so reuse needs no further synchronisation.
+//
+// `packed`: a Schur buffer holds only the 64-column tile columns of its LOWER TRIANGLE, each from its diagonal tile down
+// (tile column c: 64 columns of leading dimension L - 64 c, L = hp + 16) -- half the bytes of the square buffer.
+struct NdStage {
+    std::vector<int> ids;          // its fronts (ascending id)
+    int depth = 0;
+    int dep = -1;                  // last stage whose fronts add into this stage's fronts (-1: none)
+    int first = 0;                 // stage at whose start this stage's buffers are allocated and zeroed (its first child stage, or itself)
+    long long off = 0, doubles = 0;    // its block of the arena
+    bool keep = false;             // never freed (subtree roots of a multi-GPU fit: other GPUs pull them after the stage)
+};
+struct NdSchedule {
+    int cut = 0;
+    bool packed = false;
+    std::vector<NdStage> st;       // in execution order
+    std::vector<int> stage_of;     // [front] (-1: not eliminated by this schedule)
+    std::vector<long long> soff;   // [front] doubles into the arena (-1: the front has no buffer)
+    long long arena = 0;           // doubles: peak of the allocation
+    long long total = 0;           // doubles of all buffers (what one fit zeroes)
+};
+// doubles of the Schur buffer of a front; leading dimension argument of the kernels: lds, or -(hp + 16) for the packed form
+inline long long nd_schur_doubles(const NdFront &f, bool packed)
+{
+    if (f.hp <= 0) return 0;
+    const long long nt = f.hp / 64, L = f.hp + 16;
+    return packed ? 64 * L * nt - 2048 * nt * (nt - 1) : f.lds * (long long)f.hp;
+}
+inline long long nd_schur_ld(const NdFront &f, bool packed) { return packed ? -(long long)(f.hp + 16) : f.lds; }
+// mine: fronts this schedule eliminates (NULL: all); needs: fronts whose buffer is materialised (NULL: every front with a
+// border); dlow: fronts above this depth are left out (multi-GPU: the top phase has them), and those AT dlow > 0 are kept
+void nd_schedule(const NdTree &t, int cut, bool packed, const std::vector<char> *mine, const std::vector<char> *needs, int dlow, NdSchedule &sc);
+
 // Distribution of the tree over the R GPUs of a one-process multi-GPU fit (round 4; ndchol.hip "top phase"):
 //   * the subtrees below tree depth dcut = ceil(log2 R) are dealt to the ranks (subtree i of the depth-dcut fronts -> rank
 //     i mod R): a rank stores and eliminates ITS subtrees only (panels, Schur buffers, block inverses);

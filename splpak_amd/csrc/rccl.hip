@@ -51,14 +51,18 @@ bool rccl_load()
     if (g_rccl.tried) return g_rccl.all_reduce != nullptr;
     g_rccl.tried = true;
     void *h = nullptr;
-    if (const char *e = std::getenv("SPLPAK_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
-    // an RCCL the process already carries (PyTorch's) first: two RCCLs in one process would not share their state
-    for (const char *name : {"librccl.so.1", "librccl.so"})
-        if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
-        if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (const char *e = std::getenv("SPLPAK_RCCL_LIB")) {
+        h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);          // an explicit library is the ONLY candidate: no silent second choice
+    } else {
+        // an RCCL the process already carries (PyTorch's) first: two RCCLs in one process would not share their state
+        for (const char *name : {"librccl.so.1", "librccl.so"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    }
     if (!h) {
-        set_error(std::string("RCCL: librccl.so could not be opened (") + (dlerror() ? dlerror() : "not found") + "); set SPLPAK_RCCL_LIB");
+        const char *de = dlerror();                     // ONE call: dlerror() clears the message it returns
+        set_error(std::string("RCCL: librccl.so could not be opened (") + (de ? de : "not found") + "); set SPLPAK_RCCL_LIB");
         return false;
     }
     g_rccl.handle = h;
@@ -136,34 +140,78 @@ int32_t splpak_rccl_comm_create(const char *id128, int32_t rank, int32_t world, 
     return 0;
 }
 
-int32_t splpak_rccl_comm_create_from_file(const char *path, int32_t rank, int32_t world, double timeout_s, void **comm)
+// The id file: { "SPLPAKID", tag, publish time [ns, CLOCK_REALTIME], ncclUniqueId } = 152 bytes.  The tag names the JOB: a
+// file left behind by another run (rank 0 crashed before it could remove it, or a second job on the same path) carries
+// another tag and is ignored, so nobody enters ncclCommInitRank with a stale id -- which would hang, and no timeout of ours
+// covers that.  Rank 0 removes whatever lies at `path` before it publishes and removes its own file once ncclCommInitRank
+// has returned (the call is collective: every rank has read the id by then).
+struct IdFile { char magic[8]; uint64_t tag; int64_t published_ns; char id[128]; };
+static_assert(sizeof(IdFile) == 152, "id file layout");
+
+static uint64_t job_tag_of(const char *job)
+{
+    std::string key;
+    if (job && *job) key = job;
+    else if (const char *e = std::getenv("SPLPAK_RCCL_JOB")) key = e;
+    else {
+        // what launchers give every rank of ONE run: torchrun / torch.distributed, Slurm, Open MPI
+        for (const char *name : {"TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID", "OMPI_MCA_ess_base_jobid"})
+            if (const char *e = std::getenv(name)) { key += name; key += '='; key += e; key += ';'; }
+    }
+    uint64_t h = 1469598103934665603ull;              // FNV-1a
+    for (unsigned char c : key) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+int32_t splpak_rccl_comm_create_from_file_ex(const char *path, const char *job, int32_t rank, int32_t world, double timeout_s, void **comm)
 {
     if (!path || !comm) { set_error("null argument"); return SPLPAK_E_BADARG; }
-    char id[128];
+    if (world < 1 || rank < 0 || rank >= world) { set_error("splpak_rccl_comm_create_from_file: bad rank / world"); return SPLPAK_E_BADARG; }
+    const uint64_t tag = job_tag_of(job);
+    const double tmax = timeout_s > 0 ? timeout_s : 60.0;
+    IdFile rec;
     if (rank == 0) {
-        if (int r = splpak_rccl_unique_id(id)) return r;
+        std::remove(path);                              // a file of an earlier run must not meet this run's readers
+        std::memcpy(rec.magic, "SPLPAKID", 8);
+        rec.tag = tag;
+        rec.published_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+        if (int r = splpak_rccl_unique_id(rec.id)) return r;
         const std::string tmp = std::string(path) + ".tmp";
         FILE *f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) { if (f) std::fclose(f); set_error("RCCL: cannot write the id file"); return SPLPAK_E_COMM; }
+        if (!f || std::fwrite(&rec, 1, sizeof rec, f) != sizeof rec) { if (f) std::fclose(f); set_error("RCCL: cannot write the id file"); return SPLPAK_E_COMM; }
         std::fclose(f);
         if (std::rename(tmp.c_str(), path) != 0) { set_error("RCCL: cannot publish the id file"); return SPLPAK_E_COMM; }     // (atomic: readers never see half an id)
     } else {
         const auto t0 = std::chrono::steady_clock::now();
+        const int64_t entered_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+        bool stale_seen = false;
         for (;;) {
             FILE *f = std::fopen(path, "rb");
             if (f) {
-                const size_t n = std::fread(id, 1, sizeof id, f);
+                const size_t n = std::fread(&rec, 1, sizeof rec, f);
                 std::fclose(f);
-                if (n == sizeof id) break;
+                // this job's tag, and not older than the wait we would have granted it ourselves
+                const bool fresh = n == sizeof rec && std::memcmp(rec.magic, "SPLPAKID", 8) == 0 && rec.tag == tag &&
+                                   rec.published_ns >= entered_ns - (int64_t)(tmax * 1e9);
+                if (fresh) break;
+                stale_seen = true;
             }
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (timeout_s > 0 ? timeout_s : 60.0)) {
-                set_error("RCCL: timed out waiting for rank 0's id file");
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > tmax) {
+                set_error(stale_seen ? "RCCL: timed out waiting for rank 0's id file (the file at this path belongs to another run: wrong job tag or too old)"
+                                     : "RCCL: timed out waiting for rank 0's id file");
                 return SPLPAK_E_COMM;
             }
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
     }
-    return splpak_rccl_comm_create(id, rank, world, comm);
+    const int32_t r = splpak_rccl_comm_create(rec.id, rank, world, comm);
+    if (rank == 0) std::remove(path);                   // every rank has the id: ncclCommInitRank is collective
+    return r;
+}
+
+int32_t splpak_rccl_comm_create_from_file(const char *path, int32_t rank, int32_t world, double timeout_s, void **comm)
+{
+    return splpak_rccl_comm_create_from_file_ex(path, nullptr, rank, world, timeout_s, comm);
 }
 
 void splpak_rccl_comm_destroy(void *comm)

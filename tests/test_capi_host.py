@@ -136,3 +136,55 @@ def test_basis_table_forms_match_the_reference_basis(port, nodes):
             ref = L.oracle_bascmp(1, xi, nd0, ibc, xmin_c, dx_c, nodes_c, icol) if ibmn <= ib <= ibmx else 0.0
             worst = max(worst, abs(used[i, k] - ref) / max(1.0, abs(ref)))
     assert worst <= 1e-12, worst
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the RCCL rendezvous file (csrc/rccl.hip): host logic, no GPU and no RCCL call needed for the reader side
+def _id_file(path, job, age_s=0.0, magic=b"SPLPAKID"):
+    import struct
+    import time
+    h = 1469598103934665603
+    for c in job.encode():
+        h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    with open(path, "wb") as f:
+        f.write(magic + struct.pack("<Qq", h, int((time.time() - age_s) * 1e9)) + bytes(range(128)))
+
+
+def test_rccl_id_file_of_another_run_is_ignored(tmp_path):
+    """A rank > 0 must not pick up an id file that another run left at the same path (it would enter ncclCommInitRank with a
+    stale id and hang): files with another job tag, files older than the wait, short files and files of the round-4 layout
+    (128 bare bytes) all end in the timeout with SPLPAK_E_COMM -- never in a communicator."""
+    path = tmp_path / "id"
+    for make in (lambda: _id_file(path, "another job"),
+                 lambda: _id_file(path, "this job", age_s=3600.0),
+                 lambda: _id_file(path, "this job", magic=b"XXXXXXXX"),
+                 lambda: path.write_bytes(bytes(128)),
+                 lambda: path.write_bytes(b"short")):
+        make()
+        with pytest.raises(capi.SplpakError) as ei:
+            capi.rccl_comm_create_from_file(path, 1, 2, timeout_s=0.3, job="this job")
+        assert "-5" in str(ei.value) and "timed out" in str(ei.value)
+        assert "another run" in str(ei.value)
+    path.unlink()
+    with pytest.raises(capi.SplpakError) as ei:
+        capi.rccl_comm_create_from_file(path, 1, 2, timeout_s=0.2, job="this job")
+    assert "timed out" in str(ei.value) and "another run" not in str(ei.value)
+    with pytest.raises(capi.SplpakError):
+        capi.rccl_comm_create_from_file(path, 2, 2, timeout_s=0.2)          # rank out of range
+
+
+def test_rccl_library_missing_is_a_clean_error():
+    """with no loadable librccl the hook entry points return SPLPAK_E_COMM and a message (rccl_load used to build
+    its message from two dlerror() calls -- the second returns NULL -- and crashed)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from splpak_amd import capi\n"
+            "try:\n"
+            "    capi.rccl_unique_id()\n"
+            "except capi.SplpakError as e:\n"
+            "    print('ERR', e)\n") % ROOT
+    env = dict(os.environ, SPLPAK_RCCL_LIB="/nonexistent/librccl.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-400:]
+    assert "ERR" in r.stdout and "-5" in r.stdout and "librccl" in r.stdout

@@ -41,6 +41,43 @@ def test_tree_promises_for_the_baseline_grids():
     assert t4["flop"] < 6.2e14 / 2
 
 
+@pytest.mark.parametrize("nodes", [[16, 16, 16], [9, 17, 13], [64, 64], [150, 130], [8, 9, 10, 11], [24, 40, 24], [5, 30, 5], [33]])
+def test_schedule_invariants(nodes):
+    """Round 5 (csrc/ndtree.hpp NdSchedule): for every cut depth the schedule eliminates children before parents and no two
+    Schur buffers that are alive at the same time share a place in the arena (verified inside splpak_debug_nd_schedule);
+    cut = 0 with square buffers is exactly the two depth-parity arenas of rounds 3-4, and packing halves it."""
+    tree = capi.debug_nd_tree(nodes, check=False)
+    level = capi.debug_nd_schedule(nodes, cut=0, packed=False)
+    assert level["stages"] == int(tree["depth"]) + 1
+    assert level["arena_bytes"] == tree["arena_bytes"]
+    for cut in range(0, int(tree["depth"]) + 2):
+        for packed in (False, True):
+            sc = capi.debug_nd_schedule(nodes, cut=cut, packed=packed)
+            assert sc["stages"] >= level["stages"] and sc["factor_bytes"] == tree["factor_bytes"]
+            if packed and tree["arena_bytes"] > 0:          # (borders of a few tiles gain less than half: whole 64 x 64 tiles on the diagonal)
+                sq = capi.debug_nd_schedule(nodes, cut=cut, packed=False)["arena_bytes"]
+                assert sc["arena_bytes"] <= (0.62 if tree["max_border"] >= 2048 else 1.0) * sq + 4096
+
+
+def test_schedule_makes_the_4d_28_grid_fit_one_gpu_and_says_why_32_does_not():
+    """VERDICT r04 #1.  MI355X: 288 GiB = 309 GB of HBM.  With the level-by-level order of rounds 3-4 the 4-D 28^4 grid needed
+    205 GB of panels + 326 GB of Schur arenas; in postorder with packed buffers the arena is ~60 GB and the fit runs on one GPU
+    (tests/test_gpu_parity.py).  BASELINE config 5's own 32^4 grid: 476 GB of panels + ~131 GB of arena = twice the HBM; the
+    GPU boxes of this pool give a job 322 GB of host memory (cgroup memory.max, tools/host_probe.py), less than the >= 330 GB an
+    out-of-core factorisation would have to park there -- it stays an 8-GPU problem (test_multi_gpu_partition_of_the_4d_32_grid...)."""
+    hbm = 288 * 2.0**30
+    t28 = capi.debug_nd_tree([28] * 4, check=False)
+    assert t28["factor_bytes"] + t28["arena_bytes"] > 1.5 * hbm
+    best28 = min(capi.debug_nd_schedule([28] * 4, cut=c)["arena_bytes"] for c in range(0, 5))
+    assert best28 < 66e9 and t28["factor_bytes"] + best28 + 20e9 < hbm
+    t32 = capi.debug_nd_tree([32] * 4, check=False)
+    best32 = min(capi.debug_nd_schedule([32] * 4, cut=c)["arena_bytes"] for c in range(0, 5))
+    assert t32["factor_bytes"] > 1.5 * hbm and 120e9 < best32 < 140e9
+    assert t32["factor_bytes"] + best32 - hbm > 290e9      # what would have to live in host memory: more than the box's cgroup allows with anything else
+    # 64^3 (BASELINE configs 3 / 4): the level-by-level order stays (largest batches); packed buffers halve its arena
+    assert capi.debug_nd_schedule([64] * 3, cut=0)["arena_bytes"] < 8.2e9
+
+
 def test_tree_rejects_bad_grids_like_the_fit():
     with pytest.raises(capi.SplpakError):
         capi.debug_nd_tree([3, 8])
@@ -190,8 +227,9 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
     reserved CUs while the update waves take their items from a queue and step aside there, and the root's panel
     update is split for look-ahead.  The last Schur pass of every front adds its result into the parent itself.  None of that may
     change a bit: the same fit without reserved CUs, without the root look-ahead, with K = 256 Schur passes, with separate
-    extend-add launches, with the two subtrees below the root as two pipelines (SPLPAK_ND_PIPES=2) and entirely serial gives
-    identical coefficients."""
+    extend-add launches and entirely serial gives identical coefficients.  Round 5: so do the POSTORDER schedules (the fronts
+    above depth SPLPAK_ND_CUT one by one, the subtrees below one after the other, Schur buffers reused along the way --
+    csrc/ndtree.hpp NdSchedule) and square instead of packed Schur buffers (SPLPAK_ND_SQUARE)."""
     from splpak_amd.synth import synth_points
     nd, nod, m = 3, 32, 200000
     x, y, w = synth_points(nd, m)
@@ -199,8 +237,9 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
     ref, e, _, info = _fit_env(inp, {"SPLPAK_ND": "1"})
     assert e == 0 and info[9] < 1e-9
     for env in ({"SPLPAK_NO_PANEL_CU": "1"}, {"SPLPAK_ND_NO_ROOT_LOOKAHEAD": "1"}, {"SPLPAK_ND_KB": "1"}, {"SPLPAK_ND_NO_FUSE": "1"},
-                {"SPLPAK_ND_PIPES": "2"}, {"SPLPAK_ND_PIPES": "2", "SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_NO_OUTER": "1"}, {"SPLPAK_ND_SMALL_GRID": "0"}, {"SPLPAK_ND_WG4": "2"}, {"SPLPAK_ND_POTRF_WAVES": "4"}, {"SPLPAK_ND_POTRF_WAVES": "16"}, {"SPLPAK_ND_SMALL_QUEUE": "1"}, {"SPLPAK_ND_FULL_DIAG": "1"}, {"SPLPAK_ND_XCD": "0"},
-                {"SPLPAK_ND_NO_FUSE": "1", "SPLPAK_ND_MEMSET": "1", "SPLPAK_ND_KB": "2"},
+                {"SPLPAK_ND_CUT": "1"}, {"SPLPAK_ND_CUT": "2"}, {"SPLPAK_ND_CUT": "3", "SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_CUT": "4", "SPLPAK_ND_SQUARE": "1"},
+                {"SPLPAK_ND_CUT": "6"}, {"SPLPAK_ND_CUT": "2", "SPLPAK_ND_NO_FUSE": "1"}, {"SPLPAK_ND_SQUARE": "1"}, {"SPLPAK_ND_NO_OUTER": "1"}, {"SPLPAK_ND_SMALL_GRID": "0"}, {"SPLPAK_ND_WG4": "2"}, {"SPLPAK_ND_POTRF_WAVES": "4"}, {"SPLPAK_ND_POTRF_WAVES": "16"}, {"SPLPAK_ND_SMALL_QUEUE": "1"}, {"SPLPAK_ND_FULL_DIAG": "1"}, {"SPLPAK_ND_XCD": "0"},
+                {"SPLPAK_ND_NO_FUSE": "1", "SPLPAK_ND_SQUARE": "1", "SPLPAK_ND_KB": "2"},
                 {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_RES_CUS": "3", "SPLPAK_ND_PIN_ROUNDS": "8"}):
         c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1"))
         assert e == 0 and np.array_equal(c, ref), env
