@@ -274,8 +274,8 @@ class MultiPlan:
 
     def factorisation(self):
         """-> (code, description): 3 distributed band, 5 distributed nested dissection (one rank: the single-GPU codes)."""
-        buf = C.create_string_buffer(320)
-        code = self._L.splpak_mplan_factorisation(self._h, buf, 320)
+        buf = C.create_string_buffer(640)
+        code = self._L.splpak_mplan_factorisation(self._h, buf, 640)
         return int(code), buf.value.decode()
 
     def rank_bytes(self, rank):
@@ -454,8 +454,8 @@ class Plan:
 
     def factorisation(self):
         """-> (code, description): 0/1 band Cholesky, 2 two-ended band, 3 distributed band, 4 nested dissection."""
-        buf = C.create_string_buffer(256)
-        code = self._L.splpak_plan_factorisation(self._h, buf, 256)
+        buf = C.create_string_buffer(640)
+        code = self._L.splpak_plan_factorisation(self._h, buf, 640)
         return int(code), buf.value.decode()
 
     def enable_kernel_timing(self, on=True):

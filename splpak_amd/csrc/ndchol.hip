@@ -786,6 +786,7 @@ struct NdState {
     std::vector<std::vector<int>> starts;          // [stage] the stages whose buffers come alive (are zeroed) at its start
     int root_stage = -1;                           // stage of the root (single-GPU plans; -1 otherwise)
     int schur_kb = 4;                              // panel blocks per Schur pass (SPLPAK_ND_KB: 1 .. 4)
+    std::string desc;                              // what splpak_plan_factorisation reports
     double *V = nullptr, *Y = nullptr, *part = nullptr;
     long long part_cap = 0;                        // doubles of the backward sweep's partial sums (one launch at a time)
     int *pos = nullptr, *front_of = nullptr, *bpos = nullptr, *pmap = nullptr, *rowsrc = nullptr;
@@ -1780,7 +1781,7 @@ bool nd_make_schedule(NdState *s, int cut, size_t other_bytes)
         else if (!s->mdist) {
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 0; }
-            const double room = (double)fr - (double)other_bytes - 1.0e9;
+            const double room = (double)fr - (double)other_bytes - std::max(1.0e9, 0.03 * (double)tot);
             long long best = -1;
             int best_cut = 0;
             for (int c = 0; c <= std::min(t.maxdepth, 6); ++c) {
@@ -2099,8 +2100,15 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     p->prefit_fn = nd_prefit;
     p->factor_fn = nd_factor;
     p->solve_fn = nd_solve;
-    p->fn_name = s->mdist ? "nested-dissection multifrontal Cholesky distributed over several GPUs: subtrees per GPU, top fronts by block columns (csrc/ndchol.hip, csrc/ndtop.inc)"
-                          : "nested-dissection multifrontal Cholesky (csrc/ndtree.hip, csrc/ndchol.hip)";
+    {
+        char buf[256];
+        snprintf(buf, sizeof buf, "; %zu fronts in %zu stages (schedule cut %d), %.1f GB of factor panels, %.1f GB Schur arena (%s)", t.fr.size(), s->sc.st.size(),
+                 s->sc.cut, 8e-9 * (double)s->factor_doubles, 8e-9 * (double)s->sarena_doubles, s->sc.packed ? "packed lower triangles" : "square buffers");
+        s->desc = s->mdist ? "nested-dissection multifrontal Cholesky distributed over several GPUs: subtrees per GPU, top fronts by block columns (csrc/ndchol.hip, csrc/ndtop.inc)"
+                           : "nested-dissection multifrontal Cholesky (csrc/ndtree.hip, csrc/ndchol.hip)";
+        s->desc += buf;
+    }
+    p->fn_name = s->desc.c_str();
     p->fn_code = s->mdist ? 5 : 4;
     if (factor_arena) *factor_arena = s->factor;
     if (factor_doubles) *factor_doubles = s->factor_doubles;

@@ -394,7 +394,12 @@ def _mplan_fit(inp, ngpus, shard, coef_dev=None):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,ngpus,chunk", [("3d12", 2, 1), ("3d16", 2, 1), ("3d16", 3, 1), ("3d16", 4, 2), ("3d16", 8, 1),
                                               ("2d64_c2grid", 4, 1), ("2d64_c2grid", 8, 1), ("3d8_cc_clust", 2, 1),
-                                              ("2d16", 8, 1), ("2d16_sparse", 3, 1), ("3d_aniso", 6, 1)])     # more ranks than subtrees (a tree of 4 leaves on 8 ranks), odd rank counts
+                                              ("2d16", 8, 1), ("2d16_sparse", 3, 1), ("3d_aniso", 6, 1),     # more ranks than subtrees (a tree of 4 leaves on 8 ranks), odd rank counts
+                                              # 4-D goldens (the configuration this route exists for is 4-D).  Their trees
+                                              # have ONE front at the default leaf size (4^4 at any), so the leaves are made as small
+                                              # as the tree builder allows (SPLPAK_ND_SPLIT=5: 5^4 and 6^4 -> 31 fronts of
+                                              # 1 .. 3 nodes per dimension) -- for the single-GPU fit they are compared with as well
+                                              ("4d5_cc", 2, 1), ("4d5_cc", 4, 1), ("4d6", 2, 1), ("4d6", 4, 2), ("4d6", 8, 1)])
 def test_multi_gpu_nested_dissection_is_bitwise_the_single_gpu_fit(name, ngpus, chunk, monkeypatch):
     """splpak_mplan_* (what Fortran's set_gpus reaches) factor through the nested-dissection tree -- every rank
     stores and eliminates only its subtrees, the fronts above are distributed by block columns with peer-copied panels and
@@ -406,6 +411,9 @@ def test_multi_gpu_nested_dissection_is_bitwise_the_single_gpu_fit(name, ngpus, 
     monkeypatch.setenv("SPLPAK_VIRTUAL_GPUS", "1")
     monkeypatch.setenv("SPLPAK_ND", "1")
     monkeypatch.setenv("SPLPAK_ND_CHUNK", str(chunk))
+    if name.startswith("4d"):
+        monkeypatch.setenv("SPLPAK_ND_SPLIT", "5")
+        assert capi.debug_nd_tree(CASES[name]["nodes"], split_min=5)["fronts"] >= 31
     inp = make_inputs(CASES[name])
     gold = load_golden(name)
     args = (inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"], inp["nodes"], inp["xtrap"])

@@ -484,8 +484,10 @@ def test_fit_error_codes():
 
 
 def test_grid_beyond_one_gpu_is_a_clean_error():
-    """BASELINE config 5's 32^4 grid: the band factor alone is 852 GB (half bandwidth 101 475):
-    the plan must be refused with the library's out-of-memory status, not crash."""
+    """BASELINE config 5's 32^4 grid on ONE GPU: the nested-dissection factor panels alone are 476 GB (+ ~131 GB of Schur
+    arena in the postorder schedule; the band factor would be 852 GB) against 309 GB of HBM, and the boxes' 322 GB host-memory
+    cgroup cannot park the difference either: the plan must be refused with the library's out-of-memory
+    status, not crash.  (The largest 4-D grid one GPU holds, 28^4, runs in tests/test_nd.py; 32^4 is the 8-GPU route's.)"""
     with pytest.raises(capi.SplpakError) as e:
         capi.Plan(4, [32] * 4, [0.0] * 4, [1.0] * 4, 1.0, 1000)
     assert "-2" in str(e.value) or "memory" in str(e.value).lower()

@@ -222,6 +222,68 @@ def test_nd_4d_24_random_spline_recovery():
 
 
 @pytest.mark.gpu
+def test_nd_4d_28_the_largest_grid_one_gpu_holds(port):
+    """BASELINE config 5's fit half (4-D, 1e7 points) at the largest grid ONE MI355X holds since round 5:
+    28^4 = 614 656 columns, 1.1e15 flop, 205 GB of factor panels.  The level-by-level order of rounds 3-4 needed 326 GB of Schur
+    arenas on top (refused); the postorder schedule with packed Schur buffers (csrc/ndtree.hpp NdSchedule) needs ~63 GB.
+    (a) 1e7 points sampled from a spline with RANDOM coefficients, xtrap = 0: the fit is a projection, the coefficients come
+    back to 1e-10 and the measured backward error is at rounding level; (b) the seeded WEIGHTED workload with xtrap = 1 and its
+    ~1e6 derivative-constraint rows: the HOST-side componentwise backward error over the reference's rows
+    (oracle_rows_gradient, src/splpak.F90:788-855, :862-1046) < 1e-12, row counts and reserr as the GPU reports them.
+    Config 5's own 32^4 grid (476 GB of panels) stays refused on one GPU: test_gpu_parity.py::test_grid_beyond_one_gpu_is_a_clean_error."""
+    import time
+    import torch
+    capi.shutdown()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if free < 285e9:
+        pytest.skip(f"needs ~280 GB of free device memory, {free / 1e9:.0f} GB are free")
+    nd, nod, m = 4, 28, 10_000_000
+    nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.empty((m, nd), dtype=torch.float64, device=dev)
+    ys = torch.empty(m, dtype=torch.float64, device=dev)
+    ws = torch.empty(m, dtype=torch.float64, device=dev)
+    capi.synth_points_dev(nd, 0, m, x, ys, ws, st)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    ctrue = torch.randn(nod ** nd, dtype=torch.float64, device=dev, generator=gen)
+    y = torch.empty(m, dtype=torch.float64, device=dev)
+    capi.evaluate_dev(nd, x, None, ctrue, lo, hi, nodes, y, st)
+    coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
+    t0 = time.perf_counter()
+    plan = capi.Plan(nd, nodes, lo, hi, 0.0, m)
+    try:
+        code, what = plan.factorisation()
+        assert code == 4 and "packed" in what and "cut 0" not in what, what
+        ierr, info = plan.fit(x, y, None, coef, st)
+        torch.cuda.synchronize()
+        err = float((coef - ctrue).abs().max() / ctrue.abs().max())
+        print(f"28^4 projection: {what}; plan + fit {time.perf_counter() - t0:.1f} s (assembly {info[5]:.2f}, factorisation {info[6]:.2f}, "
+              f"solve {info[7]:.2f}); coefficient error {err:.2e}, steps {info[2]:.0f}, backward error {info[9]:.1e}")
+        assert ierr == 0 and info[0] == m
+        assert err < COEF_TOL and info[9] < 1e-9
+    finally:
+        plan.close()
+    del ctrue, y
+    plan = capi.Plan(nd, nodes, lo, hi, 1.0, m)
+    try:
+        ierr, info = plan.fit(x, ys, ws, coef, st)
+        torch.cuda.synchronize()
+        c = coef.cpu().numpy()
+    finally:
+        plan.close()
+    assert ierr == 0 and info[9] < 1e-9
+    omega, reserr, nrow, ncons = port.rows_gradient(nd, x.cpu().numpy(), ys.cpu().numpy(), ws.cpu().numpy(), lo, hi, nodes, 1.0, c)
+    print(f"28^4 weighted: host backward error {omega:.2e} (GPU's own: {info[9]:.2e}); rows {nrow}+{ncons} (GPU {info[0]:.0f}+{info[1]:.0f}); "
+          f"reserr host {reserr:.9e} GPU {info[8]:.9e}")
+    assert omega < 1e-12
+    assert nrow == info[0] == m and ncons == info[1] and ncons > 100000
+    assert abs(reserr - info[8]) <= 1e-9 * reserr
+
+
+@pytest.mark.gpu
 def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
     """32^3 (root separator 3 072 columns = 12 block steps): the diagonal blocks of the upper levels are factored on
     reserved CUs while the update waves take their items from a queue and step aside there, and the root's panel
