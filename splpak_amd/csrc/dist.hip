@@ -59,6 +59,7 @@ struct MRank {
     double *part = nullptr;         // backward sweep partial sums
     double *xs = nullptr;           // backward sweep solution / window
     double *coef = nullptr;         // this rank's copy of the coefficients (ranks > 0)
+    void *nccl = nullptr;           // this rank's RCCL communicator (SPLPAK_MPLAN_RCCL=1), else NULL
     std::vector<hipEvent_t> evReady, evArr, evBulk, evCol, evF, evB;
     hipEvent_t evTmp = nullptr;
     std::atomic<int> arr_prog{-1};
@@ -117,6 +118,17 @@ hipError_t reduce_all(MRank *me, double *buf, long long count)
 {
     splpak_mplan *mp = me->mp;
     const int R = mp->R;
+    if (me->nccl) {
+        // SPLPAK_MPLAN_RCCL=1 (round 5): "RCCL-reducing the normal equations over xGMI" on the route a Fortran caller reaches.
+        // Every rank thread enqueues its ncclAllReduce on its own stream (the calls of one collective come from R threads at
+        // once, as RCCL requires of a multi-communicator process); the sum's order is RCCL's, not rank order: the result is
+        // the same on every rank but not bitwise the peer-copy form's.
+        const int rc = rccl_allreduce_sum(me->nccl, buf, count, me->st);
+        hipError_t e = rc == 0 ? hipStreamSynchronize(me->st) : hipErrorUnknown;
+        if (e != hipSuccess) mp->abort.store(1);
+        if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;
+        return mp->abort.load() ? (e != hipSuccess ? e : hipErrorUnknown) : hipSuccess;
+    }
     me->red_ptr = buf;
     hipError_t err = hipStreamSynchronize(me->st);
     if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;
@@ -382,6 +394,7 @@ void free_rank(MRank *m)
     for (double *q : m->sbuf) if (q) (void)hipFree(q);
     for (double *q : {m->stage, m->part, m->xs, m->coef}) if (q) (void)hipFree(q);
     for (hipStream_t s : {m->st, m->sChain, m->sBulk, m->sCopy}) if (s) (void)hipStreamDestroy(s);
+    if (m->nccl) rccl_comm_free(m->nccl);
     if (m->p) splpak_plan_destroy(m->p);
     delete m;
 }
@@ -491,16 +504,44 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
         if (r != 0) ok = ok && hipMalloc((void **)&m->coef, sizeof(double) * (size_t)p->g.ncol) == hipSuccess;
         if (!ok) { set_error("device allocation of the multi-GPU plan failed"); (void)hipGetLastError(); rc = SPLPAK_E_NOMEM; }
     }
-    // peer access where the ranks sit on different devices (copies fall back to staging without it)
-    if (rc == 0)
+    // peer access where the ranks sit on different devices.  The distributed band only COPIES between devices
+    // (hipMemcpyPeerAsync stages through the host without it); the distributed nested dissection READS the other GPUs' memory
+    // from kernels (nd_pull_add_kernel: the children's Schur complements through the peer mapping) and needs it -- without it
+    // the fit would take a memory fault, so the plan is refused instead (round-4 advice)
+    if (rc == 0) {
+        bool all_peers = true;
+        int pa = -1, pb = -1;
         for (MRank *a : mp->ranks)
             for (MRank *b2 : mp->ranks)
                 if (a->dev != b2->dev) {
                     (void)hipSetDevice(a->dev);
                     int can = 0;
-                    if (hipDeviceCanAccessPeer(&can, a->dev, b2->dev) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b2->dev, 0);
+                    bool on = false;
+                    if (hipDeviceCanAccessPeer(&can, a->dev, b2->dev) == hipSuccess && can) {
+                        const hipError_t e = hipDeviceEnablePeerAccess(b2->dev, 0);
+                        on = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                    }
                     (void)hipGetLastError();
+                    if (!on || std::getenv("SPLPAK_DEBUG_NO_PEER")) { all_peers = false; pa = a->dev; pb = b2->dev; }
                 }
+        if (mp->ndgrp && !all_peers) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "multi-GPU plan: device %d cannot map device %d's memory (no peer access), which the distributed nested "
+                                      "dissection needs; SPLPAK_MPLAN_BAND=1 selects the distributed band, which only copies", pa, pb);
+            set_error(buf);
+            rc = SPLPAK_E_UNSUPPORTED;
+        }
+    }
+    // the sums over the ranks as RCCL all-reduces instead of peer copies (behind a switch: the peer-copy form is bitwise
+    // reproducible in rank order and needs no library)
+    if (rc == 0 && ngpus > 1 && std::getenv("SPLPAK_MPLAN_RCCL") && atoi(std::getenv("SPLPAK_MPLAN_RCCL")) != 0) {
+        std::vector<int> devs;
+        std::vector<void *> comms((size_t)ngpus, nullptr);
+        for (MRank *m : mp->ranks) devs.push_back(m->dev);
+        rc = rccl_comms_for_devices(ngpus, devs.data(), comms.data());
+        if (rc == 0)
+            for (int r = 0; r < ngpus; ++r) mp->ranks[(size_t)r]->nccl = comms[(size_t)r];
+    }
     (void)hipSetDevice(cur);
     if (rc != 0) {
         for (MRank *m : mp->ranks) free_rank(m);

@@ -108,6 +108,10 @@ namespace splpak {
 int build_grid(int ndim, const int *nodes, const double *xmin, const double *xmax, Grid &g, long long *ncol_out,
                bool reorder = false);
 int device_ready();
+// rccl.hip: RCCL for the one-process multi-GPU plan (SPLPAK_MPLAN_RCCL=1)
+int rccl_comms_for_devices(int n, const int *devices, void **comms);      // ncclCommInitAll; 0 or an SPLPAK_E_* code
+int rccl_allreduce_sum(void *comm, double *buf, long long count, hipStream_t st);
+void rccl_comm_free(void *comm);
 // plan for rank r of R (chunks of c block columns); R = 1 is the ordinary single-GPU plan
 // ndgrp != NULL (R > 1): the plan is rank r of a one-process multi-GPU fit whose grid takes the nested-dissection
 // factorisation -- distributed over the group's ranks by subtrees and, above them, by block columns (ndchol.hip)

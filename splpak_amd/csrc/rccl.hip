@@ -30,6 +30,7 @@ using CommInitRank_t = int (*)(void **, int, UniqueId, int);
 using CommDestroy_t = int (*)(void *);
 using AllReduce_t = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
 using GetErrorString_t = const char *(*)(int);
+using CommInitAll_t = int (*)(void **, int, const int *);
 
 struct Rccl {
     void *handle = nullptr;
@@ -38,6 +39,7 @@ struct Rccl {
     CommDestroy_t comm_destroy = nullptr;
     AllReduce_t all_reduce = nullptr;
     GetErrorString_t error_string = nullptr;
+    CommInitAll_t comm_init_all = nullptr;
     bool tried = false;
 };
 Rccl g_rccl;
@@ -71,6 +73,7 @@ bool rccl_load()
     g_rccl.comm_destroy = (CommDestroy_t)dlsym(h, "ncclCommDestroy");
     g_rccl.all_reduce = (AllReduce_t)dlsym(h, "ncclAllReduce");
     g_rccl.error_string = (GetErrorString_t)dlsym(h, "ncclGetErrorString");
+    g_rccl.comm_init_all = (CommInitAll_t)dlsym(h, "ncclCommInitAll");
     if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce) {
         set_error("RCCL: librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
         g_rccl.all_reduce = nullptr;
@@ -99,6 +102,36 @@ int32_t rccl_allreduce(void *buf, int64_t count, void *stream, void *user)
 }
 
 }  // namespace
+
+// ---- RCCL for the ONE-PROCESS multi-GPU plan (dist.hip; round 5, SPLPAK_MPLAN_RCCL=1): one communicator per device of the
+// plan from ncclCommInitAll; the plan's sums over the ranks (histogram, normal equations, residuals, solution) then are
+// ncclAllReduce calls, one per rank thread on that rank's stream, instead of the peer-copy reduce-scatter + all-gather.
+int splpak::rccl_comms_for_devices(int n, const int *devices, void **comms)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (devices[i] == devices[j]) {
+                set_error("SPLPAK_MPLAN_RCCL=1: RCCL needs one DISTINCT device per rank (ranks share a device: virtual GPUs)");
+                return SPLPAK_E_UNSUPPORTED;
+            }
+    if (!rccl_load()) return SPLPAK_E_COMM;
+    if (!g_rccl.comm_init_all) { set_error("RCCL: librccl.so lacks ncclCommInitAll"); return SPLPAK_E_COMM; }
+    const int rc = g_rccl.comm_init_all(comms, n, devices);
+    if (rc != 0) { rccl_fail("ncclCommInitAll", rc); return SPLPAK_E_COMM; }
+    return 0;
+}
+
+int splpak::rccl_allreduce_sum(void *comm, double *buf, long long count, hipStream_t st)
+{
+    const int rc = g_rccl.all_reduce(buf, buf, (size_t)count, NCCL_FLOAT64, NCCL_SUM, comm, st);
+    if (rc != 0) { rccl_fail("ncclAllReduce", rc); return SPLPAK_E_COMM; }
+    return 0;
+}
+
+void splpak::rccl_comm_free(void *comm)
+{
+    if (comm && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(comm);
+}
 
 extern "C" {
 

@@ -52,10 +52,36 @@ def make_allreduce(comm, dist, group=None):
     return _fn
 
 
-class ShardedFit:
-    """A fit plan whose reductions go through torch.distributed (any backend)."""
+def native_rccl_comm(dist, device, group=None):
+    """ncclComm_t (int) of the LIBRARY's own RCCL hook for the ranks of `group`: rank 0 draws the ncclUniqueId
+    (splpak_rccl_unique_id), torch.distributed only carries its 128 bytes to the other ranks, every rank then calls
+    splpak_rccl_comm_create on its device.  The fit's collectives do not pass through Python after that."""
+    import torch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    on_dev = dist.get_backend(group) == "nccl"
+    idt = torch.zeros(128, dtype=torch.uint8, device=device if on_dev else "cpu")
+    err = None
+    if rank == 0:
+        try:
+            idt.copy_(torch.frombuffer(bytearray(capi.rccl_unique_id()), dtype=torch.uint8))
+        except capi.SplpakError as exc:      # the others wait in the broadcast: they get a zero id and give up with rank 0
+            err = exc
+    dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    raw = bytes(idt.cpu().numpy().tobytes())
+    if err is not None or not any(raw):
+        raise capi.SplpakError(f"no ncclUniqueId from rank 0{': ' + str(err) if err else ''}")
+    with torch.cuda.device(device):
+        return capi.rccl_comm_create(raw, rank, world)
 
-    def __init__(self, ndim, nodes, xmin, xmax, xtrap, max_ndata, device, dist=None, group=None):
+
+class ShardedFit:
+    """A fit plan whose reductions go over RCCL: through the library's NATIVE hook (splpak_plan_set_rccl -- ncclAllReduce
+    enqueued on the fit's stream by the library itself, no Python and no host synchronisation in the loop) when the process
+    group's backend is nccl (= RCCL on ROCm), through a torch.distributed callback otherwise (gloo: CPU tests, one-GPU
+    rehearsals) or when `native=False` / the native communicator cannot be made.  `collective` says which."""
+
+    def __init__(self, ndim, nodes, xmin, xmax, xtrap, max_ndata, device, dist=None, group=None, native=None):
+        import os
         import torch
         self.dist = dist
         self.world = dist.get_world_size(group) if dist is not None else 1
@@ -64,11 +90,35 @@ class ShardedFit:
         self.comm_len = int(capi.lib().splpak_plan_comm_len(ndim, capi._p(nodes_a, capi._ip)))
         self.comm = torch.zeros(self.comm_len, dtype=torch.float64, device=device)
         self.plan = capi.Plan(ndim, nodes, xmin, xmax, xtrap, max_ndata, comm=self.comm)
+        self.collective = None
+        self.nccl_comm = None
+        self.native_error = None
         if self.world > 1:
-            self.plan.set_allreduce(make_allreduce(self.comm, dist, group), self.rank, self.world)
+            if native is None:
+                native = dist.get_backend(group) == "nccl" and os.environ.get("SPLPAK_NATIVE_RCCL", "1") != "0"
+            if native:
+                # every rank must take the same route: the outcome of the attempt is made collective
+                try:
+                    self.nccl_comm = native_rccl_comm(dist, device, group)
+                except Exception as exc:      # noqa: BLE001 -- whatever it is, the torch callback still works
+                    self.native_error = f"{type(exc).__name__}: {exc}"
+                ok = torch.tensor([1.0 if self.nccl_comm else 0.0], dtype=torch.float64, device=device if dist.get_backend(group) == "nccl" else "cpu")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+                if float(ok.item()) == 0.0 and self.nccl_comm:
+                    capi.rccl_comm_destroy(self.nccl_comm)
+                    self.nccl_comm = None
+            if self.nccl_comm:
+                self.plan.set_rccl(self.nccl_comm, self.rank, self.world)
+                self.collective = "rccl-native"
+            else:
+                self.plan.set_allreduce(make_allreduce(self.comm, dist, group), self.rank, self.world)
+                self.collective = "torch.distributed:" + str(dist.get_backend(group))
 
     def fit(self, xdata, ydata, wdata, coef, stream=0):
         return self.plan.fit(xdata, ydata, wdata, coef, stream)
 
     def close(self):
         self.plan.close()
+        if self.nccl_comm:
+            capi.rccl_comm_destroy(self.nccl_comm)
+            self.nccl_comm = None
