@@ -895,12 +895,17 @@ constexpr int PR_EW = 1024;        // threads of an evaluation workgroup: 16 wav
                                    // never shared a CU: 10 waves go to the SIMDs as 3,3,2,2 and two such sets can need 6 x 88 registers
                                    // on one SIMD -- the second workgroup of every CU only started when the first had ended)
 constexpr int PR_WPE = 4;          // waves per SIMD the evaluation kernel is compiled for (128 registers; it takes 88)
-constexpr int PR_MAXBINS = 64;
+// place-pass shape by dimension count.  MAXBINS: most regions of a grid; NCLS: LDS slot classes the queries of a bin are dealt
+// by (3-D: the 16 sixteen-byte slots of ds_read_b128; 4-D: 32 eight-byte slots, ds_read_b64); JMAX: rounds of the deal.
+// 2 MAXBINS JMAX = 2 PR_NT: every thread of the place pass prefixes two (bin, round) counters.
+template <int D> struct PRCfg { static constexpr int MAXBINS = 64, NCLS = 16, JMAX = 16; };
+template <> struct PRCfg<4> { static constexpr int MAXBINS = 256, NCLS = 32, JMAX = 4; };
+constexpr int PR_MAXBINS = 256;    // (scratch sizes: the largest of them)
 
 template <int D, typename T>
 __global__ void __launch_bounds__(PR_NT)
 pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int ldxq, unsigned short *__restrict__ sidx,
-                int *__restrict__ starts, T *__restrict__ xs)
+                int *__restrict__ starts, T *__restrict__ xs, unsigned char *__restrict__ scls)
 {
     // bins: 2 per region -- [2 r] the queries whose windows are interior ones in every dimension (closed-form basis table,
     // eval_table), [2 r + 1] the others (end functions / clipped windows in some dimension): the evaluation pass walks the
@@ -915,11 +920,14 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
     // start of its round + the number of classes below its own in that round (class order inside a round: 16 consecutive
     // queries then straddle two rounds with fewer repeats than in the order the counters would give, 8.4 against 9.8 LDS
     // cycles per read in a simulation of 64^3).  Ranks beyond JMAX - 1 (clustered queries) share the last round, in counter order.
-    constexpr int QPT = PR_Q / PR_NT, NB2 = 2 * PR_MAXBINS, HALF = PR_Q / 2, NCLS = 16, JMAX = 16, NKEY = NB2 * JMAX;
+    constexpr int QPT = PR_Q / PR_NT, NB2 = 2 * PRCfg<D>::MAXBINS, HALF = PR_Q / 2, NCLS = PRCfg<D>::NCLS, JMAX = PRCfg<D>::JMAX, NKEY = NB2 * JMAX;
     static_assert(NKEY == 2 * PR_NT, "the prefix below gives every thread two (bin, round) counters");
     constexpr int TAB_BYTES = NB2 * NCLS * 4 + 2 * NKEY * 4;
     constexpr int SB_BYTES = HALF * (int)sizeof(T) > TAB_BYTES ? HALF * (int)sizeof(T) : TAB_BYTES;
     __shared__ unsigned short ssort[PR_Q];
+    // 4-D: the LDS slot class of every query's window (tile offset mod 32) travels with the image as a plane of bytes -- the
+    // evaluation pass deals its chunks to the lanes by it (pr_eval4_kernel); runs of ~16 queries are too short to be dealt here
+    __shared__ __attribute__((aligned(16))) unsigned char scl[D == 4 ? PR_Q : 4];
     __shared__ __attribute__((aligned(16))) unsigned char sbuf[SB_BYTES];      // the counters, then the staging half plane
     T *splane = reinterpret_cast<T *>(sbuf);
     int *ccnt = reinterpret_cast<int *>(sbuf);                                   // [bin][class]: queries so far
@@ -939,6 +947,7 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
     __syncthreads();
     const long long base = (long long)blockIdx.x * PR_Q;
     int rid[QPT], rank[QPT];                       // rid: bin * JMAX + round; rank: within the last round, or -1 - class
+    unsigned long long clsw = 0;                   // (4-D) the classes of this thread's queries, 8 bits each
     T xr[QPT][D];
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
@@ -963,6 +972,7 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
             // (3-D tiles: an odd start reads the second copy of the tile, rg.telems entries further and one entry down)
             const int ta = (rg.telems > 0 && (tb & 1)) ? rg.telems + tb - 1 : tb;
             const int cls = rg.telems > 0 ? (ta >> 1) & (NCLS - 1) : tb & (NCLS - 1);
+            if constexpr (D == 4) clsw |= (unsigned long long)cls << (8 * j);
             const int bin = 2 * r + (inter ? 0 : 1);
             int round = atomicAdd(&ccnt[bin * NCLS + cls], 1);
             if (!rg.deal) round = JMAX - 1;
@@ -998,7 +1008,7 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
         if (tid == PR_NT - 1) lst[NB2] = excl + c0 + c1;
     }
     __syncthreads();
-    if (tid < NB2) lst[tid] = rstart[tid * JMAX];
+    for (int e = tid; e < NB2; e += PR_NT) lst[e] = rstart[e * JMAX];
     int lp[QPT];
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
@@ -1006,6 +1016,7 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
         if (rid[j] >= 0) {
             lp[j] = rstart[rid[j]] + (rank[j] >= 0 ? rank[j] : __builtin_popcount(dmask[rid[j]] & ((1u << (-1 - rank[j])) - 1u)));
             ssort[lp[j]] = (unsigned short)(j * PR_NT + tid);
+            if constexpr (D == 4) scl[lp[j]] = (unsigned char)(clsw >> (8 * j));
         }
     }
     __syncthreads();                               // (the counters give way to the staging buffer; lst is complete)
@@ -1013,6 +1024,30 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
     // the coordinates go to their sorted places in the workgroup's image (D planes of PR_Q entries: the evaluation pass reads
     // them with consecutive lanes on consecutive entries), half a plane at a time through LDS so that the stores are
     // consecutive (straight scattered 8-byte stores into the image: 1.03 ms per 5e7 queries instead of 0.25 without them)
+    if constexpr (D == 4) {
+        // 4-D: the image holds RECORDS of the four coordinates (32 bytes) instead of planes -- the evaluation pass takes its
+        // elements in an order dealt by LDS bank class, i.e. scattered over a chunk, and a scattered element then costs one
+        // sector instead of four lines (measured with planes: 2.8 of the pass's 5 ms per 1e8 queries went into these loads).
+        // Staged through LDS a quarter of the image at a time.
+        constexpr int PIECE = PR_Q / 4;
+        static_assert(PIECE * 4 * (int)sizeof(T) <= SB_BYTES, "a quarter of the records fits the staging buffer");
+        T *__restrict__ dstr = xs + (long long)blockIdx.x * PR_Q * D;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            if (pc > 0) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) {
+                const int l = lp[j] - pc * PIECE;
+                if (lp[j] >= 0 && l >= 0 && l < PIECE) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) splane[l * D + d] = xr[j][d];
+                }
+            }
+            __syncthreads();
+            const int nrec = total - pc * PIECE < PIECE ? total - pc * PIECE : PIECE;
+            for (int e = tid; e < nrec * D; e += PR_NT) __builtin_nontemporal_store(splane[e], dstr + (long long)pc * PIECE * D + e);
+        }
+    } else {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         T *__restrict__ dstp = xs + ((long long)blockIdx.x * D + d) * PR_Q;
@@ -1028,11 +1063,18 @@ pr_place_kernel(Grid g, PRegions rg, long long nq, const T *__restrict__ xq, int
             for (int e = tid; e < HALF && hf * HALF + e < total; e += PR_NT) __builtin_nontemporal_store(splane[e], dstp + hf * HALF + e);
         }
     }
-    if (tid <= nb2) starts[(long long)blockIdx.x * (nb2 + 1) + tid] = lst[tid];
+    }
+    for (int e = tid; e <= nb2; e += PR_NT) starts[(long long)blockIdx.x * (nb2 + 1) + e] = lst[e];
     unsigned *__restrict__ dst = reinterpret_cast<unsigned *>(sidx + base);
     for (int e = tid; 2 * e < total; e += PR_NT) {
         const unsigned lo = ssort[2 * e], hi = 2 * e + 1 < total ? ssort[2 * e + 1] : 0u;
         dst[e] = lo | (hi << 16);
+    }
+    if constexpr (D == 4) {
+        static_assert(QPT <= 8, "eight class bytes per thread");
+        unsigned *__restrict__ dc = reinterpret_cast<unsigned *>(scls + base);
+        const unsigned *sc4 = reinterpret_cast<const unsigned *>(scl);
+        for (int e = tid; 4 * e < total; e += PR_NT) dc[e] = sc4[e];          // (the bytes beyond `total` in the last word are never read)
     }
 }
 
@@ -1365,6 +1407,303 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
     }      // regions
 }
 
+// ---- persistent region path, 4-D (round 5) --------------------------------------------------------------------------------
+// BASELINE config 5's evaluation half (4-D 32^4, 1e8 queries) ran the three-pass global region sort of round 3: seven launches
+// per 2^24 queries, 287 B of fabric traffic per query for 40 algorithmic ones, the tile of a region (64 KB) loaded once per
+// 2 048 queries: 8.07 ms per 1e8 queries.  Here the 3-D scheme above: pr_place_kernel<4> (regions of 8 window starts per
+// dimension: 32^4 nodes give 4^4 = 256 regions, two bins each; the image holds 32-byte RECORDS of the coordinates and a byte
+// per query with the LDS bank class of its window), this kernel, pr_unsort_kernel -- 32 + 35, 35 + 8 and 10 + 8 bytes per query:
+// 6.2 ms per 1e8 queries (place 1.45, this kernel 4.4, unsort 0.33).
+//   One persistent workgroup of 12 waves per CU (3 per SIMD: 168 registers, no spills; 16 waves left 128 and spilled in the round
+//   loop) holds the tile of ONE region in LDS: (8 + 3)^4 coefficients with odd strides = 118 KB.  Its waves, each on its own,
+//   take CHUNKS of the region's runs -- c0 consecutive place-pass workgroups of one bin -- from the region's counter (the number
+//   of the next chunk is requested before the current one is worked on).  A chunk's run descriptors sit one per lane; a prefix
+//   over the lanes makes the chunk ONE stream of elements, element e of which is found by a six-step search over the lanes'
+//   prefixes -- runs of a 4-D place-pass workgroup are ~16 queries long (8 192 queries over 512 bins), too short for the 3-D
+//   kernel's four-runs-in-flight walk.
+//   What the counters and A/B builds showed, step by step (tools/eval4_bench.py, per 1e8 queries):
+//   * elements in stream order: 5.3 ms in this kernel, the LDS pipe busy for 4.7 of them, 69 % of its cycles bank conflicts
+//     (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE): the 256 window reads of a query (ds_read_b64: two groups of 32 lanes, 64 banks
+//     of 4 bytes) all have the bank class of its tile offset mod 32, and 32 random classes per group collide 2-4 ways.
+//   * so a wave DEALS every 256 elements of its chunk to its lanes by class, as round 3's region kernel dealt a workgroup's
+//     2 048 queries: a counting sort in the wave's own LDS gives lanes h and h + 32 the elements of class h, two per round; what
+//     a class holds beyond its 2 R slots goes to the free slots of short classes (conflicts: 69 % -> 43 % of the LDS cycles).
+//   * dealt elements are scattered over the chunk: with coordinate PLANES every element cost four lines (2.8 ms); records: one
+//     sector.  The 64 results of a round go to ~60 different lines: stored from the round they cost 1.2-1.4 ms (plain or
+//     non-temporal stores alike); they are parked in the wave's LDS by element and leave in stream order, consecutive lanes on
+//     consecutive slots.
+//   * with the window reads taken out the kernel takes 2.3 ms (914 vector instructions per query: 340 multiply-adds, the
+//     basis tables -- 45 % of the queries of a 32^4 grid have a window next to an end in some dimension --, two element
+//     searches), with them 4.4: the reads do not overlap the arithmetic.  Software-pipelining them in units of 8 with
+//     s_waitcnt lgkmcnt(8) broke: the compiler reloads fields of the by-value Grid argument with s_load inside the loop, which
+//     count on lgkmcnt and return out of order (wrong values on a 20^4 grid), and the registers of a second buffer spilled.
+//   A workgroup whose region is used up moves to the region with the most chunks left.  No spinning anywhere: counters,
+//   barriers, and loops every wave leaves when its region has no chunk left.
+// Arithmetic per query: eval_table + window_sum<4> as everywhere else -- identical bits.
+constexpr int PR4_EW = 768;        // threads of a 4-D evaluation workgroup: 12 waves = 3 per SIMD (168 registers each), one workgroup per CU
+template <int SPER, bool VAL, typename T>
+__global__ void __launch_bounds__(PR4_EW, 3)
+pr_eval4_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const T *__restrict__ xs, const unsigned char *__restrict__ scls,
+                const int *__restrict__ starts, int nwg_all, int c0, int *__restrict__ queue, T *__restrict__ outs)
+{
+    constexpr int D = 4, PR_EW = PR4_EW, NWAVE = PR_EW / 64, SUB = 256, RMAX = SUB / 64, CAPMAX = 2 * RMAX;
+    using PT = PTile<D, SPER>;
+    __shared__ __attribute__((aligned(16))) double pr_tile[PT::ELEMS];
+    __shared__ double w_res[NWAVE][SUB];             // results of a deal, by element: they leave in stream order (consecutive stores)
+    __shared__ unsigned short w_list[NWAVE][32][CAPMAX], w_ovf[NWAVE][SUB];
+    __shared__ int w_cnt[NWAVE][32];
+    __shared__ int s_region;
+    const int tid = threadIdx.x, lane = tid & 63, hcl = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int t1 = PT::S1, t2 = PT::S2, t3 = PT::S3;
+    const int nbins = rg.nbins, nb1 = 2 * nbins + 1;
+    const int nch = (nwg_all + c0 - 1) / c0;         // chunks per bin
+    unsigned short (*list)[CAPMAX] = w_list[wave];
+    unsigned short *ovf = w_ovf[wave];
+    double *res = w_res[wave];
+    int *cnt = w_cnt[wave];
+    if (lane < 32) cnt[lane] = 0;
+    // does region r hold windows that are not interior ones (its second bin is non-empty)?
+    auto has_edge = [&](int r) {
+        bool edge = false;
+        int rr = r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int rd = rr % rg.nreg[d], S = g.nodes[d] - 3;
+            rr /= rg.nreg[d];
+            const int lo = rd * rg.sper[d], hi = min(S, lo + rg.sper[d]);
+            edge = edge || lo < 2 || hi > g.nodes[d] - 5;
+        }
+        return edge;
+    };
+    if (tid == 0) {
+        // first region: workgroup b starts at region b mod nbins (more workgroups than regions: they share from the start)
+        const int r0 = (int)(blockIdx.x % (unsigned)nbins);
+        atomicAdd(queue + nbins + r0, 1);
+        s_region = r0;
+    }
+    __syncthreads();
+    int a[D];
+    for (;;) {
+        const int r = __builtin_amdgcn_readfirstlane(s_region);
+        if (r < 0) break;
+        {
+            int rr = r;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                a[d] = (rr % rg.nreg[d]) * rg.sper[d];
+                rr /= rg.nreg[d];
+            }
+            for (int e = tid; e < rg.tcells; e += PR_EW) {
+                int rem = e, idx = 0, te = 0;
+                bool ok = true;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int l = rem % rg.text[d];
+                    rem /= rg.text[d];
+                    const int node = a[d] + l;
+                    ok = ok && node < g.nodes[d];
+                    idx += node * g.colstride[d];
+                    te += l * PT::stride(d);
+                }
+                pr_tile[te] = ok ? (double)coef[idx] : 0.0;
+            }
+        }
+        __syncthreads();
+        const int nedge = has_edge(r) ? nch : 0;     // chunks of boundary runs come first (the costlier ones: no long tail)
+        const int ntot = nedge + nch;
+        auto take = [&]() {
+            int v = 0;
+            if (lane == 0) v = atomicAdd(queue + r, 1);
+            return v;                                // (lane 0's register; made uniform when it is looked at)
+        };
+        int cnext = take();
+        for (;;) {
+            const int c = __builtin_amdgcn_readfirstlane(cnext);
+            if (c >= ntot) break;
+            cnext = take();                          // the next chunk's number travels while this chunk is worked on
+            const int ph = c < nedge ? 1 : 0, cc = ph ? c : c - nedge;
+            const int w0 = cc * c0, nw = min(c0, nwg_all - w0), col = 2 * r + ph;
+            // one run per lane (c0 <= 64): start in its workgroup's image, inclusive prefix of the lengths
+            int st_l = 0, len_l = 0;
+            if (lane < nw) {
+                const int *sp = starts + (long long)(w0 + lane) * nb1 + col;
+                st_l = sp[0];
+                len_l = sp[1] - st_l;
+            }
+            int pre = len_l;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(pre, o, 64);
+                if (lane >= o) pre += t;
+            }
+            const int total = __builtin_amdgcn_readlane(pre, 63);
+            const int excl = pre - len_l;
+            // element e of the chunk -> its slot in the images (every lane takes part: the prefixes are read across the lanes)
+            auto locate = [&](int e) -> unsigned {
+                int lo = 0, hi = 63;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int mid = (lo + hi) >> 1;
+                    const int v = __shfl(pre, mid, 64);
+                    if (v <= e) lo = mid + 1; else hi = mid;
+                }
+                const int off = __shfl(st_l, lo, 64) + (e - __shfl(excl, lo, 64));
+                return (unsigned)(w0 + lo) * (unsigned)PR_Q + (unsigned)off;
+            };
+            auto request = [&](unsigned oq, bool act, T (&x)[D]) {
+                // (records of the four coordinates: one or two 16-byte loads)
+                typedef T rec4 __attribute__((ext_vector_type(4)));
+                rec4 v = {(T)0, (T)0, (T)0, (T)0};
+                if (act) v = __builtin_nontemporal_load(reinterpret_cast<const rec4 *>(xs) + oq);
+                x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
+            };
+            for (int E0 = 0; E0 < total; E0 += SUB) {
+                const int n = min(SUB, total - E0), R = (n + 63) >> 6, cap = 2 * R;
+                // ---- deal the n elements to the lanes by class
+                int ck[RMAX], rk[RMAX];
+                unsigned oqk[RMAX];                  // (kept: the results are stored to these slots at the end of the deal)
+#pragma unroll
+                for (int k = 0; k < RMAX; ++k) {
+                    const int i = k * 64 + lane;
+                    const bool valid = k < R && i < n;
+                    oqk[k] = locate(valid ? E0 + i : 0);
+                    ck[k] = valid ? (int)scls[oqk[k]] : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < RMAX; ++k) rk[k] = ck[k] >= 0 ? atomicAdd(&cnt[ck[k]], 1) : 0;
+                __builtin_amdgcn_wave_barrier();
+                const int n_h = __hip_atomic_load(&cnt[hcl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const int sur = n_h > cap ? n_h - cap : 0, fre = n_h < cap ? cap - n_h : 0;
+                int is = sur, ifr = fre;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    const int ts = __shfl_up(is, o, 32), tf = __shfl_up(ifr, o, 32);
+                    if (hcl >= o) { is += ts; ifr += tf; }
+                }
+                const int sur0 = is - sur, fre0 = ifr - fre, nsur = __shfl(is, 31, 32);
+#pragma unroll
+                for (int k = 0; k < RMAX; ++k) {
+                    const int so = __shfl(sur0, ck[k] >= 0 ? ck[k] : 0, 32);
+                    if (ck[k] >= 0) {
+                        const unsigned short i = (unsigned short)(k * 64 + lane);
+                        if (rk[k] < cap) list[ck[k]][rk[k]] = i;
+                        else ovf[so + rk[k] - cap] = i;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 32) cnt[lane] = 0;         // (for the next deal; every lane has read its class's count)
+                // lanes h and h + 32 walk the slots of class h (even / odd ones); a slot beyond the class's own elements takes
+                // one of the surplus elements of the long classes, if any is left
+                auto slot_element = [&](int t) -> int {
+                    const int sl = 2 * t + half;
+                    if (t >= R) return -1;
+                    if (sl < n_h) return (int)list[hcl][sl];
+                    const int f = fre0 + (sl - n_h);
+                    return f < nsur ? (int)ovf[f] : -1;
+                };
+                int inext = slot_element(0);
+                unsigned oq = locate(E0 + (inext >= 0 ? inext : 0));
+                bool act = inext >= 0;
+                T xc[D];
+                request(oq, act, xc);
+                for (int t = 0; t < R; ++t) {
+                    double b[D][4];
+                    int base = 0;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const int ws = eval_table<VAL>(g, d, (double)xc[d], nd.v[d], b[d]);
+                        base += (ws - a[d]) * PT::stride(d);
+                    }
+                    if (!act) base = 0;
+                    const bool act_c = act;
+                    const int i_c = inext;
+                    inext = slot_element(t + 1);
+                    oq = locate(E0 + (inext >= 0 ? inext : 0));
+                    act = inext >= 0;
+                    request(oq, act, xc);
+                    // window_sum<4> with the LDS reads as inline assembly, one (k2, k3) plane -- 16 ds_read_b64, 32 registers --
+                    // at a time: left to the compiler the 256 reads of a window are hoisted and spill (450 registers to scratch
+                    // in the first build of this kernel).  Same operations in the same order as window_sum<4>: identical bits.
+                    // The k3 loop stays rolled (the plane's offsets are immediates on top of a base that advances by t3).
+                    unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) double *)pr_tile + (unsigned)base * 8u;
+                    double sum = 0.0;
+                    asm volatile("; tables ready %0 %1 %2 %3" :: "v"(b[0][0]), "v"(b[1][0]), "v"(b[2][0]), "v"(b[3][0]));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+                    for (int k3 = 0; k3 < 4; ++k3) {
+                        const double b3 = k3 == 0 ? b[3][0] : (k3 == 1 ? b[3][1] : (k3 == 2 ? b[3][2] : b[3][3]));
+                        double q = 0.0;
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) {
+                            double c[4][4];
+                            asm volatile("ds_read_b64 %0, %1 offset:%2 ; after %3" : "=v"(c[0][0]) : "v"(la), "n"((k2 * t2) * 8), "v"(q));
+#pragma unroll
+                            for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+                                for (int k0 = (k1 == 0 ? 1 : 0); k0 < 4; ++k0)
+                                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(c[k1][k0]) : "v"(la), "n"((k0 + k1 * t1 + k2 * t2) * 8));
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[0][2]), "+v"(c[0][3]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[1][2]), "+v"(c[1][3]),
+                                           "+v"(c[2][0]), "+v"(c[2][1]), "+v"(c[2][2]), "+v"(c[2][3]), "+v"(c[3][0]), "+v"(c[3][1]), "+v"(c[3][2]), "+v"(c[3][3])
+                                         :: "memory");
+                            double rr = 0.0;
+#pragma unroll
+                            for (int k1 = 0; k1 < 4; ++k1) {
+                                double tt = c[k1][0] * b[0][0];
+                                tt = fma(c[k1][1], b[0][1], tt);
+                                tt = fma(c[k1][2], b[0][2], tt);
+                                tt = fma(c[k1][3], b[0][3], tt);
+                                rr = fma(tt, b[1][k1], rr);
+                            }
+                            q = fma(rr, b[2][k2], q);
+                            __builtin_amdgcn_sched_barrier(0);      // (the multiply-adds of a plane stay in front of the next plane's reads)
+                        }
+                        sum = fma(q, b3, sum);
+                        la += (unsigned)(t3 * 8);
+                    }
+                    // (the 64 results of a round belong to ~60 different lines of the images: stored from here they cost 1.2-1.4
+                    //  of the pass's 4.5 ms per 1e8 queries, plain or non-temporal; they go through the wave's LDS instead)
+                    if (act_c) res[i_c] = sum;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < RMAX; ++k)
+                    if (ck[k] >= 0) __builtin_nontemporal_store((T)res[k * 64 + lane], outs + oqk[k]);
+                __builtin_amdgcn_wave_barrier();     // (the lists are rewritten by the next deal)
+            }
+        }
+        __syncthreads();                             // every wave is done with the tile
+        if (tid < 64) {
+            // the next region: the one with the most chunks left per workgroup that would then be there
+            unsigned long long key = 0;
+            for (int q0 = 0; q0 < nbins; q0 += 64) {
+                const int q = q0 + lane;
+                if (q < nbins) {
+                    const int taken = __hip_atomic_load(queue + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int there = __hip_atomic_load(queue + nbins + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int left = (has_edge(q) ? 2 * nch : nch) - taken;
+                    const float score = left > 0 ? (float)left / (float)(there + 1) : 0.0f;
+                    const unsigned long long k = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned)q;
+                    key = k > key ? k : key;
+                }
+            }
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                const unsigned long long o = __shfl_xor(key, sft);
+                key = o > key ? o : key;
+            }
+            if (lane == 0) {
+                const int rn = (key >> 32) != 0 ? (int)(key & 0xffffffffu) : -1;
+                atomicSub(queue + nbins + r, 1);
+                if (rn >= 0) atomicAdd(queue + nbins + rn, 1);
+                s_region = rn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // results of a place-pass workgroup's queries, from the sorted order of its image back to the caller's order: staged through
 // LDS, so that both the read and the write are consecutive
 template <typename T>
@@ -1459,10 +1798,17 @@ static bool make_pregions(const Grid &g, PRegions &rg, int sper)
         rg.nbins *= rg.nreg[d];
         rg.tcells *= rg.text[d];
     }
-    if (rg.nbins < 8 || rg.nbins > PR_MAXBINS) return false;
+    if (rg.nbins < 8 || rg.nbins > PRCfg<D>::MAXBINS) return false;
     rg.deal = std::getenv("SPLPAK_PR_NODEAL") ? 0 : 1;
+    // (4-D: the runs of a place-pass workgroup hold ~16 queries for 32 slot classes -- nothing to deal; SPLPAK_PR_DEAL4=1 deals anyway)
+    if (D == 4 && !std::getenv("SPLPAK_PR_DEAL4")) rg.deal = 0;
     // what the place pass needs to know of the evaluation pass's LDS tile: its strides and the distance of its second copy
-    if (sper == 16) { using PT = PTile<D, 16>; for (int d = 0; d < D; ++d) rg.tstr[d] = PT::stride(d); rg.telems = PT::W128 ? PT::COPY : 0; }
+    if constexpr (D == 4) {
+        if (sper != 8) return false;                 // (a tile of 19^4 coefficients is 1 MB)
+        using PT = PTile<D, 8>;
+        for (int d = 0; d < D; ++d) rg.tstr[d] = PT::stride(d);
+        rg.telems = 0;
+    } else if (sper == 16) { using PT = PTile<D, 16>; for (int d = 0; d < D; ++d) rg.tstr[d] = PT::stride(d); rg.telems = PT::W128 ? PT::COPY : 0; }
     else { using PT = PTile<D, 8>; for (int d = 0; d < D; ++d) rg.tstr[d] = PT::stride(d); rg.telems = PT::W128 ? PT::COPY : 0; }
     return true;
 }
@@ -1470,6 +1816,7 @@ static bool make_pregions(const Grid &g, PRegions &rg, int sper)
 namespace {
 struct PScratch {
     unsigned short *sidx = nullptr;
+    unsigned char *scls = nullptr;                // (4-D) LDS slot class of every sorted query
     int *starts = nullptr, *claim = nullptr;
     void *xs = nullptr, *outs = nullptr;          // sorted coordinate planes [workgroup][D][PR_Q], sorted results
     long long cap_q = 0, cap_st = 0, cap_xs = 0;
@@ -1483,6 +1830,7 @@ static void pscratch_shutdown()
 {
     PScratch &s = g_pscratch;
     if (s.sidx) (void)hipFree(s.sidx);
+    if (s.scls) (void)hipFree(s.scls);
     if (s.starts) (void)hipFree(s.starts);
     if (s.claim) (void)hipFree(s.claim);
     if (s.xs) (void)hipFree(s.xs);
@@ -1498,10 +1846,10 @@ static hipError_t eval_persistent(const Grid &g, long long nq, const T *xq, int 
     if (std::getenv("SPLPAK_EVAL_NO_PERSISTENT")) return hipErrorNotSupported;
     // regions of 16 window starts per dimension (tiles of 19^3 = 55 KB: 64^3 nodes give 4 x 4 x 4 regions), of 8 for smaller grids
     PRegions rg;
-    int sper = 16;
+    int sper = D == 4 ? 8 : 16;
     if (!make_pregions<D>(g, rg, sper)) {
         sper = 8;
-        if (!make_pregions<D>(g, rg, sper)) return hipErrorNotSupported;
+        if (D == 4 || !make_pregions<D>(g, rg, sper)) return hipErrorNotSupported;
     }
     const long long nwg_ll = (nq + PR_Q - 1) / PR_Q;
     if (nwg_ll > 0x3fffffffLL / (2 * rg.nbins + 1)) return hipErrorNotSupported;
@@ -1515,6 +1863,7 @@ static hipError_t eval_persistent(const Grid &g, long long nq, const T *xq, int 
     if (s.dev != dev || s.cap_q < need_q || s.cap_st < need_st || s.cap_xs < need_xs) {
         pscratch_shutdown();
         hipError_t e = hipMalloc(&s.sidx, sizeof(unsigned short) * (size_t)need_q);
+        if (e == hipSuccess) e = hipMalloc(&s.scls, (size_t)need_q + 16);
         if (e == hipSuccess) e = hipMalloc(&s.starts, sizeof(int) * (size_t)need_st);
         if (e == hipSuccess) e = hipMalloc(&s.xs, sizeof(T) * (size_t)need_q * D);
         if (e == hipSuccess) e = hipMalloc(&s.outs, sizeof(T) * (size_t)need_q);
@@ -1531,7 +1880,7 @@ static hipError_t eval_persistent(const Grid &g, long long nq, const T *xq, int 
     for (int d = 0; d < D; ++d) value_only = value_only && nd.v[d] == 0;
     hipError_t e = hipMemsetAsync(s.claim, 0, sizeof(int) * 2 * PR_MAXBINS, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((pr_place_kernel<D, T>), dim3((unsigned)nwg), dim3(PR_NT), 0, st, g, rg, nq, xq, ldxq, s.sidx, s.starts, (T *)s.xs);
+    hipLaunchKernelGGL((pr_place_kernel<D, T>), dim3((unsigned)nwg), dim3(PR_NT), 0, st, g, rg, nq, xq, ldxq, s.sidx, s.starts, (T *)s.xs, s.scls);
     // persistent workers: one workgroup per CU
     if (s.ncu <= 0) {
         int v = 0;
@@ -1542,14 +1891,25 @@ static hipError_t eval_persistent(const Grid &g, long long nq, const T *xq, int 
     // (chunks of 4 place-pass workgroups of interior runs, 16 of boundary runs: ~400 queries; the waves of a workgroup take
     //  them from a counter in LDS, so small chunks cost nothing and keep the tails short)
     static const int c0_env = std::getenv("SPLPAK_PR_C0") ? atoi(std::getenv("SPLPAK_PR_C0")) : 0;
-    const int c0 = c0_env > 0 ? c0_env : 4;
     const dim3 grid(nworkers);
+    if constexpr (D == 4) {
+        // chunks of 32 place-pass workgroups of one bin: ~500 queries (a chunk's runs sit one per lane: at most 64)
+        const int c0 = c0_env > 0 ? (c0_env < 64 ? c0_env : 64) : 32;
+        if (value_only)
+            hipLaunchKernelGGL((pr_eval4_kernel<8, true, T>), grid, dim3(PR4_EW), 0, st, g, rg, nd, coef, (const T *)s.xs, (const unsigned char *)s.scls,
+                               (const int *)s.starts, nwg, c0, s.claim, (T *)s.outs);
+        else
+            hipLaunchKernelGGL((pr_eval4_kernel<8, false, T>), grid, dim3(PR4_EW), 0, st, g, rg, nd, coef, (const T *)s.xs, (const unsigned char *)s.scls,
+                               (const int *)s.starts, nwg, c0, s.claim, (T *)s.outs);
+    } else {
+        const int c0 = c0_env > 0 ? c0_env : 4;
 #define PR_GO(SP, VL)                                                                                                                        \
     hipLaunchKernelGGL((pr_eval_kernel<D, SP, VL, T>), grid, dim3(PR_EW), 0, st, g, rg, nd, coef, (const T *)s.xs, (const int *)s.starts, nwg, \
                        c0, s.claim, (T *)s.outs)
-    if (sper == 16) { if (value_only) PR_GO(16, true); else PR_GO(16, false); }
-    else { if (value_only) PR_GO(8, true); else PR_GO(8, false); }
+        if (sper == 16) { if (value_only) PR_GO(16, true); else PR_GO(16, false); }
+        else { if (value_only) PR_GO(8, true); else PR_GO(8, false); }
 #undef PR_GO
+    }
     hipLaunchKernelGGL((pr_unsort_kernel<T>), dim3((unsigned)nwg), dim3(PR_NT), 0, st, nq, (const unsigned short *)s.sidx, (const int *)s.starts,
                        2 * rg.nbins + 1, (const T *)s.outs, out);
     (void)hipEventRecord(s.last, st);
@@ -1624,7 +1984,7 @@ static hipError_t eval_binned(const Grid &g, const Regions &rg, long long nq, co
                               const NDeriv &nd, const T *coef, T *out, hipStream_t st,
                               int order = 0, int ldout = 1)
 {
-    if constexpr (D == 3) {
+    if constexpr (D == 3 || D == 4) {
         if (order == 0) {
             const hipError_t e = eval_persistent<D, T>(g, nq, xq, ldxq, nd, coef, out, st);
             if (e != hipErrorNotSupported) return e;

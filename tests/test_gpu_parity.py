@@ -302,6 +302,63 @@ def test_eval_persistent_path_clusters_ends_and_small_batches(port, nodes):
         capi.set_eval_mode(capi.EVAL_AUTO)
 
 
+@pytest.mark.parametrize("nodes", [(32, 32, 32, 32), (24, 20, 9, 27), (12, 35, 12, 8)])
+def test_eval_persistent_4d_path_matches_the_direct_kernel(port, nodes):
+    """The persistent 4-D path of round 5 (BASELINE config 5's evaluation half: place pass over 2 x 256 bins, one persistent
+    workgroup per CU with the (8 + 3)^4 tile of a region in LDS, waves that take chunks of runs and find their elements by a
+    search over the lanes' prefixes, unsort pass): scattered queries, every query in ONE cell (one bin: a single long run per
+    place-pass workgroup), queries in the first / last three cells of some dimension (boundary bins only), outside the grid
+    and on the nodes, batches below one place-pass workgroup and one query over a chunk boundary -- values and a derivative
+    pattern return the bits of the direct kernel and the values of the reference algorithm (oracle); REAL32 storage too."""
+    nd = 4
+    rng = np.random.default_rng(nodes[0] * 7 + nodes[3])
+    coef = rng.standard_normal(int(np.prod(nodes)))
+    lo = np.array([-0.5, 1.0, 2.0, 0.0])
+    hi = lo + np.array([1.0, 2.5, 0.75, 3.0])
+    nn = np.array(nodes)
+    dx = (hi - lo) / (nn - 1)
+    batches = {}
+    n = 300_001
+    batches["scattered"] = lo + (hi - lo) * rng.random((n, nd))
+    batches["one cell"] = lo + dx * (np.array([5, 2, nodes[2] - 3, 1]) + rng.random((n // 3, nd)))
+    ends = lo + (hi - lo) * rng.random((n // 3, nd))
+    k = rng.integers(0, nd, n // 3)
+    side = rng.integers(0, 2, n // 3)
+    cell = rng.integers(0, 3, n // 3) + rng.random(n // 3)
+    ends[np.arange(n // 3), k] = np.where(side == 0, lo[k] + dx[k] * cell, hi[k] - dx[k] * cell)
+    batches["ends"] = ends
+    mixed = lo + (hi - lo) * (-0.3 + 1.6 * rng.random((n // 3, nd)))
+    mixed[:4000] = lo + dx * rng.integers(-1, nn + 1, (4000, nd))
+    batches["outside + nodes"] = mixed
+    batches["tiny"] = lo + (hi - lo) * rng.random((37, nd))
+    batches["one workgroup + 1"] = lo + (hi - lo) * rng.random((8193, nd))
+    try:
+        for name, q in batches.items():
+            for pat in (None, [0, 1, 0, 2]):
+                if pat is not None and name not in ("scattered", "outside + nodes"):
+                    continue
+                capi.set_eval_mode(capi.EVAL_DIRECT)
+                vd, rc = capi.evaluate(nd, q, pat, coef, lo, hi, nodes)
+                assert rc == 0
+                capi.set_eval_mode(capi.EVAL_BINNED, 0)
+                vb, rc = capi.evaluate(nd, q, pat, coef, lo, hi, nodes)
+                assert rc == 0
+                assert np.array_equal(vd, vb), (nodes, name, pat)
+                m = min(len(q), 2000)
+                vo, _ = port.evaluate(nd, q[:m], pat, coef, lo, hi, nodes)
+                scale = max(np.max(np.abs(vo)), np.max(np.abs(coef)) * float(np.max(1.0 / dx)) ** sum(pat or [0]))
+                assert np.max(np.abs(vb[:m] - vo)) <= EVAL_TOL * scale, (nodes, name, pat)
+        q = batches["scattered"].astype(np.float32)
+        c32 = coef.astype(np.float32)
+        capi.set_eval_mode(capi.EVAL_DIRECT)
+        v0, _ = capi.evaluate(nd, q, None, c32, lo, hi, nodes, real32=True)
+        capi.set_eval_mode(capi.EVAL_BINNED, 0)
+        v1, _ = capi.evaluate(nd, q, None, c32, lo, hi, nodes, real32=True)
+        assert np.array_equal(v0, v1)
+    finally:
+        capi.set_eval_mode(capi.EVAL_AUTO)
+
+
 def test_eval_run_path_with_clustered_queries():
     """The 3-D run path (round 3: every place-pass workgroup leaves its own region-sorted image and the starts of its
     runs; the evaluation workgroups gather the runs of their region -- no global sort).  Scattered queries give runs of
