@@ -252,6 +252,298 @@ cell_order_kernel(Grid g, const int *__restrict__ offset, double *__restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Stable partition of the points by window (round 5).  keys_kernel / scatter_kernel above bin with one global
+// integer atomic per point and pass -- on the cell's counter, then on its cursor -- and scatter (ndim + 3) separate 8-byte
+// words per point; the cursor's order is not reproducible, so cell_order_kernel re-sorts every cell by original index:
+// 3.6 ms for the 1e7 points of BASELINE config 3 (0.04 of the HBM roofline), 0.42 of config 2's 2.0 ms (269 points on each of
+// only 3 721 counters).  Here a counting sort WITHOUT global atomics that is stable by construction -- the points of a cell
+// end up in ascending original index, which is exactly the order cell_order_kernel produced: the same bits downstream.
+//
+//   A block = SP_Q consecutive points, its 16 waves own 512 consecutive points each.
+//   sp_count:    window key of every point (kept in `key`), bin = key / cpt (one level: cpt = 1, bin = cell; the last bin holds
+//                the zero-weight points, :799); per-wave bin counts in LDS (16-bit halves of words, LDS atomics -- counting is
+//                order-free), block totals -> row [block][bin] of the count matrix.
+//   sp_colsum / sp_binscan / sp_blockbase: bin bases (exclusive scan of the bin totals) and, in place of every count, where that
+//                block's points of that bin start: bins in order, blocks in order inside a bin.
+//   sp_scatter:  the per-wave counts again, turned into exclusive prefixes over the waves; then every wave walks its 8 passes
+//                of 64 points in order: a point's rank among the EARLIER lanes with its bin comes from the ballots of the
+//                bin's bits (12 ballots: the lanes whose bin matches, below the own one), its wave's running count of the bin
+//                from LDS -- the lowest lane of every group adds the group's size to it.  One level: the point goes straight
+//                to its sorted place (SoA planes).  Two levels (more cells than bins: 64^3 has 226 981): a RECORD (coordinates,
+//                y, w, index, cell) goes to the tile-sorted intermediate image, and
+//   sp_bin2:     one workgroup per tile of cpt cells sorts the tile's records (contiguous: ~2 800 at config 3) by cell with the
+//                same machinery -- per-wave counts, prefixes over waves and sub-blocks, ballot ranks -- writes their sorted
+//                places and the offsets of its cells.
+// Every count has one writer or is a sum; no order depends on timing: bitwise reproducible without a second sort.
+constexpr int SP_NT = 1024, SP_NW = SP_NT / 64, SP_BITS = 12;
+static_assert(SP_NB == 1 << SP_BITS && SP_Q == SP_NW * 512, "bins / block shape");
+
+template <int D>
+__device__ inline int sp_cell_key(const Grid &g, const double *__restrict__ x, int ldx, const double *__restrict__ w, long long i)
+{
+    const double wv = w ? w[i] : 1.0;
+    if (wv == 0.0) return g.ncell;             // zero weight: ignored (:799, :891)
+    int k = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        int lo, hi;
+        k += window_start(g, d, x[i * ldx + g.perm[d]], lo, hi) * g.cellstride[d];
+    }
+    return k;
+}
+
+// lanes of the wave whose `bin` equals this lane's (all lanes take part; inactive ones pass bin = -1 and are matched with nobody real)
+__device__ inline unsigned long long sp_match(int bin, int bits)
+{
+    unsigned long long m = ~0ull;
+    for (int b = 0; b < bits; ++b) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(((bin >> b) & 1) != 0);
+        m &= ((bin >> b) & 1) ? bal : ~bal;
+    }
+    return m;
+}
+
+// per-wave bin counts of a block of up to SP_Q items: whist[wave][bin / 2], two 16-bit counts per word
+template <typename BinOf>
+__device__ inline void sp_wave_counts(unsigned (*whist)[SP_NB / 2], int n, BinOf &&bin_of)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int e = tid; e < SP_NW * (SP_NB / 2); e += SP_NT) (&whist[0][0])[e] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int p = wave * 512 + j * 64 + lane;
+        if (p < n) {
+            const int bin = bin_of(p);
+            atomicAdd(&whist[wave][bin >> 1], 1u << (16 * (bin & 1)));
+        }
+    }
+    __syncthreads();
+}
+
+template <int D>
+__global__ void __launch_bounds__(SP_NT)
+sp_count_kernel(Grid g, long long m, const double *__restrict__ x, int ldx, const double *__restrict__ w, int cpt,
+                int *__restrict__ key, int *__restrict__ cntm, double *__restrict__ scal)
+{
+    __shared__ unsigned whist[SP_NW][SP_NB / 2];
+    __shared__ int s_valid;
+    const long long base = (long long)blockIdx.x * SP_Q;
+    const int n = (int)(m - base < SP_Q ? m - base : SP_Q);
+    if (threadIdx.x == 0) s_valid = 0;
+    int nvalid = 0;
+    sp_wave_counts(whist, n, [&](int p) {
+        const int k = sp_cell_key<D>(g, x, ldx, w, base + p);
+        key[base + p] = k;
+        nvalid += k < g.ncell ? 1 : 0;
+        return k < g.ncell ? k / cpt : SP_NB - 1;
+    });
+    if (nvalid) atomicAdd(&s_valid, nvalid);
+    int *__restrict__ row = cntm + (long long)blockIdx.x * SP_NB;
+    for (int b2 = threadIdx.x; b2 < SP_NB / 2; b2 += SP_NT) {
+        unsigned t = 0;
+#pragma unroll
+        for (int v = 0; v < SP_NW; ++v) t += whist[v][b2];           // (both halves at once: a block total is at most 8 192)
+        row[2 * b2] = (int)(t & 0xffffu);
+        row[2 * b2 + 1] = (int)(t >> 16);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_valid) atomicAdd(&scal[SC_NROWS_DATA], (double)s_valid);      // integer-valued: exact in any order
+}
+
+constexpr int SP_ROWS = 128;       // blocks per chunk of the column sums
+__global__ void __launch_bounds__(256)
+sp_colsum_kernel(int nblk, const int *__restrict__ cntm, int *__restrict__ part)
+{
+    const int bin = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+    const int b0 = ch * SP_ROWS, b1 = b0 + SP_ROWS < nblk ? b0 + SP_ROWS : nblk;
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += cntm[(long long)b * SP_NB + bin];
+    part[(long long)ch * SP_NB + bin] = s;
+}
+// bin totals -> binbase (exclusive scan, binbase[SP_NB] = all points); part[chunk][bin] -> where the chunk's points of the bin start
+__global__ void __launch_bounds__(1024)
+sp_binscan_kernel(int nchunk, int *__restrict__ part, int *__restrict__ binbase)
+{
+    __shared__ int sc[1024];
+    const int t = threadIdx.x;
+    int tot[4], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int s = 0;
+        for (int c = 0; c < nchunk; ++c) s += part[(long long)c * SP_NB + 4 * t + u];
+        tot[u] = s;
+        sum += s;
+    }
+    sc[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? sc[t - o] : 0;
+        __syncthreads();
+        sc[t] += v;
+        __syncthreads();
+    }
+    int run = sc[t] - sum;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        binbase[4 * t + u] = run;
+        int r2 = run;
+        for (int c = 0; c < nchunk; ++c) {
+            const int v = part[(long long)c * SP_NB + 4 * t + u];
+            part[(long long)c * SP_NB + 4 * t + u] = r2;
+            r2 += v;
+        }
+        run += tot[u];
+    }
+    if (t == 1023) binbase[SP_NB] = run;
+}
+__global__ void __launch_bounds__(256)
+sp_blockbase_kernel(int nblk, int *__restrict__ cntm, const int *__restrict__ part)
+{
+    const int bin = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+    const int b0 = ch * SP_ROWS, b1 = b0 + SP_ROWS < nblk ? b0 + SP_ROWS : nblk;
+    int run = part[(long long)ch * SP_NB + bin];
+    for (int b = b0; b < b1; ++b) {
+        const int v = cntm[(long long)b * SP_NB + bin];
+        cntm[(long long)b * SP_NB + bin] = run;
+        run += v;
+    }
+}
+
+// the stable places of a block's items: `place(p, pos)` is called once per item p < n with its position pos = base of its bin
+// for this block + items of the bin before it in the block.  bbase[bin]: the block's bases (LDS), whist: the per-wave counts
+// (sp_wave_counts), turned into running exclusive prefixes here.
+template <typename BinOf, typename Place>
+__device__ inline void sp_stable_places(unsigned (*whist)[SP_NB / 2], const int *bbase, int n, int bits, BinOf &&bin_of, Place &&place)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int b2 = tid; b2 < SP_NB / 2; b2 += SP_NT) {               // exclusive prefixes over the waves, both halves of a word at once
+        unsigned run = 0;
+#pragma unroll
+        for (int v = 0; v < SP_NW; ++v) {
+            const unsigned c = whist[v][b2];
+            whist[v][b2] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+        const int p = wave * 512 + j * 64 + lane;
+        const int bin = p < n ? bin_of(p) : -1;
+        const unsigned long long mm = sp_match(bin, bits + 1);          // (+ 1: bit `bits` tells -1 from every real bin)
+        if (bin >= 0) {
+            const unsigned wv = whist[wave][bin >> 1];
+            const int before = (int)((wv >> (16 * (bin & 1))) & 0xffffu) + __builtin_popcountll(mm & lt);
+            place(p, bbase[bin] + before);
+        }
+        __builtin_amdgcn_wave_barrier();                               // (every lane has read its running count)
+        if (bin >= 0 && (mm & lt) == 0) atomicAdd(&whist[wave][bin >> 1], (unsigned)__builtin_popcountll(mm) << (16 * (bin & 1)));
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// RECORD of a point on its way through the tile-sorted image: ndim coordinates (internal order), y, w, (index, cell)
+template <int D>
+__global__ void __launch_bounds__(SP_NT)
+sp_scatter_kernel(Grid g, long long m, const double *__restrict__ x, int ldx, const double *__restrict__ y, const double *__restrict__ w,
+                  int cpt, const int *__restrict__ key, const int *__restrict__ cntm, double *__restrict__ rec,
+                  double *__restrict__ xs, double *__restrict__ ys, double *__restrict__ ws, int *__restrict__ idx, long long cap)
+{
+    __shared__ unsigned whist[SP_NW][SP_NB / 2];
+    __shared__ int bbase[SP_NB];
+    const long long base = (long long)blockIdx.x * SP_Q;
+    const int n = (int)(m - base < SP_Q ? m - base : SP_Q);
+    for (int b = threadIdx.x; b < SP_NB; b += SP_NT) bbase[b] = cntm[(long long)blockIdx.x * SP_NB + b];
+    auto bin_of = [&](int p) {
+        const int k = key[base + p];
+        return k < g.ncell ? k / cpt : SP_NB - 1;
+    };
+    sp_wave_counts(whist, n, bin_of);
+    sp_stable_places(whist, bbase, n, SP_BITS, bin_of, [&](int p, int pos) {
+        const long long i = base + p;
+        const int k = key[i];
+        if (k >= g.ncell) return;                                       // zero weight: not placed
+        if (rec) {
+            double *__restrict__ r = rec + (long long)pos * (D + 3);
+#pragma unroll
+            for (int d = 0; d < D; ++d) r[d] = x[i * ldx + g.perm[d]];
+            r[D] = y[i];
+            r[D + 1] = w ? w[i] : 1.0;
+            reinterpret_cast<int *>(r + D + 2)[0] = (int)i;
+            reinterpret_cast<int *>(r + D + 2)[1] = k;
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) xs[(long long)d * cap + pos] = x[i * ldx + g.perm[d]];
+            ys[pos] = y[i];
+            ws[pos] = w ? w[i] : 1.0;
+            idx[pos] = (int)i;
+        }
+    });
+}
+
+// second level: workgroup = tile of cpt cells; its records (binbase[tile] .. binbase[tile + 1]) -> sorted places by cell
+template <int D>
+__global__ void __launch_bounds__(SP_NT)
+sp_bin2_kernel(Grid g, int cpt, int ntile, const int *__restrict__ binbase, const double *__restrict__ rec, int *__restrict__ offset,
+               double *__restrict__ xs, double *__restrict__ ys, double *__restrict__ ws, int *__restrict__ idx, long long cap)
+{
+    __shared__ unsigned whist[SP_NW][SP_NB / 2];
+    __shared__ int bbase[SP_NB];                                       // [local cell]: where its next sub-block's records start
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tb = binbase[tile], te = binbase[tile + 1];
+    const int c0 = tile * cpt, nc = min(cpt, g.ncell - c0);
+    // cell totals of the whole tile (sub-block after sub-block), then their exclusive prefix = the cells' offsets
+    for (int b = tid; b < SP_NB; b += SP_NT) bbase[b] = 0;
+    __syncthreads();
+    auto cell_at = [&](int q) { return reinterpret_cast<const int *>(rec + (long long)q * (D + 3) + D + 2)[1] - c0; };       // local cell of record q
+    for (int sb0 = 0; sb0 < te - tb; sb0 += SP_Q) {
+        const int n = min(SP_Q, te - tb - sb0);
+        sp_wave_counts(whist, n, [&](int p) { return cell_at(tb + sb0 + p); });
+        for (int b = tid; b < nc; b += SP_NT) {
+            unsigned t = 0;
+            for (int v = 0; v < SP_NW; ++v) t += (whist[v][b >> 1] >> (16 * (b & 1))) & 0xffffu;
+            bbase[b] += (int)t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {                                                    // (at most SP_NB cells per tile: a serial scan is 4 us)
+        int run = tb;
+        for (int b = 0; b < nc; ++b) { const int v = bbase[b]; bbase[b] = run; run += v; }
+    }
+    __syncthreads();
+    for (int b = tid; b < nc; b += SP_NT) offset[c0 + b] = bbase[b];
+    if (tile == ntile - 1 && tid == 0) offset[g.ncell] = te;
+    int bits = 1;
+    while ((1 << bits) < nc) ++bits;
+    for (int sb0 = 0; sb0 < te - tb; sb0 += SP_Q) {
+        const int n = min(SP_Q, te - tb - sb0);
+        auto bin_of = [&](int p) { return cell_at(tb + sb0 + p); };
+        sp_wave_counts(whist, n, bin_of);
+        // (the block totals, for the next sub-block's bases -- taken before the counts become prefixes)
+        int add[(SP_NB + SP_NT - 1) / SP_NT];
+        for (int b = tid, u = 0; b < nc; b += SP_NT, ++u) {
+            unsigned t = 0;
+            for (int v = 0; v < SP_NW; ++v) t += (whist[v][b >> 1] >> (16 * (b & 1))) & 0xffffu;
+            add[u] = (int)t;
+        }
+        __syncthreads();
+        sp_stable_places(whist, bbase, n, bits, bin_of, [&](int p, int pos) {
+            const double *__restrict__ r = rec + (long long)(tb + sb0 + p) * (D + 3);
+#pragma unroll
+            for (int d = 0; d < D; ++d) xs[(long long)d * cap + pos] = r[d];
+            ys[pos] = r[D];
+            ws[pos] = r[D + 1];
+            idx[pos] = reinterpret_cast<const int *>(r + D + 2)[0];
+        });
+        __syncthreads();
+        for (int b = tid, u = 0; b < nc; b += SP_NT, ++u) bbase[b] += add[u];
+        __syncthreads();
+    }
+}
+
 // nearest-node histogram slot of a point INSIDE its cell's window (local index, dim 0 fastest), or -1
 // when the reference's address (:894-902) is not a node of the window: a coordinate so far outside
 // the grid that its dimension is skipped in the Horner address (the :899 quirk).  x is in the plan's
@@ -1524,9 +1816,41 @@ long long gram_scratch_doubles(const Grid &g)
     return (long long)g.ncell * (gram_tri(g.nb) + 2LL * g.nb);
 }
 
+// cells per bin of the stable partition's first level (1: the bins ARE the cells); 0: the grid has too many cells for it
+static int sp_cells_per_bin(const Grid &g)
+{
+    const long long cpt = ((long long)g.ncell + SP_NB - 2) / (SP_NB - 1);
+    return cpt <= SP_NB - 1 ? (int)(cpt < 1 ? 1 : cpt) : 0;
+}
+
+long long bin_record_doubles(const Grid &g, long long max_ndata)
+{
+    const int cpt = sp_cells_per_bin(g);
+    return cpt > 1 ? max_ndata * (long long)(g.ndim + 3) : 0;
+}
+
 hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ldx, const double *y,
                              const double *w, const SortScratch &s, double *scal, hipStream_t st)
 {
+    static const bool old_form = std::getenv("SPLPAK_BIN_ATOMIC") != nullptr;      // A/B switch: rounds 1-4 (global atomics + in-cell re-sort)
+    const int cpt = sp_cells_per_bin(g);
+    if (!old_form && cpt > 0 && s.cntm && s.binbase && s.sppart && (cpt == 1 || s.rec)) {
+        if (m <= 0) return hipMemsetAsync(s.offset, 0, sizeof(int) * (size_t)(g.ncell + 2), st);
+        const int nblk = (int)((m + SP_Q - 1) / SP_Q), nchunk = (nblk + SP_ROWS - 1) / SP_ROWS;
+        double *rec = cpt > 1 ? s.rec : nullptr;
+        DISPATCH_D(g.ndim, hipLaunchKernelGGL(sp_count_kernel<D>, dim3((unsigned)nblk), dim3(SP_NT), 0, st, g, m, x, ldx, w, cpt, s.key, s.cntm, scal));
+        hipLaunchKernelGGL(sp_colsum_kernel, dim3(SP_NB / 256, (unsigned)nchunk), dim3(256), 0, st, nblk, (const int *)s.cntm, s.sppart);
+        hipLaunchKernelGGL(sp_binscan_kernel, dim3(1), dim3(1024), 0, st, nchunk, s.sppart, s.binbase);
+        hipLaunchKernelGGL(sp_blockbase_kernel, dim3(SP_NB / 256, (unsigned)nchunk), dim3(256), 0, st, nblk, s.cntm, (const int *)s.sppart);
+        DISPATCH_D(g.ndim, hipLaunchKernelGGL(sp_scatter_kernel<D>, dim3((unsigned)nblk), dim3(SP_NT), 0, st, g, m, x, ldx, y, w, cpt, (const int *)s.key,
+                                              (const int *)s.cntm, rec, s.xs, s.ys, s.ws, s.idx, s.cap));
+        if (cpt == 1)      // the bins are the cells: their bases are the offsets (bins ncell .. SP_NB - 2 are empty)
+            return hipMemcpyAsync(s.offset, s.binbase, sizeof(int) * (size_t)(g.ncell + 1), hipMemcpyDeviceToDevice, st);
+        const int ntile = (g.ncell + cpt - 1) / cpt;
+        DISPATCH_D(g.ndim, hipLaunchKernelGGL(sp_bin2_kernel<D>, dim3((unsigned)ntile), dim3(SP_NT), 0, st, g, cpt, ntile, (const int *)s.binbase,
+                                              (const double *)rec, s.offset, s.xs, s.ys, s.ws, s.idx, s.cap));
+        return hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(s.count, 0, sizeof(int) * (size_t)(g.ncell + 2), st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(s.cursor, 0, sizeof(int) * (size_t)(g.ncell + 1), st);

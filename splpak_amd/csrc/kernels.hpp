@@ -45,7 +45,16 @@ struct SortScratch {
     double *ws;      // [cap]
     int *idx;        // [cap] original index of the sorted points (orders the points inside a cell)
     long long cap;   // max_ndata
+    // stable partition (round 5; sp_* kernels of assemble.hip): per-block bin counts / bases, bin bases, intermediate records
+    int *cntm;       // [ceil(cap / SP_Q)][SP_NB]
+    int *binbase;    // [SP_NB + 1]
+    int *sppart;     // [chunks of 128 blocks][SP_NB]
+    double *rec;     // [cap][ndim + 3] records sorted by tile (grids of more cells than bins; else NULL)
 };
+constexpr int SP_Q = 8192;         // points per block of the stable partition
+constexpr int SP_NB = 4096;        // bins (the last one holds the zero-weight points)
+// doubles of SortScratch::rec a grid needs (0: one level suffices)
+long long bin_record_doubles(const Grid &g, long long max_ndata);
 
 // binning: window keys + per-cell counts + scalars -> scan -> counting-sort scatter -> points of every
 // cell ordered by original index
