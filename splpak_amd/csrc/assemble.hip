@@ -41,6 +41,7 @@ namespace splpak {
 namespace {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
 __device__ inline double wave_sum(double v)
 {
@@ -277,6 +278,9 @@ cell_order_kernel(Grid g, const int *__restrict__ offset, double *__restrict__ x
 //                places and the offsets of its cells.
 // Every count has one writer or is a sum; no order depends on timing: bitwise reproducible without a second sort.
 constexpr int SP_NT = 1024, SP_NW = SP_NT / 64, SP_BITS = 12;
+// doubles of a record: ndim coordinates, y, w, (index, cell) -- rounded up to an even count: records move as 16-byte words (a
+// scattered store costs this chip ~7 cycles per lane and instruction whatever its width)
+__host__ __device__ constexpr int sp_rec(int d) { return (d + 3 + 1) & ~1; }
 static_assert(SP_NB == 1 << SP_BITS && SP_Q == SP_NW * 512, "bins / block shape");
 
 template <int D>
@@ -304,121 +308,154 @@ __device__ inline unsigned long long sp_match(int bin, int bits)
     return m;
 }
 
-// per-wave bin counts of a block of up to SP_Q items: whist[wave][bin / 2], two 16-bit counts per word
-template <typename BinOf>
-__device__ inline void sp_wave_counts(unsigned (*whist)[SP_NB / 2], int n, BinOf &&bin_of)
+// per-wave bin counts of a block of up to SP_Q items: whist[wave][bin / 2], two 16-bit counts per word; nb bins in use.
+// keyv[j]: the bin of the wave's item j * 64 + lane (-1: none)
+template <int NBW>
+__device__ inline void sp_wave_counts(unsigned (*whist)[NBW], int nb, const int (&binv)[8])
 {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int e = tid; e < SP_NW * (SP_NB / 2); e += SP_NT) (&whist[0][0])[e] = 0u;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int nw = (nb + 1) >> 1;
+    for (int v = 0; v < SP_NW; ++v)
+        for (int e = tid; e < nw; e += SP_NT) whist[v][e] = 0u;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int p = wave * 512 + j * 64 + lane;
-        if (p < n) {
-            const int bin = bin_of(p);
-            atomicAdd(&whist[wave][bin >> 1], 1u << (16 * (bin & 1)));
-        }
-    }
+    for (int j = 0; j < 8; ++j)
+        if (binv[j] >= 0) atomicAdd(&whist[wave][binv[j] >> 1], 1u << (16 * (binv[j] & 1)));
     __syncthreads();
 }
 
+// first level, counts: a block only needs its TOTALS per bin -- one histogram for all waves (16 KB of LDS: several workgroups
+// per CU; with per-wave counts, 128 KB, the kernel ran one workgroup per CU at 0.38 ms for the 1e7 points of config 3)
 template <int D>
 __global__ void __launch_bounds__(SP_NT)
 sp_count_kernel(Grid g, long long m, const double *__restrict__ x, int ldx, const double *__restrict__ w, int cpt,
                 int *__restrict__ key, int *__restrict__ cntm, double *__restrict__ scal)
 {
-    __shared__ unsigned whist[SP_NW][SP_NB / 2];
+    __shared__ int hist[SP_NB];
     __shared__ int s_valid;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long base = (long long)blockIdx.x * SP_Q;
     const int n = (int)(m - base < SP_Q ? m - base : SP_Q);
-    if (threadIdx.x == 0) s_valid = 0;
-    int nvalid = 0;
-    sp_wave_counts(whist, n, [&](int p) {
-        const int k = sp_cell_key<D>(g, x, ldx, w, base + p);
-        key[base + p] = k;
-        nvalid += k < g.ncell ? 1 : 0;
-        return k < g.ncell ? k / cpt : SP_NB - 1;
-    });
-    if (nvalid) atomicAdd(&s_valid, nvalid);
-    int *__restrict__ row = cntm + (long long)blockIdx.x * SP_NB;
-    for (int b2 = threadIdx.x; b2 < SP_NB / 2; b2 += SP_NT) {
-        unsigned t = 0;
-#pragma unroll
-        for (int v = 0; v < SP_NW; ++v) t += whist[v][b2];           // (both halves at once: a block total is at most 8 192)
-        row[2 * b2] = (int)(t & 0xffffu);
-        row[2 * b2 + 1] = (int)(t >> 16);
-    }
+    for (int b = tid; b < SP_NB; b += SP_NT) hist[b] = 0;
+    if (tid == 0) s_valid = 0;
     __syncthreads();
-    if (threadIdx.x == 0 && s_valid) atomicAdd(&scal[SC_NROWS_DATA], (double)s_valid);      // integer-valued: exact in any order
+    int nvalid = 0;
+    // (all loads of a thread's 8 points in flight together: one dependent round trip per point made this pass latency bound)
+    double xv[8][D], wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int p = wave * 512 + j * 64 + lane;
+        const long long i = base + (p < n ? p : 0);
+        wv[j] = p < n ? (w ? w[i] : 1.0) : 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) xv[j][d] = x[i * ldx + g.perm[d]];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int p = wave * 512 + j * 64 + lane;
+        if (p < n) {
+            int k = g.ncell;                       // zero weight: ignored (:799, :891)
+            if (wv[j] != 0.0) {
+                k = 0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    int lo, hi;
+                    k += window_start(g, d, xv[j][d], lo, hi) * g.cellstride[d];
+                }
+            }
+            key[base + p] = k;
+            nvalid += k < g.ncell ? 1 : 0;
+            atomicAdd(&hist[k < g.ncell ? k / cpt : SP_NB - 1], 1);
+        }
+    }
+    if (nvalid) atomicAdd(&s_valid, nvalid);
+    __syncthreads();
+    int *__restrict__ row = cntm + (long long)blockIdx.x * SP_NB;
+    for (int b = tid; b < SP_NB; b += SP_NT) row[b] = hist[b];
+    if (tid == 0 && s_valid) atomicAdd(&scal[SC_NROWS_DATA], (double)s_valid);      // integer-valued: exact in any order
 }
 
-constexpr int SP_ROWS = 128;       // blocks per chunk of the column sums
+// Count matrix [block][bin] -> in place: where the block's points of the bin start (bins in order, blocks in order inside a
+// bin), and binbase = exclusive scan of the bin totals.  Four small launches: sums over chunks of SP_ROWS blocks, per bin the
+// exclusive prefix over the chunks + its total, the scan of the totals, and the walk down every chunk.
+constexpr int SP_ROWS = 16;        // blocks per chunk of the column sums
 __global__ void __launch_bounds__(256)
 sp_colsum_kernel(int nblk, const int *__restrict__ cntm, int *__restrict__ part)
 {
     const int bin = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
     const int b0 = ch * SP_ROWS, b1 = b0 + SP_ROWS < nblk ? b0 + SP_ROWS : nblk;
+    int v[SP_ROWS];
+#pragma unroll
+    for (int r = 0; r < SP_ROWS; ++r) v[r] = b0 + r < b1 ? cntm[(long long)(b0 + r) * SP_NB + bin] : 0;
     int s = 0;
-    for (int b = b0; b < b1; ++b) s += cntm[(long long)b * SP_NB + bin];
+#pragma unroll
+    for (int r = 0; r < SP_ROWS; ++r) s += v[r];
     part[(long long)ch * SP_NB + bin] = s;
 }
-// bin totals -> binbase (exclusive scan, binbase[SP_NB] = all points); part[chunk][bin] -> where the chunk's points of the bin start
+__global__ void __launch_bounds__(256)
+sp_chunkscan_kernel(int nchunk, int *__restrict__ part, int *__restrict__ tot)
+{
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    int run = 0, c = 0;
+    for (; c + 8 <= nchunk; c += 8) {             // eight loads in flight (a dependent load per chunk: 1 us each)
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long long)(c + u) * SP_NB + bin];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { part[(long long)(c + u) * SP_NB + bin] = run; run += v[u]; }
+    }
+    for (; c < nchunk; ++c) {
+        const int v = part[(long long)c * SP_NB + bin];
+        part[(long long)c * SP_NB + bin] = run;
+        run += v;
+    }
+    tot[bin] = run;
+}
 __global__ void __launch_bounds__(1024)
-sp_binscan_kernel(int nchunk, int *__restrict__ part, int *__restrict__ binbase)
+sp_binscan_kernel(const int *__restrict__ tot, int *__restrict__ binbase)
 {
     __shared__ int sc[1024];
     const int t = threadIdx.x;
-    int tot[4], sum = 0;
+    int v[4], sum = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        int s = 0;
-        for (int c = 0; c < nchunk; ++c) s += part[(long long)c * SP_NB + 4 * t + u];
-        tot[u] = s;
-        sum += s;
-    }
+    for (int u = 0; u < 4; ++u) { v[u] = tot[4 * t + u]; sum += v[u]; }
     sc[t] = sum;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-        const int v = t >= o ? sc[t - o] : 0;
+        const int a = t >= o ? sc[t - o] : 0;
         __syncthreads();
-        sc[t] += v;
+        sc[t] += a;
         __syncthreads();
     }
     int run = sc[t] - sum;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        binbase[4 * t + u] = run;
-        int r2 = run;
-        for (int c = 0; c < nchunk; ++c) {
-            const int v = part[(long long)c * SP_NB + 4 * t + u];
-            part[(long long)c * SP_NB + 4 * t + u] = r2;
-            r2 += v;
-        }
-        run += tot[u];
-    }
+    for (int u = 0; u < 4; ++u) { binbase[4 * t + u] = run; run += v[u]; }
     if (t == 1023) binbase[SP_NB] = run;
 }
 __global__ void __launch_bounds__(256)
-sp_blockbase_kernel(int nblk, int *__restrict__ cntm, const int *__restrict__ part)
+sp_blockbase_kernel(int nblk, int *__restrict__ cntm, const int *__restrict__ part, const int *__restrict__ binbase)
 {
     const int bin = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
     const int b0 = ch * SP_ROWS, b1 = b0 + SP_ROWS < nblk ? b0 + SP_ROWS : nblk;
-    int run = part[(long long)ch * SP_NB + bin];
-    for (int b = b0; b < b1; ++b) {
-        const int v = cntm[(long long)b * SP_NB + bin];
-        cntm[(long long)b * SP_NB + bin] = run;
-        run += v;
+    int v[SP_ROWS];
+#pragma unroll
+    for (int r = 0; r < SP_ROWS; ++r) v[r] = b0 + r < b1 ? cntm[(long long)(b0 + r) * SP_NB + bin] : 0;
+    int run = binbase[bin] + part[(long long)ch * SP_NB + bin];
+#pragma unroll
+    for (int r = 0; r < SP_ROWS; ++r) {
+        if (b0 + r < b1) cntm[(long long)(b0 + r) * SP_NB + bin] = run;
+        run += v[r];
     }
 }
 
-// the stable places of a block's items: `place(p, pos)` is called once per item p < n with its position pos = base of its bin
-// for this block + items of the bin before it in the block.  bbase[bin]: the block's bases (LDS), whist: the per-wave counts
-// (sp_wave_counts), turned into running exclusive prefixes here.
-template <typename BinOf, typename Place>
-__device__ inline void sp_stable_places(unsigned (*whist)[SP_NB / 2], const int *bbase, int n, int bits, BinOf &&bin_of, Place &&place)
+// the stable places of a block's items: place(j, pos) is called once per item j * 64 + lane of the wave with binv[j] >= 0, pos =
+// bbase[bin] + items of the bin before it in the block.  whist: the per-wave counts (sp_wave_counts), turned into running
+// exclusive prefixes here.
+template <int NBW, typename Place>
+__device__ inline void sp_stable_places(unsigned (*whist)[NBW], const int *bbase, int nb, int bits, const int (&binv)[8], Place &&place)
 {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int b2 = tid; b2 < SP_NB / 2; b2 += SP_NT) {               // exclusive prefixes over the waves, both halves of a word at once
+    for (int b2 = tid; b2 < ((nb + 1) >> 1); b2 += SP_NT) {         // exclusive prefixes over the waves, both halves of a word at once
         unsigned run = 0;
 #pragma unroll
         for (int v = 0; v < SP_NW; ++v) {
@@ -429,15 +466,14 @@ __device__ inline void sp_stable_places(unsigned (*whist)[SP_NB / 2], const int 
     }
     __syncthreads();
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll 1
+#pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int p = wave * 512 + j * 64 + lane;
-        const int bin = p < n ? bin_of(p) : -1;
+        const int bin = binv[j];
         const unsigned long long mm = sp_match(bin, bits + 1);          // (+ 1: bit `bits` tells -1 from every real bin)
         if (bin >= 0) {
             const unsigned wv = whist[wave][bin >> 1];
             const int before = (int)((wv >> (16 * (bin & 1))) & 0xffffu) + __builtin_popcountll(mm & lt);
-            place(p, bbase[bin] + before);
+            place(j, bbase[bin] + before);
         }
         __builtin_amdgcn_wave_barrier();                               // (every lane has read its running count)
         if (bin >= 0 && (mm & lt) == 0) atomicAdd(&whist[wave][bin >> 1], (unsigned)__builtin_popcountll(mm) << (16 * (bin & 1)));
@@ -449,98 +485,150 @@ __device__ inline void sp_stable_places(unsigned (*whist)[SP_NB / 2], const int 
 template <int D>
 __global__ void __launch_bounds__(SP_NT)
 sp_scatter_kernel(Grid g, long long m, const double *__restrict__ x, int ldx, const double *__restrict__ y, const double *__restrict__ w,
-                  int cpt, const int *__restrict__ key, const int *__restrict__ cntm, double *__restrict__ rec,
+                  int cpt, int nb, const int *__restrict__ key, const int *__restrict__ cntm, double *__restrict__ rec,
                   double *__restrict__ xs, double *__restrict__ ys, double *__restrict__ ws, int *__restrict__ idx, long long cap)
 {
     __shared__ unsigned whist[SP_NW][SP_NB / 2];
     __shared__ int bbase[SP_NB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long base = (long long)blockIdx.x * SP_Q;
     const int n = (int)(m - base < SP_Q ? m - base : SP_Q);
-    for (int b = threadIdx.x; b < SP_NB; b += SP_NT) bbase[b] = cntm[(long long)blockIdx.x * SP_NB + b];
-    auto bin_of = [&](int p) {
-        const int k = key[base + p];
-        return k < g.ncell ? k / cpt : SP_NB - 1;
-    };
-    sp_wave_counts(whist, n, bin_of);
-    sp_stable_places(whist, bbase, n, SP_BITS, bin_of, [&](int p, int pos) {
-        const long long i = base + p;
-        const int k = key[i];
-        if (k >= g.ncell) return;                                       // zero weight: not placed
-        if (rec) {
-            double *__restrict__ r = rec + (long long)pos * (D + 3);
+    for (int b = tid; b < nb; b += SP_NT) bbase[b] = cntm[(long long)blockIdx.x * SP_NB + b];
+    // the wave's 8 x 64 points, all loads of a thread in flight together (the walk below is LDS and stores only)
+    int kk[8], binv[8];
+    double xv[8][D], yv[8], wv[8];
 #pragma unroll
-            for (int d = 0; d < D; ++d) r[d] = x[i * ldx + g.perm[d]];
-            r[D] = y[i];
-            r[D + 1] = w ? w[i] : 1.0;
-            reinterpret_cast<int *>(r + D + 2)[0] = (int)i;
-            reinterpret_cast<int *>(r + D + 2)[1] = k;
+    for (int j = 0; j < 8; ++j) {
+        const int p = wave * 512 + j * 64 + lane;
+        kk[j] = p < n ? key[base + p] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long i = base + wave * 512 + j * 64 + lane;
+        const bool ok = kk[j] >= 0 && kk[j] < g.ncell;
+        binv[j] = ok ? kk[j] / cpt : -1;                                // zero weight: neither counted nor placed here
+#pragma unroll
+        for (int d = 0; d < D; ++d) xv[j][d] = ok ? x[i * ldx + g.perm[d]] : 0.0;
+        yv[j] = ok ? y[i] : 0.0;
+        wv[j] = ok ? (w ? w[i] : 1.0) : 0.0;
+    }
+    sp_wave_counts(whist, nb, binv);
+    sp_stable_places(whist, bbase, nb, SP_BITS, binv, [&](int j, int pos) {
+        const int i = (int)(base + wave * 512 + j * 64 + lane);
+        if (rec) {
+            constexpr int R = sp_rec(D);
+            double v[R];
+#pragma unroll
+            for (int d = 0; d < D; ++d) v[d] = xv[j][d];
+            v[D] = yv[j];
+            v[D + 1] = wv[j];
+            v[D + 2] = __hiloint2double(kk[j], i);                       // (low word: index, high word: cell)
+#pragma unroll
+            for (int e = D + 3; e < R; ++e) v[e] = 0.0;
+            d2_t *__restrict__ r = reinterpret_cast<d2_t *>(rec + (long long)pos * R);
+#pragma unroll
+            for (int e = 0; e < R / 2; ++e) r[e] = (d2_t){v[2 * e], v[2 * e + 1]};
         } else {
 #pragma unroll
-            for (int d = 0; d < D; ++d) xs[(long long)d * cap + pos] = x[i * ldx + g.perm[d]];
-            ys[pos] = y[i];
-            ws[pos] = w ? w[i] : 1.0;
-            idx[pos] = (int)i;
+            for (int d = 0; d < D; ++d) xs[(long long)d * cap + pos] = xv[j][d];
+            ys[pos] = yv[j];
+            ws[pos] = wv[j];
+            idx[pos] = i;
         }
     });
 }
 
-// second level: workgroup = tile of cpt cells; its records (binbase[tile] .. binbase[tile + 1]) -> sorted places by cell
-template <int D>
+// second level: workgroup = tile of cpt cells; its records (binbase[tile] .. binbase[tile + 1]) -> sorted places by cell.
+// NB2: capacity in cells of a tile (256; SP_NB for grids beyond ~1e6 cells).  A tile of at most SP_STAGE records (config 3: ~2 500)
+// is assembled in LDS -- planes of coordinates, y, w, index in sorted order -- and leaves with consecutive stores; larger tiles
+// (clustered data) are walked in sub-blocks of SP_Q records and scattered straight into place.
+constexpr int SP_STAGE = 2816;      // (x 52 bytes in 4-D + the counters: 157 KB of the 160 KB LDS)
+template <int D, int NB2>
 __global__ void __launch_bounds__(SP_NT)
 sp_bin2_kernel(Grid g, int cpt, int ntile, const int *__restrict__ binbase, const double *__restrict__ rec, int *__restrict__ offset,
                double *__restrict__ xs, double *__restrict__ ys, double *__restrict__ ws, int *__restrict__ idx, long long cap)
 {
-    __shared__ unsigned whist[SP_NW][SP_NB / 2];
-    __shared__ int bbase[SP_NB];                                       // [local cell]: where its next sub-block's records start
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    constexpr int R = sp_rec(D);
+    __shared__ unsigned whist[SP_NW][NB2 / 2];
+    __shared__ int bbase[NB2], btot[NB2];                             // [local cell]: where its next sub-block's records start / totals
+    __shared__ double stage[NB2 <= 256 ? SP_STAGE * (D + 2) : 1];
+    __shared__ int stidx[NB2 <= 256 ? SP_STAGE : 1];
+    const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tb = binbase[tile], te = binbase[tile + 1];
     const int c0 = tile * cpt, nc = min(cpt, g.ncell - c0);
-    // cell totals of the whole tile (sub-block after sub-block), then their exclusive prefix = the cells' offsets
-    for (int b = tid; b < SP_NB; b += SP_NT) bbase[b] = 0;
+    int bits = 1;
+    while ((1 << bits) < nc) ++bits;
+    auto cell_at = [&](int q) { return __double2hiint(rec[(long long)q * R + D + 2]) - c0; };       // local cell of record q
+    // cell totals of the whole tile, then their exclusive prefix = the cells' offsets
+    for (int b = tid; b < nc; b += SP_NT) btot[b] = 0;
     __syncthreads();
-    auto cell_at = [&](int q) { return reinterpret_cast<const int *>(rec + (long long)q * (D + 3) + D + 2)[1] - c0; };       // local cell of record q
-    for (int sb0 = 0; sb0 < te - tb; sb0 += SP_Q) {
-        const int n = min(SP_Q, te - tb - sb0);
-        sp_wave_counts(whist, n, [&](int p) { return cell_at(tb + sb0 + p); });
-        for (int b = tid; b < nc; b += SP_NT) {
-            unsigned t = 0;
-            for (int v = 0; v < SP_NW; ++v) t += (whist[v][b >> 1] >> (16 * (b & 1))) & 0xffffu;
-            bbase[b] += (int)t;
+    for (int q = tb + tid; q < te; q += SP_NT) atomicAdd(&btot[cell_at(q)], 1);
+    __syncthreads();
+    if (tid < 64) {                                                    // exclusive scan over the nc cells by one wave
+        int carry = tb;
+        for (int b0 = 0; b0 < nc; b0 += 64) {
+            const int v = b0 + lane < nc ? btot[b0 + lane] : 0;
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
+            }
+            if (b0 + lane < nc) bbase[b0 + lane] = carry + inc - v;
+            carry += __shfl(inc, 63, 64);
         }
-        __syncthreads();
-    }
-    if (tid == 0) {                                                    // (at most SP_NB cells per tile: a serial scan is 4 us)
-        int run = tb;
-        for (int b = 0; b < nc; ++b) { const int v = bbase[b]; bbase[b] = run; run += v; }
     }
     __syncthreads();
     for (int b = tid; b < nc; b += SP_NT) offset[c0 + b] = bbase[b];
     if (tile == ntile - 1 && tid == 0) offset[g.ncell] = te;
-    int bits = 1;
-    while ((1 << bits) < nc) ++bits;
+    const bool staged = NB2 <= 256 && te - tb <= SP_STAGE;
     for (int sb0 = 0; sb0 < te - tb; sb0 += SP_Q) {
         const int n = min(SP_Q, te - tb - sb0);
-        auto bin_of = [&](int p) { return cell_at(tb + sb0 + p); };
-        sp_wave_counts(whist, n, bin_of);
-        // (the block totals, for the next sub-block's bases -- taken before the counts become prefixes)
-        int add[(SP_NB + SP_NT - 1) / SP_NT];
-        for (int b = tid, u = 0; b < nc; b += SP_NT, ++u) {
+        int binv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = wave * 512 + j * 64 + lane;
+            binv[j] = p < n ? cell_at(tb + sb0 + p) : -1;
+        }
+        sp_wave_counts(whist, nc, binv);
+        // (the sub-block's totals, for the next sub-block's bases -- taken before the counts become prefixes)
+        for (int b = tid; b < nc; b += SP_NT) {
             unsigned t = 0;
             for (int v = 0; v < SP_NW; ++v) t += (whist[v][b >> 1] >> (16 * (b & 1))) & 0xffffu;
-            add[u] = (int)t;
+            btot[b] = (int)t;
         }
         __syncthreads();
-        sp_stable_places(whist, bbase, n, bits, bin_of, [&](int p, int pos) {
-            const double *__restrict__ r = rec + (long long)(tb + sb0 + p) * (D + 3);
+        sp_stable_places(whist, bbase, nc, bits, binv, [&](int j, int pos) {
+            const d2_t *__restrict__ r = reinterpret_cast<const d2_t *>(rec + (long long)(tb + sb0 + wave * 512 + j * 64 + lane) * R);
+            double v[R];
 #pragma unroll
-            for (int d = 0; d < D; ++d) xs[(long long)d * cap + pos] = r[d];
-            ys[pos] = r[D];
-            ws[pos] = r[D + 1];
-            idx[pos] = reinterpret_cast<const int *>(r + D + 2)[0];
+            for (int e = 0; e < R / 2; ++e) { const d2_t t = r[e]; v[2 * e] = t[0]; v[2 * e + 1] = t[1]; }
+            if (staged) {
+                const int l = pos - tb;
+#pragma unroll
+                for (int d = 0; d < D + 2; ++d) stage[d * SP_STAGE + l] = v[d];
+                stidx[l] = __double2loint(v[D + 2]);
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) xs[(long long)d * cap + pos] = v[d];
+                ys[pos] = v[D];
+                ws[pos] = v[D + 1];
+                idx[pos] = __double2loint(v[D + 2]);
+            }
         });
         __syncthreads();
-        for (int b = tid, u = 0; b < nc; b += SP_NT, ++u) bbase[b] += add[u];
+        for (int b = tid; b < nc; b += SP_NT) bbase[b] += btot[b];
         __syncthreads();
+    }
+    if (staged) {
+        const int n = te - tb;
+        for (int e = tid; e < n; e += SP_NT) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) xs[(long long)d * cap + tb + e] = stage[d * SP_STAGE + e];
+            ys[tb + e] = stage[D * SP_STAGE + e];
+            ws[tb + e] = stage[(D + 1) * SP_STAGE + e];
+            idx[tb + e] = stidx[e];
+        }
     }
 }
 
@@ -1826,7 +1914,7 @@ static int sp_cells_per_bin(const Grid &g)
 long long bin_record_doubles(const Grid &g, long long max_ndata)
 {
     const int cpt = sp_cells_per_bin(g);
-    return cpt > 1 ? max_ndata * (long long)(g.ndim + 3) : 0;
+    return cpt > 1 ? max_ndata * (long long)sp_rec(g.ndim) : 0;
 }
 
 hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ldx, const double *y,
@@ -1838,17 +1926,24 @@ hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ld
         if (m <= 0) return hipMemsetAsync(s.offset, 0, sizeof(int) * (size_t)(g.ncell + 2), st);
         const int nblk = (int)((m + SP_Q - 1) / SP_Q), nchunk = (nblk + SP_ROWS - 1) / SP_ROWS;
         double *rec = cpt > 1 ? s.rec : nullptr;
+        const int ntile = (g.ncell + cpt - 1) / cpt;                   // bins in use (one level: the cells)
+        int *tot = s.binbase + SP_NB + 8;
         DISPATCH_D(g.ndim, hipLaunchKernelGGL(sp_count_kernel<D>, dim3((unsigned)nblk), dim3(SP_NT), 0, st, g, m, x, ldx, w, cpt, s.key, s.cntm, scal));
         hipLaunchKernelGGL(sp_colsum_kernel, dim3(SP_NB / 256, (unsigned)nchunk), dim3(256), 0, st, nblk, (const int *)s.cntm, s.sppart);
-        hipLaunchKernelGGL(sp_binscan_kernel, dim3(1), dim3(1024), 0, st, nchunk, s.sppart, s.binbase);
-        hipLaunchKernelGGL(sp_blockbase_kernel, dim3(SP_NB / 256, (unsigned)nchunk), dim3(256), 0, st, nblk, s.cntm, (const int *)s.sppart);
-        DISPATCH_D(g.ndim, hipLaunchKernelGGL(sp_scatter_kernel<D>, dim3((unsigned)nblk), dim3(SP_NT), 0, st, g, m, x, ldx, y, w, cpt, (const int *)s.key,
+        hipLaunchKernelGGL(sp_chunkscan_kernel, dim3(SP_NB / 256), dim3(256), 0, st, nchunk, s.sppart, tot);
+        hipLaunchKernelGGL(sp_binscan_kernel, dim3(1), dim3(1024), 0, st, (const int *)tot, s.binbase);
+        hipLaunchKernelGGL(sp_blockbase_kernel, dim3(SP_NB / 256, (unsigned)nchunk), dim3(256), 0, st, nblk, s.cntm, (const int *)s.sppart, (const int *)s.binbase);
+        DISPATCH_D(g.ndim, hipLaunchKernelGGL(sp_scatter_kernel<D>, dim3((unsigned)nblk), dim3(SP_NT), 0, st, g, m, x, ldx, y, w, cpt, ntile, (const int *)s.key,
                                               (const int *)s.cntm, rec, s.xs, s.ys, s.ws, s.idx, s.cap));
         if (cpt == 1)      // the bins are the cells: their bases are the offsets (bins ncell .. SP_NB - 2 are empty)
             return hipMemcpyAsync(s.offset, s.binbase, sizeof(int) * (size_t)(g.ncell + 1), hipMemcpyDeviceToDevice, st);
-        const int ntile = (g.ncell + cpt - 1) / cpt;
-        DISPATCH_D(g.ndim, hipLaunchKernelGGL(sp_bin2_kernel<D>, dim3((unsigned)ntile), dim3(SP_NT), 0, st, g, cpt, ntile, (const int *)s.binbase,
-                                              (const double *)rec, s.offset, s.xs, s.ys, s.ws, s.idx, s.cap));
+        if (cpt <= 256) {
+            DISPATCH_D(g.ndim, hipLaunchKernelGGL((sp_bin2_kernel<D, 256>), dim3((unsigned)ntile), dim3(SP_NT), 0, st, g, cpt, ntile, (const int *)s.binbase,
+                                                  (const double *)rec, s.offset, s.xs, s.ys, s.ws, s.idx, s.cap));
+        } else {
+            DISPATCH_D(g.ndim, hipLaunchKernelGGL((sp_bin2_kernel<D, SP_NB>), dim3((unsigned)ntile), dim3(SP_NT), 0, st, g, cpt, ntile, (const int *)s.binbase,
+                                                  (const double *)rec, s.offset, s.xs, s.ys, s.ws, s.idx, s.cap));
+        }
         return hipGetLastError();
     }
     hipError_t e = hipMemsetAsync(s.count, 0, sizeof(int) * (size_t)(g.ncell + 2), st);

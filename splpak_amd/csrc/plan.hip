@@ -211,8 +211,8 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     {   // stable partition of the points (assemble.hip sp_*): count matrix, bin bases, tile-sorted records for grids of more cells than bins
         const size_t nblk = (size_t)((max_ndata + SP_Q - 1) / SP_Q);
         ok = ok && dev_alloc(p, &p->s.cntm, nblk * SP_NB);
-        ok = ok && dev_alloc(p, &p->s.binbase, (size_t)SP_NB + 8);
-        ok = ok && dev_alloc(p, &p->s.sppart, ((nblk + 127) / 128) * SP_NB);
+        ok = ok && dev_alloc(p, &p->s.binbase, (size_t)2 * SP_NB + 16);      // bin bases | bin totals
+        ok = ok && dev_alloc(p, &p->s.sppart, ((nblk + 15) / 16) * SP_NB);
         const long long rd = bin_record_doubles(g, max_ndata);
         if (rd > 0) ok = ok && dev_alloc(p, &p->s.rec, (size_t)rd);
     }
