@@ -1437,6 +1437,10 @@ pr_eval_kernel(Grid g, PRegions rg, NDeriv nd, const T *__restrict__ coef, const
 //     searches), with them 4.4: the reads do not overlap the arithmetic.  Software-pipelining them in units of 8 with
 //     s_waitcnt lgkmcnt(8) broke: the compiler reloads fields of the by-value Grid argument with s_load inside the loop, which
 //     count on lgkmcnt and return out of order (wrong values on a 20^4 grid), and the registers of a second buffer spilled.
+//   * interleaving TWO elements per lane (one element's next 8 reads in flight while the other's are multiplied, waits of
+//     lgkmcnt(0) only): 6.26 against 6.21 ms -- the reads are not waited for, the LDS pipe itself is the limit (its 2 cycles per
+//     read become ~3.5 with the conflicts left, plus the deal's own traffic).  "Pure rounds + a mixed round for the surplus"
+//     would cut the conflicts but adds a quarter more rounds of arithmetic at deals of 256: not built.
 //   A workgroup whose region is used up moves to the region with the most chunks left.  No spinning anywhere: counters,
 //   barriers, and loops every wave leaves when its region has no chunk left.
 // Arithmetic per query: eval_table + window_sum<4> as everywhere else -- identical bits.
