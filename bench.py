@@ -685,11 +685,11 @@ def main():
                 gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 return {"ms": ms, "algorithmic_GB": nbytes / 1e9, "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
             line["assembly"] = {
-                "binning (keys, scan, scatter, in-cell order)": hbm(m * (2 * bpp + bpp + 4.0), stages["bin_ms"]),
+                "binning (stable partition: count, prefix, scatter, second level)": hbm(m * (2 * bpp + bpp + 4.0), stages["bin_ms"]),
                 "gram blocks + stencil gather": hbm(m * bpp + 8.0 * ncol * hst, stages["gram_ms"]),
                 "constraint rows": {"ms": stages["constraints_ms"]},
                 "refinement residual pass": hbm(m * bpp, stages["residual_pass_ms"]),
-                "note": "the Gram stage moves 3.9 GB of per-cell blocks through HBM on top of its algorithmic bytes (PMC: profiles/r02_fit_pmc.json)"
+                "note": "the Gram stage moves 3.9 GB of per-cell blocks through HBM on top of its algorithmic bytes (PMC: profiles/r05_fit_pmc.json)"
                         if nd == 3 and nod == 64 else "",
             }
             if fact_code == 4:

@@ -39,6 +39,7 @@ SYMBOLS = [
 
 E_NODEVICE, E_NOMEM, E_BADARG, E_UNSUPPORTED, E_COMM = -1, -2, -3, -4, -5
 AR_ANY_POINTER = 1
+AR_STREAM_ORDERED = 4
 
 _lib = None
 
@@ -397,12 +398,14 @@ class Plan:
     def set_refine(self, max_steps, tol):
         self._L.splpak_plan_set_refine(self._h, int(max_steps), float(tol))
 
-    def set_allreduce(self, fn, rank, world, any_pointer=None):
+    def set_allreduce(self, fn, rank, world, any_pointer=None, stream_ordered=False):
         """fn(offset_elems, count) must sum-all-reduce self.comm[offset:offset+count] in place.  A hook that also takes a
         third argument -- fn(-1, count, view) with `view` a device tensor over the library's own memory -- declares
         SPLPAK_AR_ANY_POINTER (include/splpak_hip.h): the nested-dissection factorisation of the sharded fit is then
         distributed by subtrees and the fronts they report into arrive that way.  A two-argument hook (rounds 1-2) keeps
-        the replicated factorisation.  `any_pointer` overrides the detection."""
+        the replicated factorisation.  `any_pointer` overrides the detection.  `stream_ordered`: the hook only ENQUEUES its
+        work on the current stream (= the library's, made current for the call) -- SPLPAK_AR_STREAM_ORDERED: the library then does
+        not synchronise the stream before and after the call."""
         if any_pointer is None:
             import inspect
             try:
@@ -443,7 +446,8 @@ class Plan:
                 return 1
 
         self._cb = ALLREDUCE_FN(_cb)
-        _check(self._L.splpak_plan_set_allreduce_ex(self._h, self._cb, None, int(rank), int(world), AR_ANY_POINTER if any_pointer else 0))
+        _check(self._L.splpak_plan_set_allreduce_ex(self._h, self._cb, None, int(rank), int(world),
+                                                    (AR_ANY_POINTER if any_pointer else 0) | (AR_STREAM_ORDERED if stream_ordered else 0)))
 
     def device_bytes(self):
         return int(self._L.splpak_plan_device_bytes(self._h))

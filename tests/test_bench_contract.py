@@ -1,4 +1,4 @@
-"""The bench line the driver parses: the committed output of `python bench.py` on MI355X (profiles/r04_c3_bench.json)
+"""The bench line the driver parses: the committed output of `python bench.py` on MI355X (profiles/r05_c3_bench.json)
 must carry the contract's keys, BASELINE.json's metric, a roofline object for the dominant kernel whose numbers are
 consistent with each other, and a CPU baseline -- checked on the CPU tier so that a change to bench.py that drops a
 key is caught before the GPU run."""
@@ -12,7 +12,7 @@ import pytest
 
 
 def _line():
-    txt = open(os.path.join(ROOT, "profiles", "r04_c3_bench.json")).read().strip().splitlines()
+    txt = open(os.path.join(ROOT, "profiles", "r05_c3_bench.json")).read().strip().splitlines()
     lines = [ln for ln in txt if ln.startswith("{")]
     assert len(lines) == 1, "bench.py prints ONE JSON line"
     return json.loads(lines[0])
@@ -48,6 +48,13 @@ def test_roofline_object_is_consistent():
     assert r["traffic"] is None or (r["traffic"] > 0 and "not measured in this run" in r["traffic_source"])
     assert all(not isinstance(v, (dict, list)) for v in r.values())
     assert 0.3 < r["kernel_alone_frac"] < 1.0
+    # round 5: the evaluation half of the headline metric and the side configurations as scalars of THIS
+    # object, which the driver's record keeps
+    assert r["evals_per_s"] > 1e10 and abs(r["eval_frac"] - 32.0 * r["evals_per_s"] / 8e12) < 1e-9
+    assert r["eval_bytes_per_query"] is None or r["eval_bytes_per_query"] > r["eval_algorithmic_bytes_per_query"] == 32.0
+    assert 0 < r["eval_direct_kernel_frac"] < r["eval_frac"]
+    assert r["eval4d_evals_per_s"] > 1e10 and abs(r["eval4d_frac"] - 40.0 * r["eval4d_evals_per_s"] / 8e12) < 1e-9
+    assert r["c5_fit_points_per_s"] > 0 and 0.3 < r["c5_fit_factor_frac"] < 1.0 and r["c2_ms_per_fit"] > 0
 
 
 def test_cpu_baseline_and_side_objects():
@@ -66,6 +73,10 @@ def test_cpu_baseline_and_side_objects():
     assert mg["factorisation"]["code"] == 5 and mg["optimality_residual"] < 1e-9
     assert "nested-dissection" in d["config"]["factorisation"]
     assert d["c5_fit"]["optimality_residual"] < 1e-9
+    # BASELINE config 5's fit half on one GPU: 28^4 since round 5 (24^4 only if the device was shared), 32^4's refusal explained
+    assert ("28^4" in d["c5_fit"]["workload"] or "24^4" in d["c5_fit"]["workload"]) and "packed" in d["c5_fit"]["factorisation"]
+    assert d["c5_fit"]["config5_32^4_needs"]["factor_GB"] > 400 and "refused" in d["c5_fit"]["config5_32^4_needs"]["note"]
+    assert "collective_backend" in d["config"]
     assert d["c2"]["optimality_residual"] < 1e-9 and d["grid32"]["optimality_residual"] < 1e-9
 
 
@@ -110,3 +121,4 @@ def test_live_bench_line_keeps_the_contract():
     assert 0.3 < r_["frac"] < 1.0 and d["config"]["optimality_residual"] < 1e-9
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] in ("reference", "port")
     assert 0 < d["eval_roofline_frac"] < 1
+    assert r_["evals_per_s"] > 1e10 and 0 < r_["eval_frac"] < 1 and "collective_backend" in d["config"]

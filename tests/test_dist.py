@@ -637,6 +637,97 @@ def test_c4_full_size_rehearsed_on_eight_virtual_gpus(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["3d12", "2d64_c2grid"])
+def test_stream_ordered_hook_with_two_ranks_is_bitwise_the_synchronised_one(name, monkeypatch):
+    """SPLPAK_AR_STREAM_ORDERED (what the native RCCL hook declares: the library does NOT synchronise the fit's
+    stream around the hook) had only ever run with a one-rank communicator.  Two ranks here -- two plans on one GPU, a host
+    thread each, as two processes would be -- with a hook that only ENQUEUES on the stream it is handed: its buffer goes to a
+    staging slot (async copy), an event says so, the peer's event is awaited ON THE STREAM, the sum rank 0 + rank 1 is formed
+    by a kernel.  The host threads only meet at a barrier (so that the event a stream waits for has been recorded), never wait
+    for the device.  Points sharded, nested dissection distributed by subtrees (any-pointer hook): the coefficients must be
+    bit-identical on both ranks, to the same hook run with the library's synchronisations around it, and hold the golden."""
+    import threading
+    import torch
+    from splpak_amd import capi
+    from tests.cases import CASES, make_inputs
+    monkeypatch.setenv("SPLPAK_ND", "1")
+    inp = make_inputs(CASES[name])
+    gold = load_golden(name)
+    nd, m = inp["ndim"], inp["xdata"].shape[0]
+    dev = torch.device("cuda", 0)
+    ncol = int(np.prod(inp["nodes"]))
+
+    def run(stream_ordered):
+        bar = threading.Barrier(2)
+        stage = {}                                   # (generation parity, rank) -> staging tensor
+        events = {}
+        results, errors = [None, None], []
+
+        def make_hook(rank, comm):
+            gen = [0]
+
+            def hook(off, count, view=None):
+                v = comm[off:off + count] if view is None else view
+                g = gen[0]
+                gen[0] += 1
+                key = (g & 1, rank)
+                if key not in stage or stage[key].numel() < count:
+                    stage[key] = torch.empty(max(count, 1), dtype=torch.float64, device=dev)
+                stage[key][:count].copy_(v, non_blocking=True)        # on the library's stream (made current by the shim)
+                ev = torch.cuda.Event()
+                ev.record()
+                events[(g, rank)] = ev
+                bar.wait(timeout=60)                 # host only: both events are recorded, nothing waits for the device
+                torch.cuda.current_stream().wait_event(events[(g, 1 - rank)])
+                torch.add(stage[(g & 1, 0)][:count], stage[(g & 1, 1)][:count], out=v)      # rank 0 + rank 1 on both ranks
+                ev2 = torch.cuda.Event()
+                ev2.record()
+                events[("done", g, rank)] = ev2
+                bar.wait(timeout=60)
+                torch.cuda.current_stream().wait_event(events[("done", g, 1 - rank)])      # the peer has read my staging slot
+            return hook
+
+        def worker(rank):
+            try:
+                torch.cuda.set_device(0)
+                first, cnt = (0, m // 2) if rank == 0 else (m // 2, m - m // 2)
+                xs = torch.tensor(inp["xdata"][first:first + cnt], device=dev)
+                ys = torch.tensor(inp["ydata"][first:first + cnt], device=dev)
+                ws = None if inp["wdata"] is None else torch.tensor(inp["wdata"][first:first + cnt], device=dev)
+                comm_len = int(capi.lib().splpak_plan_comm_len(nd, capi._p(np.ascontiguousarray(inp["nodes"], dtype=np.int32), capi._ip)))
+                comm = torch.zeros(comm_len, dtype=torch.float64, device=dev)
+                plan = capi.Plan(nd, inp["nodes"], inp["xmin"], inp["xmax"], inp["xtrap"], cnt, comm=comm)
+                plan.set_allreduce(make_hook(rank, comm), rank, 2, stream_ordered=stream_ordered)
+                coef = torch.zeros(ncol, dtype=torch.float64, device=dev)
+                stream = torch.cuda.Stream()
+                outs = []
+                for _ in range(2):
+                    ierr, info = plan.fit(xs, ys, ws, coef, stream.cuda_stream)
+                    stream.synchronize()
+                    outs.append(coef.cpu().numpy().copy())
+                plan.close()
+                assert ierr == 0 and np.array_equal(outs[0], outs[1])
+                results[rank] = outs[0]
+            except Exception as exc:      # noqa: BLE001
+                errors.append(exc)
+                bar.abort()
+
+        th = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(300)
+        assert not errors, errors
+        return results
+
+    ordered = run(True)
+    synced = run(False)
+    assert np.array_equal(ordered[0], ordered[1]) and np.array_equal(synced[0], synced[1])
+    assert np.array_equal(ordered[0], synced[0])
+    assert relmax(ordered[0], gold["coef"]) < 1e-10
+
+
+@pytest.mark.gpu
 def test_native_rccl_hook_one_rank_smoke(tmp_path, monkeypatch):
     """the library's own RCCL hook (csrc/rccl.hip: librccl opened at run time, ncclAllReduce on the fit's
     stream) through the C ABI -- no Python in the reductions.  This pool has ONE GPU, so the communicator has one rank;
