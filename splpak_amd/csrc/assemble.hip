@@ -329,17 +329,14 @@ __device__ inline void sp_wave_counts(unsigned (*whist)[NBW], int nb, const int 
 template <int D>
 __global__ void __launch_bounds__(SP_NT)
 sp_count_kernel(Grid g, long long m, const double *__restrict__ x, int ldx, const double *__restrict__ w, int cpt,
-                int *__restrict__ key, int *__restrict__ cntm, double *__restrict__ scal)
+                int *__restrict__ key, int *__restrict__ cntm)
 {
     __shared__ int hist[SP_NB];
-    __shared__ int s_valid;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long base = (long long)blockIdx.x * SP_Q;
     const int n = (int)(m - base < SP_Q ? m - base : SP_Q);
     for (int b = tid; b < SP_NB; b += SP_NT) hist[b] = 0;
-    if (tid == 0) s_valid = 0;
     __syncthreads();
-    int nvalid = 0;
     // (all loads of a thread's 8 points in flight together: one dependent round trip per point made this pass latency bound)
     double xv[8][D], wv[8];
 #pragma unroll
@@ -364,15 +361,16 @@ sp_count_kernel(Grid g, long long m, const double *__restrict__ x, int ldx, cons
                 }
             }
             key[base + p] = k;
-            nvalid += k < g.ncell ? 1 : 0;
             atomicAdd(&hist[k < g.ncell ? k / cpt : SP_NB - 1], 1);
         }
     }
-    if (nvalid) atomicAdd(&s_valid, nvalid);
     __syncthreads();
     int *__restrict__ row = cntm + (long long)blockIdx.x * SP_NB;
     for (int b = tid; b < SP_NB; b += SP_NT) row[b] = hist[b];
-    if (tid == 0 && s_valid) atomicAdd(&scal[SC_NROWS_DATA], (double)s_valid);      // integer-valued: exact in any order
+    // (the number of data rows -- the points of non-zero weight -- is the base of the last bin: sp_binscan_kernel adds it to the
+    //  fit's scalars, no f64 atomic per block.  What this kernel's 0.25-0.3 ms per 1e7 points are, measured by taking its parts
+    //  out: 0.23 ms are the loads of the coordinates and weights themselves -- 1.4 TB/s, although all 32 of a thread are in
+    //  flight together --, the key stores, LDS atomics and the row together 0.04)
 }
 
 // Count matrix [block][bin] -> in place: where the block's points of the bin start (bins in order, blocks in order inside a
@@ -412,7 +410,7 @@ sp_chunkscan_kernel(int nchunk, int *__restrict__ part, int *__restrict__ tot)
     tot[bin] = run;
 }
 __global__ void __launch_bounds__(1024)
-sp_binscan_kernel(const int *__restrict__ tot, int *__restrict__ binbase)
+sp_binscan_kernel(const int *__restrict__ tot, int *__restrict__ binbase, double *__restrict__ scal)
 {
     __shared__ int sc[1024];
     const int t = threadIdx.x;
@@ -430,7 +428,11 @@ sp_binscan_kernel(const int *__restrict__ tot, int *__restrict__ binbase)
     int run = sc[t] - sum;
 #pragma unroll
     for (int u = 0; u < 4; ++u) { binbase[4 * t + u] = run; run += v[u]; }
-    if (t == 1023) binbase[SP_NB] = run;
+    if (t == 1023) {
+        binbase[SP_NB] = run;
+        const int nvalid = run - v[3];              // everything below the last bin (which holds the zero-weight points)
+        if (nvalid) atomicAdd(&scal[SC_NROWS_DATA], (double)nvalid);      // integer-valued: exact in any order
+    }
 }
 __global__ void __launch_bounds__(256)
 sp_blockbase_kernel(int nblk, int *__restrict__ cntm, const int *__restrict__ part, const int *__restrict__ binbase)
@@ -1580,6 +1582,24 @@ sparse_mark_kernel(Grid g, const double *__restrict__ hist, const double *__rest
     spf[node] = sn.sparse ? 1 : 0;
 }
 
+// rows of the constraint system: ndim (ndim + 1) / 2 per data-sparse node (:974-1000) -> scal_out[SC_NROWS_CONS]
+__global__ void __launch_bounds__(1024)
+count_sparse_kernel(const unsigned char *__restrict__ spf, int ncol, int rows_per_node, double *__restrict__ scal_out)
+{
+    __shared__ int red[16];
+    int c = 0;
+    for (int i = threadIdx.x; i < ncol; i += 1024) c += spf[i] != 0 ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int v = 0; v < 16; ++v) t += red[v];
+        scal_out[SC_NROWS_CONS] += (double)t * (double)rows_per_node;
+    }
+}
+
 // One wave per stencil row i: nst[i][code(j - i)] += sum over the sparse nodes n within one node of
 // both i and j, and over n's rows, of row[i] * row[j] -- neighbours and rows in a fixed order, the
 // row's owner adds with plain read-modify-writes.  Also counts the rows (scal_out[SC_NROWS_CONS]).
@@ -1646,7 +1666,8 @@ constraint_rows_kernel(Grid g, const double *__restrict__ dcw, const unsigned ch
         sn.sparse = true;
         sn.dcwght = dcw[ncol_n];
         any = true;
-        if (ne == NE / 2 && lane == 0) atomicAdd(&scal_out[SC_NROWS_CONS], (double)(D * (D + 1) / 2));   // integer-valued
+        // (the rows are counted by count_sparse_kernel: one f64 atomicAdd per data-sparse node on ONE word -- a compare-and-swap
+        //  loop on this build -- serialised 17 000 of them at config 3 and 177 000 at 4-D 28^4)
         for (int idm = 0; idm < D; ++idm)
             for (int jdm = idm; jdm < D; ++jdm) {
                 int nder[D];
@@ -1928,10 +1949,10 @@ hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ld
         double *rec = cpt > 1 ? s.rec : nullptr;
         const int ntile = (g.ncell + cpt - 1) / cpt;                   // bins in use (one level: the cells)
         int *tot = s.binbase + SP_NB + 8;
-        DISPATCH_D(g.ndim, hipLaunchKernelGGL(sp_count_kernel<D>, dim3((unsigned)nblk), dim3(SP_NT), 0, st, g, m, x, ldx, w, cpt, s.key, s.cntm, scal));
+        DISPATCH_D(g.ndim, hipLaunchKernelGGL(sp_count_kernel<D>, dim3((unsigned)nblk), dim3(SP_NT), 0, st, g, m, x, ldx, w, cpt, s.key, s.cntm));
         hipLaunchKernelGGL(sp_colsum_kernel, dim3(SP_NB / 256, (unsigned)nchunk), dim3(256), 0, st, nblk, (const int *)s.cntm, s.sppart);
         hipLaunchKernelGGL(sp_chunkscan_kernel, dim3(SP_NB / 256), dim3(256), 0, st, nchunk, s.sppart, tot);
-        hipLaunchKernelGGL(sp_binscan_kernel, dim3(1), dim3(1024), 0, st, (const int *)tot, s.binbase);
+        hipLaunchKernelGGL(sp_binscan_kernel, dim3(1), dim3(1024), 0, st, (const int *)tot, s.binbase, scal);
         hipLaunchKernelGGL(sp_blockbase_kernel, dim3(SP_NB / 256, (unsigned)nchunk), dim3(256), 0, st, nblk, s.cntm, (const int *)s.sppart, (const int *)s.binbase);
         DISPATCH_D(g.ndim, hipLaunchKernelGGL(sp_scatter_kernel<D>, dim3((unsigned)nblk), dim3(SP_NT), 0, st, g, m, x, ldx, y, w, cpt, ntile, (const int *)s.key,
                                               (const int *)s.cntm, rec, s.xs, s.ys, s.ws, s.idx, s.cap));
@@ -2049,6 +2070,7 @@ hipError_t launch_constraint_rows(const Grid &g, const double *dcw, const unsign
 {
     dim3 gr((unsigned)((g.ncol + 3) / 4)), bl(256);
     DISPATCH_D(g.ndim, hipLaunchKernelGGL(constraint_rows_kernel<D>, gr, bl, 0, st, g, dcw, spf, ctab, nst, scal_out));
+    hipLaunchKernelGGL(count_sparse_kernel, dim3(1), dim3(1024), 0, st, spf, g.ncol, g.ndim * (g.ndim + 1) / 2, scal_out);
     return hipGetLastError();
 }
 
