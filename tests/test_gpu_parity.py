@@ -1060,55 +1060,65 @@ def test_cells_of_more_than_1024_points_are_ordered_too():
     assert e0 == 0 and relmax(outs[0][0], c0[:25]) < COEF_TOL
 
 
-@pytest.mark.parametrize("case", ["1d_sparse", "2d64_c2grid", "3d16", "3d8_cc_clust", "2d16_zero_w", "4d6", "3d_cells", "2d_cluster", "2d_two_level"])
-def test_stable_partition_gives_the_bits_of_the_atomic_binning(case):
+SP_CASES = ["1d_sparse", "2d64_c2grid", "3d16", "3d8_cc_clust", "2d16_zero_w", "4d6", "3d_cells", "2d_cluster", "2d_two_level"]
+
+
+def _sp_case_args(case):
+    rng = np.random.default_rng(3)
+    if case in CASES:
+        inp = make_inputs(CASES[case])
+        return (inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"], inp["nodes"], inp["xtrap"])
+    if case == "3d_cells":              # 64^3: 226 981 windows -> two levels, tiles of 56 cells, most of them nearly empty
+        x = rng.random((300000, 3))
+        return (3, x, np.sin(x.sum(axis=1)), 0.5 + rng.random(300000), [0.0] * 3, [1.0] * 3, [64] * 3, 1.0)
+    if case == "2d_cluster":            # one level; 20 000 of 30 000 points in ONE window, a tenth of the weights zero
+        x = rng.random((30000, 2))
+        x[:20000] = 0.41 + 0.01 * rng.random((20000, 2))
+        w = 0.5 + rng.random(30000)
+        w[::10] = 0.0
+        return (2, x, np.cos(3 * x[:, 0]) + x[:, 1], w, [0.0] * 2, [1.0] * 2, [20, 20], 1.0)
+    # 2-D 90 x 80: 6 699 windows -> two levels with 2 cells per tile; a cluster of 30 000 in one tile
+    x = rng.random((60000, 2))
+    x[:30000] = [0.3, 0.6] + 0.004 * rng.random((30000, 2))
+    return (2, x, np.cos(3 * x[:, 0]) + x[:, 1], None, [0.0] * 2, [1.0] * 2, [90, 80], 0.5)
+
+
+def _sp_fit_twice(case):
+    out = []
+    for _ in range(2):
+        c, e, h, info = capi.fit(*_sp_case_args(case), want_hist=True)
+        out.append((c, h, info[8], e, info[0]))
+    assert out[0][3] == 0 and np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    return dict(coef=out[0][0], hist=out[0][1], reserr=out[0][2], rows=out[0][4])
+
+
+@pytest.fixture(scope="module")
+def atomic_binning_results(tmp_path_factory):
+    """Every case of SP_CASES through the binning of rounds 1-4 (SPLPAK_BIN_ATOMIC=1), in ONE child process: the switch is
+    read once per process."""
+    import subprocess
+    import sys
+    td = tmp_path_factory.mktemp("atomic_binning")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from tests.test_gpu_parity import SP_CASES, _sp_fit_twice\n"
+            "for case in SP_CASES:\n"
+            "    np.savez(sys.argv[1] + '/' + case + '.npz', **_sp_fit_twice(case))\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code, str(td)], env=dict(os.environ, SPLPAK_BIN_ATOMIC="1"), capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-800:]
+    return {case: dict(np.load(os.path.join(td, case + ".npz"))) for case in SP_CASES}
+
+
+@pytest.mark.parametrize("case", SP_CASES)
+def test_stable_partition_gives_the_bits_of_the_atomic_binning(case, atomic_binning_results):
     """Round 5 (assemble.hip sp_*): the points are binned by a counting sort without global atomics that is stable by
     construction -- the points of a window end up in ascending original index, the order cell_order_kernel used to restore after
     the atomic scatter.  So every fit must return the SAME BITS through both forms (SPLPAK_BIN_ATOMIC=1 = rounds 1-4, in a child
     process: the switch is read once): goldens of one level (cells <= 4 095) and two levels (tiles of cells, then cells), zero
     weights (never placed), clustered data (one window holding 20 000 points: several sub-blocks of a tile), a grid of 230 000
     windows with 300 000 points, and repeated fits through one plan."""
-    import subprocess
-    import sys
-    import tempfile
-    code = r"""
-import sys, os
-import numpy as np
-sys.path.insert(0, %r)
-from splpak_amd import capi
-from tests.cases import CASES, make_inputs
-case = sys.argv[1]
-rng = np.random.default_rng(3)
-if case in CASES:
-    inp = make_inputs(CASES[case])
-    args = (inp["ndim"], inp["xdata"], inp["ydata"], inp["wdata"], inp["xmin"], inp["xmax"], inp["nodes"], inp["xtrap"])
-elif case == "3d_cells":                # 64^3: 226 981 windows -> two levels, tiles of 56 cells, most of them nearly empty
-    x = rng.random((300000, 3)); args = (3, x, np.sin(x.sum(axis=1)), 0.5 + rng.random(300000), [0.0] * 3, [1.0] * 3, [64] * 3, 1.0)
-elif case == "2d_cluster":              # one level; 20 000 of 30 000 points in ONE window, a tenth of the weights zero
-    x = rng.random((30000, 2)); x[:20000] = 0.41 + 0.01 * rng.random((20000, 2))
-    w = 0.5 + rng.random(30000); w[::10] = 0.0
-    args = (2, x, np.cos(3 * x[:, 0]) + x[:, 1], w, [0.0] * 2, [1.0] * 2, [20, 20], 1.0)
-else:                                   # 2-D 90 x 80: 6 699 windows -> two levels with 2 cells per tile; a cluster of 30 000 in one tile
-    x = rng.random((60000, 2)); x[:30000] = [0.3, 0.6] + 0.004 * rng.random((30000, 2))
-    args = (2, x, np.cos(3 * x[:, 0]) + x[:, 1], None, [0.0] * 2, [1.0] * 2, [90, 80], 0.5)
-out = []
-for _ in range(2):
-    c, e, h, info = capi.fit(*args, want_hist=True)
-    out.append((c, h, info[8], e))
-assert out[0][3] == 0 and np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
-np.savez(sys.argv[2], coef=out[0][0], hist=out[0][1], reserr=out[0][2], rows=info[0])
-""" % ROOT
-    res = {}
-    with tempfile.TemporaryDirectory() as td:
-        for form in ("stable", "atomic"):
-            env = dict(os.environ)
-            if form == "atomic":
-                env["SPLPAK_BIN_ATOMIC"] = "1"
-            out = os.path.join(td, form + ".npz")
-            r = subprocess.run([sys.executable, "-c", code, case, out], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-            assert r.returncode == 0, (form, r.stderr[-600:])
-            res[form] = dict(np.load(out))
-    a, b = res["stable"], res["atomic"]
+    a, b = _sp_fit_twice(case), atomic_binning_results[case]
     assert a["rows"] == b["rows"]
     assert np.array_equal(a["coef"], b["coef"]) and np.array_equal(a["hist"], b["hist"]) and a["reserr"] == b["reserr"], case
 
