@@ -453,11 +453,10 @@ sp_blockbase_kernel(int nblk, int *__restrict__ cntm, const int *__restrict__ pa
 // the stable places of a block's items: place(j, pos) is called once per item j * 64 + lane of the wave with binv[j] >= 0, pos =
 // bbase[bin] + items of the bin before it in the block.  whist: the per-wave counts (sp_wave_counts), turned into running
 // exclusive prefixes here.
-template <int NBW, typename Place>
-__device__ inline void sp_stable_places(unsigned (*whist)[NBW], const int *bbase, int nb, int bits, const int (&binv)[8], Place &&place)
+template <int NBW>
+__device__ inline void sp_wave_prefix(unsigned (*whist)[NBW], int nb)
 {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int b2 = tid; b2 < ((nb + 1) >> 1); b2 += SP_NT) {         // exclusive prefixes over the waves, both halves of a word at once
+    for (int b2 = threadIdx.x; b2 < ((nb + 1) >> 1); b2 += SP_NT) {         // exclusive prefixes over the waves, both halves of a word at once
         unsigned run = 0;
 #pragma unroll
         for (int v = 0; v < SP_NW; ++v) {
@@ -467,9 +466,16 @@ __device__ inline void sp_stable_places(unsigned (*whist)[NBW], const int *bbase
         }
     }
     __syncthreads();
+}
+// (passes J0 .. J1 - 1 of the wave: a caller that has to LOAD what it places splits the eight passes in two, so that the loads of
+//  four passes are in flight together without their registers exceeding the budget)
+template <int J0, int J1, int NBW, typename Place>
+__device__ inline void sp_places(unsigned (*whist)[NBW], const int *bbase, int bits, const int (&binv)[8], Place &&place)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = J0; j < J1; ++j) {
         const int bin = binv[j];
         const unsigned long long mm = sp_match(bin, bits + 1);          // (+ 1: bit `bits` tells -1 from every real bin)
         if (bin >= 0) {
@@ -481,6 +487,12 @@ __device__ inline void sp_stable_places(unsigned (*whist)[NBW], const int *bbase
         if (bin >= 0 && (mm & lt) == 0) atomicAdd(&whist[wave][bin >> 1], (unsigned)__builtin_popcountll(mm) << (16 * (bin & 1)));
         __builtin_amdgcn_wave_barrier();
     }
+}
+template <int NBW, typename Place>
+__device__ inline void sp_stable_places(unsigned (*whist)[NBW], const int *bbase, int nb, int bits, const int (&binv)[8], Place &&place)
+{
+    sp_wave_prefix(whist, nb);
+    sp_places<0, 8>(whist, bbase, bits, binv, place);
 }
 
 // RECORD of a point on its way through the tile-sorted image: ndim coordinates (internal order), y, w, (index, cell)
@@ -499,20 +511,25 @@ sp_scatter_kernel(Grid g, long long m, const double *__restrict__ x, int ldx, co
     // the wave's 8 x 64 points, all loads of a thread in flight together (the walk below is LDS and stores only)
     int kk[8], binv[8];
     double xv[8][D], yv[8], wv[8];
+    // (UNCONDITIONAL loads, the index clamped for the tail of the last block: loads under `valid ? load : 0` wait for the key and
+    //  then for each other -- eight serialised round trips per wave, 0.82 of this kernel's 1.05 ms per 1e7 points, found by taking
+    //  the rest of the kernel out)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int p = wave * 512 + j * 64 + lane;
-        kk[j] = p < n ? key[base + p] : -1;
+        const long long i = base + (p < n ? p : 0);
+        kk[j] = key[i];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xv[j][d] = x[i * ldx + g.perm[d]];
+        yv[j] = y[i];
+        wv[j] = w ? w[i] : 1.0;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const long long i = base + wave * 512 + j * 64 + lane;
+        const int p = wave * 512 + j * 64 + lane;
+        if (p >= n) kk[j] = -1;
         const bool ok = kk[j] >= 0 && kk[j] < g.ncell;
         binv[j] = ok ? kk[j] / cpt : -1;                                // zero weight: neither counted nor placed here
-#pragma unroll
-        for (int d = 0; d < D; ++d) xv[j][d] = ok ? x[i * ldx + g.perm[d]] : 0.0;
-        yv[j] = ok ? y[i] : 0.0;
-        wv[j] = ok ? (w ? w[i] : 1.0) : 0.0;
     }
     sp_wave_counts(whist, nb, binv);
     sp_stable_places(whist, bbase, nb, SP_BITS, binv, [&](int j, int pos) {
@@ -590,7 +607,8 @@ sp_bin2_kernel(Grid g, int cpt, int ntile, const int *__restrict__ binbase, cons
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int p = wave * 512 + j * 64 + lane;
-            binv[j] = p < n ? cell_at(tb + sb0 + p) : -1;
+            const int c = cell_at(tb + sb0 + (p < n ? p : 0));          // (unconditional load, index clamped)
+            binv[j] = p < n ? c : -1;
         }
         sp_wave_counts(whist, nc, binv);
         // (the sub-block's totals, for the next sub-block's bases -- taken before the counts become prefixes)
@@ -600,11 +618,23 @@ sp_bin2_kernel(Grid g, int cpt, int ntile, const int *__restrict__ binbase, cons
             btot[b] = (int)t;
         }
         __syncthreads();
-        sp_stable_places(whist, bbase, nc, bits, binv, [&](int j, int pos) {
-            const d2_t *__restrict__ r = reinterpret_cast<const d2_t *>(rec + (long long)(tb + sb0 + wave * 512 + j * 64 + lane) * R);
+        sp_wave_prefix(whist, nc);
+        // (the records of four passes are loaded together, UNCONDITIONALLY -- index clamped --: a load per pass inside the walk was
+        //  a dependent memory round trip per pass and wave)
+        d2_t rv[4][R / 2];
+        auto preload = [&](int j0) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int p = wave * 512 + (j0 + jj) * 64 + lane;
+                const d2_t *__restrict__ r = reinterpret_cast<const d2_t *>(rec + (long long)(tb + sb0 + (p < n ? p : 0)) * R);
+#pragma unroll
+                for (int e = 0; e < R / 2; ++e) rv[jj][e] = r[e];
+            }
+        };
+        auto place = [&](int j, int pos) {
             double v[R];
 #pragma unroll
-            for (int e = 0; e < R / 2; ++e) { const d2_t t = r[e]; v[2 * e] = t[0]; v[2 * e + 1] = t[1]; }
+            for (int e = 0; e < R / 2; ++e) { v[2 * e] = rv[j & 3][e][0]; v[2 * e + 1] = rv[j & 3][e][1]; }
             if (staged) {
                 const int l = pos - tb;
 #pragma unroll
@@ -617,7 +647,11 @@ sp_bin2_kernel(Grid g, int cpt, int ntile, const int *__restrict__ binbase, cons
                 ws[pos] = v[D + 1];
                 idx[pos] = __double2loint(v[D + 2]);
             }
-        });
+        };
+        preload(0);
+        sp_places<0, 4>(whist, bbase, bits, binv, place);
+        preload(4);
+        sp_places<4, 8>(whist, bbase, bits, binv, place);
         __syncthreads();
         for (int b = tid; b < nc; b += SP_NT) bbase[b] += btot[b];
         __syncthreads();
@@ -826,139 +860,197 @@ gram_block_kernel(Grid g, const int *__restrict__ offset, const double *__restri
     }
 }
 
-// The same per-cell blocks for 2-D and 3-D grids (NB = 16 / 64) on the f64 matrix cores, ONE WAVE per cell, four cells per
-// workgroup, no workgroup barriers (round 3).  The block is B^T B with B = the cell's weighted rows
-// (points x NB), i.e. a product with K = points: per 4 points one v_mfma_f64_16x16x4_f64 per 16 x 16 tile of the lower
-// triangle (10 tiles at NB = 64).  The operands are never staged: lane (l15, q) of k-step s needs
+// The same per-cell blocks for 2-D and 3-D grids (NB = 16 / 64) on the f64 matrix cores, ONE WAVE per cell, no workgroup
+// barriers (round 3).  The block is B^T B with B = the cell's weighted rows (points x NB), i.e. a product
+// with K = points: per 4 points one v_mfma_f64_16x16x4_f64 per 16 x 16 tile of the lower triangle (10 tiles at NB = 64).
+// The operands are never staged: lane (l15, q) of k-step s needs
 // B[p = 4 s + q][16 m + l15] = (w_p b0[l15 & 3] b1[l15 >> 2]) * b2[m] -- three table reads from the wave's LDS slice and
 // one multiplication per tile block.  The result tiles have consecutive lanes on consecutive entries of a packed row
 // (first MFMA operand = the row block), so they leave with plain coalesced stores.  The workgroup-per-cell form above
 // read 8 LDS values per 16 FMAs, used 136 of its 256 threads in the triangle and passed five barriers per cell: 3.56 ms
-// at C3 for 0.65 ms of matrix-pipe time.  Right-hand side and histogram shares: lane = window function, points in
-// storage order, as before.
+// at C3 for 0.65 ms of matrix-pipe time.
+// Round 5 (in-kernel clock stamps per wave, C3: 5.1 us loads + tables, 4.1 us products, 5.1 us right-hand side, 1.5 us stores):
+//  - the right-hand side B^T (w^2 y) is summed from the matrix operands the lanes hold anyway (one multiply-add per row
+//    block and step, the four lanes of an entry added at the end); as a loop over the points with lane = window function it
+//    read five LDS words per point behind the LDS latency and cost as much as the blocks;
+//  - the histogram share of a point is one LDS atomic of lane = point onto its nearest node's word of the wave's LDS row (the
+//    lanes of one instruction that meet on a word are served one after the other by the LDS unit, the same way every run);
+//  - a wave owns a RUN of GW_RUN consecutive cells and loads the points of the next cell before the products of the current
+//    one, so that the two dependent round trips (offsets, then points) are paid once per run, not once per cell.
+constexpr int GW_RUN = 8;
 template <int D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 gram_wave_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
                  const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
                  double *__restrict__ blk, double *__restrict__ rblk, double *__restrict__ hblk,
                  double *__restrict__ hist, int cell0, int ncells)
 {
     static_assert(D == 2 || D == 3, "16 or 64 window functions");
+    static_assert(GW_RUN + 1 <= 64, "the offsets of a run sit in one register of the wave");
     constexpr int NB = 1 << (2 * D), MT = NB / 16, NTILE = MT * (MT + 1) / 2, PCH = 64, LDT = 4 * D + 1;
     constexpr long long TRI = (long long)NB * (NB + 1) / 2;
     __shared__ double s_tab[4][PCH * LDT];
     __shared__ double s_w[4][PCH];
     __shared__ double s_wy[4][PCH];
-    __shared__ int s_slot[4][PCH];
+    __shared__ double s_hist[4][NB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
-    const int rel = blockIdx.x * 4 + wave;
-    if (rel >= ncells) return;
-    const int cell = cell0 + rel;
-    const long long beg = offset[cell], end = offset[cell + 1];
-    if (beg == end) {                          // an empty cell leaves a zero block: the gather reads every block unconditionally
-        double *__restrict__ z = blk + (long long)rel * TRI;
-        for (int e = lane; e < (int)TRI; e += 64) z[e] = 0.0;
-        if (lane < NB) {
-            rblk[(long long)rel * NB + lane] = 0.0;
-            if (hblk) hblk[(long long)rel * NB + lane] = 0.0;
-        }
-        return;
-    }
-    double *tab = s_tab[wave], *sw = s_w[wave], *swy = s_wy[wave];
-    int *sslot = s_slot[wave];
+    const int first = (blockIdx.x * 4 + wave) * GW_RUN;
+    if (first >= ncells) return;
+    const int ncl = ncells - first < GW_RUN ? ncells - first : GW_RUN;
+    double *tab = s_tab[wave], *sw = s_w[wave], *swy = s_wy[wave], *sh = s_hist[wave];
     const bool hist_on = hblk != nullptr;
-
-    d4_t acc[NTILE];
+    const int offv = offset[cell0 + first + (lane <= ncl ? lane : ncl)];
+    // the points of a chunk, lane = point (zeros beyond np: zero rows pad the last k-step)
+    struct Pts { double x[D], y, w; };
+    auto fetch = [&](long long p0, int np) {
+        Pts t;
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
-    double racc = 0.0, hacc = 0.0;
-    for (long long p0 = beg; p0 < end; p0 += PCH) {
-        const int np = (int)((end - p0 < PCH) ? (end - p0) : PCH);
-        // ---- lane = point: window tables, weight, w^2 y, histogram slot (zero rows beyond np pad the last k-step)
-        {
-            double b[D][4], wv = 0.0, wyv = 0.0;
-            int sl = -2;
+        for (int d = 0; d < D; ++d) t.x[d] = 0.0;
+        t.y = 0.0;
+        t.w = 0.0;
+        if (lane < np) {
+            t.w = ws[p0 + lane];
 #pragma unroll
-            for (int d = 0; d < D; ++d)
+            for (int d = 0; d < D; ++d) t.x[d] = xs[(long long)d * cap + p0 + lane];
+            t.y = ys[p0 + lane];
+        }
+        return t;
+    };
+    long long beg = __builtin_amdgcn_readlane(offv, 0), end = __builtin_amdgcn_readlane(offv, 1);
+    Pts pre = fetch(beg, (int)(end - beg < PCH ? end - beg : PCH));
+    for (int ci = 0; ci < ncl; ++ci) {
+        const int rel = first + ci;
+        long long nbeg = end, nend = end;
+        if (ci + 1 < ncl) nend = __builtin_amdgcn_readlane(offv, ci + 2);
+        if (beg == end) {                          // an empty cell leaves a zero block: the gather reads every block unconditionally
+            double *__restrict__ z = blk + (long long)rel * TRI;
+            for (int e = lane; e < (int)TRI; e += 64) z[e] = 0.0;
+            if (lane < NB) {
+                rblk[(long long)rel * NB + lane] = 0.0;
+                if (hblk) hblk[(long long)rel * NB + lane] = 0.0;
+            }
+            if (ci + 1 < ncl) pre = fetch(nbeg, (int)(nend - nbeg < PCH ? nend - nbeg : PCH));
+            beg = nbeg;
+            end = nend;
+            continue;
+        }
+        if (hist_on && lane < NB) sh[lane] = 0.0;
+        d4_t acc[NTILE];
+        double racc[MT];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) b[d][k] = 0.0;
-            if (lane < np) {
-                double xv[D];
-                wv = ws[p0 + lane];
+        for (int t = 0; t < NTILE; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    xv[d] = xs[(long long)d * cap + p0 + lane];
-                    window_table_value(g, d, xv[d], b[d]);      // (the bits of window_table(.., 0, ..), see basis.hpp)
-                }
-                wyv = wv * ys[p0 + lane];
-                if (hist_on) {
-                    sl = nearest_slot<D>(g, xv);
-                    if (sl < 0) {                       // rare: far outside the grid (:899); the only atomic left
-                        double xr[MAXD] = {0.0, 0.0, 0.0, 0.0};
+        for (int m = 0; m < MT; ++m) racc[m] = 0.0;
+        for (long long p0 = beg; p0 < end; p0 += PCH) {
+            const int np = (int)((end - p0 < PCH) ? (end - p0) : PCH);
+            const Pts cur = (p0 == beg) ? pre : fetch(p0, np);
+            // ---- lane = point: window tables, weight, w^2 y, histogram share
+            {
+                double b[D][4];
 #pragma unroll
-                        for (int d = 0; d < D; ++d) xr[g.perm[d]] = xv[d];
-                        atomicAdd(&hist[nearest_node_address(g, xr)], wv);       // :905
+                for (int d = 0; d < D; ++d)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) b[d][k] = 0.0;
+                if (lane < np) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) window_table_value(g, d, cur.x[d], b[d]);   // (the bits of window_table(.., 0, ..), see basis.hpp)
+                    if (hist_on) {
+                        const int sl = nearest_slot<D>(g, cur.x);
+                        if (sl >= 0)
+                            __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)(sh + sl), cur.w);      // :905
+                        else {                              // rare: far outside the grid (:899); the only global atomic left
+                            double xr[MAXD] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int d = 0; d < D; ++d) xr[g.perm[d]] = cur.x[d];
+                            atomicAdd(&hist[nearest_node_address(g, xr)], cur.w);       // :905
+                        }
                     }
                 }
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) tab[lane * LDT + 4 * d + k] = b[d][k];
+                sw[lane] = cur.w;
+                swy[lane] = cur.w * cur.y;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // the next cell's first chunk is on its way while this one is multiplied
+            if (p0 + PCH >= end && ci + 1 < ncl) pre = fetch(nbeg, (int)(nend - nbeg < PCH ? nend - nbeg : PCH));
+            // ---- matrix cores: K = the chunk's points, four per step
+            const int nsteps = (np + 3) >> 2;
+            // (the LDS words of step s + 1 are asked for before the products of step s are issued)
+            struct Ops { double w, t0, t1, t2[MT], wy; };
+            auto lds_ops = [&](int s4) {
+                const int p = 4 * s4 + q;
+                Ops o;
+                o.w = sw[p];
+                o.t0 = tab[p * LDT + (l15 & 3)];
+                o.t1 = tab[p * LDT + 4 + (l15 >> 2)];
+                if constexpr (D == 3) {
 #pragma unroll
-            for (int d = 0; d < D; ++d)
+                    for (int m = 0; m < MT; ++m) o.t2[m] = tab[p * LDT + 8 + m];
+                }
+                o.wy = swy[p];
+                return o;
+            };
+            Ops nx = lds_ops(0);
+            for (int s4 = 0; s4 < nsteps; ++s4) {
+                const Ops o = nx;
+                nx = lds_ops(s4 + 1 < nsteps ? s4 + 1 : s4);
+                const double u = (o.w * o.t0) * o.t1;
+                double op[MT];
+                if constexpr (D == 2) op[0] = u;
+                else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) tab[lane * LDT + 4 * d + k] = b[d][k];
-            sw[lane] = wv;
-            swy[lane] = wyv;
-            sslot[lane] = sl;
+                    for (int m = 0; m < MT; ++m) op[m] = u * o.t2[m];
+                }
+                int t = 0;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = m; n < MT; ++n, ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[n], op[m], acc[t], 0, 0, 0);
+                // right-hand side: this lane's entries B[4 s + q][16 m + l15] times w^2 y of its point, summed over the steps;
+                // the four q of an entry meet after the last chunk
+#pragma unroll
+                for (int m = 0; m < MT; ++m) racc[m] += op[m] * o.wy;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- matrix cores: K = the chunk's points, four per step
-        const int nsteps = (np + 3) >> 2;
-        for (int s4 = 0; s4 < nsteps; ++s4) {
-            const int p = 4 * s4 + q;
-            const double u = (sw[p] * tab[p * LDT + (l15 & 3)]) * tab[p * LDT + 4 + (l15 >> 2)];
-            double op[MT];
-            if constexpr (D == 2) op[0] = u;
-            else {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) op[m] = u * tab[p * LDT + 8 + m];
-            }
+        // packed lower triangle: tile (m, n), register v of lane (l15, q) = entry (r, c) = (16 n + q + 4 v, 16 m + l15)
+        double *__restrict__ out = blk + (long long)rel * TRI;
+        {
             int t = 0;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = m; n < MT; ++n, ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[n], op[m], acc[t], 0, 0, 0);
-        }
-        // ---- right-hand side and histogram shares: lane = window function, points in storage order
-        if (lane < NB) {
-            for (int p = 0; p < np; ++p) {
-                double prod = tab[p * LDT + (lane & 3)];
 #pragma unroll
-                for (int d = 1; d < D; ++d) prod *= tab[p * LDT + 4 * d + ((lane >> (2 * d)) & 3)];
-                racc += (sw[p] * prod) * swy[p];
-                if (hist_on) hacc += (sslot[p] == lane) ? sw[p] : 0.0;       // :905
-            }
+                    for (int v = 0; v < 4; ++v) {
+                        const int r = 16 * n + q + 4 * v, c = 16 * m + l15;
+                        if (c <= r) out[r * (r + 1) / 2 + c] = acc[t][v];
+                    }
+        }
+        // right-hand side: entry 16 m + l15 = the sum over q of the lanes (l15, q) -> through LDS to lane = entry
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            double r = racc[m];
+            r += __shfl_xor(r, 16, 64);
+            r += __shfl_xor(r, 32, 64);
+            if (q == 0) sw[16 * m + l15] = r;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-    }
-    // packed lower triangle: tile (m, n), register v of lane (l15, q) = entry (r, c) = (16 n + q + 4 v, 16 m + l15)
-    double *__restrict__ out = blk + (long long)rel * TRI;
-    {
-        int t = 0;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = m; n < MT; ++n, ++t)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int r = 16 * n + q + 4 * v, c = 16 * m + l15;
-                    if (c <= r) out[r * (r + 1) / 2 + c] = acc[t][v];
-                }
-    }
-    if (lane < NB) {
-        rblk[(long long)rel * NB + lane] = racc;
-        if (hist_on) hblk[(long long)rel * NB + lane] = hacc;
+        if (lane < NB) {
+            rblk[(long long)rel * NB + lane] = sw[lane];
+            if (hist_on) hblk[(long long)rel * NB + lane] = sh[lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        beg = nbeg;
+        end = nend;
     }
 }
 
@@ -1611,6 +1703,7 @@ constraint_rows_kernel(Grid g, const double *__restrict__ dcw, const unsigned ch
     constexpr int NE = (D == 1) ? 3 : (D == 2) ? 9 : (D == 3) ? 27 : 81;
     constexpr int HS = (D == 1) ? 4 : (D == 2) ? 25 : (D == 3) ? 172 : 1201;
     __shared__ double sacc[4][HS];
+    __shared__ double sct[4][D * 27], sdn[4][NE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int node = blockIdx.x * 4 + wave;
     if (node >= g.ncol) return;
@@ -1647,6 +1740,40 @@ constraint_rows_kernel(Grid g, const double *__restrict__ dcw, const unsigned ch
         if (anyb == 0) return;
     }
     for (int e = lane; e < HS; e += 64) acc[e] = 0.0;
+    // The factors this row can meet -- nodes in[d] - 1 .. in[d] + 1 of every dimension, 27 D of them -- and the weights of the 3^D
+    // neighbours go to LDS first: the walk below then multiplies LDS words instead of chasing three dependent table loads per
+    // entry through L2 (round 5: 1.84 ms of a 9.7 ms assembly at 64^3 for 17 000 data-sparse nodes).  Same values, same order.
+    double *ct = sct[wave], *dn = sdn[wave];
+    {
+        for (int e = lane; e < D * 27; e += 64) {
+            const int d = e / 27, r = e % 27, n = in[d] + r / 9 - 1;
+            int base = 0;
+            for (int q = 0; q < d; ++q) base += 9 * g.nodes[q];
+            double v = 0.0;
+            if (n >= 0 && n <= g.nodes[d] - 1) v = ctab ? ctab[base + n * 9 + r % 9] : constraint_factor(g, d, n, (r % 9) / 3 - 1, r % 3);
+            ct[e] = v;
+        }
+        for (int ne = lane; ne < NE; ne += 64) {
+            int t = ne, col = 0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { col += (in[d] + t % 3 - 1) * g.colstride[d]; t /= 3; }
+            dn[ne] = ((sparse[ne >> 6] >> (ne & 63)) & 1ull) ? dcw[col] : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // entry of the constraint row of node nn at nn + off, from the LDS copy (constraint_entry's product, factor by factor)
+    auto entry = [&](const int *nn, const int *off, const int *nder, double rowwt) -> double {
+#pragma clang fp contract(off)
+        double basm = 1.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int ib = nn[d] + off[d];
+            if (ib < 0 || ib > g.nodes[d] - 1) return 0.0;
+            basm *= ct[d * 27 + (nn[d] - in[d] + 1) * 9 + (off[d] + 1) * 3 + nder[d]];
+        }
+        return rowwt * basm;
+    };
     bool any = false;
     for (int ne = 0; ne < NE; ++ne) {            // neighbour n = i + offn, offn_d in [-1,1], dim 0 fastest
         int nn[D], offi[D], t = ne, ncol_n = 0;
@@ -1664,7 +1791,8 @@ constraint_rows_kernel(Grid g, const double *__restrict__ dcw, const unsigned ch
         (void)ok;
         SparseNode sn;
         sn.sparse = true;
-        sn.dcwght = dcw[ncol_n];
+        sn.dcwght = dn[ne];
+        (void)ncol_n;
         any = true;
         // (the rows are counted by count_sparse_kernel: one f64 atomicAdd per data-sparse node on ONE word -- a compare-and-swap
         //  loop on this build -- serialised 17 000 of them at config 3 and 177 000 at 4-D 28^4)
@@ -1672,7 +1800,7 @@ constraint_rows_kernel(Grid g, const double *__restrict__ dcw, const unsigned ch
             for (int jdm = idm; jdm < D; ++jdm) {
                 int nder[D];
                 const double rowwt = constraint_pattern<D>(g, nn, idm, jdm, sn.dcwght, nder);
-                const double ci = constraint_entry<D>(g, ctab, nn, offi, nder, rowwt);
+                const double ci = entry(nn, offi, nder, rowwt);
                 if (ci == 0.0) continue;         // wave-uniform
                 for (int je = lane; je < NE; je += 64) {
                     int offj[D], tt = je, code = 0, m7 = 1;
@@ -1688,7 +1816,7 @@ constraint_rows_kernel(Grid g, const double *__restrict__ dcw, const unsigned ch
 #pragma unroll
                     for (int d = 0; d < D; ++d) { code += (offj[d] - offi[d] + 3) * m7; m7 *= 7; }
                     if (!lower) continue;
-                    const double cj = constraint_entry<D>(g, ctab, nn, offj, nder, rowwt);
+                    const double cj = entry(nn, offj, nder, rowwt);
                     if (cj != 0.0) acc[code] += ci * cj;
                 }
             }
@@ -2000,7 +2128,7 @@ static bool gram_cells(const Grid &g, const SortScratch &s, double *blk, double 
     static const bool old_form = std::getenv("SPLPAK_GRAM_VALU") != nullptr;       // A/B switch: the workgroup-per-cell form
     if constexpr (D == 2 || D == 3) {
         if (!old_form) {
-            hipLaunchKernelGGL(gram_wave_kernel<D>, dim3((unsigned)((ncells + 3) / 4)), dim3(256), 0, st, g, (const int *)s.offset,
+            hipLaunchKernelGGL(gram_wave_kernel<D>, dim3((unsigned)((ncells + 4 * GW_RUN - 1) / (4 * GW_RUN))), dim3(256), 0, st, g, (const int *)s.offset,
                                (const double *)s.xs, (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist,
                                cell0, ncells);
             return true;

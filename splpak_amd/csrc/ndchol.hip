@@ -544,6 +544,28 @@ nd_zero_kernel(const ZeroJob *__restrict__ jobs, int njobs)
     for (int u = 0; u < 8; ++u) *reinterpret_cast<d2_t *>(S + r2 + (long long)(c0 + 8 * u) * lds) = (d2_t){0.0, 0.0};
 }
 
+// The early clear of the panels, beside the binning of the points.  Not a memset of the runtime: that one spreads its workgroups
+// over every CU until it is done (2.2 ms for 12 GB), and the binning's scatter kernel -- one workgroup takes a whole CU: 144 KB
+// of LDS, 16 waves of 128 registers -- then only starts where a CU has drained: round 5 saw its workgroups run on the even
+// XCDs first and on the odd ones 450 us later (1.15 ms instead of 0.42 ms alone).  A few resident workgroups write as fast and
+// leave the other CUs whole.
+__global__ void __launch_bounds__(1024)
+nd_clear_kernel(double *__restrict__ p, long long n)
+{
+    if (n > 0 && (reinterpret_cast<unsigned long long>(p) & 8)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) p[0] = 0.0;
+        ++p, --n;
+    }
+    d2_t *__restrict__ q = reinterpret_cast<d2_t *>(p);
+    const long long n2 = n >> 1, step = (long long)gridDim.x * 1024 * 4;
+    for (long long i = (long long)blockIdx.x * 4096 + threadIdx.x; i < n2; i += step) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + 1024 * u < n2) __builtin_nontemporal_store((d2_t){0.0, 0.0}, q + i + 1024 * u);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
+}
+
 // distributed factorisation: the lower-triangle tiles of a Schur buffer <-> a contiguous image (tile after tile, column-major
 // inside a tile), so that the join sums half the bytes of the square buffer
 template <bool PACK>
@@ -1399,7 +1421,14 @@ hipError_t nd_prefit(splpak_plan *p, hipStream_t st, void *user)
     if (head >= s->factor_doubles) return hipSuccess;
     hipError_t e = hipEventRecord(s->evPre, st);                 // the previous fit's solves have read the factor by now
     if (e == hipSuccess) e = hipStreamWaitEvent(s->sU, s->evPre, 0);
-    if (e == hipSuccess) e = hipMemsetAsync(s->factor + head, 0, sizeof(double) * (size_t)(s->factor_doubles - head), s->sU);
+    static const int clear_wgs = std::getenv("SPLPAK_ND_CLEAR_WGS") ? atoi(std::getenv("SPLPAK_ND_CLEAR_WGS")) : 64;
+    if (e == hipSuccess) {
+        if (clear_wgs > 0) {
+            hipLaunchKernelGGL(nd_clear_kernel, dim3((unsigned)clear_wgs), dim3(1024), 0, s->sU, s->factor + head, s->factor_doubles - head);
+            e = hipGetLastError();
+        } else
+            e = hipMemsetAsync(s->factor + head, 0, sizeof(double) * (size_t)(s->factor_doubles - head), s->sU);
+    }
     if (e == hipSuccess) e = hipEventRecord(s->evTail, s->sU);
     if (e != hipSuccess) return e;
     s->tail_pending = true;

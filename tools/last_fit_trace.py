@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Every launch of the LAST fit in a rocprofv3 kernel-trace CSV (from its keys_kernel on): start offset, duration, gap to
+"""Every launch of the LAST fit in a rocprofv3 kernel-trace CSV (from its first binning kernel on): start offset, duration, gap to
 the previous launch's end on any queue, queue, workgroups, kernel.   tools/last_fit_trace.py <kernel_trace.csv>"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-i0 = max(i for i, r in enumerate(rows) if "keys_kernel" in r["Kernel_Name"])
+i0 = max(i for i, r in enumerate(rows) if "keys_kernel" in r["Kernel_Name"] or "sp_count_kernel" in r["Kernel_Name"])
 sel = rows[i0:]
 t0 = int(sel[0]["Start_Timestamp"])
 end = t0
