@@ -694,11 +694,11 @@ def main():
             }
             if fact_code == 4:
                 fbytes = capi.debug_nd_tree(nodes, check=False)["factor_bytes"]
-                # (no bandwidth figure for this stage: most of the arena is cleared on a second stream BESIDE the binning and the
-                #  Gram stage -- nd_prefit -- so the stamped interval holds only the head of the arena and the scatter of the
-                #  half stencil into the fronts; round 3 divided the whole arena's bytes by it and reported 1.07 of the HBM peak)
-                line["assembly"]["front assembly (+ clearing the head of the factor arena)"] = {
-                    "ms": stages["expand_ms"], "stencil_GB": 8.0 * ncol * hst / 1e9, "arena_GB_cleared_beside_the_assembly": fbytes / 1e9}
+                # (round 5: the panels are written stage by stage from the half stencil -- zeros and entries, nd_init_kernel; the
+                #  stamped interval holds the stages that are alive when the factorisation starts, the others are written inside
+                #  the factor phase on the update stream.  SPLPAK_ND_STAGED_INIT=0 / the distributed forms: clear all, then scatter)
+                line["assembly"]["panels of the first stages (zeros + entries of the half stencil)"] = {
+                    "ms": stages["expand_ms"], "stencil_GB": 8.0 * ncol * hst / 1e9, "arena_GB_written_stage_by_stage": fbytes / 1e9}
                 line["assembly"]["one solve (forward + backward tree sweep)"] = hbm(2 * fbytes, stages["solve_ms"])
             else:
                 line["assembly"]["band memset + expansion"] = hbm(8.0 * ncol * hst + 8.0 * ncol * ldband, stages["expand_ms"])

@@ -54,6 +54,7 @@ struct SyrkJob {
 // (a job of the root's look-ahead may be a RECTANGLE of tiles instead: zinit < 0 means tile rows start at rb = -zinit for every
 //  one of its nc <= rb tile columns)   // kb = 256-column blocks of P per pass, ksl = k-steps (4 columns each, multiple of 4) of the LAST of them that hold real columns
 struct ZeroJob { double *S; long long lds; int nt; int tile0; };
+struct InitJob { int front; int col0; };         // the panel columns [col0, col0 + wp) of a stage's launch belong to `front`
 struct TrinvJob { const double *L; const double *inv16; double *dinv; double *dinvt; long long ld; };
 // child's Schur buffer -> parent's panel (columns < wpp) / Schur buffer
 struct AddJob { const double *S; const int *pm; double *P; double *Sp; long long lds, ldp, ldsp; int h, nt, wpp, tile0; };
@@ -445,6 +446,79 @@ nd_assemble_kernel(Grid g, const double *__restrict__ nst, const int *__restrict
     }
 }
 
+// The panels of ONE STAGE from scratch (round 5): a workgroup per panel column writes the column's zeros and then its entries of
+// N -- the FULL stencil of the column's node, those neighbours that are eliminated later (own rows below the diagonal, border
+// rows by bisection, as above); a padding column gets its unit diagonal.  Replaces, per stage, the clearing of the whole factor
+// arena (14 GB at 64^3: 2.2 ms of memset that either ran before the assembly or shared the memory system with it) and
+// nd_assemble_kernel's pass over all of N: the stages whose panels are alive when the factorisation starts are written
+// behind the assembly (2.4 GB at 64^3), every later stage when its buffers come alive -- on the update stream at the start of
+// the first stage that adds into them, beside that stage's diagonal blocks and panel solves.
+template <int D>
+__global__ void __launch_bounds__(256)
+nd_init_kernel(Grid g, const double *__restrict__ nst, const int *__restrict__ pos, const int *__restrict__ ipos,
+               const FrontDev *__restrict__ fd, const int *__restrict__ bpos, double *__restrict__ factor,
+               const InitJob *__restrict__ jobs, int njobs)
+{
+    constexpr int NE = (D == 1) ? 7 : (D == 2) ? 49 : (D == 3) ? 343 : 2401;
+    const int b = blockIdx.x;
+    const int ji = find_job(jobs, njobs, b, [](const InitJob &t) { return t.col0; });
+    const InitJob jb = jobs[ji];
+    const FrontDev f = fd[jb.front];
+    const int col = b - jb.col0;
+    if (col >= f.wp || f.panel_off < 0) return;
+    double *__restrict__ cp = factor + f.panel_off + (long long)col * f.ld;
+    {
+        double *z = cp;
+        long long n = f.ld;
+        if (reinterpret_cast<unsigned long long>(z) & 8) {
+            if (threadIdx.x == 0) z[0] = 0.0;
+            ++z, --n;
+        }
+        d2_t *__restrict__ z2 = reinterpret_cast<d2_t *>(z);
+        for (long long i = threadIdx.x; i < (n >> 1); i += 256) __builtin_nontemporal_store((d2_t){0.0, 0.0}, z2 + i);
+        if ((n & 1) && threadIdx.x == 0) z[n - 1] = 0.0;
+    }
+    __syncthreads();                              // (the zeros of the other waves have arrived before an entry goes on top)
+    if (col >= f.w) {
+        if (threadIdx.x == 0) cp[col] = 1.0;
+        return;
+    }
+    const int pc = f.own0 + col, c = ipos[pc];
+    int cd[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) cd[d] = (c / g.colstride[d]) % g.nodes[d];
+    for (int e = threadIdx.x; e < NE; e += 256) {
+        int j = c, code = e, t = e;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int o = (t % 7) - 3;
+            t /= 7;
+            const int jd = cd[d] + o;
+            if (jd < 0 || jd > g.nodes[d] - 1) ok = false;
+            j += o * g.colstride[d];
+        }
+        if (!ok) continue;
+        const int pj = pos[j];
+        if (pj < pc) continue;                    // that entry lives in the column of j
+        // N(c, j): the half stencil keeps it in the row of the larger natural index, code of (smaller - larger)
+        const double v = j <= c ? nst[(long long)c * g.hstencil + code] : nst[(long long)j * g.hstencil + (NE - 1 - code)];
+        int row;
+        if (pj < f.own0 + f.w) row = pj - f.own0;
+        else {
+            const int *__restrict__ bp = bpos + f.bofs;
+            int lo = 0, hi = f.h - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (bp[mid] < pj) lo = mid + 1;
+                else hi = mid;
+            }
+            row = f.wp + lo;
+        }
+        cp[row] = v;
+    }
+}
+
 // extend-add into a distributed front (see PullJob): workgroup = 64 x 64 tile of the child's columns [c0, c1), rows >= c0
 __global__ void __launch_bounds__(256)
 nd_pull_add_kernel(const PullJob *__restrict__ jobs, int njobs)
@@ -822,6 +896,14 @@ struct NdState {
     JobTable<TrinvJob> trinv;
     JobTable<AddJob> add;
     JobTable<ZeroJob> zero;
+    JobTable<InitJob> init;                        // [stage] the panel columns of its fronts (nd_init_kernel)
+    std::vector<Launch> l_init;
+    int *ipos = nullptr;                           // node at an elimination position (-1: none)
+    bool staged_init = false;                      // the panels are written stage by stage (not the distributed forms)
+    std::vector<std::vector<int>> istarts;         // [stage i] the stages whose panels are written at the start of stage i: the first
+                                                   // stage that adds into them; a stage without children (nothing orders its diagonal
+                                                   // blocks behind the update stream) one stage early, and waited for through evP
+    std::vector<hipEvent_t> evP;
     JobTable<MvJob> mv;
     JobTable<FwdJob> fwd;
     JobTable<DotJob> dot;
@@ -956,7 +1038,7 @@ void nd_destroy(void *user)
     (void)hipDeviceSynchronize();
     (void)hipSetDevice(s->device);
     for (hipStream_t *q : {&s->sP, &s->sU, &s->sR, &s->sCopy}) if (*q) (void)hipStreamDestroy(*q);
-    for (auto *v : {&s->evT, &s->evE, &s->evA, &s->evB, &s->evI, &s->evW, &s->evF, &s->evReady, &s->evArr,
+    for (auto *v : {&s->evT, &s->evE, &s->evP, &s->evA, &s->evB, &s->evI, &s->evW, &s->evF, &s->evReady, &s->evArr,
                     &s->evCol, &s->evBulk, &s->evSF, &s->evSB, &s->evAdd})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {s->ev0, s->evJ, s->evU, s->evZlast, s->evDone, s->evPre, s->evTail, s->f0, s->f1, s->evR0, s->evSub, s->evTop}) if (e) (void)hipEventDestroy(e);
@@ -985,6 +1067,7 @@ bool nd_build_factor_jobs(NdState *s)
     s->lookahead.assign((size_t)nstage, 0);
     for (int sl = 0; sl < 2; ++sl) { s->l_fin[sl].assign((size_t)nstage, {}); s->l_add[sl].assign((size_t)nstage, Launch()); }
     s->l_zero.assign((size_t)nstage, Launch());
+    s->l_init.assign((size_t)nstage, Launch());
     // Schur buffer passes: groups of up to schur_kb panel blocks (K = 1024: the C tiles are read and written once per
     // group; measured at 64^3: 257.6 ms per factorisation against 262.4 with K = 512 and 270.9 with K = 256; groups that
     // ramp up 1, 2, 4, 4, .. so that the first pass of a depth starts earlier made no difference)
@@ -1195,6 +1278,22 @@ bool nd_build_factor_jobs(NdState *s)
             lz.grid = (unsigned)tiles;
             if (lz.count) s->zero.host.push_back(ZeroJob{nullptr, 0, 0, (int)tiles});
             s->l_zero[(size_t)stg] = lz;
+        }
+        // panel columns of the stage's fronts
+        {
+            Launch li;
+            li.first = (int)s->init.host.size();
+            long long cols = 0;
+            for (int id : ids) {
+                if (s->poff[(size_t)id] < 0) continue;
+                s->init.host.push_back(InitJob{id, (int)cols});
+                cols += t.fr[(size_t)id].wp;
+                ++li.count;
+            }
+            if (cols > 0x7fffffffLL) { set_error("nested dissection: launch too large"); return false; }
+            li.grid = (unsigned)cols;
+            if (li.count) s->init.host.push_back(InitJob{-1, (int)cols});
+            s->l_init[(size_t)stg] = li;
         }
         // separate extend-add launches (SPLPAK_ND_NO_FUSE): children of this stage -> their parents
         if (d >= 1 && !s->fused) {
@@ -1407,6 +1506,23 @@ void launch_syrk(NdState *s, const JobTable<SyrkJob> &tab, const Launch &l, hipS
 
 #include "ndtop.inc"
 
+// panels of stage x from the half stencil (nd_init_kernel)
+static void nd_init_stage(NdState *s, splpak_plan *p, int x, hipStream_t q)
+{
+    const Launch &li = s->l_init[(size_t)x];
+    if (!li.count) return;
+    const Grid &g = p->g;
+#define ND_INIT_GO(DD) hipLaunchKernelGGL(nd_init_kernel<DD>, dim3(li.grid), dim3(256), 0, q, g, (const double *)p->nst, (const int *)s->pos, (const int *)s->ipos, \
+                                          (const FrontDev *)s->fdev, (const int *)s->bpos, s->factor, (const InitJob *)(s->init.dev + li.first), li.count)
+    switch (g.ndim) {
+    case 1: ND_INIT_GO(1); break;
+    case 2: ND_INIT_GO(2); break;
+    case 3: ND_INIT_GO(3); break;
+    default: ND_INIT_GO(4); break;
+    }
+#undef ND_INIT_GO
+}
+
 // The panels start from zero (14 GB at 64^3: 2.2 ms of memset).  Only the head of the arena is busy during the assembly -- the
 // per-cell Gram blocks live there until the stencil gather has read them -- so the rest is cleared on the second stream
 // while the points are binned and the blocks computed, and nd_assemble clears the head.
@@ -1414,6 +1530,7 @@ hipError_t nd_prefit(splpak_plan *p, hipStream_t st, void *user)
 {
     NdState *s = static_cast<NdState *>(user);
     s->tail_pending = false;
+    if (s->staged_init && !s->dist) return hipSuccess;         // (nothing to clear: nd_init_kernel writes every panel column whole)
     if (!s->sU || !s->evPre || std::getenv("SPLPAK_ND_NO_EARLY_CLEAR")) return hipSuccess;
     long long head = 0;
     if (p->gscratch == s->factor) head = p->gscratch_doubles < s->factor_doubles ? p->gscratch_doubles : s->factor_doubles;
@@ -1441,6 +1558,11 @@ hipError_t nd_assemble(splpak_plan *p, hipStream_t st, void *user)
     NdState *s = static_cast<NdState *>(user);
     const Grid &g = p->g;
     hipError_t e = hipSuccess;
+    if (s->staged_init && !s->dist) {             // the stages whose panels are alive when the first stage starts; the others in nd_factor
+        if (!s->istarts.empty())
+            for (int x : s->istarts[0]) nd_init_stage(s, p, x, st);
+        return hipGetLastError();
+    }
     if (s->tail_pending) {
         if (s->head_doubles > 0) e = hipMemsetAsync(s->factor, 0, sizeof(double) * (size_t)s->head_doubles, st);
         if (e == hipSuccess) e = hipStreamWaitEvent(st, s->evTail, 0);
@@ -1623,8 +1745,16 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     for (int i = 0; i < ns; ++i) {
         const NdStage &S = s->sc.st[(size_t)i];
         if (s->dist && !joined && S.depth <= s->dcut - 1) { dist_join(); joined = true; }
-        if (i > 0)
+        if (i > 0) {
             for (int x : s->starts[(size_t)i]) zero_block(x, sU);
+            if (s->staged_init && !s->dist) {
+                for (int x : s->istarts[(size_t)i]) {
+                    nd_init_stage(s, p, x, sU);
+                    if (s->sc.st[(size_t)x].dep < 0 && sU != sP) (void)hipEventRecord(s->evP[(size_t)x], sU);
+                }
+                if (S.dep < 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evP[(size_t)i], 0);   // (its panels were written one stage ago)
+            }
+        }
         // the fronts' children have added their Schur complements (their last passes run on the update stream)
         if (s->fused && S.dep >= 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evF[(size_t)S.dep], 0);
         if (i == s->root_stage) {
@@ -1776,6 +1906,7 @@ void nd_free_jobs(NdState *s)
     nd_free_dev(s, &s->potrf.dev); nd_free_dev(s, &s->trsm.dev); nd_free_dev(s, &s->trsmb.dev); nd_free_dev(s, &s->upd.dev);
     nd_free_dev(s, &s->updr.dev); nd_free_dev(s, &s->updo.dev); nd_free_dev(s, &s->fin[0].dev); nd_free_dev(s, &s->fin[1].dev);
     nd_free_dev(s, &s->schur.dev); nd_free_dev(s, &s->trinv.dev); nd_free_dev(s, &s->add.dev); nd_free_dev(s, &s->zero.dev);
+    nd_free_dev(s, &s->init.dev);
     nd_free_dev(s, &s->mv.dev); nd_free_dev(s, &s->fwd.dev); nd_free_dev(s, &s->dot.dev); nd_free_dev(s, &s->bwd.dev);
     nd_free_dev(s, &s->map.dev); nd_free_dev(s, &s->rowsrc_out);
 }
@@ -1786,6 +1917,7 @@ bool nd_upload_jobs(NdState *s)
            nd_upload(s, &s->upd.dev, s->upd.host) && nd_upload(s, &s->updr.dev, s->updr.host) && nd_upload(s, &s->updo.dev, s->updo.host) &&
            nd_upload(s, &s->fin[0].dev, s->fin[0].host) && nd_upload(s, &s->fin[1].dev, s->fin[1].host) && nd_upload(s, &s->schur.dev, s->schur.host) &&
            nd_upload(s, &s->trinv.dev, s->trinv.host) && nd_upload(s, &s->add.dev, s->add.host) && nd_upload(s, &s->zero.dev, s->zero.host) &&
+           nd_upload(s, &s->init.dev, s->init.host) &&
            nd_upload(s, &s->mv.dev, s->mv.host) && nd_upload(s, &s->fwd.dev, s->fwd.host) && nd_upload(s, &s->dot.dev, s->dot.host) &&
            nd_upload(s, &s->bwd.dev, s->bwd.host) && nd_upload(s, &s->map.dev, s->map.host);
 }
@@ -1830,7 +1962,20 @@ bool nd_make_schedule(NdState *s, int cut, size_t other_bytes)
         s->starts[(size_t)S.first].push_back(i);
         if (S.ids.size() == 1 && t.fr[(size_t)S.ids[0]].parent < 0 && !s->mdist) s->root_stage = i;
     }
-    for (auto *v : {&s->evF, &s->evE})
+    if (std::getenv("SPLPAK_ND_DEBUG_STAGES"))
+        for (int i = 0; i < ns; ++i) {
+            const NdStage &S = s->sc.st[(size_t)i];
+            long long pd = 0, cols = 0;
+            for (int id : S.ids) { const NdFront &f = t.fr[(size_t)id]; pd += f.ld * (long long)f.wp; cols += f.wp; }
+            fprintf(stderr, "[nd stage %d] depth %d, %zu fronts, first %d, dep %d, panels %.3f GB in %lld columns, Schur %.3f GB\n", i, S.depth, S.ids.size(), S.first, S.dep,
+                    8e-9 * (double)pd, cols, 8e-9 * (double)S.doubles);
+        }
+    s->istarts.assign((size_t)std::max(ns, 1), {});
+    for (int i = 0; i < ns; ++i) {
+        const NdStage &S = s->sc.st[(size_t)i];
+        s->istarts[(size_t)((S.first == i && i > 0) ? i - 1 : S.first)].push_back(i);
+    }
+    for (auto *v : {&s->evF, &s->evE, &s->evP})
         while ((int)v->size() < ns + 1) {
             hipEvent_t e = nullptr;
             (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -1882,7 +2027,7 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
     }
     if (!nd_make_schedule(s, want ? 0 : -1, 0)) return SPLPAK_E_NOMEM;
     for (auto *h : {&s->upd, &s->updr, &s->updo, &s->schur, &s->fin[0], &s->fin[1]}) h->host.clear();
-    s->potrf.host.clear(); s->trsm.host.clear(); s->trsmb.host.clear(); s->trinv.host.clear(); s->add.host.clear(); s->zero.host.clear();
+    s->potrf.host.clear(); s->trsm.host.clear(); s->trsmb.host.clear(); s->trinv.host.clear(); s->add.host.clear(); s->zero.host.clear(); s->init.host.clear();
     s->mv.host.clear(); s->fwd.host.clear(); s->dot.host.clear(); s->bwd.host.clear(); s->map.host.clear();
     if (!nd_build_jobs(s)) { set_error("nested dissection: job tables (ranks)"); return SPLPAK_E_UNSUPPORTED; }
     nd_free_jobs(s);                                           // the superseded device tables
@@ -2045,6 +2190,15 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
         fdev.push_back(FrontDev{s->poff[id], f.ld, f.bofs, f.own0, f.w, f.wp, f.h, ti >= 0 ? (int)s->tbase[(size_t)ti] : -1, 0});
     }
     s->npad = (int)padwhere.size();
+    {
+        int maxpos = -1;
+        for (int v : t.pos) maxpos = std::max(maxpos, v);
+        std::vector<int> ipos((size_t)(maxpos + 1), -1);
+        for (size_t i = 0; i < t.pos.size(); ++i)
+            if (t.pos[i] >= 0) ipos[(size_t)t.pos[i]] = (int)i;
+        if (!nd_upload(s, &s->ipos, ipos)) return SPLPAK_E_NOMEM;
+    }
+    s->staged_init = !s->mdist && !(std::getenv("SPLPAK_ND_STAGED_INIT") && atoi(std::getenv("SPLPAK_ND_STAGED_INIT")) == 0);
     ok = nd_upload(s, &s->pos, t.pos) && nd_upload(s, &s->front_of, t.front_of) && nd_upload(s, &s->bpos, t.bpos) &&
          nd_upload(s, &s->pmap, t.pmap) && nd_upload(s, &s->rowsrc, rowsrc) && nd_upload(s, &s->padwhere, padwhere) &&
          nd_upload(s, &s->fdev, fdev) && nd_upload(s, &s->topcol_dev, s->topcol);
