@@ -1224,7 +1224,10 @@ stencil_gather_kernel(Grid g, const int *__restrict__ offset, const double *__re
     constexpr long long TRI = (long long)NB * (NB + 1) / 2;
     constexpr int HS = (D == 1) ? 4 : (D == 2) ? 25 : (D == 3) ? 172 : 1201;
     __shared__ double sacc[4][HS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the wave index as a SCALAR: node, cell walk, row and block addresses below are then scalar arithmetic -- as vector
+    //  code with a division per dimension and cell, and seven integer operations per lane for the stencil code, the kernel ran
+    //  at the same 10.7 ns per node whether its blocks came from HBM or from the Infinity Cache: issue-bound, round 5)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // the cells [cell0, cell1) of the current slab (whole hyper-rows of the slowest dimension) touch the
     // nodes [node0, node1); with one slab that is everything.  Sums of successive slabs add up in nst
     // (zero on entry), in slab order: still one owner and a fixed order per entry.
@@ -1243,13 +1246,112 @@ stencil_gather_kernel(Grid g, const int *__restrict__ offset, const double *__re
     // wave wait out two dependent memory round trips per cell (3.4 ms at 64^3).
     constexpr int GB = (D <= 3) ? 8 : 4;
     constexpr int NCH = (NB + 63) / 64;              // 64-column chunks of a block row
+    // stencil code of entry (r, c) = K(c) - K(r) + centre with K(v) = sum_d v_d 7^d over the 2-bit digits of v: K(c) once per
+    // lane, K(r) with the row
+    int kc[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = lane + 64 * ch;
+        int k = 0, m7 = 1;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { k += ((c >> (2 * d)) & 3) * m7; m7 *= 7; }
+        kc[ch] = k + (HS - 1);
+    }
+    if constexpr (D == 3 && ZEROED) {
+        // 3-D: the walk as three nested loops with the row address carried along a row of cells (next cell: + TRI, one row up
+        // in the triangle: - r) -- a dozen scalar instructions per cell.  The generic walk below spends ~140 (64-bit products
+        // for every address, the counters' carries, the slab tests): the kernel took 1.8 ms of its 2.9 ms at 64^3 with every
+        // load, LDS access and store removed (round 5).  Same cells in the same order.
+        // Right-hand side and histogram shares: lane = cell, two gathers for the node instead of two one-lane loads per cell
+        {
+            double rv = 0.0, hv = 0.0;
+            if (lane < cr.total) {
+                int cell, r;
+                cr.get(g, in, lane, cell, r);
+                if (cell >= cell0 && cell < cell1) {
+                    const long long cb = (long long)(cell - cell0);
+                    rv = rblk[cb * NB + r];
+                    if (hblk) hv = hblk[cb * NB + r];
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                rv += __shfl_xor(rv, o, 64);
+                hv += __shfl_xor(hv, o, 64);
+            }
+            racc = rv;
+            hacc = hv;
+        }
+        const int nx = cr.cnt[0], ny = cr.cnt[1], nz = cr.cnt[2];
+        const int rx0 = in[0] - cr.lo[0];
+        for (int iz = 0; iz < nz; ++iz) {
+            const int cz = cr.lo[2] + iz;
+            const int cellz = cz * g.cellstride[2];
+            const bool zok = cellz >= cell0 && cellz < cell1;       // (a slab = whole hyper-rows of the slowest dimension)
+            if (!zok) continue;
+            for (int iy = 0; iy < ny; iy += 2) {
+                double v[2][4];
+                int rs[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool yok = iy + h < ny;
+                    const int cy = cr.lo[1] + (yok ? iy + h : iy);
+                    const int cell = cellz + cy * g.cellstride[1] + cr.lo[0];
+                    int r = ((in[2] - cz) << 4) + ((in[1] - cy) << 2) + rx0;
+                    rs[h] = yok ? r : -1;
+                    long long off = (long long)(cell - cell0) * TRI + (long long)r * (r + 1) / 2;
+#pragma unroll
+                    for (int xi = 0; xi < 4; ++xi) {
+                        const bool ok = yok && xi < nx;
+                        v[h][xi] = (ok && lane <= r) ? blk[off + lane] : 0.0;
+                        off += TRI - r;
+                        r -= 1;
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int r = rs[h];
+                    if (r < 0) continue;
+                    int k = (in[2] - cz) * 49 + ((r >> 2) & 3) * 7 + rx0;
+#pragma unroll
+                    for (int xi = 0; xi < 4; ++xi) {
+                        if (xi < nx && lane <= r) acc[kc[0] - k] += v[h][xi];
+                        r -= 1;
+                        k -= 1;
+                    }
+                }
+            }
+        }
+    } else {
+    // the cells in CellRange order (dimension 0 fastest) by counters, not by divisions
+    int ix[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ix[d] = 0;
     for (int e0 = 0; e0 < cr.total; e0 += GB) {
-        int cl[GB], rr[GB], o0[GB], o1[GB];
+        int cl[GB], rr[GB], kr[GB], o0[GB], o1[GB];
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
-            int cell = 0, r = 0;
+            int cell = 0, r = 0, k = 0;
             const bool have = e0 + u < cr.total;
-            if (have) cr.get(g, in, e0 + u, cell, r);
+            if (have) {
+                int m7 = 1;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int wsd = cr.lo[d] + ix[d];
+                    cell += wsd * g.cellstride[d];
+                    r += (in[d] - wsd) << (2 * d);
+                    k += (in[d] - wsd) * m7;
+                    m7 *= 7;
+                }
+                bool carry = true;
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    if (carry) {
+                        if (++ix[d] < cr.cnt[d]) carry = false;
+                        else ix[d] = 0;
+                    }
+            }
+            kr[u] = k;
             const bool ok = have && cell >= cell0 && cell < cell1;
             cl[u] = ok ? cell : cell0;               // a harmless cell for the lookups below
             rr[u] = ok ? r : -1;
@@ -1280,19 +1382,12 @@ stencil_gather_kernel(Grid g, const int *__restrict__ offset, const double *__re
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int c = lane + 64 * ch;
-                if (c <= r) {
-                    int code = 0, m7 = 1;
-#pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        code += (((c >> (2 * d)) & 3) - ((r >> (2 * d)) & 3) + 3) * m7;
-                        m7 *= 7;
-                    }
-                    acc[code] += v[u][ch];
-                }
+                if (c <= r) acc[kc[ch] - kr[u]] += v[u][ch];
             }
             racc += rv[u];
             hacc += hv[u];
         }
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
