@@ -875,7 +875,7 @@ gram_block_kernel(Grid g, const int *__restrict__ offset, const double *__restri
 //    read five LDS words per point behind the LDS latency and cost as much as the blocks;
 //  - the histogram share of a point is one LDS atomic of lane = point onto its nearest node's word of the wave's LDS row (the
 //    lanes of one instruction that meet on a word are served one after the other by the LDS unit, the same way every run);
-//  - a wave owns a RUN of GW_RUN consecutive cells and loads the points of the next cell before the products of the current
+//  - a wave owns a RUN of up to GW_RUN consecutive cells (fewer on a small grid: launch_gram) and loads the points of the next cell before the products of the current
 //    one, so that the two dependent round trips (offsets, then points) are paid once per run, not once per cell.
 constexpr int GW_RUN = 8;
 template <int D>
@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 gram_wave_kernel(Grid g, const int *__restrict__ offset, const double *__restrict__ xs,
                  const double *__restrict__ ys, const double *__restrict__ ws, long long cap,
                  double *__restrict__ blk, double *__restrict__ rblk, double *__restrict__ hblk,
-                 double *__restrict__ hist, int cell0, int ncells)
+                 double *__restrict__ hist, int cell0, int ncells, int run)
 {
     static_assert(D == 2 || D == 3, "16 or 64 window functions");
     static_assert(GW_RUN + 1 <= 64, "the offsets of a run sit in one register of the wave");
@@ -894,9 +894,9 @@ gram_wave_kernel(Grid g, const int *__restrict__ offset, const double *__restric
     __shared__ double s_wy[4][PCH];
     __shared__ double s_hist[4][NB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
-    const int first = (blockIdx.x * 4 + wave) * GW_RUN;
+    const int first = (blockIdx.x * 4 + wave) * run;
     if (first >= ncells) return;
-    const int ncl = ncells - first < GW_RUN ? ncells - first : GW_RUN;
+    const int ncl = ncells - first < run ? ncells - first : run;
     double *tab = s_tab[wave], *sw = s_w[wave], *swy = s_wy[wave], *sh = s_hist[wave];
     const bool hist_on = hblk != nullptr;
     const int offv = offset[cell0 + first + (lane <= ncl ? lane : ncl)];
@@ -2043,33 +2043,41 @@ rho_gather_kernel(Grid g, const int *__restrict__ offset, const double *__restri
 // for the node's own row -- reads every line of the transposed part for ONE entry: 3.0 instead of 1.3 ms at 64^3, round 3.)
 template <int D>
 __global__ void __launch_bounds__(256)
-backward_error_kernel(Grid g, const double *__restrict__ nst, const double *__restrict__ xvec,
-                      const double *__restrict__ rho, const double *__restrict__ rhs,
-                      unsigned long long *__restrict__ out)
+backward_denominators_kernel(Grid g, const double *__restrict__ nst, const double *__restrict__ xvec,
+                             const double *__restrict__ rhs, double *__restrict__ den)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.ncol) return;
+    int in[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) in[d] = (i / g.colstride[d]) % g.nodes[d];
+    const int centre = g.hstencil - 1;
+    double s = fabs(nst[(long long)i * g.hstencil + centre] * xvec[i]) + fabs(rhs[i]);
+    for (int code = 0; code < centre; ++code) {
+        int c = code, jl = i, ju = i;
+        bool okl = true, oku = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int o = c % 7 - 3;
+            c /= 7;
+            okl = okl && in[d] + o >= 0 && in[d] + o <= g.nodes[d] - 1;
+            oku = oku && in[d] - o >= 0 && in[d] - o <= g.nodes[d] - 1;
+            jl += o * g.colstride[d];
+            ju -= o * g.colstride[d];
+        }
+        if (okl) s += fabs(nst[(long long)i * g.hstencil + code] * xvec[jl]);       // N(i, jl), jl < i
+        if (oku) s += fabs(nst[(long long)ju * g.hstencil + code] * xvec[ju]);      // N(i, ju) = N(ju, i), ju > i
+    }
+    den[i] = s;
+}
+
+__global__ void __launch_bounds__(256)
+backward_error_kernel(int ncol, const double *__restrict__ den, const double *__restrict__ rho, unsigned long long *__restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double om = 0.0;
-    if (i < g.ncol) {
-        int in[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) in[d] = (i / g.colstride[d]) % g.nodes[d];
-        const int centre = g.hstencil - 1;
-        double s = fabs(nst[(long long)i * g.hstencil + centre] * xvec[i]) + fabs(rhs[i]);
-        for (int code = 0; code < centre; ++code) {
-            int c = code, jl = i, ju = i;
-            bool okl = true, oku = true;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const int o = c % 7 - 3;
-                c /= 7;
-                okl = okl && in[d] + o >= 0 && in[d] + o <= g.nodes[d] - 1;
-                oku = oku && in[d] - o >= 0 && in[d] - o <= g.nodes[d] - 1;
-                jl += o * g.colstride[d];
-                ju -= o * g.colstride[d];
-            }
-            if (okl) s += fabs(nst[(long long)i * g.hstencil + code] * xvec[jl]);       // N(i, jl), jl < i
-            if (oku) s += fabs(nst[(long long)ju * g.hstencil + code] * xvec[ju]);      // N(i, ju) = N(ju, i), ju > i
-        }
+    if (i < ncol) {
+        const double s = den[i];
         om = s > 0.0 ? fabs(rho[i]) / s : fabs(rho[i]);
     }
 #pragma unroll
@@ -2228,9 +2236,12 @@ static bool gram_cells(const Grid &g, const SortScratch &s, double *blk, double 
     static const bool old_form = std::getenv("SPLPAK_GRAM_VALU") != nullptr;       // A/B switch: the workgroup-per-cell form
     if constexpr (D == 2 || D == 3) {
         if (!old_form) {
-            hipLaunchKernelGGL(gram_wave_kernel<D>, dim3((unsigned)((ncells + 4 * GW_RUN - 1) / (4 * GW_RUN))), dim3(256), 0, st, g, (const int *)s.offset,
+            // cells per wave: GW_RUN where that still leaves four rounds of waves for the chip (two per SIMD), fewer on a small grid
+            int run = (int)(ncells / (4LL * 2048));
+            run = run < 1 ? 1 : run > GW_RUN ? GW_RUN : run;
+            hipLaunchKernelGGL(gram_wave_kernel<D>, dim3((unsigned)((ncells + 4 * run - 1) / (4 * run))), dim3(256), 0, st, g, (const int *)s.offset,
                                (const double *)s.xs, (const double *)s.ys, (const double *)s.ws, s.cap, blk, rblk, hblk, hist,
-                               cell0, ncells);
+                               cell0, ncells, run);
             return true;
         }
     }
@@ -2375,14 +2386,19 @@ hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xv
     return hipGetLastError();
 }
 
-hipError_t launch_backward_error(const Grid &g, const double *nst, const double *xvec, const double *rho,
-                                 const double *rhs, double *out, hipStream_t st)
+hipError_t launch_backward_denominators(const Grid &g, const double *nst, const double *xvec, const double *rhs, double *den, hipStream_t st)
+{
+    dim3 gr((unsigned)((g.ncol + 255) / 256)), bl(256);
+    DISPATCH_D(g.ndim, hipLaunchKernelGGL(backward_denominators_kernel<D>, gr, bl, 0, st, g, nst, xvec, rhs, den));
+    return hipGetLastError();
+}
+
+hipError_t launch_backward_error(const Grid &g, const double *den, const double *rho, double *out, hipStream_t st)
 {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
     if (e != hipSuccess) return e;
-    dim3 gr((unsigned)((g.ncol + 255) / 256)), bl(256);
-    DISPATCH_D(g.ndim, hipLaunchKernelGGL(backward_error_kernel<D>, gr, bl, 0, st, g, nst, xvec, rho, rhs,
-                                          reinterpret_cast<unsigned long long *>(out)));
+    hipLaunchKernelGGL(backward_error_kernel, dim3((unsigned)((g.ncol + 255) / 256)), dim3(256), 0, st, g.ncol, den, rho,
+                       reinterpret_cast<unsigned long long *>(out));
     return hipGetLastError();
 }
 

@@ -85,9 +85,10 @@ hipError_t launch_constraint_table(const Grid &g, double *ctab, hipStream_t st);
 hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rcell,
                            const double *dcw, const unsigned char *spf, const double *ctab, bool constraints,
                            double *tbuf, double *rho, double *ssq, double *e2buf, hipStream_t st);
-// out[0] = max_i |rho_i| / ((|N||x|)_i + |rhs_i|): componentwise backward error with respect to the rows
-hipError_t launch_backward_error(const Grid &g, const double *nst, const double *xvec, const double *rho,
-                                 const double *rhs, double *out, hipStream_t st);
+// out[0] = max_i |rho_i| / ((|N||x|)_i + |rhs_i|): componentwise backward error with respect to the rows -- the denominators
+// den[i] first (they need the coefficients only: beside the residual pass, on another stream), then the maximum of the ratios
+hipError_t launch_backward_denominators(const Grid &g, const double *nst, const double *xvec, const double *rhs, double *den, hipStream_t st);
+hipError_t launch_backward_error(const Grid &g, const double *den, const double *rho, double *out, hipStream_t st);
 
 // coef[reference column] = xvec[internal column] (a plain copy when the plan did not reorder the dimensions)
 hipError_t launch_to_reference_order(const Grid &g, const double *xvec, double *coef, hipStream_t st);
