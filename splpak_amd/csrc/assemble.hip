@@ -1559,14 +1559,27 @@ residual_wave_kernel(Grid g, const int *__restrict__ offset, const double *__res
             we[lane] = e;
             sw[lane] = wv;
             e2 = fma(e, e, e2);
+        } else {                                                  // zero rows pad the last group of the loop below
+#pragma unroll
+            for (int k = 0; k < 4 * D; ++k) tab[lane * LDT + k] = 0.0;
+            we[lane] = 0.0;
+            sw[lane] = 0.0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int p = grp; p < np; p += G) {
-            double prod = sw[p] * tab[p * LDT + (c & 3)];
+        // four points per trip, their LDS words asked for together (one point per trip waited out the LDS latency for each:
+        // 5 us of a wave's time per cell at C3, as in the Gram kernel's right-hand side before round 5); the padding rows
+        // add +0.0, the order of the sum is the points' order as before
+        const int ntrip = (np + 4 * G - 1) / (4 * G);
+        for (int it = 0; it < ntrip; ++it) {
 #pragma unroll
-            for (int d = 1; d < D; ++d) prod *= tab[p * LDT + 4 * d + ((c >> (2 * d)) & 3)];
-            racc = fma(prod, we[p], racc);
+            for (int k = 0; k < 4; ++k) {
+                const int p = grp + G * (4 * it + k);
+                double prod = sw[p] * tab[p * LDT + (c & 3)];
+#pragma unroll
+                for (int d = 1; d < D; ++d) prod *= tab[p * LDT + 4 * d + ((c >> (2 * d)) & 3)];
+                racc = fma(prod, we[p], racc);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2041,34 +2054,75 @@ rho_gather_kernel(Grid g, const int *__restrict__ offset, const double *__restri
 // (Thread per node on purpose: neighbouring threads walk neighbouring rows code by code, so every 128-byte line of nst that
 // is fetched serves 16 iterations of the same wave from the L1.  A wave per node with the lanes over the codes -- coalesced
 // for the node's own row -- reads every line of the transposed part for ONE entry: 3.0 instead of 1.3 ms at 64^3, round 3.)
+// den[i] = (|N| |x|)_i + |rhs_i| from the half stencil: sum over code < centre of |N(i, jl) x_jl| (jl = i + off(code), the entry
+// of row i) and |N(ju, i) x_ju| (ju = i - off(code), the entry of row ju at the same code), code ascending.
+// A thread per row that walked its 171 codes touched a new 64-byte sector of another row at every step (N(ju, i) of
+// consecutive codes lie in consecutive ROWS): 45 M sector fetches, 1.2 ms at 64^3 -- and beside another kernel it starved
+// that one.  Here a workgroup owns 256 consecutive rows and stages, for the seven codes of one (o_1, .., o_{D-1}) at a time
+// (they differ in the offset along dimension 0 only), the 7-double pieces of its own rows and of the 256 + 6 rows
+// i0 - base - 3 .. that hold the transposed entries, and the two windows of x: every fetched sector is used whole.  Same terms
+// in the same order per row.
 template <int D>
 __global__ void __launch_bounds__(256)
 backward_denominators_kernel(Grid g, const double *__restrict__ nst, const double *__restrict__ xvec,
                              const double *__restrict__ rhs, double *__restrict__ den)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.ncol) return;
+    constexpr int TR = 256, HALO = TR + 6;
+    __shared__ double HA[TR * 7], HB[HALO * 7], xa[HALO], xb[HALO];
+    const int tid = threadIdx.x;
+    const long long i0 = (long long)blockIdx.x * TR;
+    const long long i = i0 + tid;
+    const bool live = i < g.ncol;
+    const int centre = g.hstencil - 1;
     int in[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) in[d] = (i / g.colstride[d]) % g.nodes[d];
-    const int centre = g.hstencil - 1;
-    double s = fabs(nst[(long long)i * g.hstencil + centre] * xvec[i]) + fabs(rhs[i]);
-    for (int code = 0; code < centre; ++code) {
-        int c = code, jl = i, ju = i;
-        bool okl = true, oku = true;
+    for (int d = 0; d < D; ++d) in[d] = live ? (int)((i / g.colstride[d]) % g.nodes[d]) : 0;
+    double s = live ? fabs(nst[i * g.hstencil + centre] * xvec[i]) + fabs(rhs[i]) : 0.0;
+    const int ngroups = centre / 7 + 1;
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int c0 = 7 * gi, nk = gi + 1 < ngroups ? 7 : centre - c0;      // (the last group: the codes below the centre)
+        int oh[D], t = gi;
+        long long base = 0;
+        oh[0] = 0;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int o = c % 7 - 3;
-            c /= 7;
-            okl = okl && in[d] + o >= 0 && in[d] + o <= g.nodes[d] - 1;
-            oku = oku && in[d] - o >= 0 && in[d] - o <= g.nodes[d] - 1;
-            jl += o * g.colstride[d];
-            ju -= o * g.colstride[d];
+        for (int d = 1; d < D; ++d) {
+            oh[d] = t % 7 - 3;
+            t /= 7;
+            base += (long long)oh[d] * g.colstride[d];
         }
-        if (okl) s += fabs(nst[(long long)i * g.hstencil + code] * xvec[jl]);       // N(i, jl), jl < i
-        if (oku) s += fabs(nst[(long long)ju * g.hstencil + code] * xvec[ju]);      // N(i, ju) = N(ju, i), ju > i
+        __syncthreads();
+        for (int e = tid; e < TR * 7; e += 256) {
+            const long long r = i0 + e / 7;
+            const int k = e % 7;
+            HA[e] = (r < g.ncol && k < nk) ? nst[r * g.hstencil + c0 + k] : 0.0;
+        }
+        for (int e = tid; e < HALO * 7; e += 256) {
+            const long long r = i0 - base - 3 + e / 7;
+            const int k = e % 7;
+            HB[e] = (r >= 0 && r < g.ncol && k < nk) ? nst[r * g.hstencil + c0 + k] : 0.0;
+        }
+        for (int e = tid; e < HALO; e += 256) {
+            const long long ra = i0 + base - 3 + e, rb = i0 - base - 3 + e;
+            xa[e] = (ra >= 0 && ra < g.ncol) ? xvec[ra] : 0.0;
+            xb[e] = (rb >= 0 && rb < g.ncol) ? xvec[rb] : 0.0;
+        }
+        __syncthreads();
+        if (!live) continue;
+        bool okh_l = true, okh_u = true;                // the higher dimensions' share of the two in-grid tests
+#pragma unroll
+        for (int d = 1; d < D; ++d) {
+            okh_l = okh_l && in[d] + oh[d] >= 0 && in[d] + oh[d] <= g.nodes[d] - 1;
+            okh_u = okh_u && in[d] - oh[d] >= 0 && in[d] - oh[d] <= g.nodes[d] - 1;
+        }
+        for (int k = 0; k < nk; ++k) {
+            const int ox = k - 3;
+            const bool okl = okh_l && in[0] + ox >= 0 && in[0] + ox <= g.nodes[0] - 1;
+            const bool oku = okh_u && in[0] - ox >= 0 && in[0] - ox <= g.nodes[0] - 1;
+            if (okl) s += fabs(HA[tid * 7 + k] * xa[tid + ox + 3]);                     // N(i, jl), jl = i + base + ox < i
+            if (oku) s += fabs(HB[(tid - ox + 3) * 7 + k] * xb[tid - ox + 3]);          // N(ju, i), ju = i - base - ox > i
+        }
     }
-    den[i] = s;
+    if (live) den[i] = s;
 }
 
 __global__ void __launch_bounds__(256)
@@ -2388,7 +2442,7 @@ hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xv
 
 hipError_t launch_backward_denominators(const Grid &g, const double *nst, const double *xvec, const double *rhs, double *den, hipStream_t st)
 {
-    dim3 gr((unsigned)((g.ncol + 255) / 256)), bl(256);
+    dim3 gr((unsigned)((g.ncol + 255) / 256)), bl(256);           // (256 rows per workgroup: the kernel's tile)
     DISPATCH_D(g.ndim, hipLaunchKernelGGL(backward_denominators_kernel<D>, gr, bl, 0, st, g, nst, xvec, rhs, den));
     return hipGetLastError();
 }
