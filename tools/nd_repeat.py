@@ -23,5 +23,7 @@ for i in range(n):
     c = coef.cpu()
     if ref is None:
         ref = c.clone()
-    print(f"fit {i}: ierr {ierr} steps {info[2]:.0f} last {info[3]:.2e} omega {info[9]:.2e} factor {info[6]*1e3:.2f} ms  max diff to fit 0: {float((c - ref).abs().max()):.2e}", flush=True)
+    import hashlib
+    print(f"fit {i}: ierr {ierr} steps {info[2]:.0f} last {info[3]:.2e} omega {info[9]:.2e} factor {info[6]*1e3:.2f} ms solve {info[7]*1e3:.2f} ms  max diff to fit 0: {float((c - ref).abs().max()):.2e}  "
+          f"sha {hashlib.sha1(c.numpy().tobytes()).hexdigest()[:12]}", flush=True)
 plan.close()
