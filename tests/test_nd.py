@@ -291,7 +291,9 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
     change a bit: the same fit without reserved CUs, without the root look-ahead, with K = 256 Schur passes, with separate
     extend-add launches and entirely serial gives identical coefficients.  Round 5: so do the POSTORDER schedules (the fronts
     above depth SPLPAK_ND_CUT one by one, the subtrees below one after the other, Schur buffers reused along the way --
-    csrc/ndtree.hpp NdSchedule) and square instead of packed Schur buffers (SPLPAK_ND_SQUARE)."""
+    csrc/ndtree.hpp NdSchedule) and square instead of packed Schur buffers (SPLPAK_ND_SQUARE); and so does the way the panels
+    come to hold the normal equations: written column by column, zeros and entries, when their stage comes alive (nd_init_kernel)
+    or cleared as a whole (by the runtime's memset or by resident workgroups) and scattered into."""
     from splpak_amd.synth import synth_points
     nd, nod, m = 3, 32, 200000
     x, y, w = synth_points(nd, m)
@@ -302,7 +304,10 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
                 {"SPLPAK_ND_CUT": "1"}, {"SPLPAK_ND_CUT": "2"}, {"SPLPAK_ND_CUT": "3", "SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_CUT": "4", "SPLPAK_ND_SQUARE": "1"},
                 {"SPLPAK_ND_CUT": "6"}, {"SPLPAK_ND_CUT": "2", "SPLPAK_ND_NO_FUSE": "1"}, {"SPLPAK_ND_SQUARE": "1"}, {"SPLPAK_ND_NO_OUTER": "1"}, {"SPLPAK_ND_SMALL_GRID": "0"}, {"SPLPAK_ND_WG4": "2"}, {"SPLPAK_ND_POTRF_WAVES": "4"}, {"SPLPAK_ND_POTRF_WAVES": "16"}, {"SPLPAK_ND_SMALL_QUEUE": "1"}, {"SPLPAK_ND_FULL_DIAG": "1"}, {"SPLPAK_ND_XCD": "0"},
                 {"SPLPAK_ND_NO_FUSE": "1", "SPLPAK_ND_SQUARE": "1", "SPLPAK_ND_KB": "2"},
-                {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_RES_CUS": "3", "SPLPAK_ND_PIN_ROUNDS": "8"}):
+                {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_RES_CUS": "3", "SPLPAK_ND_PIN_ROUNDS": "8"},
+                # the panels written stage by stage (nd_init_kernel, the default) | cleared as a whole, then scattered into
+                {"SPLPAK_ND_STAGED_INIT": "0"}, {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_CLEAR_WGS": "0"}, {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_NO_EARLY_CLEAR": "1"},
+                {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_CUT": "2"}):
         c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1"))
         assert e == 0 and np.array_equal(c, ref), env
 
