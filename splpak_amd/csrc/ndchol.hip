@@ -1091,7 +1091,11 @@ bool nd_build_factor_jobs(NdState *s)
         bool any_schur = false;
         for (int id : ids) any_schur = any_schur || t.fr[(size_t)id].hp > 0;
         const bool la = !any_schur && steps >= 4 && !std::getenv("SPLPAK_ND_NO_ROOT_LOOKAHEAD");
-        s->lookahead[(size_t)stg] = la ? 1 : 0;
+        // 2: the WHOLE next block column is updated on the chain (its diagonal block and the rows below it), so that the next
+        // panel solve runs beside the trailing pass of this step instead of behind it (round 5); 1: only the next diagonal block
+        // (round 4: the panel solve of every step, 50 us, waited for the trailing pass and was waited for by the next one)
+        const bool la2 = la && !(std::getenv("SPLPAK_ND_ROOT_LA") && atoi(std::getenv("SPLPAK_ND_ROOT_LA")) == 1);
+        s->lookahead[(size_t)stg] = la ? (la2 ? 2 : 1) : 0;
         for (int k = 0; k < steps; ++k) {
             Launch lp, lt, ltb, lu, lur, luo, ls, lfin[2];
             long long tbwg = 0, twg = 0, ui = 0, uri = 0, uoi = 0, si = 0;
@@ -1120,7 +1124,7 @@ bool nd_build_factor_jobs(NdState *s)
                 const int nc = (f.wp - (k + 1) * 256) / 64, nr = nrows / 64;
                 if (nrows > 0) {
                     // with look-ahead (the root) only the rows of the NEXT diagonal block are solved on the chain, the rest beside it
-                    const int ntop = (la && nc > 0) ? std::min(nrows, 256) : nrows;
+                    const int ntop = (la && !la2 && nc > 0) ? std::min(nrows, 256) : nrows;
                     s->trsm.host.push_back(TrsmJob{diag, below, i16, f.ld, ntop, (int)twg, (ncols + 15) / 16, 0});
                     twg += ntop / 16;
                     ++lt.count;
@@ -1174,7 +1178,13 @@ bool nd_build_factor_jobs(NdState *s)
                         s->upd.host.push_back(a);
                         ui += trapezoid_items(a.nc, a.nr);
                         ++lu.count;
-                        if (nr > 4) {                                        // rows below it in the next block column
+                        if (nr > 4 && la2) {                                 // rows below it in the next block column: on the chain too
+                            SyrkJob r = proto;
+                            r.nc = n4; r.nr = nr; r.item0 = (int)ui; r.zinit = -4;
+                            s->upd.host.push_back(r);
+                            ui += (long long)n4 * (nr - 4);
+                            ++lu.count;
+                        } else if (nr > 4) {                                 // ... or beside it
                             SyrkJob r = proto;
                             r.nc = n4; r.nr = nr; r.item0 = (int)uri; r.zinit = -4;
                             s->updr.host.push_back(r);
@@ -1709,7 +1719,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         const int steps = (int)s->l_potrf[(size_t)stg].size();
         ensure_events(steps);
         const bool pinned = sR != nullptr && s->nres > 0 && steps > 0 && (int)s->l_potrf[(size_t)stg][0].grid <= pin_rounds * s->nres;
-        const bool la = s->lookahead[(size_t)stg] != 0;
+        const bool la = s->lookahead[(size_t)stg] != 0, la2 = s->lookahead[(size_t)stg] == 2;
         for (int k = 0; k < steps; ++k) {
             if (!la) { chain_step(stg, k, pinned); continue; }
             const Launch &lp = s->l_potrf[(size_t)stg][(size_t)k], &lt = s->l_trsm[(size_t)stg][(size_t)k], &ltb = s->l_trsmb[(size_t)stg][(size_t)k];
@@ -1730,14 +1740,17 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
                 hipLaunchKernelGGL(nd_trsm_kernel, dim3(ltb.grid), dim3(64), 0, sU, (const TrsmJob *)(s->trsmb.dev + ltb.first), ltb.count);
             }
             // everything of step k - 1 that is not the next diagonal block ran beside the chain; the panel rows this step
-            // solves and the block it updates were last written there
-            if (k > 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evW[(size_t)(k - 1)], 0);
+            // solves and the block it updates were last written there.  (la2: block column k was completed on the chain by step
+            // k - 1 -- which waited for the trailing pass of step k - 2 --, so the whole panel is solved here, beside the trailing
+            // pass of step k - 1; only the update of block column k + 1 below has to wait for that pass)
+            if (!la2 && k > 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evW[(size_t)(k - 1)], 0);
             if (lt.count)
                 hipLaunchKernelGGL(nd_trsm_kernel, dim3(lt.grid), dim3(64), 0, sP, (const TrsmJob *)(s->trsm.dev + lt.first), lt.count);
             if (lur.count && sU != sP) {
                 (void)hipEventRecord(s->evT[(size_t)k], sP);
                 (void)hipStreamWaitEvent(sU, s->evT[(size_t)k], 0);
             }
+            if (la2 && k > 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evW[(size_t)(k - 1)], 0);
             launch_syrk(s, s->upd, lu, sP, stats, timing, false, pinned, qnext);
             launch_syrk(s, s->updr, lur, sU, stats, timing, false, pinned, qnext);
             if (sU != sP) (void)hipEventRecord(s->evW[(size_t)k], sU);
