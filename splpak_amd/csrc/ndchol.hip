@@ -938,9 +938,6 @@ struct NdState {
     long long join_scratch_doubles = 0;
     int *rowsrc_out = nullptr;                     // rowsrc restricted to the variables this rank reports (the rest arrive by all-reduce)
     int ntrinv = 0;
-    int ntrinv_early = 0;                          // the blocks of the fronts below the root: inverted beside the root's elimination
-    hipStream_t sT = nullptr;                      // (low priority)
-    hipEvent_t evTi[2] = {nullptr, nullptr};
     // ---- per-rank storage (round 4).  A plan of the one-process multi-GPU fit (mdist) keeps only ITS subtrees' panels, Schur
     // buffers and block inverses, plus its block columns of the top fronts; everything is addressed through these tables
     // (single GPU: poff = the tree's panel_off, lblk = blk0).
@@ -1040,8 +1037,7 @@ void nd_destroy(void *user)
     if (!s) return;
     (void)hipDeviceSynchronize();
     (void)hipSetDevice(s->device);
-    for (hipStream_t *q : {&s->sP, &s->sU, &s->sR, &s->sCopy, &s->sT}) if (*q) (void)hipStreamDestroy(*q);
-    for (hipEvent_t e : s->evTi) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t *q : {&s->sP, &s->sU, &s->sR, &s->sCopy}) if (*q) (void)hipStreamDestroy(*q);
     for (auto *v : {&s->evT, &s->evE, &s->evP, &s->evA, &s->evB, &s->evI, &s->evW, &s->evF, &s->evReady, &s->evArr,
                     &s->evCol, &s->evBulk, &s->evSF, &s->evSB, &s->evAdd})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
@@ -1342,10 +1338,6 @@ bool nd_build_factor_jobs(NdState *s)
         }
     }
     s->ntrinv = (int)s->trinv.host.size();
-    // (the jobs are in front order, the root last)
-    s->ntrinv_early = 0;
-    if (!s->mdist && t.root >= 0 && (s->mine.empty() || s->mine[(size_t)t.root]) && std::getenv("SPLPAK_ND_TRINV_LATE") == nullptr)
-        s->ntrinv_early = s->ntrinv - t.fr[(size_t)t.root].nsteps;
     return true;
 }
 
@@ -1763,7 +1755,6 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     // ---- the stages in schedule order (children before parents).  A rank of a one-process multi-GPU fit eliminates its
     // subtrees here and the fronts above them in the top phase, together with the other ranks (ndtop.inc).
     bool joined = false;
-    int trinv_done = 0;
     for (int i = 0; i < ns; ++i) {
         const NdStage &S = s->sc.st[(size_t)i];
         if (s->dist && !joined && S.depth <= s->dcut - 1) { dist_join(); joined = true; }
@@ -1780,15 +1771,6 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         // the fronts' children have added their Schur complements (their last passes run on the update stream)
         if (s->fused && S.dep >= 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evF[(size_t)S.dep], 0);
         if (i == s->root_stage) {
-            // the inverses of the diagonal blocks below the root (the solves' operands: 1.0 ms at 64^3 when they all waited for the
-            // end) are computed beside the root's elimination, on a low-priority stream
-            if (s->ntrinv_early > 0 && s->sT && sP != st) {
-                (void)hipEventRecord(s->evTi[0], sP);
-                (void)hipStreamWaitEvent(s->sT, s->evTi[0], 0);
-                hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)s->ntrinv_early), dim3(64), 0, s->sT, (const TrinvJob *)s->trinv.dev);
-                (void)hipEventRecord(s->evTi[1], s->sT);
-                trinv_done = s->ntrinv_early;
-            }
             root_stage(i);
             continue;
         }
@@ -1822,11 +1804,10 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     if (top_err == hipSuccess && ns > 0)
         for (int x : s->starts[0]) zero_block(x, sU);
     // inverses of all diagonal blocks (the solves' operands)
-    if (s->ntrinv > trinv_done)
-        hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)(s->ntrinv - trinv_done)), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev + trinv_done);
+    if (s->ntrinv > 0)
+        hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)s->ntrinv), dim3(64), 0, sP, (const TrinvJob *)s->trinv.dev);
     (void)hipEventRecord(s->evJ, sP);
     if (sP != st) (void)hipStreamWaitEvent(st, s->evJ, 0);
-    if (trinv_done > 0) (void)hipStreamWaitEvent(st, s->evTi[1], 0);
     if (s->mdist && top_err == hipSuccess) top_err = nd_top_pivots(s, st, info_dev, minpiv_dev);
     if (s->dist) {      // (a failed pivot poisons the fronts above it with NaN, so every rank fails anyway; this makes it explicit)
         hipLaunchKernelGGL(nd_flag_kernel, dim3(1), dim3(1), 0, st, (const int *)info_dev, s->part, 0);
@@ -2260,8 +2241,6 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     (void)hipStreamCreateWithPriority(&s->sP, hipStreamNonBlocking, hi);
     (void)hipStreamCreateWithFlags(&s->sU, hipStreamNonBlocking);
-    (void)hipStreamCreateWithPriority(&s->sT, hipStreamNonBlocking, lo);
-    for (hipEvent_t &e : s->evTi) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone, &s->evPre, &s->evTail, &s->evR0}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
     // item queues of the update launches (two per step at most)
     s->nqueues = 8 * t.nblocks + 64;

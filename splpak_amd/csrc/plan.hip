@@ -326,8 +326,6 @@ void splpak_plan_destroy(splpak_plan *p)
     if (p->fn_destroy) p->fn_destroy(p->fn_user);
     band_pipeline_destroy(p->band.pipe);
     for (hipEvent_t e : p->evStage) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : p->evDiag) if (e) (void)hipEventDestroy(e);
-    if (p->sDiag) (void)hipStreamDestroy(p->sDiag);
     for (void *q : p->owned) (void)hipFree(q);
     std::free(p->ar_owned);
     delete p;
@@ -623,16 +621,10 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     double ssq = 0.0, omega = 0.0;
     if (info || stagnated) {
         double *scalR = p->rho + b.npad;
-        // the backward error's denominators (|N| |x| + |rhs|: a pass over the half stencil, 1.2 ms at 64^3) need the
-        // coefficients only: on a stream of their own beside the residual pass over the rows, into the solves' scratch vector
-        if (!p->sDiag) {
-            SPLPAK_HIP_TRY(hipStreamCreateWithFlags(&p->sDiag, hipStreamNonBlocking), SPLPAK_E_NODEVICE);
-            for (hipEvent_t &e : p->evDiag) SPLPAK_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), SPLPAK_E_NODEVICE);
-        }
-        SPLPAK_HIP_TRY(hipEventRecord(p->evDiag[0], st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(hipStreamWaitEvent(p->sDiag, p->evDiag[0], 0), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(launch_backward_denominators(g, p->nst, p->xvec, p->rhs, p->tmp, p->sDiag), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(hipEventRecord(p->evDiag[1], p->sDiag), SPLPAK_E_NODEVICE);
+        // the backward error's denominators (|N| |x| + |rhs|: a pass over the half stencil) need the coefficients only; into the
+        // solves' scratch vector.  (On a stream of their own beside the residual pass they gained nothing -- the two kernels
+        // slowed each other down by what the overlap saved -- and one more stream per plan is not free: round 5)
+        SPLPAK_HIP_TRY(launch_backward_denominators(g, p->nst, p->xvec, p->rhs, p->tmp, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
         hipEvent_t r0 = stamps ? p->evStage[8] : nullptr, r1 = stamps ? p->evStage[9] : nullptr;   // (created with the other stage events)
         if (r0 && r1) (void)hipEventRecord(r0, st);
@@ -645,7 +637,6 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
             if (hipEventElapsedTime(&ms, r0, r1) == hipSuccess) p->stage_ms[4] = ms;
         }
         if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
-        SPLPAK_HIP_TRY(hipStreamWaitEvent(st, p->evDiag[1], 0), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(launch_backward_error(g, p->tmp, p->rho, p->small + 3, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(hipMemcpyAsync(&ssq, scalR, sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(hipMemcpyAsync(&omega, p->small + 3, sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);

@@ -77,8 +77,6 @@ struct splpak_plan {
     double tol = 1e-11;           // on the ESTIMATED remaining error; the parity bar is 1e-10
     splpak::CholStats stats;
     // stage timing of the assembly and of one residual pass (HIP events on the fit's stream, kernel timing only)
-    hipStream_t sDiag = nullptr;  // the denominators of the backward error run beside the diagnostic residual pass
-    hipEvent_t evDiag[2] = {nullptr, nullptr};
     hipEvent_t evStage[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [8], [9]: the diagnostic residual pass
     double stage_ms[6] = {0, 0, 0, 0, 0, 0};    // bin, gram blocks + gather, constraint rows, expand (+ band memset), residual pass, solve
     std::vector<void *> owned;

@@ -308,8 +308,8 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
                 # the panels written stage by stage (nd_init_kernel, the default) | cleared as a whole, then scattered into
                 {"SPLPAK_ND_STAGED_INIT": "0"}, {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_CLEAR_WGS": "0"}, {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_NO_EARLY_CLEAR": "1"},
                 {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_CUT": "2"},
-                # the root's look-ahead over the next diagonal block only (round 4) | all inverses after the root
-                {"SPLPAK_ND_ROOT_LA": "1"}, {"SPLPAK_ND_TRINV_LATE": "1"}):
+                # the root's look-ahead over the next diagonal block only (round 4)
+                {"SPLPAK_ND_ROOT_LA": "1"}):
         c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1"))
         assert e == 0 and np.array_equal(c, ref), env
 
