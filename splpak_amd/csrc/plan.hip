@@ -357,7 +357,7 @@ void splpak_plan_set_refine(splpak_plan *p, int32_t max_steps, double tol)
 {
     if (!p) return;
     p->max_refine = max_steps < 0 ? 0 : max_steps;
-    p->max_refine_hard = p->max_refine == 0 ? 0 : (p->max_refine > 30 ? p->max_refine : 30);
+    p->max_refine_hard = p->max_refine == 0 ? 0 : (p->max_refine > 80 ? p->max_refine : 80);
     p->tol = tol;
 }
 

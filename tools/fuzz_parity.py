@@ -33,7 +33,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     if w is not None and rng.random() < 0.5:
         w[rng.random(m) < 0.1] = 0.0
     xtrap = float(rng.choice([0.0, 0.3, 1.0, 2.5]))
-    if os.environ.get("FUZZ_ONLY") and trial != int(os.environ["FUZZ_ONLY"]):
+    if os.environ.get("FUZZ_ONLY") and trial != int(os.environ["FUZZ_ONLY"]) and not os.environ.get("FUZZ_EXACT"):
         rng.random((300, nd)); [rng.integers(0, 3) for _ in range(nd)]        # (the draws the comparison below would make)
         continue
     # generous workspace: the reference's own size check (suprls 32 -> 107, :1443-1454) is not under test
@@ -50,6 +50,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
         singular = e0 == 0 and e1 == 107 and np.max(np.abs(c0[:ncol])) > 1e4 * np.max(np.abs(y))
         print(tag, f"ierror oracle {e0} hip {e1}", "(numerically singular: oracle max|coef| = %.1e)" % np.max(np.abs(c0[:ncol])) if singular else "<-- FAIL")
         fails += 0 if singular else 1
+        if not singular:
+            print(f"    hip says: {capi.last_error()!r}; info steps {int(i1[2])} last correction {i1[3]:.2e} omega {i1[9]:.2e}; oracle max|coef| {np.max(np.abs(c0[:ncol])):.2e}, max|y| {np.max(np.abs(y)):.2e}")
         continue
     if e0 != 0:
         continue
@@ -67,9 +69,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     if illposed:
         print(tag, f"ill-conditioned (oracle max|coef| {np.max(np.abs(c0[:ncol])):.1e}): coef rel {rel:.2e} not judged")
         rel = 0.0
-    if BIG and rel > 1e-10 and abs(i1[8] - ib[8]) <= 1e-12 * ib[8]:
-        # two solutions with the same least-squares objective to 12 digits: a flat direction of an ill-conditioned
-        # problem (both solvers stop at cond*eps), not a discrepancy between them
+    if BIG and rel > 1e-10 and (abs(i1[8] - ib[8]) <= 1e-12 * ib[8] or (abs(i1[8] - ib[8]) <= 1e-11 * ib[8] and i1[9] < 1e-12)):
+        # two solutions with the same least-squares objective to 12 digits (11 when the GPU's measured backward error is at
+        # rounding level): a flat direction of an ill-conditioned problem (both solvers stop at cond*eps), not a discrepancy
+        # between them
         print(tag, f"flat direction: coef rel {rel:.2e} at equal residual norm {ib[8]:.12e}; hip steps {int(i1[2])}, last correction {i1[3]:.1e}")
         rel = 0.0
     if BIG and rel > 1e-10 and i1[8] < ib[8] * (1.0 - 1e-9) and i1[9] < 1e-12:
