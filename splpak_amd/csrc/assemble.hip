@@ -1889,23 +1889,18 @@ constraint_rows_kernel(Grid g, const double *__restrict__ dcw, const unsigned ch
     };
     bool any = false;
     for (int ne = 0; ne < NE; ++ne) {            // neighbour n = i + offn, offn_d in [-1,1], dim 0 fastest
-        int nn[D], offi[D], t = ne, ncol_n = 0;
-        bool ok = true;
+        if (!((sparse[ne >> 6] >> (ne & 63)) & 1ull)) continue;        // (in the grid and data sparse)
+        int nn[D], offi[D], t = ne;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int o = t % 3 - 1;
             t /= 3;
             nn[d] = in[d] + o;
             offi[d] = -o;                        // i = n + offi
-            ok = ok && nn[d] >= 0 && nn[d] <= g.nodes[d] - 1;
-            ncol_n += nn[d] * g.colstride[d];
         }
-        if (!((sparse[ne >> 6] >> (ne & 63)) & 1ull)) continue;        // (in the grid and data sparse)
-        (void)ok;
         SparseNode sn;
         sn.sparse = true;
         sn.dcwght = dn[ne];
-        (void)ncol_n;
         any = true;
         // (the rows are counted by count_sparse_kernel: one f64 atomicAdd per data-sparse node on ONE word -- a compare-and-swap
         //  loop on this build -- serialised 17 000 of them at config 3 and 177 000 at 4-D 28^4)

@@ -2239,6 +2239,8 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     std::vector<int>().swap(t.bvar);
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (const char *e = std::getenv("SPLPAK_ND_DUMMY_STREAMS"))        // (experiment: how the streams fall onto the hardware queues)
+        for (int i = 0; i < atoi(e); ++i) { hipStream_t q; (void)hipStreamCreateWithFlags(&q, hipStreamNonBlocking); }
     (void)hipStreamCreateWithPriority(&s->sP, hipStreamNonBlocking, hi);
     (void)hipStreamCreateWithFlags(&s->sU, hipStreamNonBlocking);
     for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone, &s->evPre, &s->evTail, &s->evR0}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
