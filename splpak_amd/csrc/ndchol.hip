@@ -1075,13 +1075,14 @@ bool nd_build_factor_jobs(NdState *s)
     // groups of panel blocks that share a Schur pass (and the outer panel pass): schur_kb blocks each -- after a RAMP of smaller
     // first groups for the fronts that have more than one group anyway, so that the first pass of a stage does not wait for the
     // chain of four block steps (round 5: at 64^3 only the chain runs for 1 .. 5.5 ms at the start of every stage, 25 ms in all).
-    // Default: a first group of 2 blocks (-1.2 ms of 225 at 64^3; "1,2", "2,2", "1,3" the same within 0.5 ms -- the earlier
-    // passes take CU time from the chain they run beside).  SPLPAK_ND_RAMP="1,2": 1, then 2, then schur_kb blocks; "0": no ramp.
-    // The sums of an entry keep the order of the blocks whatever the grouping: the same bits.
+    // Measured: a first group of 2 blocks is -1.2 ms of 225 at 64^3 ("1,2", "2,2", "1,3" the same within 0.5 ms -- the earlier
+    // passes take CU time from the chain they run beside), and the K = 512 passes it adds run at a lower rate (the Schur-pass
+    // kernel's average goes from 0.575 to 0.55 of the peak): not the default.  SPLPAK_ND_RAMP="2": 2, then schur_kb blocks;
+    // "1,2": 1, then 2, then schur_kb.  The sums of an entry keep the order of the blocks whatever the grouping: the same bits.
     int ramp[4] = {0, 0, 0, 0}, nramp = 0;
     {
         const char *e = std::getenv("SPLPAK_ND_RAMP");
-        for (const char *q = e ? e : "2"; *q && nramp < 4; ++q)
+        for (const char *q = e ? e : ""; *q && nramp < 4; ++q)
             if (*q >= '1' && *q <= '4') ramp[nramp++] = std::min(*q - '0', schur_kb);
     }
     auto group_of = [&](int k, int nsteps, int &g0, int &gend) {
