@@ -1634,8 +1634,9 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     hipStream_t sP = s->sP, sU = s->sU, sR = s->sR;
     if (serial) sP = sU = st;
     if (serial || !sR || std::getenv("SPLPAK_NO_PANEL_CU")) sR = nullptr;
-    // potrf goes to the reserved CUs while a stage has at most this many diagonal blocks per step per reserved CU
-    const int pin_rounds = std::getenv("SPLPAK_ND_PIN_ROUNDS") ? atoi(std::getenv("SPLPAK_ND_PIN_ROUNDS")) : 2;
+    // potrf goes to the reserved CUs while a stage has at most this many diagonal blocks per step per reserved CU (round 5: 1 --
+    // two rounds of 140 us on the reserved CUs lose against one round on the whole chip beside the pass: 219.3 against 220.7 ms at 64^3)
+    const int pin_rounds = std::getenv("SPLPAK_ND_PIN_ROUNDS") ? atoi(std::getenv("SPLPAK_ND_PIN_ROUNDS")) : 1;
     if (timing) {
         if (!s->f0) { (void)hipEventCreate(&s->f0); (void)hipEventCreate(&s->f1); }
         (void)hipEventRecord(s->f0, st);
@@ -1707,12 +1708,14 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     };
     // one block step of a stage's chain: potrf (on the reserved CUs when pinned) -> panel solve -> panel update, on the
     // chain stream; the Schur passes that become ready go to the update stream
-    auto chain_step = [&](int stg, int k, bool pinned) {
+    // (pin_potrf: the diagonal blocks go to the reserved CUs -- only once a Schur pass of the stage is running beside the chain:
+    //  before the first one the chip is idle, and 16 blocks on 8 reserved CUs are two rounds of 140 us where one would do)
+    auto chain_step = [&](int stg, int k, bool pinned, bool pin_potrf) {
         hipStream_t sC = sP;
         const Launch &lp = s->l_potrf[(size_t)stg][(size_t)k], &lt = s->l_trsm[(size_t)stg][(size_t)k];
         const Launch &lu = s->l_upd[(size_t)stg][(size_t)k], &ls = s->l_schur[(size_t)stg][(size_t)k];
         const Launch &lf0 = s->l_fin[0][(size_t)stg][(size_t)k], &lf1 = s->l_fin[1][(size_t)stg][(size_t)k];
-        if (pinned) {           // two event hops: chain -> reserved CUs -> chain
+        if (pinned && pin_potrf) {           // two event hops: chain -> reserved CUs -> chain
             (void)hipEventRecord(s->evR0, sC);
             (void)hipStreamWaitEvent(sR, s->evR0, 0);
             launch_potrf(s, lp, sR, info_dev, minpiv_dev);
@@ -1739,7 +1742,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         const bool pinned = sR != nullptr && s->nres > 0 && steps > 0 && (int)s->l_potrf[(size_t)stg][0].grid <= pin_rounds * s->nres;
         const bool la = s->lookahead[(size_t)stg] != 0, la2 = s->lookahead[(size_t)stg] == 2;
         for (int k = 0; k < steps; ++k) {
-            if (!la) { chain_step(stg, k, pinned); continue; }
+            if (!la) { chain_step(stg, k, pinned, true); continue; }
             const Launch &lp = s->l_potrf[(size_t)stg][(size_t)k], &lt = s->l_trsm[(size_t)stg][(size_t)k], &ltb = s->l_trsmb[(size_t)stg][(size_t)k];
             const Launch &lu = s->l_upd[(size_t)stg][(size_t)k], &lur = s->l_updr[(size_t)stg][(size_t)k];
             if (pinned) {
@@ -1803,7 +1806,12 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         const int steps = (int)s->l_potrf[(size_t)i].size();
         ensure_events(steps);
         const bool pinned = sR != nullptr && s->nres > 0 && steps > 0 && (int)s->l_potrf[(size_t)i][0].grid <= pin_rounds * s->nres;
-        for (int k = 0; k < steps; ++k) chain_step(i, k, pinned);
+        static const bool unpin_first = std::getenv("SPLPAK_ND_PIN_FIRST") == nullptr;
+        bool pass_running = !unpin_first;
+        for (int k = 0; k < steps; ++k) {
+            chain_step(i, k, pinned, pass_running);
+            if (s->l_schur[(size_t)i][(size_t)k].count || s->l_fin[0][(size_t)i][(size_t)k].count || s->l_fin[1][(size_t)i][(size_t)k].count) pass_running = true;
+        }
         if (s->fused) (void)hipEventRecord(s->evF[(size_t)i], sU);     // (stream order: the stage's last passes are behind it)
         else {                  // separate extend-add launches: the stage's passes, then slot 0, then slot 1
             if (sU != sP) {
