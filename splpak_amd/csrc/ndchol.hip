@@ -25,6 +25,7 @@
 // diagonal blocks as in bandchol.hip.
 #include "plan.hpp"
 #include "ndtree.hpp"
+#include <functional>
 #include "chol_device.hpp"
 #include <hip/hip_ext.h>
 #include <algorithm>
@@ -1710,6 +1711,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     // chain stream; the Schur passes that become ready go to the update stream
     // (pin_potrf: the diagonal blocks go to the reserved CUs -- only once a Schur pass of the stage is running beside the chain:
     //  before the first one the chip is idle, and 16 blocks on 8 reserved CUs are two rounds of 140 us where one would do)
+    std::function<void()> after_solve;                   // (set for one call: launched on the update stream behind the step's panel solve)
     auto chain_step = [&](int stg, int k, bool pinned, bool pin_potrf) {
         hipStream_t sC = sP;
         const Launch &lp = s->l_potrf[(size_t)stg][(size_t)k], &lt = s->l_trsm[(size_t)stg][(size_t)k];
@@ -1725,6 +1727,12 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             launch_potrf(s, lp, sC, info_dev, minpiv_dev);
         if (lt.count)
             hipLaunchKernelGGL(nd_trsm_kernel, dim3(lt.grid), dim3(64), 0, sC, (const TrsmJob *)(s->trsm.dev + lt.first), lt.count);
+        if (after_solve) {
+            (void)hipEventRecord(s->evU, sC);
+            (void)hipStreamWaitEvent(sU, s->evU, 0);
+            after_solve();
+            after_solve = nullptr;
+        }
         if ((ls.count || lf0.count || lf1.count) && sU != sC) {
             (void)hipEventRecord(s->evT[(size_t)k], sC);
             (void)hipStreamWaitEvent(sU, s->evT[(size_t)k], 0);
@@ -1787,15 +1795,25 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     for (int i = 0; i < ns; ++i) {
         const NdStage &S = s->sc.st[(size_t)i];
         if (s->dist && !joined && S.depth <= s->dcut - 1) { dist_join(); joined = true; }
-        if (i > 0) {
+        // what comes alive with this stage: the Schur buffers are zeroed, the panels written (zeros + entries), on the update
+        // stream.  2.6 .. 3.5 GB of stores per stage at 64^3: beside the stage's FIRST diagonal blocks they made those 0.93 ms
+        // instead of 0.3 -- so they are launched behind the first block step of the chain (beside its panel update), when the
+        // update stream has nothing to do before that anyway (round 5)
+        auto stage_prep = [&]() {
             for (int x : s->starts[(size_t)i]) zero_block(x, sU);
-            if (s->staged_init && !s->dist) {
+            if (s->staged_init && !s->dist)
                 for (int x : s->istarts[(size_t)i]) {
                     nd_init_stage(s, p, x, sU);
                     if (s->sc.st[(size_t)x].dep < 0 && sU != sP) (void)hipEventRecord(s->evP[(size_t)x], sU);
                 }
-                if (S.dep < 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evP[(size_t)i], 0);   // (its panels were written one stage ago)
-            }
+        };
+        const int nsteps_i = (int)s->l_potrf[(size_t)i].size();
+        static const bool prep_late = std::getenv("SPLPAK_ND_PREP_EARLY") == nullptr;
+        const bool defer = prep_late && i > 0 && i != s->root_stage && sU != sP && nsteps_i >= 2 && !s->l_schur[(size_t)i][0].count &&
+                           !s->l_fin[0][(size_t)i][0].count && !s->l_fin[1][(size_t)i][0].count;
+        if (i > 0) {
+            if (!defer) stage_prep();
+            if (s->staged_init && !s->dist && S.dep < 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evP[(size_t)i], 0);   // (its panels were written one stage ago)
         }
         // the fronts' children have added their Schur complements (their last passes run on the update stream)
         if (s->fused && S.dep >= 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evF[(size_t)S.dep], 0);
@@ -1809,6 +1827,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         static const bool unpin_first = std::getenv("SPLPAK_ND_PIN_FIRST") == nullptr;
         bool pass_running = !unpin_first;
         for (int k = 0; k < steps; ++k) {
+            if (k == 0 && defer) after_solve = stage_prep;        // (behind the first diagonal blocks and panel solve of the chain)
             chain_step(i, k, pinned, pass_running);
             if (s->l_schur[(size_t)i][(size_t)k].count || s->l_fin[0][(size_t)i][(size_t)k].count || s->l_fin[1][(size_t)i][(size_t)k].count) pass_running = true;
         }
