@@ -913,6 +913,9 @@ struct NdState {
     std::vector<std::vector<Launch>> l_potrf, l_trsm, l_trsmb, l_upd, l_updr, l_updo, l_schur, l_mv, l_fwd, l_dot, l_bwd;
     std::vector<char> lookahead;                   // per depth: no Schur buffers (the root) -> the panel update is split: next block column on the chain, the rest beside it
     JobTable<SyrkJob> updr;
+    std::vector<char> chain_la;                    // [stage] look-ahead inside the groups of the chain: the in-group panel update of a step
+                                                   // is split into the next diagonal block (l_upd) and the rest (l_updr, same stream),
+                                                   // and the next step's diagonal blocks are factored on the reserved CUs beside the rest
     JobTable<SyrkJob> updo;                        // outer panel passes: K = 1024 update of the panel columns right of a group of blocks
     JobTable<SyrkJob> fin[2];                      // final Schur passes fused with the extend-add, by child slot
     std::vector<std::vector<Launch>> l_fin[2];
@@ -1066,6 +1069,7 @@ bool nd_build_factor_jobs(NdState *s)
     for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_updo, &s->l_schur}) L->assign((size_t)nstage, {});
     const bool two_level = std::getenv("SPLPAK_ND_NO_OUTER") == nullptr;
     s->lookahead.assign((size_t)nstage, 0);
+    s->chain_la.assign((size_t)nstage, 0);
     for (int sl = 0; sl < 2; ++sl) { s->l_fin[sl].assign((size_t)nstage, {}); s->l_add[sl].assign((size_t)nstage, Launch()); }
     s->l_zero.assign((size_t)nstage, Launch());
     s->l_init.assign((size_t)nstage, Launch());
@@ -1118,6 +1122,9 @@ bool nd_build_factor_jobs(NdState *s)
         // panel solve runs beside the trailing pass of this step instead of behind it (round 5); 1: only the next diagonal block
         // (round 4: the panel solve of every step, 50 us, waited for the trailing pass and was waited for by the next one)
         const bool la2 = la && !(std::getenv("SPLPAK_ND_ROOT_LA") && atoi(std::getenv("SPLPAK_ND_ROOT_LA")) == 1);
+        const int cla_blocks = std::getenv("SPLPAK_ND_CHAIN_LA") ? atoi(std::getenv("SPLPAK_ND_CHAIN_LA")) : 8;   // (64^3: 219.2 ms with 8, 219.9 with 16, 221.0 with 64 or 0)
+        const bool cla = !la && two_level && steps >= 2 && (int)ids.size() <= cla_blocks && !s->mdist;
+        s->chain_la[(size_t)stg] = cla ? 1 : 0;
         s->lookahead[(size_t)stg] = la ? (la2 ? 2 : 1) : 0;
         for (int k = 0; k < steps; ++k) {
             Launch lp, lt, ltb, lu, lur, luo, ls, lfin[2];
@@ -1171,7 +1178,31 @@ bool nd_build_factor_jobs(NdState *s)
                         int pg0 = 0, pgend = 0;
                         group_of(k, f.nsteps, pg0, pgend);
                         const int nc_in = std::min(nc, (pgend - k) * 4);
-                        if (nc_in > 0) {
+                        if (nc_in > 0 && cla) {
+                            // look-ahead inside the group: the next diagonal block first, the rest of the group's columns behind it
+                            const int n4 = std::min(nc_in, 4);
+                            SyrkJob a = proto;
+                            a.nc = n4; a.nr = std::min(nr, 4); a.item0 = (int)ui;
+                            s->upd.host.push_back(a);
+                            ui += trapezoid_items(a.nc, a.nr);
+                            ++lu.count;
+                            if (nr > 4) {
+                                SyrkJob r = proto;
+                                r.nc = n4; r.nr = nr; r.item0 = (int)uri; r.zinit = -4;
+                                s->updr.host.push_back(r);
+                                uri += (long long)n4 * (nr - 4);
+                                ++lur.count;
+                            }
+                            if (nc_in > 4) {
+                                SyrkJob t2 = proto;
+                                t2.P = below + 256;
+                                t2.C = below + (long long)256 * f.ld + 256 + (long long)256 * f.ld;
+                                t2.nc = nc_in - 4; t2.nr = nr - 4; t2.item0 = (int)uri;
+                                s->updr.host.push_back(t2);
+                                uri += trapezoid_items(nc_in - 4, nr - 4);
+                                ++lur.count;
+                            }
+                        } else if (nc_in > 0) {
                             SyrkJob a = proto;
                             a.nc = nc_in; a.nr = nr; a.item0 = (int)ui;
                             s->upd.host.push_back(a);
@@ -1712,14 +1743,19 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     // (pin_potrf: the diagonal blocks go to the reserved CUs -- only once a Schur pass of the stage is running beside the chain:
     //  before the first one the chip is idle, and 16 blocks on 8 reserved CUs are two rounds of 140 us where one would do)
     std::function<void()> after_solve;                   // (set for one call: launched on the update stream behind the step's panel solve)
+    int la_evt = -1;                                     // step whose next-diagonal-block update is marked by evW (look-ahead inside a group)
     auto chain_step = [&](int stg, int k, bool pinned, bool pin_potrf) {
         hipStream_t sC = sP;
         const Launch &lp = s->l_potrf[(size_t)stg][(size_t)k], &lt = s->l_trsm[(size_t)stg][(size_t)k];
         const Launch &lu = s->l_upd[(size_t)stg][(size_t)k], &ls = s->l_schur[(size_t)stg][(size_t)k];
         const Launch &lf0 = s->l_fin[0][(size_t)stg][(size_t)k], &lf1 = s->l_fin[1][(size_t)stg][(size_t)k];
-        if (pinned && pin_potrf) {           // two event hops: chain -> reserved CUs -> chain
-            (void)hipEventRecord(s->evR0, sC);
-            (void)hipStreamWaitEvent(sR, s->evR0, 0);
+        const bool ahead = pinned && k > 0 && la_evt == k - 1;    // these diagonal blocks were updated before the rest of step k - 1
+        if (pinned && (pin_potrf || ahead)) {           // two event hops: chain -> reserved CUs -> chain
+            if (ahead) (void)hipStreamWaitEvent(sR, s->evW[(size_t)(k - 1)], 0);
+            else {
+                (void)hipEventRecord(s->evR0, sC);
+                (void)hipStreamWaitEvent(sR, s->evR0, 0);
+            }
             launch_potrf(s, lp, sR, info_dev, minpiv_dev);
             (void)hipEventRecord(s->evI[(size_t)k], sR);
             (void)hipStreamWaitEvent(sC, s->evI[(size_t)k], 0);
@@ -1738,6 +1774,13 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             (void)hipStreamWaitEvent(sU, s->evT[(size_t)k], 0);
         }
         launch_syrk(s, s->upd, lu, sC, stats, timing, false, pinned, qnext);
+        if (s->chain_la[(size_t)stg] && s->l_updr[(size_t)stg][(size_t)k].count) {      // the rest of the in-group update, behind the next diagonal block
+            if (pinned) {
+                (void)hipEventRecord(s->evW[(size_t)k], sC);
+                la_evt = k;
+            }
+            launch_syrk(s, s->updr, s->l_updr[(size_t)stg][(size_t)k], sC, stats, timing, false, pinned, qnext);
+        }
         launch_syrk(s, s->updo, s->l_updo[(size_t)stg][(size_t)k], sC, stats, timing, false, pinned, qnext);     // the group's outer panel pass
         launch_syrk(s, s->schur, ls, sU, stats, timing, true, pinned, qnext);
         launch_syrk(s, s->fin[0], lf0, sU, stats, timing, true, pinned, qnext);      // final passes, fused with the extend-add:
@@ -1818,12 +1861,17 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         // the fronts' children have added their Schur complements (their last passes run on the update stream)
         if (s->fused && S.dep >= 0 && sU != sP) (void)hipStreamWaitEvent(sP, s->evF[(size_t)S.dep], 0);
         if (i == s->root_stage) {
+            la_evt = -1;
             root_stage(i);
             continue;
         }
         const int steps = (int)s->l_potrf[(size_t)i].size();
         ensure_events(steps);
-        const bool pinned = sR != nullptr && s->nres > 0 && steps > 0 && (int)s->l_potrf[(size_t)i][0].grid <= pin_rounds * s->nres;
+        // (a stage with look-ahead inside its groups uses the reserved CUs whatever the number of rounds: its diagonal blocks are
+        //  factored beside the rest of the previous step's update)
+        const bool pinned = sR != nullptr && s->nres > 0 && steps > 0 &&
+                            ((int)s->l_potrf[(size_t)i][0].grid <= pin_rounds * s->nres || s->chain_la[(size_t)i]);
+        la_evt = -1;
         static const bool unpin_first = std::getenv("SPLPAK_ND_PIN_FIRST") == nullptr;
         bool pass_running = !unpin_first;
         for (int k = 0; k < steps; ++k) {

@@ -304,7 +304,7 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
                 {"SPLPAK_ND_CUT": "1"}, {"SPLPAK_ND_CUT": "2"}, {"SPLPAK_ND_CUT": "3", "SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_CUT": "4", "SPLPAK_ND_SQUARE": "1"},
                 {"SPLPAK_ND_CUT": "6"}, {"SPLPAK_ND_CUT": "2", "SPLPAK_ND_NO_FUSE": "1"}, {"SPLPAK_ND_SQUARE": "1"}, {"SPLPAK_ND_NO_OUTER": "1"}, {"SPLPAK_ND_SMALL_GRID": "0"}, {"SPLPAK_ND_WG4": "2"}, {"SPLPAK_ND_POTRF_WAVES": "4"}, {"SPLPAK_ND_POTRF_WAVES": "16"}, {"SPLPAK_ND_SMALL_QUEUE": "1"}, {"SPLPAK_ND_FULL_DIAG": "1"}, {"SPLPAK_ND_XCD": "0"},
                 {"SPLPAK_ND_NO_FUSE": "1", "SPLPAK_ND_SQUARE": "1", "SPLPAK_ND_KB": "2"},
-                {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_RES_CUS": "3", "SPLPAK_ND_PIN_ROUNDS": "8"}, {"SPLPAK_ND_PIN_FIRST": "1", "SPLPAK_ND_PIN_ROUNDS": "2"}, {"SPLPAK_ND_PREP_EARLY": "1"},
+                {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_RES_CUS": "3", "SPLPAK_ND_PIN_ROUNDS": "8"}, {"SPLPAK_ND_PIN_FIRST": "1", "SPLPAK_ND_PIN_ROUNDS": "2"}, {"SPLPAK_ND_PREP_EARLY": "1"}, {"SPLPAK_ND_CHAIN_LA": "0"}, {"SPLPAK_ND_CHAIN_LA": "64"},
                 # the panels written stage by stage (nd_init_kernel, the default) | cleared as a whole, then scattered into
                 {"SPLPAK_ND_STAGED_INIT": "0"}, {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_CLEAR_WGS": "0"}, {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_NO_EARLY_CLEAR": "1"},
                 {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_CUT": "2"},
