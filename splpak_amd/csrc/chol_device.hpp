@@ -328,7 +328,11 @@ __device__ __forceinline__ void potrf_strip_body(double *__restrict__ A, long lo
 // EYE: the right-hand side is the identity (rows r0.. of it, never read from memory), X has its own leading
 // dimension ldx and is also stored transposed into Xt: X = L^{-T}, i.e. the inverse of the diagonal block
 // (trinv_kernel below).
-template <bool EYE>
+// KREG (round 5): the first KREG finished blocks are parked in registers, not in LDS -- the operand a later product needs from
+// a parked block is the value the SAME lane produced (accumulator register v = k-step s), so LDS is only storage here, and at
+// 30 KB per wave it held the panel solves to 5 waves per CU; with 6 blocks in registers xs is (NBLK - 16 - 16 KREG) x 16
+// doubles = 18 KB and 8 waves fit.
+template <bool EYE, int KREG = 0>
 __device__ __forceinline__ void trsm_rows(const double *__restrict__ L, double *__restrict__ Xbase, long long lda,
                                           long long ldx, const double *__restrict__ inv16, double *__restrict__ Xt,
                                           int r0, double *__restrict__ xs, int ncb = NBLK / 16)
@@ -338,6 +342,7 @@ __device__ __forceinline__ void trsm_rows(const double *__restrict__ L, double *
     constexpr int NCB = NBLK / 16;
 
     double lb[NCB - 1][4];        // lb[kb][s] = L(16 cb + l15, 16 kb + 4 s + q), block row cb (then cb+1)
+    double xp[KREG > 0 ? KREG : 1][4];       // parked blocks 0 .. KREG-1 (negated), this lane's four values of each
     d4_t Tn;
 #pragma unroll
     for (int v = 0; v < 4; ++v) Tn[v] = EYE ? (r0 + l15 == q + 4 * v ? 1.0 : 0.0) : Xr[(long long)(q + 4 * v) * ldx];
@@ -359,8 +364,13 @@ __device__ __forceinline__ void trsm_rows(const double *__restrict__ L, double *
         for (int kb = 0; kb < NCB - 1; ++kb) {
             if (kb < cb) {
                 double bq[4];
+                if (kb < KREG) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) bq[s] = xs[(16 * kb + 4 * s + q) * 16 + l15];
+                    for (int s = 0; s < 4; ++s) bq[s] = xp[kb < KREG ? kb : 0][s];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bq[s] = xs[(16 * (kb - KREG) + 4 * s + q) * 16 + l15];
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) T = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[kb][s], bq[s], T, 0, 0, 0);
             }
@@ -377,7 +387,15 @@ __device__ __forceinline__ void trsm_rows(const double *__restrict__ L, double *
             const int c = 16 * cb + q + 4 * v;
             Xr[(long long)c * ldx] = X[v];
             if (EYE) Xt[(long long)(r0 + l15) * ldx + c] = X[v];
-            if (more) xs[c * 16 + l15] = -X[v];
+            if (more && cb >= KREG) xs[(c - 16 * KREG) * 16 + l15] = -X[v];
+        }
+        if (more && cb < KREG) {
+#pragma unroll
+            for (int kk = 0; kk < KREG; ++kk)
+                if (cb == kk) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) xp[kk][v] = -X[v];
+                }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

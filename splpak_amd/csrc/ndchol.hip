@@ -132,22 +132,24 @@ nd_potrf_kernel(const PotrfJob *__restrict__ jobs, int *__restrict__ info, doubl
 __global__ void __launch_bounds__(64)
 nd_trsm_kernel(const TrsmJob *__restrict__ jobs, int njobs)
 {
-    __shared__ double xs[(NBLK - 16) * 16];
+    constexpr int KREG = 6;                     // parked blocks in registers (chol_device.hpp: trsm_rows): 18 KB of LDS per wave, 8 waves per CU
+    __shared__ double xs[(NBLK - 16 - 16 * KREG) * 16];
     const int b = blockIdx.x;
     const int ji = find_job(jobs, njobs, b, [](const TrsmJob &t) { return t.wg0; });
     const TrsmJob j = jobs[ji];
     const int r0 = (b - j.wg0) * 16;
     if (r0 >= j.nrows) return;
     __builtin_amdgcn_s_setprio(3);
-    trsm_rows<false>(j.L, j.X, j.ld, j.ld, j.inv16, nullptr, r0, xs, j.ncb);
+    trsm_rows<false, KREG>(j.L, j.X, j.ld, j.ld, j.inv16, nullptr, r0, xs, j.ncb);
 }
 
 __global__ void __launch_bounds__(64)
 nd_trinv_kernel(const TrinvJob *__restrict__ jobs)
 {
-    __shared__ double xs[(NBLK - 16) * 16];
+    constexpr int KREG = 6;                     // (as in nd_trsm_kernel)
+    __shared__ double xs[(NBLK - 16 - 16 * KREG) * 16];
     const TrinvJob j = jobs[blockIdx.y];
-    trsm_rows<true>(j.L, j.dinv, j.ld, NBLK, j.inv16, j.dinvt, blockIdx.x * 16, xs);
+    trsm_rows<true, KREG>(j.L, j.dinv, j.ld, NBLK, j.inv16, j.dinvt, blockIdx.x * 16, xs);
 }
 
 // ints per item queue: [0] item counter, [1] waves that stepped aside, [2 .. 9] item counters of the eight XCD slices (xmode)
