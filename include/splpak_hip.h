@@ -188,8 +188,20 @@ int64_t splpak_plan_device_bytes(const splpak_plan *plan);
  * (src/splpak.F90:1516-1619): returns 0 band Cholesky (four-stream pipeline), 1 its narrow form, 2 two-ended band,
  * 3 band distributed over several GPUs, 4 nested-dissection multifrontal (2-D / 3-D grids of >= 4 096 columns, 4-D grids of
  * >= 20 000), 5 the same distributed over the GPUs of a one-process multi-GPU plan (subtrees per GPU, the fronts above them by
- * block columns); a description is copied into buf. */
+ * block columns), 6 NO factorisation: the iterative solve below (grids whose factor does not fit the device, or by request);
+ * a description is copied into buf. */
 int32_t splpak_plan_factorisation(const splpak_plan *plan, char *buf, int32_t buflen);
+/* The iterative solve (round 6; csrc/pcg.hip): preconditioned conjugate gradients on the normal equations with the operator
+ * applied from the rows (data rows :788-855, constraint rows :921-1046) and a separable preconditioner, inside the same
+ * refinement against the rows as the factorisations.  It replaces suprls (:1375-1695) for the grids the reference accepts
+ * (any grid, :512-534) and no factorisation fits: BASELINE config 5's 4-D 32^4 grid on one GPU.  Selected automatically when
+ * the factor storage cannot be allocated, or with SPLPAK_SOLVER=pcg (iteration only) / pcg+direct (iteration first, the
+ * factorisation when it stagnates) in the environment at plan creation.  A fit whose iteration stagnates and whose plan
+ * has no factorisation returns 107 with an explanatory message.
+ * out6: [0] iterations of the last fit over all its solves, [1] solves, [2] iterations of the last solve, [3] its final
+ * preconditioned residual (relative), [4] [5] the preconditioner's two moments (density of w^2, mean squared constraint weight);
+ * zeros for a plan without the iteration. */
+void splpak_plan_pcg_stats(const splpak_plan *plan, double *out6);
 
 /* Per-kernel accounting of the last splpak_plan_fit_dev call, measured with HIP
  * events on the stream the kernels ran on (bench.py's roofline object).  Every BULK

@@ -32,7 +32,7 @@ SYMBOLS = [
     "splpak_eval_dev_f64", "splpak_eval_dev_f32", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
     "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_rank_bytes", "splpak_mplan_factorisation", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
-    "splpak_plan_device_bytes",
+    "splpak_plan_device_bytes", "splpak_plan_pcg_stats",
     "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_debug_nd_partition", "splpak_debug_nd_schedule", "splpak_debug_window_values", "splpak_shutdown", "splpak_set_eval_mode",
     "splpak_last_error_message", "splpak_device_name",
 ]
@@ -145,6 +145,8 @@ def lib() -> C.CDLL:
     L.splpak_mplan_factorisation.argtypes = [vp, C.c_char_p, i32]
     L.splpak_mplan_rank_bytes.restype = i64
     L.splpak_mplan_rank_bytes.argtypes = [vp, i32]
+    L.splpak_plan_pcg_stats.restype = None
+    L.splpak_plan_pcg_stats.argtypes = [vp, _dp]
     L.splpak_plan_device_bytes.restype = i64
     L.splpak_plan_device_bytes.argtypes = [vp]
     L.splpak_mplan_fit_dev.restype = i32
@@ -451,6 +453,13 @@ class Plan:
 
     def device_bytes(self):
         return int(self._L.splpak_plan_device_bytes(self._h))
+
+    def pcg_stats(self):
+        """Iterative solve of the last fit: dict(iterations, solves, last_iterations, last_residual, rho, lam); zeros without it."""
+        out = np.zeros(6)
+        self._L.splpak_plan_pcg_stats(self._h, _p(out, _dp))
+        return dict(iterations=int(out[0]), solves=int(out[1]), last_iterations=int(out[2]), last_residual=float(out[3]),
+                    rho=float(out[4]), lam=float(out[5]))
 
     def set_rccl(self, comm, rank, world):
         """The library's own RCCL hook (no Python in the reductions): `comm` is an ncclComm_t as an integer / c_void_p."""

@@ -715,7 +715,7 @@ __device__ inline void stage_points(const Grid &g, const double *__restrict__ xs
 #pragma unroll
             for (int k = 0; k < 4; ++k) tab[(p * D + d) * 4 + k] = b[k];
         }
-        wy[p] = wv * ys[p0 + p];
+        wy[p] = ys ? wv * ys[p0 + p] : 0.0;      // (ys == NULL: the rows applied to a vector, residual pass as operator -- pcg.hip)
         wt[p] = wv;
         if (hslot) {
             const int sl = nearest_slot<D>(g, xv);
@@ -1555,7 +1555,7 @@ residual_wave_kernel(Grid g, const int *__restrict__ offset, const double *__res
                             for (int k0 = 0; k0 < 4; ++k0) t = fma(u[k1][k0] * b[2][k2], xl[k0 + 4 * k1 + 16 * k2], t);
                 }
             }
-            const double e = wv * ys[p0 + lane] - t;              // row residual  w y - (w b) . x
+            const double e = (ys ? wv * ys[p0 + lane] : 0.0) - t; // row residual  w y - (w b) . x  (ys == NULL: -(w b) . x, the rows as an operator)
             we[lane] = e;
             sw[lane] = wv;
             e2 = fma(e, e, e2);
@@ -1629,7 +1629,7 @@ residual_cell4_kernel(Grid g, const int *__restrict__ offset, const double *__re
                 for (int k = 0; k < 4; ++k) tab[tid * LDT + 4 * d + k] = b[k];
             }
             sw[tid] = ws[p0 + tid];
-            sy[tid] = ys[p0 + tid];
+            sy[tid] = ys ? ys[p0 + tid] : 0.0;      // (ys == NULL: the rows as an operator, rho = -N x: pcg.hip)
         }
         __syncthreads();
         if (lane < np) {                        // slab k3 = wave of the window sum of point `lane`

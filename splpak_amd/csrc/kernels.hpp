@@ -32,7 +32,7 @@ hipError_t launch_synth_queries(int ndim, long long skip_draws, long long nq, do
 
 // ---- assemble.hip
 // scalars (device doubles) written by the assembly kernels
-enum { SC_TOTLWT = 0, SC_NROWS_DATA = 1, SC_NROWS_CONS = 2, SC_ERRFLAG = 3, SC_COUNT = 8 };
+enum { SC_TOTLWT = 0, SC_NROWS_DATA = 1, SC_NROWS_CONS = 2, SC_ERRFLAG = 3, SC_SUMW2 = 4 /* pcg.hip: sum of w^2 */, SC_COUNT = 8 };
 
 struct SortScratch {
     int *key;        // [max_ndata] cell key per point (ncell = zero-weight sentinel)

@@ -1,0 +1,576 @@
+// Iterative solve of the fit's least-squares problem: preconditioned conjugate gradients on the normal equations, with the
+// operator applied MATRIX-FREE FROM THE ROWS and a separable ("fast diagonalisation") preconditioner (round 6).
+//
+// Why: the direct factorisations need O(n^1.5) .. O(n^2) reals -- BASELINE config 5's grid (4-D, 32^4 = 1 048 576 columns) takes
+// 476 GB of nested-dissection panels (band: 851 GB) against 309 GB of HBM, while its rows are 0.4 GB of points.  The reference
+// accepts any grid (src/splpak.F90:512-534); SURVEY section 7.2-H3 names PCG beside the two factorisations.
+//
+//   operator      q = N p = A^T W^2 A p + C^T C p from the rows themselves: the refinement's residual pass (assemble.hip:
+//                 launch_residual) run with y = 0.  At 32^4 / 1e7 points the rows are 0.4 GB of sorted points and the per-cell
+//                 shares 1.45 GB, the assembled half stencil would be 10 GB per product.  The residual the iteration works on is
+//                 therefore the one the fit is judged by (rows, not the rounded N).
+//   preconditioner  E[N] for uniformly scattered points and uniformly scattered data-sparse nodes is separable:
+//                     E[N] = rho (x)_k M_k  +  lambda [ sum_i K2_i (x)_{k != i} K0_k  +  4 sum_{i<j} K1_i K1_j (x)_{k != i,j} K0_k ],
+//                 M_k the 1-D mass matrix of the basis, K0/K1/K2 the Gram matrices of its values / first / second derivatives at
+//                 the nodes (the constraint rows' factors, :921-1046; boundary nodes use the first derivative, :998).  Per
+//                 dimension the generalised eigenvectors V_k of (K2_k, K0_k) diagonalise two of the four matrices exactly and the
+//                 other two nearly (all four are Toeplitz away from the ends); M^-1 = V diag^-1 V^T with V = (x)_k V_k costs
+//                 2 d mode products of nodes_k x nodes_k matrices (0.5 GFLOP at 32^4) -- nothing beside one pass over the rows.
+//   outer loop    the fit's own refinement against the rows (plan.hip) with this solve in place of the triangular solves.
+//
+// Where it works and where it does not (measured): the preconditioner knows the DENSITY of data-sparse nodes,
+// not where they are.  4-D at config 5's density (26 % of the nodes data sparse, 10 rows each: the constraint rows alone have
+// full column rank) converges in a few hundred iterations, slowly growing with the grid.  3-D grids (6 rows per sparse node) at
+// 8 .. 25 % leave half of the spectrum to the data rows, 10^8 below the constraint rows: > 3 000 iterations at 24^3, the direct
+// factorisation wins by far.  Hence: automatic only when no factorisation fits the device; a stagnation rule hands over to the
+// factorisation when the plan has one, and reports 107 when it has not.
+#include "plan.hpp"
+#include "basis.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace splpak {
+
+namespace {
+
+constexpr int DOT_BLOCKS = 512;
+
+// ---- host: small dense symmetric eigenproblems (nodes_k x nodes_k, once per plan) ------------------------------------------
+// cyclic Jacobi: A (n x n, symmetric, row-major) -> eigenvalues in w, eigenvectors in the COLUMNS of U
+void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &w, std::vector<double> &U)
+{
+    U.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) U[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < n; ++i) {
+            dg += A[(size_t)i * n + i] * A[(size_t)i * n + i];
+            for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+        }
+        if (off <= 1e-30 * dg || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {           // columns p, q
+                    const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                    A[(size_t)k * n + p] = c * akp - s * akq;
+                    A[(size_t)k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {           // rows p, q
+                    const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                    A[(size_t)p * n + k] = c * apk - s * aqk;
+                    A[(size_t)q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double ukp = U[(size_t)k * n + p], ukq = U[(size_t)k * n + q];
+                    U[(size_t)k * n + p] = c * ukp - s * ukq;
+                    U[(size_t)k * n + q] = s * ukp + c * ukq;
+                }
+            }
+    }
+    w.resize((size_t)n);
+    for (int i = 0; i < n; ++i) w[(size_t)i] = A[(size_t)i * n + i];
+}
+
+// generalised problem K v = w B v, B positive definite: V^T B V = I, V^T K V = diag(w); V row-major, eigenvectors in columns
+bool gen_eig(int n, const std::vector<double> &K, const std::vector<double> &B, std::vector<double> &w, std::vector<double> &V)
+{
+    std::vector<double> L(B);                           // B = L L^T
+    for (int j = 0; j < n; ++j) {
+        double d = L[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+        if (!(d > 0.0)) return false;
+        d = std::sqrt(d);
+        L[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = L[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+            L[(size_t)i * n + j] = s / d;
+        }
+        for (int i = 0; i < j; ++i) L[(size_t)i * n + j] = 0.0;
+    }
+    // C = L^-1 K L^-T
+    std::vector<double> C(K);
+    for (int c = 0; c < n; ++c)                          // L^-1 K (column by column: forward substitution)
+        for (int i = 0; i < n; ++i) {
+            double s = C[(size_t)i * n + c];
+            for (int k = 0; k < i; ++k) s -= L[(size_t)i * n + k] * C[(size_t)k * n + c];
+            C[(size_t)i * n + c] = s / L[(size_t)i * n + i];
+        }
+    for (int r = 0; r < n; ++r)                          // (.) L^-T (row by row)
+        for (int i = 0; i < n; ++i) {
+            double s = C[(size_t)r * n + i];
+            for (int k = 0; k < i; ++k) s -= L[(size_t)i * n + k] * C[(size_t)r * n + k];
+            C[(size_t)r * n + i] = s / L[(size_t)i * n + i];
+        }
+    for (int i = 0; i < n; ++i)                          // symmetrise the rounding
+        for (int j = i + 1; j < n; ++j) C[(size_t)i * n + j] = C[(size_t)j * n + i] = 0.5 * (C[(size_t)i * n + j] + C[(size_t)j * n + i]);
+    std::vector<double> U;
+    jacobi_eig(n, C, w, U);
+    // V = L^-T U (back substitution per column)
+    V.assign((size_t)n * n, 0.0);
+    for (int c = 0; c < n; ++c)
+        for (int i = n - 1; i >= 0; --i) {
+            double s = U[(size_t)i * n + c];
+            for (int k = i + 1; k < n; ++k) s -= L[(size_t)k * n + i] * V[(size_t)k * n + c];
+            V[(size_t)i * n + c] = s / L[(size_t)i * n + i];
+        }
+    return true;
+}
+
+// diag(V^T X V)
+void congruence_diag(int n, const std::vector<double> &V, const std::vector<double> &X, std::vector<double> &out)
+{
+    out.assign((size_t)n, 0.0);
+    std::vector<double> t((size_t)n);
+    for (int j = 0; j < n; ++j) {
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += X[(size_t)i * n + k] * V[(size_t)k * n + j];
+            t[(size_t)i] = s;
+        }
+        double d = 0.0;
+        for (int i = 0; i < n; ++i) d += V[(size_t)i * n + j] * t[(size_t)i];
+        out[(size_t)j] = d;
+    }
+}
+
+// ---- kernels ----------------------------------------------------------------------------------------------------------------
+// Y[o][j][in] = sum_i MT[i * nk + j] X[o][i][in] (mode product along one dimension), optionally scaled elementwise
+__global__ void __launch_bounds__(256)
+mode_product_kernel(int nk, long long inner, long long total, const double *__restrict__ MT, const double *__restrict__ X,
+                    double *__restrict__ Y, const double *__restrict__ scale)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long long in = e % inner, t = e / inner;
+    const int j = (int)(t % nk);
+    const long long o = t / nk;
+    const double *__restrict__ xb = X + (o * nk) * inner + in;
+    double acc = 0.0;
+    for (int i = 0; i < nk; ++i) acc = fma(MT[(long long)i * nk + j], xb[(long long)i * inner], acc);
+    if (scale) acc *= scale[e];
+    Y[e] = acc;
+}
+
+struct EvTabs {             // per-dimension diagonals in the eigenbasis (device arrays of nodes_k doubles each)
+    const double *mu[MAXD], *k0[MAXD], *d1[MAXD], *l2[MAXD];
+};
+
+// 1 / (rho prod mu + lambda (sum_i l2_i prod_{k != i} k0_k + 4 sum_{i<j} d1_i d1_j prod_{k != i,j} k0_k))
+__global__ void __launch_bounds__(256)
+fd_diag_kernel(Grid g, EvTabs tb, double rho, double lambda, double *__restrict__ dinv)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.ncol) return;
+    double mu[MAXD], k0[MAXD], d1[MAXD], l2[MAXD];
+    for (int k = 0; k < g.ndim; ++k) {
+        const int j = (e / g.colstride[k]) % g.nodes[k];
+        mu[k] = tb.mu[k][j]; k0[k] = tb.k0[k][j]; d1[k] = tb.d1[k][j]; l2[k] = tb.l2[k][j];
+    }
+    double dm = rho, pen = 0.0;
+    for (int k = 0; k < g.ndim; ++k) dm *= mu[k];
+    for (int i = 0; i < g.ndim; ++i) {
+        double t = l2[i];
+        for (int k = 0; k < g.ndim; ++k) if (k != i) t *= k0[k];
+        pen += t;
+        for (int j = i + 1; j < g.ndim; ++j) {
+            double u = 4.0 * d1[i] * d1[j];
+            for (int k = 0; k < g.ndim; ++k) if (k != i && k != j) u *= k0[k];
+            pen += u;
+        }
+    }
+    dinv[e] = 1.0 / (dm + lambda * pen);
+}
+
+// partial[b] = sum over block b's contiguous chunk of a[i] * b[i] (fixed order: reproducible)
+__global__ void __launch_bounds__(256)
+dot_partial_kernel(long long n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ partial)
+{
+    __shared__ double red[256];
+    const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+    const long long beg = (long long)blockIdx.x * chunk, end = beg + chunk < n ? beg + chunk : n;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    long long i = beg + threadIdx.x;
+    for (; i + 768 < end; i += 1024) {
+        s0 = fma(a[i], b[i], s0);
+        s1 = fma(a[i + 256], b[i + 256], s1);
+        s2 = fma(a[i + 512], b[i + 512], s2);
+        s3 = fma(a[i + 768], b[i + 768], s3);
+    }
+    for (; i < end; i += 256) s0 = fma(a[i], b[i], s0);
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// sc[slot] = sign * sum(partial); hist != NULL: also hist[0] = that value
+__global__ void __launch_bounds__(DOT_BLOCKS)
+dot_finish_kernel(const double *__restrict__ partial, double sign, double *__restrict__ sc, int slot, double *__restrict__ hist)
+{
+    __shared__ double red[DOT_BLOCKS];
+    red[threadIdx.x] = partial[threadIdx.x];
+    __syncthreads();
+    for (int o = DOT_BLOCKS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double v = sign * red[0];
+        sc[slot] = v;
+        if (hist) hist[0] = v;
+    }
+}
+
+enum { S_RZ = 0, S_PQ = 1, S_RZNEW = 2, S_COUNT = 8 };
+
+// alpha = rz / pq;  x += alpha p;  r += alpha nq   (nq = -N p, the residual pass's sign)
+__global__ void __launch_bounds__(256)
+update_xr_kernel(long long n, const double *__restrict__ sc, double *__restrict__ x, double *__restrict__ r,
+                 const double *__restrict__ pv, const double *__restrict__ nq)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double pq = sc[S_PQ];
+    const double alpha = pq > 0.0 ? sc[S_RZ] / pq : 0.0;
+    x[i] = fma(alpha, pv[i], x[i]);
+    r[i] = fma(alpha, nq[i], r[i]);
+}
+
+// beta = rz_new / rz;  p = z + beta p
+__global__ void __launch_bounds__(256)
+update_p_kernel(long long n, const double *__restrict__ sc, double *__restrict__ pv, const double *__restrict__ z)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double rz = sc[S_RZ];
+    const double beta = rz > 0.0 ? sc[S_RZNEW] / rz : 0.0;
+    pv[i] = fma(beta, pv[i], z[i]);
+}
+
+__global__ void advance_kernel(double *__restrict__ sc) { sc[S_RZ] = sc[S_RZNEW]; }
+
+// out[0] = sum of w^2 over the sorted points [0, offset[ncell]) -- the zero-weight points sit behind them (fixed order)
+__global__ void __launch_bounds__(1024)
+fd_sumw2_kernel(const double *__restrict__ ws, const int *__restrict__ offset, int ncell, double *__restrict__ out)
+{
+    __shared__ double red[1024];
+    const int t = threadIdx.x;
+    const long long m = offset[ncell];
+    double s0 = 0.0, s1 = 0.0;
+    long long i = t;
+    for (; i + 1024 < m; i += 2048) { s0 = fma(ws[i], ws[i], s0); s1 = fma(ws[i + 1024], ws[i + 1024], s1); }
+    if (i < m) s0 = fma(ws[i], ws[i], s0);
+    red[t] = s0 + s1;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) out[0] = red[0];
+}
+
+// out[0] = sum over the nodes of (data sparse ? dcw^2 : 0)  (fixed order)
+__global__ void __launch_bounds__(1024)
+fd_lambda_kernel(const double *__restrict__ dcw, const unsigned char *__restrict__ spf, int ncol, double *__restrict__ out)
+{
+    __shared__ double red[1024];
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int i = t; i < ncol; i += 1024) if (spf[i]) s = fma(dcw[i], dcw[i], s);
+    red[t] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) out[0] = red[0];
+}
+
+}  // namespace
+
+struct PcgState {
+    int device = 0;
+    Grid g{};
+    double *V[MAXD] = {nullptr, nullptr, nullptr, nullptr};      // V_k row-major (component i of eigenvector j at [i * n + j])
+    double *VT[MAXD] = {nullptr, nullptr, nullptr, nullptr};     // its transpose
+    double *tabs = nullptr;                                      // mu | k0 | d1 | l2 per dimension
+    EvTabs ev{};
+    double *dinv = nullptr;
+    double *bvec = nullptr, *x = nullptr, *r = nullptr, *z = nullptr, *pv = nullptr, *t1 = nullptr, *t2 = nullptr;
+    double *partial = nullptr, *sc = nullptr, *hist = nullptr, *mom = nullptr;
+    std::vector<double> hhist;
+    int maxit = 4000;
+    std::vector<void *> owned;
+    size_t bytes = 0;
+    // statistics of the last fit
+    int total_iters = 0, solves = 0, last_iters = 0;
+    double last_rel = 0.0, rho = 0.0, lambda = 0.0;
+    bool failed = false;
+};
+
+static bool pcg_alloc(PcgState *s, double **q, size_t count)
+{
+    void *v = nullptr;
+    if (count == 0) count = 1;
+    if (hipMalloc(&v, count * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("pcg: device allocation failed");
+        return false;
+    }
+    s->owned.push_back(v);
+    s->bytes += count * sizeof(double);
+    *q = static_cast<double *>(v);
+    return true;
+}
+
+void pcg_destroy(PcgState *s)
+{
+    if (!s) return;
+    for (void *q : s->owned) (void)hipFree(q);
+    delete s;
+}
+
+size_t pcg_bytes(const PcgState *s) { return s ? s->bytes : 0; }
+
+void pcg_stats(const PcgState *s, double *out6)
+{
+    if (!s || !out6) return;
+    out6[0] = s->total_iters; out6[1] = s->solves; out6[2] = s->last_iters; out6[3] = s->last_rel; out6[4] = s->rho; out6[5] = s->lambda;
+}
+
+// Builds the separable preconditioner's per-dimension matrices for the plan's grid (internal dimension order).
+// 0, or an SPLPAK_E_* code.
+int pcg_attach(splpak_plan *p, PcgState **out)
+{
+    *out = nullptr;
+    const Grid &g = p->g;
+    for (int k = 0; k < g.ndim; ++k)
+        if (g.nodes[k] > 512) { set_error("pcg: more than 512 nodes in one dimension (the per-dimension eigenproblems are dense)"); return SPLPAK_E_UNSUPPORTED; }
+    PcgState *s = new PcgState();
+    (void)hipGetDevice(&s->device);
+    s->g = g;
+    if (const char *e = std::getenv("SPLPAK_PCG_MAXIT")) s->maxit = std::max(1, atoi(e));
+    bool ok = true;
+    long long ntab = 0;
+    for (int k = 0; k < g.ndim; ++k) ntab += 4LL * g.nodes[k];
+    ok = ok && pcg_alloc(s, &s->tabs, (size_t)ntab);
+    std::vector<double> htabs((size_t)ntab);
+    long long toff = 0;
+    const double qb = 0.5;          // boundary nodes: half the expected weight (:928) -> a quarter of dcw^2, about twice as often sparse
+    for (int k = 0; k < g.ndim && ok; ++k) {
+        const int n = g.nodes[k];
+        const double dx = g.dx[k], s1 = g.dxin[k], x0 = g.xmin[k];
+        std::vector<double> T0((size_t)n * n, 0.0), T1(T0), T2(T0), M(T0), K0(T0), K1(T0), K2(T0);
+        for (int nd = 0; nd < n; ++nd)
+            for (int ib = std::max(0, nd - 1); ib <= std::min(n - 1, nd + 1); ++ib) {
+                const double xn = x0 + (double)nd * dx, xb = x0 + (double)ib * dx;
+                const int kind = basis_kind(ib, n);
+                T0[(size_t)nd * n + ib] = basis_1d(kind, 0, xn, xb, s1);
+                T1[(size_t)nd * n + ib] = basis_1d(kind, 1, xn, xb, s1);
+                T2[(size_t)nd * n + ib] = basis_1d(kind, (nd == 0 || nd == n - 1) ? 1 : 2, xn, xb, s1);      // :998
+            }
+        // mass matrix: 6-point Gauss-Legendre per interval (the integrand is a polynomial of degree 6)
+        static const double gp[6] = {-0.932469514203152, -0.661209386466265, -0.238619186083197, 0.238619186083197, 0.661209386466265, 0.932469514203152};
+        static const double gw[6] = {0.171324492379170, 0.360761573048139, 0.467913934572691, 0.467913934572691, 0.360761573048139, 0.171324492379170};
+        for (int c = 0; c < n - 1; ++c)
+            for (int q = 0; q < 6; ++q) {
+                const double xq = x0 + ((double)c + 0.5 * (gp[q] + 1.0)) * dx, wq = 0.5 * gw[q] * dx;
+                const int lo = std::max(0, c - 1), hi = std::min(n - 1, c + 2);
+                double bv[4];
+                for (int ib = lo; ib <= hi; ++ib) bv[ib - lo] = basis_1d(basis_kind(ib, n), 0, xq, x0 + (double)ib * dx, s1);
+                for (int a = lo; a <= hi; ++a)
+                    for (int b = lo; b <= hi; ++b) M[(size_t)a * n + b] += wq * bv[a - lo] * bv[b - lo];
+            }
+        auto gram = [&](const std::vector<double> &T, std::vector<double> &K) {
+            for (int a = 0; a < n; ++a)
+                for (int b = 0; b < n; ++b) {
+                    double sum = 0.0;
+                    for (int nd = std::max(0, std::max(a, b) - 1); nd <= std::min(n - 1, std::min(a, b) + 1); ++nd)
+                        sum += ((nd == 0 || nd == n - 1) ? qb : 1.0) * T[(size_t)nd * n + a] * T[(size_t)nd * n + b];
+                    K[(size_t)a * n + b] = sum;
+                }
+        };
+        gram(T0, K0); gram(T1, K1); gram(T2, K2);
+        std::vector<double> w, V, mu, k0, d1, l2;
+        if (!gen_eig(n, K2, K0, w, V)) { set_error("pcg: the nodal Gram matrix of a dimension is not positive definite"); ok = false; break; }
+        congruence_diag(n, V, M, mu);
+        congruence_diag(n, V, K0, k0);
+        congruence_diag(n, V, K1, d1);
+        congruence_diag(n, V, K2, l2);
+        std::vector<double> VTh((size_t)n * n);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) VTh[(size_t)j * n + i] = V[(size_t)i * n + j];
+        ok = ok && pcg_alloc(s, &s->V[k], (size_t)n * n) && pcg_alloc(s, &s->VT[k], (size_t)n * n);
+        if (!ok) break;
+        ok = ok && hip_ok(hipMemcpy(s->V[k], V.data(), sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice), "pcg: upload")
+                && hip_ok(hipMemcpy(s->VT[k], VTh.data(), sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice), "pcg: upload");
+        const std::vector<double> *arr[4] = {&mu, &k0, &d1, &l2};
+        const double **dst[4] = {&s->ev.mu[k], &s->ev.k0[k], &s->ev.d1[k], &s->ev.l2[k]};
+        for (int a = 0; a < 4; ++a) {
+            std::memcpy(htabs.data() + toff, arr[a]->data(), sizeof(double) * (size_t)n);
+            *dst[a] = s->tabs + toff;
+            toff += n;
+        }
+    }
+    for (int k = g.ndim; k < MAXD; ++k) { s->ev.mu[k] = s->ev.k0[k] = s->ev.d1[k] = s->ev.l2[k] = s->tabs; }
+    ok = ok && hip_ok(hipMemcpy(s->tabs, htabs.data(), sizeof(double) * (size_t)ntab, hipMemcpyHostToDevice), "pcg: upload");
+    const size_t n = (size_t)g.ncol;
+    for (double **q : {&s->dinv, &s->bvec, &s->x, &s->r, &s->z, &s->pv, &s->t1, &s->t2}) ok = ok && pcg_alloc(s, q, n);
+    ok = ok && pcg_alloc(s, &s->partial, DOT_BLOCKS) && pcg_alloc(s, &s->sc, S_COUNT) && pcg_alloc(s, &s->hist, (size_t)s->maxit + 8) &&
+         pcg_alloc(s, &s->mom, 2);
+    if (!ok) { pcg_destroy(s); return SPLPAK_E_NOMEM; }
+    *out = s;
+    return 0;
+}
+
+// After the binning: sum of w^2 of this rank's points into the histogram window's scalars (it travels through the sharded fit's first
+// all-reduce, so that every rank builds the same preconditioner).
+hipError_t pcg_sum_w2(splpak_plan *p, hipStream_t st)
+{
+    hipLaunchKernelGGL(fd_sumw2_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->s.ws, (const int *)p->s.offset, p->g.ncell, p->scalH + SC_SUMW2);
+    return hipGetLastError();
+}
+
+// Per fit, after the assembly: the two moments of the preconditioner (density of w^2: sumw2 as reduced over the ranks; mean squared
+// constraint weight: from dcw / spf, which every rank of a fit that iterates computes) and its diagonal.
+hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, hipStream_t st)
+{
+    const Grid &g = p->g;
+    double lam = 0.0;
+    if (smooth) {
+        hipLaunchKernelGGL(fd_lambda_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->dcw, (const unsigned char *)p->spf, g.ncol, s->mom);
+        hipError_t e = hipMemcpyAsync(&lam, s->mom, sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+    }
+    double vol = 1.0;
+    for (int k = 0; k < g.ndim; ++k) vol *= (double)(g.nodes[k] - 1) * g.dx[k];
+    s->rho = sumw2 / std::fabs(vol);
+    s->lambda = lam / (double)g.ncol;
+    if (!(s->rho > 0.0)) s->rho = 1.0;
+    hipLaunchKernelGGL(fd_diag_kernel, dim3((unsigned)((g.ncol + 255) / 256)), dim3(256), 0, st, g, s->ev, s->rho, s->lambda, s->dinv);
+    s->total_iters = 0;
+    s->solves = 0;
+    s->failed = false;
+    return hipGetLastError();
+}
+
+// z = M^-1 r
+static hipError_t pcg_precondition(PcgState *s, const double *r, double *z, hipStream_t st)
+{
+    const Grid &g = s->g;
+    const long long total = g.ncol;
+    const dim3 gr((unsigned)((total + 255) / 256)), bl(256);
+    const double *src = r;
+    double *bufs[2] = {s->t1, s->t2};
+    int which = 0;
+    for (int k = 0; k < g.ndim; ++k) {                   // V_k^T along every dimension, the last one scaled by 1 / diag
+        double *dst = bufs[which];
+        hipLaunchKernelGGL(mode_product_kernel, gr, bl, 0, st, g.nodes[k], (long long)g.colstride[k], total, (const double *)s->V[k], src, dst,
+                           k == g.ndim - 1 ? (const double *)s->dinv : (const double *)nullptr);
+        src = dst;
+        which ^= 1;
+    }
+    for (int k = 0; k < g.ndim; ++k) {                   // V_k along every dimension
+        double *dst = (k == g.ndim - 1) ? z : bufs[which];
+        hipLaunchKernelGGL(mode_product_kernel, gr, bl, 0, st, g.nodes[k], (long long)g.colstride[k], total, (const double *)s->VT[k], src, dst,
+                           (const double *)nullptr);
+        src = dst;
+        which ^= 1;
+    }
+    return hipGetLastError();
+}
+
+static hipError_t pcg_dot(PcgState *s, const double *a, const double *b, double sign, int slot, double *hist, hipStream_t st)
+{
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st, (long long)s->g.ncol, a, b, s->partial);
+    hipLaunchKernelGGL(dot_finish_kernel, dim3(1), dim3(DOT_BLOCKS), 0, st, (const double *)s->partial, sign, s->sc, slot, hist);
+    return hipGetLastError();
+}
+
+// v <- N^-1 v (approximately): conjugate gradients from a zero start until the preconditioned residual norm has fallen by `tol`.
+// Returns 0 (converged), 1 (stagnated / iteration limit / breakdown: v holds the best iterate reached), or an SPLPAK_E_* code.
+int pcg_solve(splpak_plan *p, PcgState *s, double *v, double tol, bool smooth, hipStream_t st)
+{
+    const Grid &g = p->g;
+    const long long n = g.ncol;
+    const dim3 gr((unsigned)((n + 255) / 256)), bl(256);
+    const size_t nb = sizeof(double) * (size_t)n;
+    const bool debug = std::getenv("SPLPAK_DEBUG") != nullptr;
+    SortScratch rows = p->s;
+    rows.ys = nullptr;                                   // the residual pass as operator: rho = -N x
+    SPLPAK_HIP_TRY(hipMemcpyAsync(s->r, v, nb, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(hipMemsetAsync(s->x, 0, nb, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(pcg_precondition(s, s->r, s->z, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(hipMemcpyAsync(s->pv, s->z, nb, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
+    SPLPAK_HIP_TRY(pcg_dot(s, s->r, s->z, 1.0, S_RZ, s->hist, st), SPLPAK_E_NODEVICE);
+    const int check = 5;
+    s->hhist.assign((size_t)s->maxit + 8, 0.0);
+    double rz0 = 0.0, best = 1.0;
+    int it = 0, best_it = 0, status = 1, read_from = 0;
+    double rel = 1.0;
+    int last_gain_it = 0;                                // stagnation: the iteration at which the last factor of ten was gained
+    double gain_level = 1.0;
+    while (it < s->maxit) {
+        const int upto = std::min(s->maxit, it + check);
+        for (; it < upto; ++it) {
+            SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(p->band.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
+            SPLPAK_HIP_TRY(launch_residual(g, rows, s->pv, p->rcell, p->dcw, p->spf, p->ctab, smooth && p->rank == 0, p->tbuf, p->rho,
+                                           nullptr, nullptr, st), SPLPAK_E_NODEVICE);
+            if (int rc = plan_allreduce(p, p->rho, p->lenR, st)) return rc;
+            SPLPAK_HIP_TRY(pcg_dot(s, s->pv, p->rho, -1.0, S_PQ, nullptr, st), SPLPAK_E_NODEVICE);
+            hipLaunchKernelGGL(update_xr_kernel, gr, bl, 0, st, n, (const double *)s->sc, s->x, s->r, (const double *)s->pv, (const double *)p->rho);
+            SPLPAK_HIP_TRY(pcg_precondition(s, s->r, s->z, st), SPLPAK_E_NODEVICE);
+            SPLPAK_HIP_TRY(pcg_dot(s, s->r, s->z, 1.0, S_RZNEW, s->hist + it + 1, st), SPLPAK_E_NODEVICE);
+            hipLaunchKernelGGL(update_p_kernel, gr, bl, 0, st, n, (const double *)s->sc, s->pv, (const double *)s->z);
+            hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->sc);
+        }
+        const int first = read_from;
+        read_from = it + 1;
+        SPLPAK_HIP_TRY(hipMemcpyAsync(s->hhist.data() + first, s->hist + first, sizeof(double) * (size_t)(it - first + 1), hipMemcpyDeviceToHost, st),
+                       SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+        if (rz0 == 0.0) {
+            rz0 = s->hhist[0];
+            if (rz0 == 0.0) { status = 0; rel = 0.0; break; }            // zero right-hand side
+            if (!(rz0 > 0.0)) { status = 1; break; }
+        }
+        bool bad = false;
+        for (int k = std::max(1, first); k <= it; ++k) {
+            const double v2 = s->hhist[(size_t)k];
+            if (!(v2 >= 0.0) || !std::isfinite(v2)) { bad = true; break; }
+            rel = std::sqrt(v2 / rz0);
+            if (rel < best) { best = rel; best_it = k; }
+            if (rel < 0.1 * gain_level) { gain_level = rel; last_gain_it = k; }
+        }
+        if (debug) fprintf(stderr, "[splpak pcg] iteration %d: preconditioned residual %.3e (best %.3e at %d)\n", it, rel, best, best_it);
+        if (bad) { status = 1; break; }
+        if (rel <= tol) { status = 0; break; }
+        // stagnation: no factor of ten gained in 400 iterations (a converging 4-D fit gains one in 40 .. 60)
+        if (it - last_gain_it > 400) { status = 1; break; }
+    }
+    s->last_iters = it;
+    s->last_rel = rel;
+    s->total_iters += it;
+    s->solves += 1;
+    SPLPAK_HIP_TRY(hipMemcpyAsync(v, s->x, nb, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
+    if (status != 0) s->failed = true;
+    return status;
+}
+
+}  // namespace splpak

@@ -234,19 +234,42 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     // band.  It owns its storage; the factor arena stands in for the band as the home of the Gram scratch.
     // Several GPUs driven by one process (ndgrp): the same factorisation, distributed -- every rank keeps its own subtrees and
     // its block columns of the fronts above them (round 4; ndchol.hip, ndtop.inc).
-    const bool use_nd = allow_nd && (p->dm.R == 1 || ndgrp != nullptr) && nd_wanted(g, p->band);
+    // How the least-squares problem is solved (round 6): a factorisation (band / nested dissection) whenever one fits the device;
+    // the iteration of pcg.hip for the grids none fits (4-D from about 29^4 on one GPU) or by request -- SPLPAK_SOLVER =
+    // direct | pcg | pcg+direct (the iteration first, the factorisation when it stagnates) | auto.
+    int mode = 0;
+    if (const char *e = std::getenv("SPLPAK_SOLVER")) {
+        if (!std::strcmp(e, "direct")) mode = 1;
+        else if (!std::strcmp(e, "pcg")) mode = 2;
+        else if (!std::strcmp(e, "pcg+direct")) mode = 3;
+    }
+    if (p->dm.R > 1) mode = 1;                      // (the one-process multi-GPU plans distribute a factorisation)
+    bool direct = mode != 2;
+    const bool use_nd = direct && allow_nd && (p->dm.R == 1 || ndgrp != nullptr) && nd_wanted(g, p->band);
     if (use_nd && ok) {
         double *arena = nullptr;
         long long arena_doubles = 0;
         const int rc = nd_attach(p, &arena, &arena_doubles, p->dm.R > 1 ? ndgrp : nullptr, r);
-        if (rc != 0) {
+        if (rc == SPLPAK_E_NOMEM && mode == 0 && p->dm.R == 1) {
+            // no factorisation of this grid fits the device: the iteration instead
+            if (p->fn_destroy) p->fn_destroy(p->fn_user);
+            p->fn_user = nullptr; p->fn_destroy = nullptr; p->fn_bytes = nullptr; p->fn_name = nullptr; p->fn_code = 0;
+            p->factor_fn = nullptr; p->solve_fn = nullptr; p->expand_fn = nullptr; p->prefit_fn = nullptr;
+            (void)hipGetLastError();
+            direct = false;
+        } else if (rc != 0) {
             splpak_plan_destroy(p);
             return rc;
+        } else {
+            p->band.ab = arena;
+            p->band.bytes = (size_t)arena_doubles * sizeof(double);
         }
-        p->band.ab = arena;
-        p->band.bytes = (size_t)arena_doubles * sizeof(double);
-    } else
-        ok = ok && dev_alloc(p, &p->band.ab, p->band.bytes / sizeof(double));
+    } else if (direct && ok) {
+        const bool okb = dev_alloc(p, &p->band.ab, p->band.bytes / sizeof(double));
+        if (!okb && mode == 0 && p->dm.R == 1) direct = false;
+        else ok = ok && okb;
+    }
+    if (!direct) { p->band.ab = nullptr; p->band.bytes = 0; }
     {
         // scratch of the per-cell Gram blocks: everything at once if <= 8 GB (or if the band storage, which is
         // idle until the gather is done, holds it); otherwise slabs of what there is (launch_gram)
@@ -264,7 +287,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
             p->gscratch_doubles = want;
         }
     }
-    const size_t nloc = use_nd ? 0 : (size_t)(p->nown > 0 ? p->nown : 1);      // (the band's block inverses: not with nested dissection)
+    const size_t nloc = (use_nd || !direct) ? 0 : (size_t)(p->nown > 0 ? p->nown : 1);      // (the band's block inverses: not with nested dissection)
     ok = ok && dev_alloc(p, &p->band.dinv, nloc * NBLK * NBLK);
     ok = ok && dev_alloc(p, &p->band.dinvt, nloc * NBLK * NBLK);
     ok = ok && dev_alloc(p, &p->band.inv64, nloc * 4 * 64 * 64);
@@ -313,7 +336,15 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
         splpak_plan_destroy(p);
         return SPLPAK_E_NODEVICE;
     }
-    twoend_attach(p);
+    if (direct) twoend_attach(p);
+    if (!direct || mode == 3) {
+        const int rc = pcg_attach(p, &p->pcg);
+        if (rc != 0) {
+            splpak_plan_destroy(p);
+            return rc;
+        }
+    }
+    p->solver_mode = !direct ? 2 : (mode == 3 ? 3 : 0);
     *plan = p;
     return 0;
 }
@@ -324,6 +355,7 @@ void splpak_plan_destroy(splpak_plan *p)
 {
     if (!p) return;
     if (p->fn_destroy) p->fn_destroy(p->fn_user);
+    pcg_destroy(p->pcg);
     band_pipeline_destroy(p->band.pipe);
     for (hipEvent_t e : p->evStage) if (e) (void)hipEventDestroy(e);
     for (void *q : p->owned) (void)hipFree(q);
@@ -384,12 +416,19 @@ void splpak_plan_stage_timing(const splpak_plan *p, double *out6)
     for (int i = 0; i < 6; ++i) out6[i] = p->stage_ms[i];
 }
 
+void splpak_plan_pcg_stats(const splpak_plan *p, double *out6)
+{
+    if (!out6) return;
+    for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+    if (p && p->pcg) pcg_stats(p->pcg, out6);
+}
+
 const double *splpak_plan_hist_dev(const splpak_plan *p) { return p ? p->hist : nullptr; }
 
 int64_t splpak_plan_device_bytes(const splpak_plan *p)
 {
     if (!p) return 0;
-    return (int64_t)(p->owned_bytes + (p->fn_bytes ? p->fn_bytes(p->fn_user) : 0));
+    return (int64_t)(p->owned_bytes + (p->fn_bytes ? p->fn_bytes(p->fn_user) : 0) + pcg_bytes(p->pcg));
 }
 
 int32_t splpak_plan_factorisation(const splpak_plan *p, char *buf, int32_t buflen)
@@ -397,7 +436,8 @@ int32_t splpak_plan_factorisation(const splpak_plan *p, char *buf, int32_t bufle
     if (!p) return SPLPAK_E_BADARG;
     int code = 0;
     const char *what = "band Cholesky, four-stream look-ahead pipeline (csrc/bandchol.hip)";
-    if (p->fn_name) { code = p->fn_code; what = p->fn_name; }
+    if (p->solver_mode == 2) { code = 6; what = "preconditioned conjugate gradients on the rows, separable preconditioner (csrc/pcg.hip); no factorisation"; }
+    else if (p->fn_name) { code = p->fn_code; what = p->fn_name; }
     else if (p->dm.R > 1) { code = 3; what = "band Cholesky distributed over several GPUs by block columns (csrc/dist.hip)"; }
     else if (p->band.bw < narrow_band_limit()) { code = 1; what = "band Cholesky, narrow (chain-bound) form (csrc/bandchol.hip)"; }
     if (buf && buflen > 0) {
@@ -486,6 +526,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     if (p->prefit_fn) SPLPAK_HIP_TRY(p->prefit_fn(p, st, p->fn_user), SPLPAK_E_NODEVICE);
     stamp(0);
     SPLPAK_HIP_TRY(launch_bin_points(g, ndata, x, l1xdat, y, w, p->s, p->scalH, st), SPLPAK_E_NODEVICE);
+    if (p->pcg) SPLPAK_HIP_TRY(pcg_sum_w2(p, st), SPLPAK_E_NODEVICE);       // (rides the histogram's all-reduce)
     stamp(1);
     SPLPAK_HIP_TRY(launch_gram(g, p->s, p->gscratch, p->gscratch_doubles, smooth, p->nst, p->rhs, p->hist, p->scalH, st), SPLPAK_E_NODEVICE);
     stamp(2);
@@ -503,8 +544,9 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
             return SPLPAK_E_COMM;
         }
     }
-    if (smooth && p->rank == 0) {
+    if (smooth && (p->rank == 0 || p->pcg))      // (every rank of an iterating fit: the preconditioner's second moment)
         SPLPAK_HIP_TRY(launch_sparse_mark(g, p->hist, p->scalH, p->xtrap, p->dcw, p->spf, st), SPLPAK_E_NODEVICE);
+    if (smooth && p->rank == 0) {
         SPLPAK_HIP_TRY(launch_constraint_rows(g, p->dcw, p->spf, p->ctab, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
     }
     stamp(3);
@@ -530,81 +572,125 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         return 107;
     }
 
-    // ---- factorisation --------------------------------------------------
+    // ---- solve + refinement, around any solver of N z = v -----------------
     const double inf = std::numeric_limits<double>::infinity();
-    SPLPAK_HIP_TRY(hipMemsetAsync(p->info, 0, 2 * sizeof(int), st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(hipMemcpyAsync(p->small + 2, &inf, sizeof(double), hipMemcpyHostToDevice, st), SPLPAK_E_NODEVICE);
-    stamp(4);
-    SPLPAK_HIP_TRY(p->expand_fn ? p->expand_fn(p, st, p->fn_user) : launch_expand(g, p->nst, b, p->dm, st), SPLPAK_E_NODEVICE);
-    stamp(5);
-    SPLPAK_HOOK_TRY(p->factor_fn ? p->factor_fn(p, p->info, p->small + 2, st, p->fn_user) : band_cholesky(b, p->info, p->small + 2, st, &p->stats));
-    int hinfo = 0;
-    double minpiv = 0.0;
-    SPLPAK_HIP_TRY(hipMemcpyAsync(&hinfo, p->info, sizeof(int), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(hipMemcpyAsync(&minpiv, p->small + 2, sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
-    auto t2 = clk::now();
-    if (info) {
-        info[4] = minpiv;
-        info[6] = std::chrono::duration<double>(t2 - t1).count();
-    }
-    if (hinfo != 0) {
-        // not positive definite: the reference's "system is singular" (suprls 34 -> 107)
-        SPLPAK_HIP_TRY(hipMemsetAsync(coef_dev, 0, sizeof(double) * (size_t)g.ncol, st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
-        set_error("normal equations not positive definite (suprls 34)");
-        return 107;
-    }
-
-    // ---- solve + refinement --------------------------------------------
-    SPLPAK_HIP_TRY(hipMemsetAsync(p->xvec, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
-    SPLPAK_HIP_TRY(hipMemcpyAsync(p->xvec, p->rhs, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
-    stamp(6);
-    SPLPAK_HOOK_TRY(p->solve_fn ? p->solve_fn(p, p->xvec, p->tmp, st, p->fn_user) : band_solve(b, p->xvec, p->tmp, st));
-    stamp(7);
     int steps = 0;
-    double last_rel = 0.0, prev_rel = inf, ratio = 0.0;
+    double last_rel = 0.0, ratio = 0.0;
     // converged: the (estimated) remaining error is below tol, or the corrections sit at the rounding
     // floor; diverged: they stopped contracting while still large.  A solve that is still contracting
     // after the nominal number of steps goes on up to max_refine_hard; if even that leaves an estimated
     // error above the parity bar the fit is reported as failed (107) instead of returning coefficients
     // that silently miss it.
-    bool converged = p->max_refine == 0, diverged = false, stagnated = false;
-    for (int it = 0; it < p->max_refine_hard && !converged; ++it) {
-        // (the scalars behind rho travel with it through the all-reduce: zeroed too, or every collective doubles them)
-        SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, p->ctab, smooth && p->rank == 0,
-                                       p->tbuf, p->rho, nullptr, nullptr, st), SPLPAK_E_NODEVICE);
-        if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
-        SPLPAK_HOOK_TRY(p->solve_fn ? p->solve_fn(p, p->rho, p->tmp, st, p->fn_user) : band_solve(b, p->rho, p->tmp, st));
-        SPLPAK_HIP_TRY(launch_axpy_absmax(g.ncol, p->xvec, p->rho, p->small, st), SPLPAK_E_NODEVICE);
-        double am[2];
-        SPLPAK_HIP_TRY(hipMemcpyAsync(am, p->small, 2 * sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
-        SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
-        ++steps;
-        last_rel = (am[1] > 0.0) ? am[0] / am[1] : 0.0;
-        if (std::getenv("SPLPAK_DEBUG"))
-            fprintf(stderr, "[splpak] refinement step %d: |dx|/|x| = %.3e\n", steps, last_rel);
-        if (!(last_rel == last_rel)) break;                   // NaN
-        if (last_rel <= p->tol) { converged = true; break; }
-        if (it >= 1) {
-            // linear convergence: after this step the error is ~ dx * ratio / (1 - ratio); stop as soon
-            // as that estimate is below the tolerance instead of paying for one more solve
-            ratio = last_rel / prev_rel;
-            if (ratio < 0.9 && last_rel * ratio / (1.0 - ratio) <= p->tol) { converged = true; break; }
-            if (ratio >= 0.9) {                               // stagnation: fine at the rounding floor, a failure if the
-                diverged = last_rel > 1e-8;                   // corrections are still large; in between (1e-10 .. 1e-8) the
-                converged = !diverged;                        // MEASURED backward error decides below (round-2 advice: the
-                stagnated = converged && last_rel > 1e-10;    // estimate alone let coefficients that miss the bar through)
-                break;
+    bool converged = false, diverged = false, stagnated = false;
+    // solve(v, first): v <- N^-1 v; 0, a status to return (negative, SPLPAK_E_COMM), or 1 = this solver gives up (the iteration)
+    auto solve_and_refine = [&](auto &&solve) -> int {
+        steps = 0;
+        last_rel = 0.0;
+        ratio = 0.0;
+        double prev_rel = inf;
+        converged = p->max_refine == 0;
+        diverged = stagnated = false;
+        SPLPAK_HIP_TRY(hipMemsetAsync(p->xvec, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(hipMemcpyAsync(p->xvec, p->rhs, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);
+        stamp(6);
+        if (int r = solve(p->xvec, true)) return r;
+        stamp(7);
+        for (int it = 0; it < p->max_refine_hard && !converged; ++it) {
+            // (the scalars behind rho travel with it through the all-reduce: zeroed too, or every collective doubles them)
+            SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
+            SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, p->ctab, smooth && p->rank == 0,
+                                           p->tbuf, p->rho, nullptr, nullptr, st), SPLPAK_E_NODEVICE);
+            if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
+            if (int r = solve(p->rho, false)) return r;
+            SPLPAK_HIP_TRY(launch_axpy_absmax(g.ncol, p->xvec, p->rho, p->small, st), SPLPAK_E_NODEVICE);
+            double am[2];
+            SPLPAK_HIP_TRY(hipMemcpyAsync(am, p->small, 2 * sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+            SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+            ++steps;
+            last_rel = (am[1] > 0.0) ? am[0] / am[1] : 0.0;
+            if (std::getenv("SPLPAK_DEBUG"))
+                fprintf(stderr, "[splpak] refinement step %d: |dx|/|x| = %.3e\n", steps, last_rel);
+            if (!(last_rel == last_rel)) break;                   // NaN
+            if (last_rel <= p->tol) { converged = true; break; }
+            if (it >= 1) {
+                // linear convergence: after this step the error is ~ dx * ratio / (1 - ratio); stop as soon
+                // as that estimate is below the tolerance instead of paying for one more solve
+                ratio = last_rel / prev_rel;
+                if (ratio < 0.9 && last_rel * ratio / (1.0 - ratio) <= p->tol) { converged = true; break; }
+                if (ratio >= 0.9) {                               // stagnation: fine at the rounding floor, a failure if the
+                    diverged = last_rel > 1e-8;                   // corrections are still large; in between (1e-10 .. 1e-8) the
+                    converged = !diverged;                        // MEASURED backward error decides below (round-2 advice: the
+                    stagnated = converged && last_rel > 1e-10;    // estimate alone let coefficients that miss the bar through)
+                    break;
+                }
+                // 0.5 .. 0.9: an ill-conditioned grid whose corrections still shrink -- go on (up to max_refine_hard):
+                // stopping here left 1-D grids of 2 000-3 000 nodes 1e-7 .. 1e-10 away from the converged solution
+                // (randomized sweep, tools/fuzz_parity.py big)
             }
-            // 0.5 .. 0.9: an ill-conditioned grid whose corrections still shrink -- go on (up to max_refine_hard):
-            // stopping here left 1-D grids of 2 000-3 000 nodes 1e-7 .. 1e-10 away from the converged solution
-            // (randomized sweep, tools/fuzz_parity.py big)
+            prev_rel = last_rel;
+            if (it + 1 >= p->max_refine && it + 1 < p->max_refine_hard && std::getenv("SPLPAK_DEBUG"))
+                fprintf(stderr, "[splpak] still contracting after %d steps: continuing\n", it + 1);
         }
-        prev_rel = last_rel;
-        if (it + 1 >= p->max_refine && it + 1 < p->max_refine_hard && std::getenv("SPLPAK_DEBUG"))
-            fprintf(stderr, "[splpak] still contracting after %d steps: continuing\n", it + 1);
+        return 0;
+    };
+
+    // ---- the iteration (pcg.hip), where the plan has it --------------------
+    bool solved = false;
+    auto t2 = t1;
+    if (p->pcg) {
+        SPLPAK_HIP_TRY(pcg_prepare(p, p->pcg, hs[SC_COUNT + SC_SUMW2], smooth, st), SPLPAK_E_NODEVICE);
+        const double tol_first = std::getenv("SPLPAK_PCG_TOL1") ? atof(std::getenv("SPLPAK_PCG_TOL1")) : 1e-10;
+        const double tol_next = std::getenv("SPLPAK_PCG_TOL2") ? atof(std::getenv("SPLPAK_PCG_TOL2")) : 1e-6;
+        const int r = solve_and_refine([&](double *v, bool first) -> int { return pcg_solve(p, p->pcg, v, first ? tol_first : tol_next, smooth, st); });
+        if (r != 0 && r != 1) return r;
+        double est = last_rel;
+        if (steps >= 2 && ratio > 0.0 && ratio < 1.0) est = last_rel * ratio / (1.0 - ratio);
+        solved = r == 0 && last_rel == last_rel && !diverged && (converged || est <= 1e-10);
+        if (!solved && p->solver_mode == 2) {
+            SPLPAK_HIP_TRY(hipMemsetAsync(coef_dev, 0, sizeof(double) * (size_t)g.ncol, st), SPLPAK_E_NODEVICE);
+            SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+            double ps[6];
+            pcg_stats(p->pcg, ps);
+            char buf[320];
+            snprintf(buf, sizeof buf, "the iterative solve did not converge (%.0f iterations in %.0f solves, last preconditioned residual %.1e, last correction %.1e) "
+                     "and no factorisation of this grid fits the device: data too clustered for the separable preconditioner", ps[0], ps[1], ps[3], last_rel);
+            set_error(buf);
+            if (info) { info[2] = steps; info[3] = last_rel; }
+            return 107;
+        }
+        if (!solved && std::getenv("SPLPAK_DEBUG")) fprintf(stderr, "[splpak] the iteration gave up: factorisation instead\n");
+    }
+
+    // ---- factorisation --------------------------------------------------
+    if (!solved) {
+        SPLPAK_HIP_TRY(hipMemsetAsync(p->info, 0, 2 * sizeof(int), st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(hipMemcpyAsync(p->small + 2, &inf, sizeof(double), hipMemcpyHostToDevice, st), SPLPAK_E_NODEVICE);
+        stamp(4);
+        SPLPAK_HIP_TRY(p->expand_fn ? p->expand_fn(p, st, p->fn_user) : launch_expand(g, p->nst, b, p->dm, st), SPLPAK_E_NODEVICE);
+        stamp(5);
+        SPLPAK_HOOK_TRY(p->factor_fn ? p->factor_fn(p, p->info, p->small + 2, st, p->fn_user) : band_cholesky(b, p->info, p->small + 2, st, &p->stats));
+        int hinfo = 0;
+        double minpiv = 0.0;
+        SPLPAK_HIP_TRY(hipMemcpyAsync(&hinfo, p->info, sizeof(int), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(hipMemcpyAsync(&minpiv, p->small + 2, sizeof(double), hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+        t2 = clk::now();
+        if (info) {
+            info[4] = minpiv;
+            info[6] = std::chrono::duration<double>(t2 - t1).count();
+        }
+        if (hinfo != 0) {
+            // not positive definite: the reference's "system is singular" (suprls 34 -> 107)
+            SPLPAK_HIP_TRY(hipMemsetAsync(coef_dev, 0, sizeof(double) * (size_t)g.ncol, st), SPLPAK_E_NODEVICE);
+            SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+            set_error("normal equations not positive definite (suprls 34)");
+            return 107;
+        }
+        const int r = solve_and_refine([&](double *v, bool) -> int {
+            SPLPAK_HOOK_TRY(p->solve_fn ? p->solve_fn(p, v, p->tmp, st, p->fn_user) : band_solve(b, v, p->tmp, st));
+            return 0;
+        });
+        if (r != 0) return r;
     }
     // estimated error left after the last step (exact 0 when it met the tolerance outright)
     double est_err = last_rel;

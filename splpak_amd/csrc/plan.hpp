@@ -38,6 +38,7 @@ struct HostBarrier {
         ++phase;
     }
 };
+struct PcgState;       // iterative solve of the least-squares problem (pcg.hip)
 struct NdGroup;        // the ranks of a one-process multi-GPU nested-dissection factorisation (ndchol.hip)
 }  // namespace splpak
 
@@ -98,6 +99,10 @@ struct splpak_plan {
     hipError_t (*prefit_fn)(splpak_plan *p, hipStream_t st, void *user) = nullptr;
     void *fn_user = nullptr;
     void (*fn_destroy)(void *user) = nullptr;      // releases fn_user with the plan (NULL: not the plan's to release)
+    // iterative solve (pcg.hip): NULL = none.  solver_mode: 0 a factorisation only, 2 the iteration only (no factor storage: grids
+    // no factorisation fits, or by request), 3 the iteration first and the factorisation when it stagnates
+    splpak::PcgState *pcg = nullptr;
+    int solver_mode = 0;
     const char *fn_name = nullptr;                 // what the hooks are (splpak_plan_factorisation); fn_code: 2 two-ended band, 4 nested dissection, 3 distributed band
     int fn_code = 0;
 };
@@ -137,5 +142,13 @@ int plan_allreduce(splpak_plan *p, double *buf, long long count, hipStream_t st)
 // narrow bands on one GPU: install the two-ended factorisation (twoend.hip) when it shortens the chain
 void twoend_attach(splpak_plan *p);
 void twoend_detach(splpak_plan *p);
+// pcg.hip
+int pcg_attach(splpak_plan *p, PcgState **out);
+void pcg_destroy(PcgState *s);
+size_t pcg_bytes(const PcgState *s);
+void pcg_stats(const PcgState *s, double *out6);
+hipError_t pcg_sum_w2(splpak_plan *p, hipStream_t st);
+hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, hipStream_t st);
+int pcg_solve(splpak_plan *p, PcgState *s, double *v, double tol, bool smooth, hipStream_t st);
 int twoend_debug_solve(int n, int halfbw, const double *a_lower, const double *bvec, double *x_out, int *hinfo_out);
 }  // namespace splpak
