@@ -639,8 +639,8 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     auto t2 = t1;
     if (p->pcg) {
         SPLPAK_HIP_TRY(pcg_prepare(p, p->pcg, hs[SC_COUNT + SC_SUMW2], smooth, st), SPLPAK_E_NODEVICE);
-        const double tol_first = std::getenv("SPLPAK_PCG_TOL1") ? atof(std::getenv("SPLPAK_PCG_TOL1")) : 1e-10;
-        const double tol_next = std::getenv("SPLPAK_PCG_TOL2") ? atof(std::getenv("SPLPAK_PCG_TOL2")) : 1e-6;
+        const double tol_first = std::getenv("SPLPAK_PCG_TOL1") ? atof(std::getenv("SPLPAK_PCG_TOL1")) : 1e-11;
+        const double tol_next = std::getenv("SPLPAK_PCG_TOL2") ? atof(std::getenv("SPLPAK_PCG_TOL2")) : 1e-3;
         const int r = solve_and_refine([&](double *v, bool first) -> int { return pcg_solve(p, p->pcg, v, first ? tol_first : tol_next, smooth, st); });
         if (r != 0 && r != 1) return r;
         double est = last_rel;
@@ -844,6 +844,7 @@ static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const
     int nd_env = std::getenv("SPLPAK_ND") ? atoi(std::getenv("SPLPAK_ND")) : -1;
     for (const char *v : {"SPLPAK_ND_SPLIT", "SPLPAK_ND_KB", "SPLPAK_ND_RES_CUS", "SPLPAK_NO_PANEL_CU", "SPLPAK_ND_NO_ROOT_LOOKAHEAD", "SPLPAK_ND_NO_FUSE", "SPLPAK_ND_PIPES", "SPLPAK_ND_NO_OUTER", "SPLPAK_ND_SMALL_GRID", "SPLPAK_ND_WG4", "SPLPAK_ND_NO_EARLY_CLEAR", "SPLPAK_ND_PINNED_SPLIT", "SPLPAK_ND_SMALL_QUEUE", "SPLPAK_ND_POTRF_WAVES", "SPLPAK_ND_FULL_DIAG", "SPLPAK_ND_XCD"})
         if (const char *e = std::getenv(v)) nd_env = nd_env * 31 + 7 * atoi(e) + (int)v[10];
+    if (const char *e = std::getenv("SPLPAK_SOLVER")) nd_env = nd_env * 31 + (int)std::strlen(e) * 131 + (int)e[0];
     bool same = hc.plan && hc.dev == dev && hc.ndim == ndim && hc.xtrap == xtrap && hc.plan->max_ndata >= ndata && hc.nd_env == nd_env;
     for (int d = 0; same && d < ndim; ++d)
         same = hc.nodes[d] == nodes[d] && hc.xmin[d] == xmin[d] && hc.xmax[d] == xmax[d];

@@ -542,11 +542,13 @@ def test_fit_error_codes():
     assert capi.fit(2, xc, xc.sum(axis=1), None, [0.0, 0.0], [1.0, 1.0], [8, 8], 0.0)[1] == 107
 
 
-def test_grid_beyond_one_gpu_is_a_clean_error():
+def test_grid_beyond_one_gpu_is_a_clean_error(monkeypatch):
     """BASELINE config 5's 32^4 grid on ONE GPU: the nested-dissection factor panels alone are 476 GB (+ ~131 GB of Schur
     arena in the postorder schedule; the band factor would be 852 GB) against 309 GB of HBM, and the boxes' 322 GB host-memory
-    cgroup cannot park the difference either: the plan must be refused with the library's out-of-memory
-    status, not crash.  (The largest 4-D grid one GPU holds, 28^4, runs in tests/test_nd.py; 32^4 is the 8-GPU route's.)"""
+    cgroup cannot park the difference either: asked for a FACTORISATION (SPLPAK_SOLVER=direct) the plan must be refused with
+    the library's out-of-memory status, not crash.  Left to itself the plan takes the iterative solve of round 6 and the fit
+    runs (tests/test_pcg.py::test_config5_fit_4d_32_on_one_gpu)."""
+    monkeypatch.setenv("SPLPAK_SOLVER", "direct")
     with pytest.raises(capi.SplpakError) as e:
         capi.Plan(4, [32] * 4, [0.0] * 4, [1.0] * 4, 1.0, 1000)
     assert "-2" in str(e.value) or "memory" in str(e.value).lower()
@@ -554,6 +556,12 @@ def test_grid_beyond_one_gpu_is_a_clean_error():
     x = np.random.default_rng(1).random((100, 4))
     with pytest.raises(capi.SplpakError):
         capi.fit(4, x, x.sum(axis=1), None, [0.0] * 4, [1.0] * 4, [32] * 4, 1.0)
+    monkeypatch.delenv("SPLPAK_SOLVER")
+    plan = capi.Plan(4, [32] * 4, [0.0] * 4, [1.0] * 4, 1.0, 1000)
+    try:
+        assert plan.factorisation()[0] == 6
+    finally:
+        plan.close()
 
 
 def test_eval_4d_32_real32_vs_real64_sweep(port):

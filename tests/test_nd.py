@@ -281,6 +281,27 @@ def test_nd_4d_28_the_largest_grid_one_gpu_holds(port):
     assert omega < 1e-12
     assert nrow == info[0] == m and ncons == info[1] and ncons > 100000
     assert abs(reserr - info[8]) <= 1e-9 * reserr
+    # round 6: the iterative solve (csrc/pcg.hip) on the same rows, without any factorisation, agrees to 1e-10
+    os.environ["SPLPAK_SOLVER"] = "pcg"
+    try:
+        plan = capi.Plan(nd, nodes, lo, hi, 1.0, m)
+    finally:
+        os.environ.pop("SPLPAK_SOLVER", None)
+    try:
+        assert plan.factorisation()[0] == 6
+        t0 = time.perf_counter()
+        ierr, info_it = plan.fit(x, ys, ws, coef, st)
+        torch.cuda.synchronize()
+        t_it = time.perf_counter() - t0
+        ps = plan.pcg_stats()
+        c_it = coef.cpu().numpy()
+    finally:
+        plan.close()
+    err = float(np.abs(c_it - c).max() / np.abs(c).max())
+    print(f"28^4 weighted, iteration alone: {t_it:.2f} s, {ps['iterations']} iterations in {ps['solves']} solves; {err:.2e} from the factorisation's coefficients; "
+          f"backward error {info_it[9]:.1e}")
+    assert ierr == 0 and err < COEF_TOL and info_it[9] < 1e-9
+    assert info_it[0] == info[0] and info_it[1] == info[1]
 
 
 @pytest.mark.gpu
