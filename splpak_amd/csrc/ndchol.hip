@@ -1079,35 +1079,15 @@ bool nd_build_factor_jobs(NdState *s)
     // group; measured at 64^3: 257.6 ms per factorisation against 262.4 with K = 512 and 270.9 with K = 256; groups that
     // ramp up 1, 2, 4, 4, .. so that the first pass of a depth starts earlier made no difference)
     const int schur_kb = s->schur_kb;
-    // groups of panel blocks that share a Schur pass (and the outer panel pass): schur_kb blocks each -- after a RAMP of smaller
-    // first groups for the fronts that have more than one group anyway, so that the first pass of a stage does not wait for the
-    // chain of four block steps (round 5: at 64^3 only the chain runs for 1 .. 5.5 ms at the start of every stage, 25 ms in all).
-    // Measured: a first group of 2 blocks is -1.2 ms of 225 at 64^3 ("1,2", "2,2", "1,3" the same within 0.5 ms -- the earlier
-    // passes take CU time from the chain they run beside), and the K = 512 passes it adds run at a lower rate (the Schur-pass
-    // kernel's average goes from 0.575 to 0.55 of the peak): not the default.  SPLPAK_ND_RAMP="2": 2, then schur_kb blocks;
-    // "1,2": 1, then 2, then schur_kb.  The sums of an entry keep the order of the blocks whatever the grouping: the same bits.
-    int ramp[4] = {0, 0, 0, 0}, nramp = 0;
-    {
-        const char *e = std::getenv("SPLPAK_ND_RAMP");
-        for (const char *q = e ? e : ""; *q && nramp < 4; ++q)
-            if (*q >= '1' && *q <= '4') ramp[nramp++] = std::min(*q - '0', schur_kb);
-    }
+    // groups of panel blocks that share a Schur pass (and the outer panel pass): schur_kb blocks each, the same boundaries for every
+    // front of a stage.  (Round 5 tried a RAMP of smaller first groups -- 2, then 4 blocks -- so that the first pass of a stage would
+    // not wait for a chain of four block steps: -1.2 ms of 225 at 64^3, paid for with slower K = 512 passes; it made the group
+    // boundaries differ between the fronts of one stage, which the look-ahead inside the groups did not allow for -- a front whose
+    // group ended at step k - 1 could have its block k factored while the outer pass was still writing it (round-5 advice).  The
+    // switch is gone.)
     auto group_of = [&](int k, int nsteps, int &g0, int &gend) {
-        if (nsteps <= schur_kb || nramp == 0) {
-            g0 = (k / schur_kb) * schur_kb;
-            gend = std::min(g0 + schur_kb, nsteps) - 1;
-            return;
-        }
-        int start = 0;
-        for (int gi = 0;; ++gi) {
-            const int size = gi < nramp ? ramp[gi] : schur_kb;
-            if (k < start + size) {
-                g0 = start;
-                gend = std::min(start + size, nsteps) - 1;
-                return;
-            }
-            start += size;
-        }
+        g0 = (k / schur_kb) * schur_kb;
+        gend = std::min(g0 + schur_kb, nsteps) - 1;
     };
     const SyrkJob syrk_end{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     for (int stg = 0; stg < nstage; ++stg) {

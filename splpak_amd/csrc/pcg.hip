@@ -530,8 +530,7 @@ int pcg_solve(splpak_plan *p, PcgState *s, double *v, double tol, bool smooth, h
         const int upto = std::min(s->maxit, it + check);
         for (; it < upto; ++it) {
             SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(p->band.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
-            SPLPAK_HIP_TRY(launch_residual(g, rows, s->pv, p->rcell, p->dcw, p->spf, p->ctab, smooth && p->rank == 0, p->tbuf, p->rho,
-                                           nullptr, nullptr, st), SPLPAK_E_NODEVICE);
+            SPLPAK_HIP_TRY(plan_rows_residual(p, rows, s->pv, smooth && p->rank == 0, p->rho, st), SPLPAK_E_NODEVICE);
             if (int rc = plan_allreduce(p, p->rho, p->lenR, st)) return rc;
             SPLPAK_HIP_TRY(pcg_dot(s, s->pv, p->rho, -1.0, S_PQ, nullptr, st), SPLPAK_E_NODEVICE);
             hipLaunchKernelGGL(update_xr_kernel, gr, bl, 0, st, n, (const double *)s->sc, s->x, s->r, (const double *)s->pv, (const double *)p->rho);

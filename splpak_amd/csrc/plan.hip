@@ -336,6 +336,13 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
         splpak_plan_destroy(p);
         return SPLPAK_E_NODEVICE;
     }
+    if (p->ctab) {
+        const int rc = rowsop_create(g, &p->rowsop);
+        if (rc != 0) {
+            splpak_plan_destroy(p);
+            return rc;
+        }
+    }
     if (direct) twoend_attach(p);
     if (!direct || mode == 3) {
         const int rc = pcg_attach(p, &p->pcg);
@@ -356,6 +363,7 @@ void splpak_plan_destroy(splpak_plan *p)
     if (!p) return;
     if (p->fn_destroy) p->fn_destroy(p->fn_user);
     pcg_destroy(p->pcg);
+    rowsop_destroy(p->rowsop);
     band_pipeline_destroy(p->band.pipe);
     for (hipEvent_t e : p->evStage) if (e) (void)hipEventDestroy(e);
     for (void *q : p->owned) (void)hipFree(q);
@@ -428,7 +436,7 @@ const double *splpak_plan_hist_dev(const splpak_plan *p) { return p ? p->hist : 
 int64_t splpak_plan_device_bytes(const splpak_plan *p)
 {
     if (!p) return 0;
-    return (int64_t)(p->owned_bytes + (p->fn_bytes ? p->fn_bytes(p->fn_user) : 0) + pcg_bytes(p->pcg));
+    return (int64_t)(p->owned_bytes + (p->fn_bytes ? p->fn_bytes(p->fn_user) : 0) + pcg_bytes(p->pcg) + rowsop_bytes(p->rowsop));
 }
 
 int32_t splpak_plan_factorisation(const splpak_plan *p, char *buf, int32_t buflen)
@@ -598,8 +606,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         for (int it = 0; it < p->max_refine_hard && !converged; ++it) {
             // (the scalars behind rho travel with it through the all-reduce: zeroed too, or every collective doubles them)
             SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
-            SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, p->ctab, smooth && p->rank == 0,
-                                           p->tbuf, p->rho, nullptr, nullptr, st), SPLPAK_E_NODEVICE);
+            SPLPAK_HIP_TRY(plan_rows_residual(p, p->s, p->xvec, smooth && p->rank == 0, p->rho, st), SPLPAK_E_NODEVICE);
             if (int r = do_allreduce(p, p->rho, p->lenR, st)) return r;
             if (int r = solve(p->rho, false)) return r;
             SPLPAK_HIP_TRY(launch_axpy_absmax(g.ncol, p->xvec, p->rho, p->small, st), SPLPAK_E_NODEVICE);

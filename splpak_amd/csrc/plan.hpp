@@ -38,6 +38,7 @@ struct HostBarrier {
         ++phase;
     }
 };
+struct RowsOp;         // the rows of a 4-D fit applied to a vector, tile by tile (rowsop.hip)
 struct PcgState;       // iterative solve of the least-squares problem (pcg.hip)
 struct NdGroup;        // the ranks of a one-process multi-GPU nested-dissection factorisation (ndchol.hip)
 }  // namespace splpak
@@ -101,6 +102,7 @@ struct splpak_plan {
     void (*fn_destroy)(void *user) = nullptr;      // releases fn_user with the plan (NULL: not the plan's to release)
     // iterative solve (pcg.hip): NULL = none.  solver_mode: 0 a factorisation only, 2 the iteration only (no factor storage: grids
     // no factorisation fits, or by request), 3 the iteration first and the factorisation when it stagnates
+    splpak::RowsOp *rowsop = nullptr;         // 4-D grids: the tiled residual pass (NULL: the cell-by-cell passes of assemble.hip)
     splpak::PcgState *pcg = nullptr;
     int solver_mode = 0;
     const char *fn_name = nullptr;                 // what the hooks are (splpak_plan_factorisation); fn_code: 2 two-ended band, 4 nested dissection, 3 distributed band
@@ -142,6 +144,18 @@ int plan_allreduce(splpak_plan *p, double *buf, long long count, hipStream_t st)
 // narrow bands on one GPU: install the two-ended factorisation (twoend.hip) when it shortens the chain
 void twoend_attach(splpak_plan *p);
 void twoend_detach(splpak_plan *p);
+// rowsop.hip
+int rowsop_create(const Grid &g, RowsOp **out);
+void rowsop_destroy(RowsOp *r);
+size_t rowsop_bytes(const RowsOp *r);
+hipError_t rowsop_apply(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
+                        const double *ctab, bool constraints, double *rho, hipStream_t st);
+// rho = A^T W (W y - W A x) [- C^T C x] of the plan's binned points (rows.ys == NULL: y = 0), by whichever pass the plan has
+inline hipError_t plan_rows_residual(splpak_plan *p, const SortScratch &rows, const double *xvec, bool constraints, double *rho, hipStream_t st)
+{
+    if (p->rowsop && p->ctab) return rowsop_apply(p->g, p->rowsop, rows, xvec, p->dcw, p->spf, p->ctab, constraints, rho, st);
+    return launch_residual(p->g, rows, xvec, p->rcell, p->dcw, p->spf, p->ctab, constraints, p->tbuf, rho, nullptr, nullptr, st);
+}
 // pcg.hip
 int pcg_attach(splpak_plan *p, PcgState **out);
 void pcg_destroy(PcgState *s);

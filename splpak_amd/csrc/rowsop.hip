@@ -1,0 +1,375 @@
+// The rows of a 4-D fit applied to a vector, tile by tile (round 6): rho = A^T W (W y - W A x) - C^T C x, the pass that the
+// refinement runs a few times per fit and the iterative solve (pcg.hip) runs once per iteration with y = 0.
+//
+// The cell-by-cell form of rounds 2-5 (assemble.hip: residual_cell4_kernel, constraint_dots_kernel, rho_gather_kernel) writes a
+// 256-double share per cell (1.45 GB at 32^4) that a thread per node gathers back 8 bytes at a time from 256 different cells
+// (every 64-byte sector fetched for one double: 5.0 ms), evaluates the constraint rows entry by entry (1.8 ms + most of the
+// gather), and re-reads the cell's 256 coefficients from global memory for every cell: 10.3 ms per pass at 32^4 / 1e7 points
+// (profiles/r06_c5_pcg_first_kernel_stats.csv).  Here:
+//
+//   data rows (src/splpak.F90:788-855)   a workgroup owns a TILE of 3^4 cells: the 6^4 coefficients it touches sit in LDS once,
+//       each of its four waves takes every fourth cell (points of a cell in their sorted order: lanes = (point, slab) for the
+//       factorised window sum, lanes = window function for the transposed product), adds the cell's 256 shares into ITS OWN LDS
+//       image of the tile's nodes, and the four images are added in a fixed order into the tile's partial sums: 104 MB instead of
+//       1.45 GB, coalesced, no atomics -- the bits do not depend on the schedule.
+//   constraint rows (:921-1046)   every row is a tensor product of tridiagonal node matrices (values / first / second derivative of
+//       the three basis functions around a node; boundary nodes take the first derivative, :998) times a node weight: C x and
+//       C^T (C x) are d + d passes of tridiagonal mode products over arrays that share their prefixes (3, 6, 10, 10 arrays
+//       forward, 10, 6, 3, 1 back in 4-D) -- 0.5 GB of cache traffic instead of 81 entries x 10 rows x 4 table look-ups per node.
+//   gather   node i adds the <= 16 tile partials that hold it (tile order) and subtracts the constraint term.
+#include "plan.hpp"
+#include "basis.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace splpak {
+
+namespace {
+
+constexpr int TCELL = 3;                 // cells per tile and dimension
+constexpr int TB = TCELL + 3;            // nodes per tile and dimension
+constexpr int TB4 = TB * TB * TB * TB;   // 1296
+constexpr int PCHUNK = 16;               // points per trip of a wave
+constexpr int TLD = 17;                  // 16 table values per point + 1 (bank spread)
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// data rows
+__global__ void __launch_bounds__(256)
+rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ offset, const double *__restrict__ xs,
+                  const double *__restrict__ ys, const double *__restrict__ ws, long long cap, const double *__restrict__ xvec,
+                  double *__restrict__ partial)
+{
+    __shared__ double pt[TB4];
+    __shared__ double acc[4][TB4];
+    __shared__ double tab[4][PCHUNK * TLD];
+    __shared__ double swe[4][PCHUNK];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int t = blockIdx.x;
+    int cb[4];
+    cb[0] = (t % nt0) * TCELL; t /= nt0;
+    cb[1] = (t % nt1) * TCELL; t /= nt1;
+    cb[2] = (t % nt2) * TCELL; t /= nt2;
+    cb[3] = t * TCELL;
+    for (int idx = tid; idx < TB4; idx += 256) {
+        int r = idx, col = 0;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int nd = cb[d] + r % TB;
+            r /= TB;
+            ok = ok && nd < g.nodes[d];
+            col += nd * g.colstride[d];
+        }
+        pt[idx] = ok ? xvec[col] : 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc[w][idx] = 0.0;
+    }
+    __syncthreads();
+    double *__restrict__ mytab = tab[wave];
+    double *__restrict__ mywe = swe[wave];
+    double *__restrict__ myacc = acc[wave];
+    const int k0 = lane & 3, k1 = (lane >> 2) & 3, k2 = lane >> 4;        // phase 2: the lane's window functions (k0, k1, k2, *)
+    const int pi = lane & 15, sl = lane >> 4;                              // staging: (point, dimension); phase 1: (point, slab k3)
+    for (int lc = wave; lc < TCELL * TCELL * TCELL * TCELL; lc += 4) {
+        int r = lc, cell = 0, lbase = 0, mul = 1;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int a = r % TCELL;
+            r /= TCELL;
+            ok = ok && cb[d] + a < g.cells[d];
+            cell += (cb[d] + a) * g.cellstride[d];
+            lbase += a * mul;
+            mul *= TB;
+        }
+        if (!ok) continue;
+        const long long beg = offset[cell], end = offset[cell + 1];
+        if (beg == end) continue;
+        double racc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (long long p0 = beg; p0 < end; p0 += PCHUNK) {
+            const int np = (int)((end - p0 < PCHUNK) ? (end - p0) : PCHUNK);
+            {   // window tables: lane = (point pi, dimension sl)
+                double b[4] = {0.0, 0.0, 0.0, 0.0};
+                if (pi < np) window_table_value(g, sl, xs[(long long)sl * cap + p0 + pi], b);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mytab[pi * TLD + 4 * sl + k] = b[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {   // phase 1: lane = (point pi, slab k3 = sl): b3[k3] * sum_{k2} b2 sum_{k1} b1 sum_{k0} b0 x
+                const double *__restrict__ tb = mytab + pi * TLD;
+                const double *__restrict__ px = pt + lbase + sl * (TB * TB * TB);
+                double r3 = 0.0;
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    double r2 = 0.0;
+#pragma unroll
+                    for (int j1 = 0; j1 < 4; ++j1) {
+                        double r1 = 0.0;
+#pragma unroll
+                        for (int j0 = 0; j0 < 4; ++j0) r1 = fma(tb[j0], px[j0 + TB * j1 + TB * TB * j2], r1);
+                        r2 = fma(tb[4 + j1], r1, r2);
+                    }
+                    r3 = fma(tb[8 + j2], r2, r3);
+                }
+                const double part = tb[12 + sl] * r3;
+                const double q0 = __shfl(part, pi, 64), q1 = __shfl(part, pi + 16, 64), q2 = __shfl(part, pi + 32, 64), q3 = __shfl(part, pi + 48, 64);
+                const double tsum = ((q0 + q1) + q2) + q3;
+                if (sl == 0) {
+                    double we = 0.0;
+                    if (pi < np) {
+                        const double wv = ws[p0 + pi];
+                        const double e = (ys ? wv * ys[p0 + pi] : 0.0) - wv * tsum;      // row residual w y - (w b) . x
+                        we = wv * e;
+                    }
+                    mywe[pi] = we;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // phase 2: lane = window functions (k0, k1, k2, 0..3): racc += (w b)_c e over the points (their order)
+            for (int q = 0; q < np; ++q) {
+                const double *__restrict__ tb = mytab + q * TLD;
+                const double c = ((mywe[q] * tb[k0]) * tb[4 + k1]) * tb[8 + k2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) racc[j] = fma(c, tb[12 + j], racc[j]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int li = lbase + k0 + TB * k1 + TB * TB * k2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) myacc[li + TB * TB * TB * j] += racc[j];
+    }
+    __syncthreads();
+    double *__restrict__ out = partial + (long long)blockIdx.x * TB4;
+    for (int idx = tid; idx < TB4; idx += 256) out[idx] = ((acc[0][idx] + acc[1][idx]) + acc[2][idx]) + acc[3][idx];
+}
+
+// rho[i] = sum of the tile partials that hold node i (tile order, dimension 0 fastest) - cterm[i]
+__global__ void __launch_bounds__(256)
+rows4_gather_kernel(Grid g, int nt0, int nt1, int nt2, int nt3, const double *__restrict__ partial, const double *__restrict__ cterm,
+                    double *__restrict__ rho)
+{
+    const int node = blockIdx.x * 256 + threadIdx.x;
+    if (node >= g.ncol) return;
+    const int nt[4] = {nt0, nt1, nt2, nt3};
+    int tlo[4], tcnt[4], in[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        in[d] = (node / g.colstride[d]) % g.nodes[d];
+        // tiles t with TCELL t <= in <= TCELL t + TB - 1
+        int lo = in[d] - (TB - 1);
+        lo = lo <= 0 ? 0 : (lo + TCELL - 1) / TCELL;
+        int hi = in[d] / TCELL;
+        if (hi > nt[d] - 1) hi = nt[d] - 1;
+        tlo[d] = lo;
+        tcnt[d] = hi - lo + 1;
+    }
+    double acc = 0.0;
+    for (int e3 = 0; e3 < tcnt[3]; ++e3)
+        for (int e2 = 0; e2 < tcnt[2]; ++e2)
+            for (int e1 = 0; e1 < tcnt[1]; ++e1)
+                for (int e0 = 0; e0 < tcnt[0]; ++e0) {
+                    const int t0 = tlo[0] + e0, t1 = tlo[1] + e1, t2 = tlo[2] + e2, t3 = tlo[3] + e3;
+                    const long long tile = ((long long)(t3 * nt2 + t2) * nt1 + t1) * nt0 + t0;
+                    const int li = (in[0] - TCELL * t0) + TB * ((in[1] - TCELL * t1) + TB * ((in[2] - TCELL * t2) + TB * (in[3] - TCELL * t3)));
+                    acc += partial[tile * TB4 + li];
+                }
+    rho[node] = cterm ? acc - cterm[node] : acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// constraint rows as tridiagonal mode products
+struct PassJob {            // one output array of a pass
+    int nsrc;               // forward: 1
+    int src[3];             // index of the source array in the input pool
+    int ord[3];             // derivative order of the factor along the pass's dimension (2 = second derivative, first at the ends)
+    int wsel;               // forward, last pass: 0 none, 1 weight dcw^2, 2 weight (2 dcw)^2 on the data-sparse nodes (0 elsewhere)
+};
+constexpr int MAXJOBS = 10;
+struct PassTable {
+    PassJob job[MAXJOBS];
+};
+
+// factor of basis function n + o at node n along dimension d, derivative order `ord` (2: the first derivative at the two ends, :998)
+__device__ inline double node_factor(const Grid &g, const double *__restrict__ ctab, int base, int d, int n, int o, int ord)
+{
+    const int nder = (ord == 2 && (n == 0 || n == g.nodes[d] - 1)) ? 1 : ord;
+    return ctab[base + (n * 3 + o + 1) * 3 + nder];
+}
+
+// forward: out_j[n] = w(n) sum_o F(n_k, o) in_src(j)[n + o e_k];  transposed: out_j[m] = sum_{sources} sum_o F(m_k + o, -o) in_s[m + o e_k]
+template <bool TRANSPOSED>
+__global__ void __launch_bounds__(256)
+tri_pass_kernel(Grid g, int k, int ctbase, PassTable tabl, const double *__restrict__ ctab, const double *__restrict__ inpool,
+                double *__restrict__ outpool, const double *__restrict__ dcw, const unsigned char *__restrict__ spf)
+{
+    const int node = blockIdx.x * 256 + threadIdx.x;
+    if (node >= g.ncol) return;
+    const PassJob &jb = tabl.job[blockIdx.y];
+    const int nk = g.nodes[k], stride = g.colstride[k];
+    const int ik = (node / stride) % nk;
+    const long long ncol = g.ncol;
+    double acc = 0.0;
+    for (int s = 0; s < jb.nsrc; ++s) {
+        const double *__restrict__ in = inpool + (long long)jb.src[s] * ncol;
+        const int ord = jb.ord[s];
+#pragma unroll
+        for (int o = -1; o <= 1; ++o) {
+            const int jk = ik + o;
+            if (jk < 0 || jk > nk - 1) continue;
+            const double f = TRANSPOSED ? node_factor(g, ctab, ctbase, k, jk, -o, ord) : node_factor(g, ctab, ctbase, k, ik, o, ord);
+            acc = fma(f, in[node + o * stride], acc);
+        }
+    }
+    if (!TRANSPOSED && jb.wsel != 0) {
+        double wgt = 0.0;
+        if (spf[node]) {
+            const double dc = jb.wsel == 1 ? dcw[node] : 2.0 * dcw[node];      // :983
+            wgt = dc * dc;
+        }
+        acc *= wgt;
+    }
+    outpool[(long long)blockIdx.y * ncol + node] = acc;
+}
+
+}  // namespace
+
+struct RowsOp {
+    int nt[4] = {1, 1, 1, 1};
+    long long ntiles = 0;
+    double *partial = nullptr;        // [ntiles][TB4]
+    double *poolA = nullptr, *poolB = nullptr;      // [10][ncol] each
+    int ctbase[MAXD] = {0, 0, 0, 0};
+    // passes: forward k = 0 .. D-1, transposed k = D-1 .. 0
+    PassTable fwd[MAXD], bwd[MAXD];
+    int nfwd[MAXD] = {0, 0, 0, 0}, nbwd[MAXD] = {0, 0, 0, 0};
+    size_t bytes = 0;
+    std::vector<void *> owned;
+};
+
+void rowsop_destroy(RowsOp *r)
+{
+    if (!r) return;
+    for (void *q : r->owned) (void)hipFree(q);
+    delete r;
+}
+
+size_t rowsop_bytes(const RowsOp *r) { return r ? r->bytes : 0; }
+
+// 4-D grids only (the 1-D .. 3-D passes of assemble.hip take 1.7 ms at 64^3 / 1e7 points); NULL for the others
+int rowsop_create(const Grid &g, RowsOp **out)
+{
+    *out = nullptr;
+    const char *sw = std::getenv("SPLPAK_ROWS_TILES");           // A/B switch: 0 = the cell-by-cell passes
+    if (g.ndim != 4 || (sw && atoi(sw) == 0)) return 0;
+    RowsOp *r = new RowsOp();
+    r->ntiles = 1;
+    for (int d = 0; d < 4; ++d) {
+        r->nt[d] = (g.cells[d] + TCELL - 1) / TCELL;
+        r->ntiles *= r->nt[d];
+    }
+    auto alloc = [&](double **q, size_t count) {
+        void *v = nullptr;
+        if (hipMalloc(&v, count * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        r->owned.push_back(v);
+        r->bytes += count * sizeof(double);
+        *q = static_cast<double *>(v);
+        return true;
+    };
+    if (!alloc(&r->partial, (size_t)r->ntiles * TB4) || !alloc(&r->poolA, (size_t)MAXJOBS * g.ncol) || !alloc(&r->poolB, (size_t)MAXJOBS * g.ncol)) {
+        rowsop_destroy(r);
+        set_error("rows operator: device allocation failed");
+        return SPLPAK_E_NOMEM;
+    }
+    int base = 0;
+    for (int d = 0; d < g.ndim; ++d) { r->ctbase[d] = base; base += 9 * g.nodes[d]; }
+    // The rows' patterns (derivative order per dimension): (i, i) -> 2 e_i, (i < j) -> e_i + e_j, in the reference's row order.
+    const int D = g.ndim;
+    std::vector<std::vector<int>> fin;
+    std::vector<int> wsel;
+    for (int i = 0; i < D; ++i)
+        for (int j = i; j < D; ++j) {
+            std::vector<int> a((size_t)D, 0);
+            if (i == j) a[(size_t)i] = 2; else { a[(size_t)i] = 1; a[(size_t)j] = 1; }
+            fin.push_back(a);
+            wsel.push_back(i == j ? 1 : 2);
+        }
+    // prefixes[k] = distinct prefixes of length k + 1 (in order of first appearance); prefixes[D-1] = fin
+    std::vector<std::vector<std::vector<int>>> pre((size_t)D);
+    for (int k = 0; k < D; ++k)
+        for (const auto &a : fin) {
+            std::vector<int> p(a.begin(), a.begin() + k + 1);
+            if (std::find(pre[(size_t)k].begin(), pre[(size_t)k].end(), p) == pre[(size_t)k].end()) pre[(size_t)k].push_back(p);
+        }
+    auto index_of = [&](int k, const std::vector<int> &p) {
+        return (int)(std::find(pre[(size_t)k].begin(), pre[(size_t)k].end(), p) - pre[(size_t)k].begin());
+    };
+    for (int k = 0; k < D; ++k) {
+        // forward pass k: output prefix (a_0 .. a_k) from its prefix (a_0 .. a_{k-1}) (k = 0: from x itself, source 0)
+        r->nfwd[k] = (int)pre[(size_t)k].size();
+        for (int j = 0; j < r->nfwd[k]; ++j) {
+            const auto &p = pre[(size_t)k][(size_t)j];
+            PassJob jb{};
+            jb.nsrc = 1;
+            jb.src[0] = k == 0 ? 0 : index_of(k - 1, std::vector<int>(p.begin(), p.end() - 1));
+            jb.ord[0] = p.back();
+            jb.wsel = 0;
+            if (k == D - 1) jb.wsel = wsel[(size_t)j];       // (pre[D-1] is `fin` in its own order)
+            r->fwd[k].job[j] = jb;
+        }
+        // transposed pass k: output prefix of length k (k = 0: the single result) from the arrays of length k + 1 that extend it
+        r->nbwd[k] = k == 0 ? 1 : (int)pre[(size_t)k - 1].size();
+        for (int j = 0; j < r->nbwd[k]; ++j) {
+            PassJob jb{};
+            jb.nsrc = 0;
+            for (int s = 0; s < (int)pre[(size_t)k].size(); ++s) {
+                const auto &p = pre[(size_t)k][(size_t)s];
+                const bool ext = k == 0 || std::equal(p.begin(), p.end() - 1, pre[(size_t)k - 1][(size_t)j].begin());
+                if (!ext) continue;
+                jb.src[jb.nsrc] = s;
+                jb.ord[jb.nsrc] = p.back();
+                ++jb.nsrc;
+            }
+            r->bwd[k].job[j] = jb;
+        }
+    }
+    *out = r;
+    return 0;
+}
+
+// rho = A^T W (W y - W A x) [- C^T C x]   (rows.ys == NULL: y = 0)
+hipError_t rowsop_apply(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
+                        const double *ctab, bool constraints, double *rho, hipStream_t st)
+{
+    hipLaunchKernelGGL(rows4_tile_kernel, dim3((unsigned)r->ntiles), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], (const int *)rows.offset,
+                       (const double *)rows.xs, (const double *)rows.ys, (const double *)rows.ws, rows.cap, xvec, r->partial);
+    const double *cterm = nullptr;
+    if (constraints) {
+        const int D = g.ndim;
+        const dim3 bl(256);
+        const unsigned gx = (unsigned)((g.ncol + 255) / 256);
+        const double *in = xvec;
+        double *pools[2] = {r->poolA, r->poolB};
+        int which = 0;
+        for (int k = 0; k < D; ++k) {
+            hipLaunchKernelGGL(tri_pass_kernel<false>, dim3(gx, (unsigned)r->nfwd[k]), bl, 0, st, g, k, r->ctbase[k], r->fwd[k], ctab, in, pools[which], dcw, spf);
+            in = pools[which];
+            which ^= 1;
+        }
+        for (int k = D - 1; k >= 0; --k) {
+            hipLaunchKernelGGL(tri_pass_kernel<true>, dim3(gx, (unsigned)r->nbwd[k]), bl, 0, st, g, k, r->ctbase[k], r->bwd[k], ctab, in, pools[which], dcw, spf);
+            in = pools[which];
+            which ^= 1;
+        }
+        cterm = in;
+    }
+    hipLaunchKernelGGL(rows4_gather_kernel, dim3((unsigned)((g.ncol + 255) / 256)), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], r->nt[3],
+                       (const double *)r->partial, cterm, rho);
+    return hipGetLastError();
+}
+
+}  // namespace splpak

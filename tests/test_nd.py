@@ -330,9 +330,7 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
                 {"SPLPAK_ND_STAGED_INIT": "0"}, {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_CLEAR_WGS": "0"}, {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_NO_EARLY_CLEAR": "1"},
                 {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_CUT": "2"},
                 # the root's look-ahead over the next diagonal block only (round 4)
-                {"SPLPAK_ND_ROOT_LA": "1"},
-                # groups of panel blocks per Schur pass: 2, then 4 | 1, 2, then 4 (default: 4 from the start)
-                {"SPLPAK_ND_RAMP": "2"}, {"SPLPAK_ND_RAMP": "1,2"}):
+                {"SPLPAK_ND_ROOT_LA": "1"}):
         c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1"))
         assert e == 0 and np.array_equal(c, ref), env
 
