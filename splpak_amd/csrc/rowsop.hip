@@ -28,7 +28,7 @@ namespace splpak {
 
 namespace {
 
-constexpr int TCELL = 3;                 // cells per tile and dimension
+constexpr int TCELL = 2;                 // cells per tile and dimension
 constexpr int TB = TCELL + 3;            // nodes per tile and dimension
 constexpr int TB4 = TB * TB * TB * TB;   // 1296
 constexpr int PCHUNK = 16;               // points per trip of a wave
@@ -45,6 +45,7 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     __shared__ double acc[4][TB4];
     __shared__ double tab[4][PCHUNK * TLD];
     __shared__ double swe[4][PCHUNK];
+    __shared__ int cbeg[TCELL * TCELL * TCELL * TCELL], cend[TCELL * TCELL * TCELL * TCELL], clb[TCELL * TCELL * TCELL * TCELL];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int t = blockIdx.x;
     int cb[4];
@@ -66,14 +67,11 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
 #pragma unroll
         for (int w = 0; w < 4; ++w) acc[w][idx] = 0.0;
     }
-    __syncthreads();
-    double *__restrict__ mytab = tab[wave];
-    double *__restrict__ mywe = swe[wave];
-    double *__restrict__ myacc = acc[wave];
-    const int k0 = lane & 3, k1 = (lane >> 2) & 3, k2 = lane >> 4;        // phase 2: the lane's window functions (k0, k1, k2, *)
-    const int pi = lane & 15, sl = lane >> 4;                              // staging: (point, dimension); phase 1: (point, slab k3)
-    for (int lc = wave; lc < TCELL * TCELL * TCELL * TCELL; lc += 4) {
-        int r = lc, cell = 0, lbase = 0, mul = 1;
+    // the point ranges of the tile's cells, looked up once (a wave that asked for them cell by cell waited out two dependent global
+    // round trips per cell -- with two workgroups per CU nothing hid them: 1.85 ms per pass at 32^4, twice the LDS-bound estimate)
+    constexpr int NCT = TCELL * TCELL * TCELL * TCELL;
+    if (tid < NCT) {
+        int r = tid, cell = 0, lb = 0, mul = 1;
         bool ok = true;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -81,67 +79,106 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
             r /= TCELL;
             ok = ok && cb[d] + a < g.cells[d];
             cell += (cb[d] + a) * g.cellstride[d];
-            lbase += a * mul;
+            lb += a * mul;
             mul *= TB;
         }
-        if (!ok) continue;
-        const long long beg = offset[cell], end = offset[cell + 1];
-        if (beg == end) continue;
-        double racc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (long long p0 = beg; p0 < end; p0 += PCHUNK) {
-            const int np = (int)((end - p0 < PCHUNK) ? (end - p0) : PCHUNK);
-            {   // window tables: lane = (point pi, dimension sl)
-                double b[4] = {0.0, 0.0, 0.0, 0.0};
-                if (pi < np) window_table_value(g, sl, xs[(long long)sl * cap + p0 + pi], b);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) mytab[pi * TLD + 4 * sl + k] = b[k];
+        cbeg[tid] = ok ? offset[cell] : 0;
+        cend[tid] = ok ? offset[cell + 1] : 0;
+        clb[tid] = lb;
+    }
+    __syncthreads();
+    double *__restrict__ mytab = tab[wave];
+    double *__restrict__ mywe = swe[wave];
+    double *__restrict__ myacc = acc[wave];
+    const int k0 = lane & 3, k1 = (lane >> 2) & 3, k2 = lane >> 4;        // phase 2: the lane's window functions (k0, k1, k2, *)
+    const int pi = lane & 15, sl = lane >> 4;                              // staging: (point, dimension); phase 1: (point, slab k3)
+    auto next_cell = [&](int lc) { while (lc < NCT && cbeg[lc] == cend[lc]) lc += 4; return lc; };
+    // the chunk after the current one is loaded while the current one is worked on
+    double xpre = 0.0, wpre = 0.0, ypre = 0.0;
+    auto issue = [&](int lc, int p0) {
+        if (lc >= NCT) return;
+        if (p0 + pi < cend[lc]) {
+            xpre = xs[(long long)sl * cap + p0 + pi];
+            if (sl == 0) {
+                wpre = ws[p0 + pi];
+                ypre = ys ? ys[p0 + pi] : 0.0;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            {   // phase 1: lane = (point pi, slab k3 = sl): b3[k3] * sum_{k2} b2 sum_{k1} b1 sum_{k0} b0 x
-                const double *__restrict__ tb = mytab + pi * TLD;
-                const double *__restrict__ px = pt + lbase + sl * (TB * TB * TB);
-                double r3 = 0.0;
-#pragma unroll
-                for (int j2 = 0; j2 < 4; ++j2) {
-                    double r2 = 0.0;
-#pragma unroll
-                    for (int j1 = 0; j1 < 4; ++j1) {
-                        double r1 = 0.0;
-#pragma unroll
-                        for (int j0 = 0; j0 < 4; ++j0) r1 = fma(tb[j0], px[j0 + TB * j1 + TB * TB * j2], r1);
-                        r2 = fma(tb[4 + j1], r1, r2);
-                    }
-                    r3 = fma(tb[8 + j2], r2, r3);
-                }
-                const double part = tb[12 + sl] * r3;
-                const double q0 = __shfl(part, pi, 64), q1 = __shfl(part, pi + 16, 64), q2 = __shfl(part, pi + 32, 64), q3 = __shfl(part, pi + 48, 64);
-                const double tsum = ((q0 + q1) + q2) + q3;
-                if (sl == 0) {
-                    double we = 0.0;
-                    if (pi < np) {
-                        const double wv = ws[p0 + pi];
-                        const double e = (ys ? wv * ys[p0 + pi] : 0.0) - wv * tsum;      // row residual w y - (w b) . x
-                        we = wv * e;
-                    }
-                    mywe[pi] = we;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // phase 2: lane = window functions (k0, k1, k2, 0..3): racc += (w b)_c e over the points (their order)
-            for (int q = 0; q < np; ++q) {
-                const double *__restrict__ tb = mytab + q * TLD;
-                const double c = ((mywe[q] * tb[k0]) * tb[4 + k1]) * tb[8 + k2];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) racc[j] = fma(c, tb[12 + j], racc[j]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
-        const int li = lbase + k0 + TB * k1 + TB * TB * k2;
+    };
+    int lc = next_cell(wave);
+    int p0 = lc < NCT ? cbeg[lc] : 0;
+    issue(lc, p0);
+    double racc[4] = {0.0, 0.0, 0.0, 0.0};
+    while (lc < NCT) {
+        const int end = cend[lc], lbase = clb[lc];
+        const int np = end - p0 < PCHUNK ? end - p0 : PCHUNK;
+        const double xcur = xpre, wcur = wpre, ycur = ypre;
+        int lcn = lc, p0n = p0 + PCHUNK;
+        if (p0n >= end) {
+            lcn = next_cell(lc + 4);
+            p0n = lcn < NCT ? cbeg[lcn] : 0;
+        }
+        issue(lcn, p0n);
+        {   // window tables: lane = (point pi, dimension sl)
+            double b[4] = {0.0, 0.0, 0.0, 0.0};
+            // (the closed forms of the evaluation kernels -- interior window / next to an end / general, basis.hpp -- : the general form
+            //  alone was 360 of the ~650 instructions of a trip, and the trip is issue bound; same values to rounding)
+            int form;
+            if (pi < np) window_table_selected(g, sl, xcur, b, form);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) myacc[li + TB * TB * TB * j] += racc[j];
+            for (int k = 0; k < 4; ++k) mytab[pi * TLD + 4 * sl + k] = b[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {   // phase 1: lane = (point pi, slab k3 = sl): b3[k3] * sum_{k2} b2 sum_{k1} b1 sum_{k0} b0 x
+            const double *__restrict__ tb = mytab + pi * TLD;
+            const double *__restrict__ px = pt + lbase + sl * (TB * TB * TB);
+            double r3 = 0.0;
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                double r2 = 0.0;
+#pragma unroll
+                for (int j1 = 0; j1 < 4; ++j1) {
+                    double r1 = 0.0;
+#pragma unroll
+                    for (int j0 = 0; j0 < 4; ++j0) r1 = fma(tb[j0], px[j0 + TB * j1 + TB * TB * j2], r1);
+                    r2 = fma(tb[4 + j1], r1, r2);
+                }
+                r3 = fma(tb[8 + j2], r2, r3);
+            }
+            const double part = tb[12 + sl] * r3;
+            const double q0 = __shfl(part, pi, 64), q1 = __shfl(part, pi + 16, 64), q2 = __shfl(part, pi + 32, 64), q3 = __shfl(part, pi + 48, 64);
+            const double tsum = ((q0 + q1) + q2) + q3;
+            if (sl == 0) {
+                double we = 0.0;
+                if (pi < np) {
+                    const double e = wcur * ycur - wcur * tsum;      // row residual w y - (w b) . x  (y = 0: the rows as an operator)
+                    we = wcur * e;
+                }
+                mywe[pi] = we;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // phase 2: lane = window functions (k0, k1, k2, 0..3): racc += (w b)_c e over the points (their order)
+        for (int q = 0; q < np; ++q) {
+            const double *__restrict__ tb = mytab + q * TLD;
+            const double c = ((mywe[q] * tb[k0]) * tb[4 + k1]) * tb[8 + k2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) racc[j] = fma(c, tb[12 + j], racc[j]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lcn != lc) {                  // the cell is done: its 256 shares into this wave's image of the tile
+            const int li = lbase + k0 + TB * k1 + TB * TB * k2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                myacc[li + TB * TB * TB * j] += racc[j];
+                racc[j] = 0.0;
+            }
+        }
+        lc = lcn;
+        p0 = p0n;
     }
     __syncthreads();
     double *__restrict__ out = partial + (long long)blockIdx.x * TB4;
