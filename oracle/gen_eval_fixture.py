@@ -17,7 +17,7 @@ re-writes a few of them as plain text, inputs included:
 Queries are tests.cases.make_queries(spec): exact node and boundary locations first, points outside the
 grid, then the seeded stream on [-0.25, 1.25]^d of the box.  No reference code runs here: data only.
 
-    python oracle/gen_eval_fixture.py [case ...]        default: 3d12 4d6 3d_aniso
+    python oracle/gen_eval_fixture.py [case ...]        default: 3d12 4d6 3d_aniso 5d4
 """
 import os
 import sys
@@ -27,7 +27,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from tests.cases import CASES, make_inputs, make_queries  # noqa: E402
+from tests.cases import CASES as _GPU_CASES, HOST_CASES, make_inputs, make_queries  # noqa: E402
+
+CASES = {**_GPU_CASES, **HOST_CASES}
 
 NQ_KEEP = 96          # the node / boundary / outside queries come first in make_queries
 
@@ -56,5 +58,5 @@ def write_case(name):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or ["3d12", "4d6", "3d_aniso"]):
+    for n in (sys.argv[1:] or ["3d12", "4d6", "3d_aniso", "5d4"]):
         write_case(n)

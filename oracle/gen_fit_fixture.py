@@ -19,11 +19,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from tests.cases import CASES  # noqa: E402
+from tests.cases import CASES as _GPU_CASES, HOST_CASES  # noqa: E402
+
+CASES = {**_GPU_CASES, **HOST_CASES}
 
 VARIANT = {"dense": 0, "zero_w": 1, "outside": 2, "clustered": 3}
 DEFAULT = ["c1_1d16", "c1_1d16_xt0", "1d_sparse", "2d8_cc", "2d16", "2d16_sparse", "2d16_zero_w", "2d16_outside",
-           "2d32_cc_xt0", "3d8", "3d8_sparse", "3d8_cc_clust", "3d12", "4d4", "4d5_cc"]
+           "2d32_cc_xt0", "3d8", "3d8_sparse", "3d8_cc_clust", "3d12", "4d4", "4d5_cc", "5d4"]
 
 
 def write_case(name):

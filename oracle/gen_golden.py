@@ -30,7 +30,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle.binding import Reference  # noqa: E402
-from tests.cases import CASES, make_inputs, make_queries, nderiv_patterns  # noqa: E402
+from tests.cases import CASES as _GPU_CASES, HOST_CASES, make_inputs, make_queries, nderiv_patterns  # noqa: E402
+
+CASES = {**_GPU_CASES, **HOST_CASES}
 
 
 def run_case(R, name, spec, outdir):

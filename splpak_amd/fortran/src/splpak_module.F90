@@ -46,6 +46,9 @@ module splpak_module
 
     integer,parameter,public :: splpak_wp = wp   !! working precision
 
+    integer,save :: no_gpu_optin = -1            !! SPLPAK_HOST_IF_NO_GPU as read once (-1: not read yet)
+    logical,save :: no_gpu_said = .false.        !! the one line about it has been printed
+
     type,public :: splpak_type
         private
         integer :: mdim = 0    !! dimension of the last call (the reference keeps scratch here, :95-111)
@@ -204,6 +207,40 @@ module splpak_module
     end subroutine report
 
     !> a negative status is an infrastructure failure (no GPU, out of device memory, ...)
+    !> .true. when a call has to run on the host solver whatever the GPU could do: `set_host(.true.)`, or more than four
+    !! dimensions -- the reference takes any ndim >= 1 (:716-722, :1166-1172; "1..4" is a remark in its documentation, :1099),
+    !! the HIP kernels are written for 1..4 (include/splpak_hip.h SPLPAK_MAXDIM), the host solver is written for any ndim.
+    pure logical function host_takes(me,ndim)
+        class(splpak_type),intent(in) :: me
+        integer,intent(in) :: ndim
+        host_takes = me%host .or. ndim > 4
+    end function host_takes
+
+    !> Opt-in for machines without a GPU (fpm dependents running their tests, SURVEY section 8f-4): with
+    !! SPLPAK_HOST_IF_NO_GPU=1 in the environment a call that the HIP library refuses with "no usable device" (-1) runs on
+    !! the host solver instead, and says so once per process on output_unit.  Never a default, never silent; any other
+    !! failure of the library is reported as before.
+    logical function host_if_no_gpu(rc)
+        integer,intent(in) :: rc
+        character(len=8) :: val
+        integer :: n, stat
+        host_if_no_gpu = .false.
+        if (rc /= -1) return
+        if (no_gpu_optin < 0) then
+            no_gpu_optin = 0
+            call get_environment_variable('SPLPAK_HOST_IF_NO_GPU', val, n, stat)
+            if (stat == 0 .and. n >= 1) then
+                if (val(1:1) == '1') no_gpu_optin = 1
+            end if
+        end if
+        host_if_no_gpu = no_gpu_optin == 1
+        if (host_if_no_gpu .and. .not. no_gpu_said) then
+            no_gpu_said = .true.
+            write(output_unit,'(a)') ' splpak: no usable GPU (HIP library status -1); '// &
+                                     'SPLPAK_HOST_IF_NO_GPU=1: running on the host solver'
+        end if
+    end function host_if_no_gpu
+
     subroutine report_library_failure(ierr,who)
         integer,intent(in) :: ierr
         character(len=*),intent(in) :: who
@@ -304,7 +341,7 @@ module splpak_module
             ncol = ncol*int(max(nodes(idim),1),c_int64_t)
         end do
         if (ndim >= 1 .and. xtrap /= 0.0_wp .and. int(nwrk,c_int64_t) >= ncol) hist = c_loc(work)
-        if (me%host) then
+        if (host_takes(me,ndim)) then
             call fit_on_host(me,ndim,xdata,l1xdat,ydata,wdata,ndata,xmin,xmax,nodes,xtrap,coef,ncf,work,nwrk,ierror)
             return
         end if
@@ -323,6 +360,10 @@ module splpak_module
         end if
 #endif
         ierror = int(rc)
+        if (host_if_no_gpu(ierror)) then
+            call fit_on_host(me,ndim,xdata,l1xdat,ydata,wdata,ndata,xmin,xmax,nodes,xtrap,coef,ncf,work,nwrk,ierror)
+            return
+        end if
         if (rc > 0) then
             call report_fit(ierror)
         else if (rc < 0) then
@@ -553,7 +594,15 @@ module splpak_module
         integer(c_int32_t) :: rc
         integer :: iq, idm, jdm, col, nder(max(ndim,1)), ie
         me%mdim = ndim
-        if (me%host) then             ! host solver selected: every column is the scalar splde of its pattern
+        rc = 0
+#ifndef REAL128
+        if (.not. host_takes(me,ndim)) then
+            rc = c_eval_derivs(int(ndim,c_int32_t), int(nq,c_int64_t), c_loc(x), int(ldx,c_int32_t), &
+                               int(order,c_int32_t), c_loc(coef), c_loc(xmin), c_loc(xmax), c_loc(nodes), &
+                               c_loc(f), int(ldf,c_int32_t))
+        end if
+#endif
+        if (host_takes(me,ndim) .or. host_if_no_gpu(int(rc))) then      ! host solver: every column is the scalar splde of its pattern
             ierror = 0
             if (order < 1 .or. order > 2 .or. ldf < 1 + ndim + merge(ndim*(ndim+1)/2, 0, order == 2)) then
                 ierror = -3
@@ -587,11 +636,8 @@ module splpak_module
             end do
             return
         end if
+#ifdef REAL128
         rc = -1
-#ifndef REAL128
-        rc = c_eval_derivs(int(ndim,c_int32_t), int(nq,c_int64_t), c_loc(x), int(ldx,c_int32_t), &
-                           int(order,c_int32_t), c_loc(coef), c_loc(xmin), c_loc(xmax), c_loc(nodes), &
-                           c_loc(f), int(ldf,c_int32_t))
 #endif
         ierror = int(rc)
         select case (ierror)
@@ -615,7 +661,12 @@ module splpak_module
         integer,pointer :: pn(:), pd(:)
         integer :: iq, ie, zero(max(ndim,1)), ncol, idim
         me%mdim = ndim
-        if (me%host .and. ndim >= 1) then         ! host solver selected: a loop over the scalar evaluation
+        rc = 0
+#ifndef REAL128
+        if (.not. (host_takes(me,ndim) .and. ndim >= 1)) &
+            rc = c_eval(int(ndim,c_int32_t), nq, x, int(ldx,c_int32_t), nderiv, coef, xmin, xmax, nodes, f)
+#endif
+        if ((host_takes(me,ndim) .or. host_if_no_gpu(int(rc))) .and. ndim >= 1) then   ! host solver: a loop over the scalar evaluation
             call c_f_pointer(nodes, pn, [ndim])
             ncol = 1
             do idim = 1, ndim
@@ -640,9 +691,8 @@ module splpak_module
             end do
             return
         end if
+#ifdef REAL128
         rc = -1
-#ifndef REAL128
-        rc = c_eval(int(ndim,c_int32_t), nq, x, int(ldx,c_int32_t), nderiv, coef, xmin, xmax, nodes, f)
 #endif
         ierror = int(rc)
         select case (ierror)

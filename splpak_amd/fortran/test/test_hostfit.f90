@@ -29,8 +29,8 @@ contains
 
     subroutine one(file)
         character(len=*),intent(in) :: file
-        integer :: u, ndim, m, iw, variant, ncol, nhist, nodes(4), i, d, ierror, nrows, ncons, nsteps, nwrk
-        real(wp) :: xtrap, xmin(4), xmax(4), t, err, cmax, herr, omega, reserr
+        integer :: u, ndim, m, iw, variant, ncol, nhist, nodes(8), i, d, ierror, nrows, ncons, nsteps, nwrk
+        real(wp) :: xtrap, xmin(8), xmax(8), t, err, cmax, herr, omega, reserr
         real(wp),allocatable :: xdata(:,:), ydata(:), wdata(:), coef(:), cref(:), href(:), work(:)
         logical :: host
         type(splpak_type) :: s
@@ -79,12 +79,16 @@ contains
         nwrk = ncol + 1
         allocate(work(nwrk))
         work = -1.0_wp
-        call s%set_host(.true.)
-        call s%last_fit_info(on_host=host)
-        if (.not. host) then
-            nbad = nbad + 1
-            write(*,*) 'set_host did not take'
+        if (ndim <= 4) then
+            call s%set_host(.true.)
+            call s%last_fit_info(on_host=host)
+            if (.not. host) then
+                nbad = nbad + 1
+                write(*,*) 'set_host did not take'
+            end if
         end if
+        ! (more than four dimensions: no set_host -- the module itself routes the call to the host solver, the reference
+        !  accepts any ndim, src/splpak.F90:716-722)
         if (iw == 1) then
             call s%initialize(ndim,xdata,ndim,ydata,wdata,m,xmin(1:ndim),xmax(1:ndim),nodes(1:ndim),xtrap,coef,ncol,work,nwrk,ierror)
         else

@@ -48,6 +48,12 @@ CASES = {
     "2d64_c2grid":    dict(ndim=2, nodes=[64, 64], m=12000, weighted=False, xtrap=1.0, variant="dense", slow=True),
 }
 
+# More than four dimensions: the reference takes any ndim >= 1 (src/splpak.F90:716-722); the HIP kernels are written for 1..4, the
+# Fortran module routes such calls to its host solver (round 6).  Kept apart from CASES: the GPU tests iterate over those.
+HOST_CASES = {
+    "5d4":            dict(ndim=5, nodes=[4, 5, 4, 4, 4], m=4000, weighted=True, xtrap=1.0, variant="dense"),
+}
+
 NQ = 256  # evaluation queries stored per nderiv pattern
 
 
@@ -119,5 +125,7 @@ def nderiv_patterns(nd):
     if nd == 3:
         return [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [2, 0, 0], [0, 2, 0], [0, 0, 2],
                 [1, 1, 0], [1, 0, 1], [0, 1, 1], [2, 1, 0], [1, 1, 1], [2, 2, 2]]
-    return [[0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 1], [0, 2, 0, 0], [1, 1, 0, 0],
-            [0, 1, 0, 1], [1, 1, 1, 1], [2, 0, 1, 0], [2, 2, 2, 2]]
+    if nd == 4:
+        return [[0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 1], [0, 2, 0, 0], [1, 1, 0, 0],
+                [0, 1, 0, 1], [1, 1, 1, 1], [2, 0, 1, 0], [2, 2, 2, 2]]
+    return [[0] * nd, [1] + [0] * (nd - 1), [0] * (nd - 1) + [2], [1, 1] + [0] * (nd - 2), [2] * nd]

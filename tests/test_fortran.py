@@ -51,7 +51,7 @@ def test_fortran_scalar_evaluate_matches_reference_goldens_3d_4d():
     reference's own values on 3-D / 4-D grids, incl. node / boundary / outside queries and nderiv = 2, at 1e-12
     (VERDICT r02 #6a).  No GPU needed."""
     _ensure_built()
-    fx = [os.path.join(ROOT, "tests", "golden", f"eval_{n}.txt") for n in ("3d12", "4d6", "3d_aniso")]
+    fx = [os.path.join(ROOT, "tests", "golden", f"eval_{n}.txt") for n in ("3d12", "4d6", "3d_aniso", "5d4")]   # 5d4: ndim > 4, also the batch call
     r = subprocess.run([os.path.join(BUILD, "test_evalfix")] + fx, capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout + r.stderr
@@ -70,7 +70,7 @@ def test_fortran_host_solver_matches_reference_goldens():
     clustered data): 1e-10 max-norm on the coefficients, 1e-12 on the histogram.  No GPU, and not the oracle."""
     _ensure_built()
     fx = _fit_fixtures()
-    assert len(fx) >= 15
+    assert len(fx) >= 16 and any("fit_5d4" in f for f in fx)      # 5d4: ndim = 5, routed to the host solver by the module itself
     r = subprocess.run([os.path.join(BUILD, "test_hostfit")] + fx, capture_output=True, text=True, timeout=600)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout + r.stderr
@@ -86,6 +86,25 @@ def test_fortran_reference_scenarios_on_the_host_solver(prog):
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"PASS {prog}" in r.stdout
+
+
+@pytest.mark.parametrize("prog", ["test_linear", "test_noisy"])
+def test_unchanged_caller_runs_without_gpu_when_opted_in(prog):
+    """SURVEY 8f-4 / round-5 verdict: an UNCHANGED caller (no set_host in its source) on a machine without a GPU.  By default the
+    call fails loudly (test_fortran_fails_loudly_without_gpu); with SPLPAK_HOST_IF_NO_GPU=1 in the environment the module says so
+    once and runs the host solver -- the reference's own scenarios pass."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    _ensure_built()
+    env = dict(os.environ, SPLPAK_HOST_IF_NO_GPU="1")
+    r = subprocess.run([os.path.join(BUILD, prog)], capture_output=True, text=True, timeout=300, env=env)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0 and f"PASS {prog}" in r.stdout
+    assert r.stdout.count("SPLPAK_HOST_IF_NO_GPU=1: running on the host solver") == 1
+    env["SPLPAK_HOST_IF_NO_GPU"] = "0"
+    r = subprocess.run([os.path.join(BUILD, prog)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "HIP library failure" in r.stdout + r.stderr
 
 
 def test_fortran_real128_build_runs_on_the_host_solver():

@@ -361,6 +361,68 @@ def test_eval_persistent_4d_path_matches_the_direct_kernel(port, nodes):
         capi.set_eval_mode(capi.EVAL_AUTO)
 
 
+def test_config5_evaluation_at_full_size_1e8_queries(port):
+    """BASELINE config 5's evaluation half AT ITS OWN SIZE (round-5 verdict: only bench.py ran it, unchecked): 4-D 32^4
+    coefficients, 1e8 scattered queries resident in HBM (the seeded query stream of splpak_amd.synth), splfe values and two splde
+    derivative patterns, real64 and REAL32 storage.  The persistent region path (what the automatic choice takes at this size) must
+    return the BITS of the one-thread-per-query kernel on the whole batch (src/splpak.F90:1089-1240 is the arithmetic of both),
+    and the values of the reference algorithm (oracle port.evaluate) on a sample of 2 000 queries spread over the batch."""
+    import torch
+    capi.shutdown()
+    torch.cuda.empty_cache()
+    nd, nod, nq = 4, 32, 100_000_000
+    nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(2026)
+    coef_h = rng.standard_normal(nod ** nd)
+    coef = torch.from_numpy(coef_h).to(dev)
+    q = torch.empty((nq, nd), dtype=torch.float64, device=dev)
+    capi.synth_queries_dev(nd, 10_000_000, 0, nq, q, st)
+    vd = torch.empty(nq, dtype=torch.float64, device=dev)
+    vb = torch.empty(nq, dtype=torch.float64, device=dev)
+    sample = np.linspace(0, nq - 1, 2000).astype(np.int64)
+    qs = q[torch.from_numpy(sample).to(dev)].cpu().numpy()
+    try:
+        for pat in (None, [1, 0, 0, 0], [0, 2, 0, 1]):
+            capi.set_eval_mode(capi.EVAL_DIRECT)
+            capi.evaluate_dev(nd, q, pat, coef, lo, hi, nodes, vd, st)
+            capi.set_eval_mode(capi.EVAL_BINNED, 0)
+            capi.evaluate_dev(nd, q, pat, coef, lo, hi, nodes, vb, st)
+            torch.cuda.synchronize()
+            assert torch.equal(vd, vb), pat
+            capi.set_eval_mode(capi.EVAL_AUTO)
+            capi.evaluate_dev(nd, q, pat, coef, lo, hi, nodes, vb, st)
+            torch.cuda.synchronize()
+            assert torch.equal(vd, vb), pat
+            vo, _ = port.evaluate(nd, qs, pat, coef_h, lo, hi, nodes)
+            got = vd[torch.from_numpy(sample).to(dev)].cpu().numpy()
+            scale = max(np.max(np.abs(vo)), np.max(np.abs(coef_h)) * 31.0 ** sum(pat or [0]))
+            assert np.max(np.abs(got - vo)) <= EVAL_TOL * scale, pat
+        del vd, vb
+        # REAL32 storage (f64 arithmetic inside): the two paths agree bitwise, and with real64 to single-precision rounding of the inputs
+        q32 = q.to(torch.float32)
+        del q
+        c32 = coef.to(torch.float32)
+        v0 = torch.empty(nq, dtype=torch.float32, device=dev)
+        v1 = torch.empty(nq, dtype=torch.float32, device=dev)
+        for pat in (None, [0, 2, 0, 1]):
+            capi.set_eval_mode(capi.EVAL_DIRECT)
+            capi.evaluate_dev(nd, q32, pat, c32, lo, hi, nodes, v0, st)
+            capi.set_eval_mode(capi.EVAL_BINNED, 0)
+            capi.evaluate_dev(nd, q32, pat, c32, lo, hi, nodes, v1, st)
+            torch.cuda.synchronize()
+            assert torch.equal(v0, v1), pat
+            vo, _ = port.evaluate(nd, qs.astype(np.float32).astype(np.float64), pat, coef_h.astype(np.float32).astype(np.float64), lo, hi, nodes)
+            got = v0[torch.from_numpy(sample).to(dev)].cpu().numpy().astype(np.float64)
+            scale = max(np.max(np.abs(vo)), np.max(np.abs(coef_h)) * 31.0 ** sum(pat or [0]))
+            assert np.max(np.abs(got - vo)) <= 2e-6 * scale, pat
+    finally:
+        capi.set_eval_mode(capi.EVAL_AUTO)
+        capi.shutdown()
+        torch.cuda.empty_cache()
+
+
 def test_eval_run_path_with_clustered_queries():
     """The 3-D run path (round 3: every place-pass workgroup leaves its own region-sorted image and the starts of its
     runs; the evaluation workgroups gather the runs of their region -- no global sort).  Scattered queries give runs of

@@ -236,8 +236,11 @@ def test_nd_4d_28_the_largest_grid_one_gpu_holds(port):
     capi.shutdown()
     torch.cuda.empty_cache()
     free, total = torch.cuda.mem_get_info()
-    if free < 285e9:
-        pytest.skip(f"needs ~280 GB of free device memory, {free / 1e9:.0f} GB are free")
+    if total < 300e9:
+        pytest.skip(f"needs a 288 GiB device, this one has {total / 1e9:.0f} GB")
+    # (a fresh box -- the driver's lease -- has 308 of 309 GB free; a busier one must not drop config 5's only full-pipeline
+    #  factorised 4-D check silently: round-5 verdict)
+    assert free >= 285e9, f"needs ~280 GB of free device memory, only {free / 1e9:.0f} of {total / 1e9:.0f} GB are free: something else holds the device"
     nd, nod, m = 4, 28, 10_000_000
     nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
     dev = torch.device("cuda", 0)
