@@ -292,7 +292,11 @@ def bench_c5_fit_nd28(capi, dev, stream):
     capi.synth_points_dev(nd, 0, m, x, y, w, stream)
     coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
     t0 = time.perf_counter()
-    plan = capi.Plan(nd, nodes, [0.0] * nd, [1.0] * nd, 1.0, m)
+    os.environ["SPLPAK_SOLVER"] = "direct"                            # (left to itself a grid of this size tries the iteration first)
+    try:
+        plan = capi.Plan(nd, nodes, [0.0] * nd, [1.0] * nd, 1.0, m)
+    finally:
+        os.environ.pop("SPLPAK_SOLVER", None)
     t_plan = time.perf_counter() - t0
     try:
         fact = plan.factorisation()[1]

@@ -191,12 +191,25 @@ int64_t splpak_plan_device_bytes(const splpak_plan *plan);
  * block columns), 6 NO factorisation: the iterative solve below (grids whose factor does not fit the device, or by request);
  * a description is copied into buf. */
 int32_t splpak_plan_factorisation(const splpak_plan *plan, char *buf, int32_t buflen);
+/* Options (round 6).  Every switch of the library is a named option; a plan takes a snapshot of them when it is created --
+ * the process defaults set here over the SPLPAK_<NAME> variables of the environment -- and a fit reads nothing else (no getenv
+ * on the fit path; the one-shot entry's cached plan is keyed by the snapshot).  `name` is "nd_kb", "ND_KB" or "SPLPAK_ND_KB";
+ * `value` is the text the environment variable would hold, NULL removes the setting.  Returns 0, SPLPAK_E_BADARG for an
+ * unknown name, and (plan_set_option) SPLPAK_E_UNSUPPORTED for an option that shapes the plan's storage or job tables and is
+ * therefore consumed at creation (solver, nd, nd_split, nd_cut, nd_kb, nd_res_cus, no_reorder, gram_scratch_mb, pcg_maxit,
+ * mplan_rccl, rccl_lib): set those as defaults before splpak_plan_create.  The documented options are listed in
+ * INTEGRATION.md; the other names are A/B switches of the test suite and may disappear.
+ * splpak_plan_get_option: 1 if set (value copied into buf), 0 if not. */
+int32_t splpak_set_default_option(const char *name, const char *value);
+int32_t splpak_plan_set_option(splpak_plan *plan, const char *name, const char *value);
+int32_t splpak_plan_get_option(const splpak_plan *plan, const char *name, char *buf, int32_t buflen);
+
 /* The iterative solve (round 6; csrc/pcg.hip): preconditioned conjugate gradients on the normal equations with the operator
  * applied from the rows (data rows :788-855, constraint rows :921-1046) and a separable preconditioner, inside the same
  * refinement against the rows as the factorisations.  It replaces suprls (:1375-1695) for the grids the reference accepts
  * (any grid, :512-534) and no factorisation fits: BASELINE config 5's 4-D 32^4 grid on one GPU.  Selected automatically when
- * the factor storage cannot be allocated, or with SPLPAK_SOLVER=pcg (iteration only) / pcg+direct (iteration first, the
- * factorisation when it stagnates) in the environment at plan creation.  A fit whose iteration stagnates and whose plan
+ * the factor storage cannot be allocated and, in front of the factorisation, for 4-D grids of 160 000 columns or more; or with
+ * the option solver = pcg (iteration only) / pcg+direct (iteration first, the factorisation when it stagnates) / direct.  A fit whose iteration stagnates and whose plan
  * has no factorisation returns 107 with an explanatory message.
  * out6: [0] iterations of the last fit over all its solves, [1] solves, [2] iterations of the last solve, [3] its final
  * preconditioned residual (relative), [4] [5] the preconditioner's two moments (density of w^2, mean squared constraint weight);

@@ -32,7 +32,7 @@ SYMBOLS = [
     "splpak_eval_dev_f64", "splpak_eval_dev_f32", "splpak_eval_derivs_f64", "splpak_eval_derivs_f32", "splpak_eval_derivs_dev_f64",
     "splpak_synth_points_f64", "splpak_synth_queries_f64",
     "splpak_mplan_create", "splpak_mplan_destroy", "splpak_mplan_device", "splpak_mplan_rank_bytes", "splpak_mplan_factorisation", "splpak_mplan_fit_dev", "splpak_fit_multi_f64",
-    "splpak_plan_device_bytes", "splpak_plan_pcg_stats",
+    "splpak_plan_device_bytes", "splpak_plan_pcg_stats", "splpak_set_default_option", "splpak_plan_set_option", "splpak_plan_get_option",
     "splpak_debug_spd_band_solve_f64", "splpak_debug_nd_tree", "splpak_debug_nd_partition", "splpak_debug_nd_schedule", "splpak_debug_window_values", "splpak_shutdown", "splpak_set_eval_mode",
     "splpak_last_error_message", "splpak_device_name",
 ]
@@ -145,6 +145,12 @@ def lib() -> C.CDLL:
     L.splpak_mplan_factorisation.argtypes = [vp, C.c_char_p, i32]
     L.splpak_mplan_rank_bytes.restype = i64
     L.splpak_mplan_rank_bytes.argtypes = [vp, i32]
+    L.splpak_set_default_option.restype = i32
+    L.splpak_set_default_option.argtypes = [C.c_char_p, C.c_char_p]
+    L.splpak_plan_set_option.restype = i32
+    L.splpak_plan_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.splpak_plan_get_option.restype = i32
+    L.splpak_plan_get_option.argtypes = [vp, C.c_char_p, C.c_char_p, i32]
     L.splpak_plan_pcg_stats.restype = None
     L.splpak_plan_pcg_stats.argtypes = [vp, _dp]
     L.splpak_plan_device_bytes.restype = i64
@@ -178,6 +184,12 @@ def _check(rc: int) -> int:
     if rc < 0:
         raise SplpakError(f"splpak HIP library error {rc}: {last_error()}")
     return rc
+
+
+def set_default_option(name, value) -> int:
+    """Process-wide default of an option (what SPLPAK_<NAME> in the environment would set) for plans created afterwards;
+    value None removes it.  Raises on an unknown name."""
+    return _check(lib().splpak_set_default_option(name.encode(), None if value is None else str(value).encode()))
 
 
 def shutdown() -> None:
@@ -453,6 +465,14 @@ class Plan:
 
     def device_bytes(self):
         return int(self._L.splpak_plan_device_bytes(self._h))
+
+    def set_option(self, name, value):
+        """A per-fit option of this plan (value as text, None removes it); options that shape the plan raise: set_default_option."""
+        return _check(self._L.splpak_plan_set_option(self._h, name.encode(), None if value is None else str(value).encode()))
+
+    def get_option(self, name):
+        buf = C.create_string_buffer(256)
+        return buf.value.decode() if _check(self._L.splpak_plan_get_option(self._h, name.encode(), buf, 256)) == 1 else None
 
     def pcg_stats(self):
         """Iterative solve of the last fit: dict(iterations, solves, last_iterations, last_residual, rho, lam); zeros without it."""

@@ -2226,7 +2226,7 @@ long long bin_record_doubles(const Grid &g, long long max_ndata)
 hipError_t launch_bin_points(const Grid &g, long long m, const double *x, int ldx, const double *y,
                              const double *w, const SortScratch &s, double *scal, hipStream_t st)
 {
-    static const bool old_form = std::getenv("SPLPAK_BIN_ATOMIC") != nullptr;      // A/B switch: rounds 1-4 (global atomics + in-cell re-sort)
+    const bool old_form = splpak::opt_get("SPLPAK_BIN_ATOMIC") != nullptr;      // A/B switch: rounds 1-4 (global atomics + in-cell re-sort)
     const int cpt = sp_cells_per_bin(g);
     if (!old_form && cpt > 0 && s.cntm && s.binbase && s.sppart && (cpt == 1 || s.rec)) {
         if (m <= 0) return hipMemsetAsync(s.offset, 0, sizeof(int) * (size_t)(g.ncell + 2), st);
@@ -2282,7 +2282,7 @@ template <int D>
 static bool gram_cells(const Grid &g, const SortScratch &s, double *blk, double *rblk, double *hblk, double *hist, int cell0,
                        int ncells, hipStream_t st)
 {
-    static const bool old_form = std::getenv("SPLPAK_GRAM_VALU") != nullptr;       // A/B switch: the workgroup-per-cell form
+    const bool old_form = splpak::opt_get("SPLPAK_GRAM_VALU") != nullptr;       // A/B switch: the workgroup-per-cell form
     if constexpr (D == 2 || D == 3) {
         if (!old_form) {
             // cells per wave: GW_RUN where that still leaves four rounds of waves for the chip (two per SIMD), fewer on a small grid
@@ -2329,7 +2329,7 @@ hipError_t launch_gram(const Grid &g, const SortScratch &s, double *scratch, lon
         double *rblk = blk + (long long)ncells * gram_tri(g.nb);
         double *hblk = smooth ? rblk + (long long)ncells * g.nb : nullptr;
         DISPATCH_D(g.ndim, {
-            const bool zeroed = gram_cells<D>(g, s, blk, rblk, hblk, hist, cell0, ncells, st) && !std::getenv("SPLPAK_GATHER_LOOKUP");
+            const bool zeroed = gram_cells<D>(g, s, blk, rblk, hblk, hist, cell0, ncells, st) && !splpak::opt_get("SPLPAK_GATHER_LOOKUP");
             const dim3 gg((unsigned)((node1 - node0 + 3) / 4));
             if (zeroed)
                 hipLaunchKernelGGL((stencil_gather_kernel<D, true>), gg, dim3(256), 0, st, g,
@@ -2398,7 +2398,7 @@ static void residual_cells(const Grid &g, const SortScratch &s, const double *xv
                            (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,
                            s.cap, xvec, rcell, e2c);
     } else {
-        static const bool old_form = std::getenv("SPLPAK_RESIDUAL_STAGED") != nullptr;      // A/B switch
+        const bool old_form = splpak::opt_get("SPLPAK_RESIDUAL_STAGED") != nullptr;      // A/B switch
         if (old_form)
             hipLaunchKernelGGL(residual_block_kernel<D>, dim3((unsigned)g.ncell), dim3(ResCfg<D>::NT), 0, st, g,
                                (const int *)s.offset, (const double *)s.xs, (const double *)s.ys, (const double *)s.ws,

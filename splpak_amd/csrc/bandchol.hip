@@ -862,7 +862,7 @@ Pipeline &pipeline(void *&slot, int nblk, bool wide, bool want_res)
         // itself on the reserved CU steps aside (syrk64_kernel).  The CU's id is read back once.
         // (Only created for bands wide enough to use it: every stream is a hardware queue, and the
         // fewer of them a two-ended factorisation holds, the better its two chains overlap.)
-        if (!std::getenv("SPLPAK_NO_PANEL_CU")) {
+        if (!splpak::opt_get("SPLPAK_NO_PANEL_CU")) {
             hipDeviceProp_t prop;
             (void)hipGetDeviceProperties(&prop, dev);
             const int ncu = prop.multiProcessorCount;
@@ -928,7 +928,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     if (kbeg < 0 || kbeg >= kend) return hipErrorInvalidValue;
     const bool partial = kend < b.nblk;
     {   // narrow bands: the two-stream form below (SPLPAK_NO_NARROW keeps the four-stream pipeline, for comparison)
-        if (b.bw < narrow_band_limit() && !std::getenv("SPLPAK_NO_NARROW")) {
+        if (b.bw < narrow_band_limit() && !splpak::opt_get("SPLPAK_NO_NARROW")) {
             if (stats) *stats = CholStats{stats->enabled};
             return band_cholesky_narrow(b, info_dev, minpiv_dev, st, kbeg, kend, nfinish);
         }
@@ -937,11 +937,11 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     const auto t_enq = std::chrono::steady_clock::now();
     // potrf is pinned to the reserved CU (own stream, two event hops per step) when the trailing update is
     // heavy enough to starve it; with a narrow band the step is bound by the chain itself and the hops cost more
-    const int pin_bw = std::getenv("SPLPAK_PIN_BW") ? atoi(std::getenv("SPLPAK_PIN_BW")) : 24;
+    const int pin_bw = splpak::opt_get("SPLPAK_PIN_BW") ? atoi(splpak::opt_get("SPLPAK_PIN_BW")) : 24;
     Pipeline &pl = pipeline(b.pipe, b.nblk, true, b.bw >= pin_bw);
     hipStream_t sP = pl.panel, sC = pl.col, sU = pl.upd;
     hipStream_t sR = (pl.res && b.bw >= pin_bw) ? pl.res : pl.panel;
-    if (!sP || !sC || !sU || std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = sC = sU = sR = st;   // no streams / diagnostics: no overlap
+    if (!sP || !sC || !sU || splpak::opt_get("SPLPAK_NO_LOOKAHEAD")) sP = sC = sU = sR = st;   // no streams / diagnostics: no overlap
     // the item queues and events belong to the pipeline, not to the caller's stream: a factorisation
     // enqueued from another stream must not clear them while the previous one is still running
     if (pl.used && pl.done) (void)hipStreamWaitEvent(st, pl.done, 0);
@@ -966,7 +966,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     // bulk = true: the launch that carries ~92 % of the flops; it is a separate template
     // instantiation (ABL bit 8, no functional difference) so that profilers list it under its own
     // name, and it alone feeds the roofline statistics
-    const bool bulk_stop_event = std::getenv("SPLPAK_NO_STOPEV") == nullptr;
+    const bool bulk_stop_event = splpak::opt_get("SPLPAK_NO_STOPEV") == nullptr;
     auto syrk = [&](hipStream_t s, int k, int cb, int ce, int rb, int re, bool bulk = false) {
         const int k0 = k * NBLK;
         long long items = 0;
@@ -1001,7 +1001,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
             stats->bulk_flop += 2.0 * (double)items * 64 * 64 * NBLK;
         }
     };
-    const bool top32 = std::getenv("SPLPAK_TOPA64") == nullptr;          // topA in 32x32 pieces (36 waves) unless asked otherwise
+    const bool top32 = splpak::opt_get("SPLPAK_TOPA64") == nullptr;          // topA in 32x32 pieces (36 waves) unless asked otherwise
     auto potrf = [&](int k) {        // potrf(k) (+ the 16x16 leaf inverses) pinned to the reserved CU
         const int k0 = k * NBLK;
         if (sR != sP) {
@@ -1084,7 +1084,7 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
     }
     (void)hipEventRecord(pl.evC[b.nblk], sU);      // join: the caller's stream continues after the pipeline
     (void)hipStreamWaitEvent(st, pl.evC[b.nblk], 0);
-    if (std::getenv("SPLPAK_DEBUG"))
+    if (splpak::opt_get("SPLPAK_DEBUG"))
         std::fprintf(stderr, "[splpak] band_cholesky: host enqueue of %d steps took %.1f ms\n", b.nblk,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
     // (computing these block by block on a side stream beside a narrow-band chain was tried: the 256-thread
@@ -1135,7 +1135,7 @@ hipError_t band_cholesky_narrow(const Band &b, int *info_dev, double *minpiv_dev
     if (kbeg < 0 || kbeg >= kend) return hipErrorInvalidValue;
     Pipeline &pl = pipeline(b.pipe, b.nblk, false, false);
     hipStream_t sP = pl.panel;
-    if (!sP || std::getenv("SPLPAK_NO_LOOKAHEAD")) sP = st;
+    if (!sP || splpak::opt_get("SPLPAK_NO_LOOKAHEAD")) sP = st;
     if (pl.used && pl.done) (void)hipStreamWaitEvent(st, pl.done, 0);
     auto tb_of = [&](int k) { int t = b.nblk - 1 - k; return t > b.bw ? b.bw : t; };
     auto potrf = [&](int k) {

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include "options.hpp"
 
 namespace splpak {
 

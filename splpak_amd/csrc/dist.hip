@@ -414,7 +414,7 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
     int ndev = 0, cur = 0;
     (void)hipGetDeviceCount(&ndev);
     (void)hipGetDevice(&cur);
-    const bool virt = std::getenv("SPLPAK_VIRTUAL_GPUS") != nullptr;
+    const bool virt = splpak::opt_get("SPLPAK_VIRTUAL_GPUS") != nullptr;
     splpak_mplan *mp = new splpak_mplan();
     mp->R = ngpus;
     if (chunk < 1) {
@@ -426,7 +426,7 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
         long long nc = 0;
         Band b0{};
         chunk = 1;
-        if (build_grid(ndim, nodes, xmin, xmax, g0, &nc, std::getenv("SPLPAK_NO_REORDER") == nullptr) == 0) {
+        if (build_grid(ndim, nodes, xmin, xmax, g0, &nc, splpak::opt_get("SPLPAK_NO_REORDER") == nullptr) == 0) {
             band_bytes(g0.ncol, g0.halfbw, &b0);
             chunk = b0.bw / ngpus;
             if (chunk > 8) chunk = 8;
@@ -437,9 +437,9 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
     mp->bar.n = ngpus;
     // Grids that take the nested-dissection factorisation on one GPU take it here too, distributed: subtrees per GPU, the
     // fronts above them by block columns (round 4; SPLPAK_MPLAN_BAND=1 keeps the distributed band of round 2).
-    const bool want_nd = ngpus > 1 && !std::getenv("SPLPAK_MPLAN_BAND") && nd_wanted_for(ndim, nodes, xmin, xmax);
+    const bool want_nd = ngpus > 1 && !splpak::opt_get("SPLPAK_MPLAN_BAND") && nd_wanted_for(ndim, nodes, xmin, xmax);
     if (want_nd) {
-        const char *ck = std::getenv("SPLPAK_ND_CHUNK");
+        const char *ck = splpak::opt_get("SPLPAK_ND_CHUNK");
         mp->ndgrp = nd_group_create(ngpus, ck ? atoi(ck) : 1, &mp->abort);
     }
     int rc = 0;
@@ -522,7 +522,7 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
                         on = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
                     }
                     (void)hipGetLastError();
-                    if (!on || std::getenv("SPLPAK_DEBUG_NO_PEER")) { all_peers = false; pa = a->dev; pb = b2->dev; }
+                    if (!on || splpak::opt_get("SPLPAK_DEBUG_NO_PEER")) { all_peers = false; pa = a->dev; pb = b2->dev; }
                 }
         if (mp->ndgrp && !all_peers) {
             char buf[256];
@@ -534,7 +534,7 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
     }
     // the sums over the ranks as RCCL all-reduces instead of peer copies (behind a switch: the peer-copy form is bitwise
     // reproducible in rank order and needs no library)
-    if (rc == 0 && ngpus > 1 && std::getenv("SPLPAK_MPLAN_RCCL") && atoi(std::getenv("SPLPAK_MPLAN_RCCL")) != 0) {
+    if (rc == 0 && ngpus > 1 && splpak::opt_get("SPLPAK_MPLAN_RCCL") && atoi(splpak::opt_get("SPLPAK_MPLAN_RCCL")) != 0) {
         std::vector<int> devs;
         std::vector<void *> comms((size_t)ngpus, nullptr);
         for (MRank *m : mp->ranks) devs.push_back(m->dev);
@@ -655,7 +655,7 @@ int32_t splpak_fit_multi_f64(int32_t ngpus, int32_t ndim, const double *xdata, i
     if (wdata && wdata[0] < 0.0) wdata = nullptr;
     const long long per = (ndata + ngpus - 1) / ngpus;
     splpak_mplan *mp = nullptr;
-    const char *ck = std::getenv("SPLPAK_DIST_CHUNK");
+    const char *ck = splpak::opt_get("SPLPAK_DIST_CHUNK");
     int rc = splpak_mplan_create(ngpus, nullptr, ck ? atoi(ck) : 0, ndim, nodes, xmin, xmax, xtrap, per, &mp);
     if (rc != 0) return rc;
     int cur = 0;

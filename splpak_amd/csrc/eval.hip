@@ -1803,9 +1803,9 @@ static bool make_pregions(const Grid &g, PRegions &rg, int sper)
         rg.tcells *= rg.text[d];
     }
     if (rg.nbins < 8 || rg.nbins > PRCfg<D>::MAXBINS) return false;
-    rg.deal = std::getenv("SPLPAK_PR_NODEAL") ? 0 : 1;
+    rg.deal = splpak::opt_get("SPLPAK_PR_NODEAL") ? 0 : 1;
     // (4-D: the runs of a place-pass workgroup hold ~16 queries for 32 slot classes -- nothing to deal; SPLPAK_PR_DEAL4=1 deals anyway)
-    if (D == 4 && !std::getenv("SPLPAK_PR_DEAL4")) rg.deal = 0;
+    if (D == 4 && !splpak::opt_get("SPLPAK_PR_DEAL4")) rg.deal = 0;
     // what the place pass needs to know of the evaluation pass's LDS tile: its strides and the distance of its second copy
     if constexpr (D == 4) {
         if (sper != 8) return false;                 // (a tile of 19^4 coefficients is 1 MB)
@@ -1847,7 +1847,7 @@ static void pscratch_shutdown()
 template <int D, typename T>
 static hipError_t eval_persistent(const Grid &g, long long nq, const T *xq, int ldxq, const NDeriv &nd, const T *coef, T *out, hipStream_t st)
 {
-    if (std::getenv("SPLPAK_EVAL_NO_PERSISTENT")) return hipErrorNotSupported;
+    if (splpak::opt_get("SPLPAK_EVAL_NO_PERSISTENT")) return hipErrorNotSupported;
     // regions of 16 window starts per dimension (tiles of 19^3 = 55 KB: 64^3 nodes give 4 x 4 x 4 regions), of 8 for smaller grids
     PRegions rg;
     int sper = D == 4 ? 8 : 16;
@@ -1894,7 +1894,7 @@ static hipError_t eval_persistent(const Grid &g, long long nq, const T *xq, int 
     const unsigned nworkers = (unsigned)ncu;
     // (chunks of 4 place-pass workgroups of interior runs, 16 of boundary runs: ~400 queries; the waves of a workgroup take
     //  them from a counter in LDS, so small chunks cost nothing and keep the tails short)
-    static const int c0_env = std::getenv("SPLPAK_PR_C0") ? atoi(std::getenv("SPLPAK_PR_C0")) : 0;
+    static const int c0_env = splpak::opt_get("SPLPAK_PR_C0") ? atoi(splpak::opt_get("SPLPAK_PR_C0")) : 0;
     const dim3 grid(nworkers);
     if constexpr (D == 4) {
         // chunks of 32 place-pass workgroups of one bin: ~500 queries (a chunk's runs sit one per lane: at most 64)
@@ -1930,8 +1930,8 @@ static hipError_t eval_runs(const Grid &g, const Regions &rg, long long nq, cons
     // Measured at 4-D 32^4 (648 regions, runs of 3 records = one 128-byte line): place 0.30 ms instead of count + prefixes +
     // place 0.70, but the evaluation pass 1.30 instead of 0.82 ms (fragments, a 10-step search per record, twice with the class
     // dealing) -- 1.09 against 1.18e10 evals/s: the sort stays for grids of more than 256 regions.
-    static const int max_bins = std::getenv("SPLPAK_EVAL_RUNS_MAXBINS") ? atoi(std::getenv("SPLPAK_EVAL_RUNS_MAXBINS")) : 256;
-    if (rg.nbins > RUN_GROUP_MAX || rg.nbins > max_bins || std::getenv("SPLPAK_EVAL_SORT")) return hipErrorNotSupported;
+    static const int max_bins = splpak::opt_get("SPLPAK_EVAL_RUNS_MAXBINS") ? atoi(splpak::opt_get("SPLPAK_EVAL_RUNS_MAXBINS")) : 256;
+    if (rg.nbins > RUN_GROUP_MAX || rg.nbins > max_bins || splpak::opt_get("SPLPAK_EVAL_SORT")) return hipErrorNotSupported;
     // place-pass workgroups per evaluation workgroup: ~1 950 queries of a region (two rounds of 1 024 threads; the 4-D
     // class dealing works in batches of 2 048)
     int grp = (int)(0.95 * rg.nbins + 0.5);

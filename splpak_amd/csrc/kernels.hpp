@@ -155,8 +155,8 @@ hipError_t band_cholesky(const Band &b, int *info_dev, double *minpiv_dev, hipSt
 // that pipeline onto small grids.
 inline int narrow_band_limit()
 {
-    if (const char *e = std::getenv("SPLPAK_NARROW_BW")) return atoi(e);
-    if (const char *e = std::getenv("SPLPAK_PIN_BW")) return atoi(e);
+    if (const char *e = splpak::opt_get("SPLPAK_NARROW_BW")) return atoi(e);
+    if (const char *e = splpak::opt_get("SPLPAK_PIN_BW")) return atoi(e);
     return 28;
 }
 // the same for narrow (chain-bound) bands: one extra stream, one update launch per step (see bandchol.hip)

@@ -1069,7 +1069,7 @@ bool nd_build_factor_jobs(NdState *s)
     NdTree &t = s->t;
     const int nstage = (int)s->sc.st.size();
     for (auto *L : {&s->l_potrf, &s->l_trsm, &s->l_trsmb, &s->l_upd, &s->l_updr, &s->l_updo, &s->l_schur}) L->assign((size_t)nstage, {});
-    const bool two_level = std::getenv("SPLPAK_ND_NO_OUTER") == nullptr;
+    const bool two_level = splpak::opt_get("SPLPAK_ND_NO_OUTER") == nullptr;
     s->lookahead.assign((size_t)nstage, 0);
     s->chain_la.assign((size_t)nstage, 0);
     for (int sl = 0; sl < 2; ++sl) { s->l_fin[sl].assign((size_t)nstage, {}); s->l_add[sl].assign((size_t)nstage, Launch()); }
@@ -1099,12 +1099,12 @@ bool nd_build_factor_jobs(NdState *s)
         for (int sl = 0; sl < 2; ++sl) s->l_fin[sl][(size_t)stg].assign((size_t)steps, Launch());
         bool any_schur = false;
         for (int id : ids) any_schur = any_schur || t.fr[(size_t)id].hp > 0;
-        const bool la = !any_schur && steps >= 4 && !std::getenv("SPLPAK_ND_NO_ROOT_LOOKAHEAD");
+        const bool la = !any_schur && steps >= 4 && !splpak::opt_get("SPLPAK_ND_NO_ROOT_LOOKAHEAD");
         // 2: the WHOLE next block column is updated on the chain (its diagonal block and the rows below it), so that the next
         // panel solve runs beside the trailing pass of this step instead of behind it (round 5); 1: only the next diagonal block
         // (round 4: the panel solve of every step, 50 us, waited for the trailing pass and was waited for by the next one)
-        const bool la2 = la && !(std::getenv("SPLPAK_ND_ROOT_LA") && atoi(std::getenv("SPLPAK_ND_ROOT_LA")) == 1);
-        const int cla_blocks = std::getenv("SPLPAK_ND_CHAIN_LA") ? atoi(std::getenv("SPLPAK_ND_CHAIN_LA")) : 8;   // (64^3: 219.2 ms with 8, 219.9 with 16, 221.0 with 64 or 0)
+        const bool la2 = la && !(splpak::opt_get("SPLPAK_ND_ROOT_LA") && atoi(splpak::opt_get("SPLPAK_ND_ROOT_LA")) == 1);
+        const int cla_blocks = splpak::opt_get("SPLPAK_ND_CHAIN_LA") ? atoi(splpak::opt_get("SPLPAK_ND_CHAIN_LA")) : 8;   // (64^3: 219.2 ms with 8, 219.9 with 16, 221.0 with 64 or 0)
         const bool cla = !la && two_level && steps >= 2 && (int)ids.size() <= cla_blocks && !s->mdist;
         s->chain_la[(size_t)stg] = cla ? 1 : 0;
         s->lookahead[(size_t)stg] = la ? (la2 ? 2 : 1) : 0;
@@ -1581,14 +1581,14 @@ hipError_t nd_prefit(splpak_plan *p, hipStream_t st, void *user)
     NdState *s = static_cast<NdState *>(user);
     s->tail_pending = false;
     if (s->staged_init && !s->dist) return hipSuccess;         // (nothing to clear: nd_init_kernel writes every panel column whole)
-    if (!s->sU || !s->evPre || std::getenv("SPLPAK_ND_NO_EARLY_CLEAR")) return hipSuccess;
+    if (!s->sU || !s->evPre || splpak::opt_get("SPLPAK_ND_NO_EARLY_CLEAR")) return hipSuccess;
     long long head = 0;
     if (p->gscratch == s->factor) head = p->gscratch_doubles < s->factor_doubles ? p->gscratch_doubles : s->factor_doubles;
     else if (p->gscratch >= s->factor && p->gscratch < s->factor + s->factor_doubles) return hipSuccess;     // (not laid out that way)
     if (head >= s->factor_doubles) return hipSuccess;
     hipError_t e = hipEventRecord(s->evPre, st);                 // the previous fit's solves have read the factor by now
     if (e == hipSuccess) e = hipStreamWaitEvent(s->sU, s->evPre, 0);
-    static const int clear_wgs = std::getenv("SPLPAK_ND_CLEAR_WGS") ? atoi(std::getenv("SPLPAK_ND_CLEAR_WGS")) : 128;
+    const int clear_wgs = splpak::opt_get("SPLPAK_ND_CLEAR_WGS") ? atoi(splpak::opt_get("SPLPAK_ND_CLEAR_WGS")) : 128;
     if (e == hipSuccess) {
         if (clear_wgs > 0) {
             hipLaunchKernelGGL(nd_clear_kernel, dim3((unsigned)clear_wgs), dim3(1024), 0, s->sU, s->factor + head, s->factor_doubles - head);
@@ -1644,13 +1644,13 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
     *stats = CholStats{};
     stats->enabled = enabled;
     const int ns = (int)s->sc.st.size();
-    const bool serial = std::getenv("SPLPAK_NO_LOOKAHEAD") != nullptr;
+    const bool serial = splpak::opt_get("SPLPAK_NO_LOOKAHEAD") != nullptr;
     hipStream_t sP = s->sP, sU = s->sU, sR = s->sR;
     if (serial) sP = sU = st;
-    if (serial || !sR || std::getenv("SPLPAK_NO_PANEL_CU")) sR = nullptr;
+    if (serial || !sR || splpak::opt_get("SPLPAK_NO_PANEL_CU")) sR = nullptr;
     // potrf goes to the reserved CUs while a stage has at most this many diagonal blocks per step per reserved CU (round 5: 1 --
     // two rounds of 140 us on the reserved CUs lose against one round on the whole chip beside the pass: 219.3 against 220.7 ms at 64^3)
-    const int pin_rounds = std::getenv("SPLPAK_ND_PIN_ROUNDS") ? atoi(std::getenv("SPLPAK_ND_PIN_ROUNDS")) : 1;
+    const int pin_rounds = splpak::opt_get("SPLPAK_ND_PIN_ROUNDS") ? atoi(splpak::opt_get("SPLPAK_ND_PIN_ROUNDS")) : 1;
     if (timing) {
         if (!s->f0) { (void)hipEventCreate(&s->f0); (void)hipEventCreate(&s->f1); }
         (void)hipEventRecord(s->f0, st);
@@ -1698,7 +1698,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
             const long long tiles = trapezoid_items(nt, nt);
             if (s->sc.packed) {
                 if (plan_allreduce(p, s_ptr(s, id), nd_schur_doubles(f, true), st) != 0) comm_failed = true;
-            } else if (tiles * 4096 <= scap && !std::getenv("SPLPAK_ND_JOIN_SQUARE")) {
+            } else if (tiles * 4096 <= scap && !splpak::opt_get("SPLPAK_ND_JOIN_SQUARE")) {
                 hipLaunchKernelGGL(nd_tripack_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, st, s_ptr(s, id), f.lds, nt, scratch);
                 if (plan_allreduce(p, scratch, tiles * 4096, st) != 0) comm_failed = true;
                 hipLaunchKernelGGL(nd_tripack_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, st, s_ptr(s, id), f.lds, nt, scratch);
@@ -1833,7 +1833,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
                 }
         };
         const int nsteps_i = (int)s->l_potrf[(size_t)i].size();
-        static const bool prep_late = std::getenv("SPLPAK_ND_PREP_EARLY") == nullptr;
+        const bool prep_late = splpak::opt_get("SPLPAK_ND_PREP_EARLY") == nullptr;
         const bool defer = prep_late && i > 0 && i != s->root_stage && sU != sP && nsteps_i >= 2 && !s->l_schur[(size_t)i][0].count &&
                            !s->l_fin[0][(size_t)i][0].count && !s->l_fin[1][(size_t)i][0].count;
         if (i > 0) {
@@ -1854,7 +1854,7 @@ hipError_t nd_factor(splpak_plan *p, int *info_dev, double *minpiv_dev, hipStrea
         const bool pinned = sR != nullptr && s->nres > 0 && steps > 0 &&
                             ((int)s->l_potrf[(size_t)i][0].grid <= pin_rounds * s->nres || s->chain_la[(size_t)i]);
         la_evt = -1;
-        static const bool unpin_first = std::getenv("SPLPAK_ND_PIN_FIRST") == nullptr;
+        const bool unpin_first = splpak::opt_get("SPLPAK_ND_PIN_FIRST") == nullptr;
         bool pass_running = !unpin_first;
         for (int k = 0; k < steps; ++k) {
             if (k == 0 && defer) after_solve = stage_prep;        // (behind the first diagonal blocks and panel solve of the chain)
@@ -2024,7 +2024,7 @@ bool nd_upload_jobs(NdState *s)
 bool nd_make_schedule(NdState *s, int cut, size_t other_bytes)
 {
     NdTree &t = s->t;
-    const bool packed = !s->mdist && std::getenv("SPLPAK_ND_SQUARE") == nullptr;
+    const bool packed = !s->mdist && splpak::opt_get("SPLPAK_ND_SQUARE") == nullptr;
     const int dlow = s->mdist ? s->pt.dcut : 0;
     s->needs.assign(t.fr.size(), 0);
     for (size_t id = 0; id < t.fr.size(); ++id) {
@@ -2034,7 +2034,7 @@ bool nd_make_schedule(NdState *s, int cut, size_t other_bytes)
     }
     if (cut < 0) {
         cut = 0;
-        if (const char *e = std::getenv("SPLPAK_ND_CUT")) cut = std::max(0, std::min(t.maxdepth, atoi(e)));
+        if (const char *e = splpak::opt_get("SPLPAK_ND_CUT")) cut = std::max(0, std::min(t.maxdepth, atoi(e)));
         else if (!s->mdist) {
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 0; }
@@ -2058,7 +2058,7 @@ bool nd_make_schedule(NdState *s, int cut, size_t other_bytes)
         s->starts[(size_t)S.first].push_back(i);
         if (S.ids.size() == 1 && t.fr[(size_t)S.ids[0]].parent < 0 && !s->mdist) s->root_stage = i;
     }
-    if (std::getenv("SPLPAK_ND_DEBUG_STAGES"))
+    if (splpak::opt_get("SPLPAK_ND_DEBUG_STAGES"))
         for (int i = 0; i < ns; ++i) {
             const NdStage &S = s->sc.st[(size_t)i];
             long long pd = 0, cols = 0;
@@ -2099,7 +2099,7 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
     NdTree &t = s->t;
     int dcut = 0;
     while ((1 << dcut) < world) ++dcut;
-    const char *sw = std::getenv("SPLPAK_ND_DIST");                  // 0 = every rank factors everything (round 2's form)
+    const char *sw = splpak::opt_get("SPLPAK_ND_DIST");                  // 0 = every rank factors everything (round 2's form)
     // (the join sums front panels, Schur buffers and solve vectors that live outside the plan's communication buffer: only with a
     //  hook that declared it accepts any device pointer -- SPLPAK_AR_ANY_POINTER; round-3 advice)
     const bool want = world > 1 && p->ar != nullptr && (p->ar_flags & SPLPAK_AR_ANY_POINTER) != 0 && !(sw && atoi(sw) == 0) && dcut >= 1 &&
@@ -2153,7 +2153,7 @@ int nd_set_ranks_impl(splpak_plan *p, int rank, int world)
         }
     }
     s->s_clean = false;
-    if (std::getenv("SPLPAK_DEBUG")) {
+    if (splpak::opt_get("SPLPAK_DEBUG")) {
         int nm = 0;
         for (char c : s->mine) nm += c;
         fprintf(stderr, "[splpak] nested dissection: rank %d of %d eliminates %d of %zu fronts (subtrees below depth %d)\n", rank, world, nm, t.fr.size(), dcut);
@@ -2173,7 +2173,7 @@ int nd_set_ranks(splpak_plan *p, int rank, int world) { return (p && p->fn_code 
 bool nd_wanted_for(int ndim, const int *nodes, const double *xmin, const double *xmax)
 {
     Grid g;
-    if (build_grid(ndim, nodes, xmin, xmax, g, nullptr, std::getenv("SPLPAK_NO_REORDER") == nullptr) != 0) return false;
+    if (build_grid(ndim, nodes, xmin, xmax, g, nullptr, splpak::opt_get("SPLPAK_NO_REORDER") == nullptr) != 0) return false;
     Band b{};
     return nd_wanted(g, b);
 }
@@ -2181,7 +2181,7 @@ bool nd_wanted_for(int ndim, const int *nodes, const double *xmin, const double 
 bool nd_wanted(const Grid &g, const Band &band)
 {
     (void)band;
-    if (const char *e = std::getenv("SPLPAK_ND")) return atoi(e) != 0;
+    if (const char *e = splpak::opt_get("SPLPAK_ND")) return atoi(e) != 0;
     if (g.ndim == 2 || g.ndim == 3) return g.ncol >= 4096;
     return g.ndim == 4 && g.ncol >= 20000;
 }
@@ -2215,8 +2215,8 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
         for (size_t id = 0; id < t.fr.size(); ++id) s->mine[id] = pt.owner[id] == rank ? 1 : 0;
     // (round 3 also knew two PIPELINES -- the two subtrees below the root side by side on two chain streams, SPLPAK_ND_PIPES=2:
     //  235.0 against 234.9 ms per factorisation at 64^3; removed in round 5, the postorder schedule gives the same overlap)
-    s->fused = std::getenv("SPLPAK_ND_NO_FUSE") == nullptr;
-    if (const char *e = std::getenv("SPLPAK_ND_KB")) s->schur_kb = std::max(1, std::min(4, atoi(e)));
+    s->fused = splpak::opt_get("SPLPAK_ND_NO_FUSE") == nullptr;
+    if (const char *e = splpak::opt_get("SPLPAK_ND_KB")) s->schur_kb = std::max(1, std::min(4, atoi(e)));
     // this rank's storage: panels and Schur buffers of the fronts it eliminates, then its block columns of the top fronts
     s->poff.assign(t.fr.size(), -1);
     s->lblk.assign(t.fr.size(), -1);
@@ -2294,16 +2294,16 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
             if (t.pos[i] >= 0) ipos[(size_t)t.pos[i]] = (int)i;
         if (!nd_upload(s, &s->ipos, ipos)) return SPLPAK_E_NOMEM;
     }
-    s->staged_init = !s->mdist && !(std::getenv("SPLPAK_ND_STAGED_INIT") && atoi(std::getenv("SPLPAK_ND_STAGED_INIT")) == 0);
+    s->staged_init = !s->mdist && !(splpak::opt_get("SPLPAK_ND_STAGED_INIT") && atoi(splpak::opt_get("SPLPAK_ND_STAGED_INIT")) == 0);
     ok = nd_upload(s, &s->pos, t.pos) && nd_upload(s, &s->front_of, t.front_of) && nd_upload(s, &s->bpos, t.bpos) &&
          nd_upload(s, &s->pmap, t.pmap) && nd_upload(s, &s->rowsrc, rowsrc) && nd_upload(s, &s->padwhere, padwhere) &&
          nd_upload(s, &s->fdev, fdev) && nd_upload(s, &s->topcol_dev, s->topcol);
     if (!ok) return SPLPAK_E_NOMEM;
     s->rowsrc_host.swap(rowsrc);
-    s->full_diag = std::getenv("SPLPAK_ND_FULL_DIAG") != nullptr ? 1 : 0;      // (before the job tables: it enters their flop counts)
+    s->full_diag = splpak::opt_get("SPLPAK_ND_FULL_DIAG") != nullptr ? 1 : 0;      // (before the job tables: it enters their flop counts)
     // XCD-aware item map of the Schur passes: on (round 4) -- half the fabric traffic per launch for the same factor bits at
     // +0.2 .. 0.4 % time (SPLPAK_ND_XCD=0: the plain map)
-    s->xmode = std::getenv("SPLPAK_ND_XCD") ? atoi(std::getenv("SPLPAK_ND_XCD")) : 1;
+    s->xmode = splpak::opt_get("SPLPAK_ND_XCD") ? atoi(splpak::opt_get("SPLPAK_ND_XCD")) : 1;
     if (!nd_build_jobs(s)) { if (true) set_error("nested dissection: job tables"); return SPLPAK_E_UNSUPPORTED; }
     ok = nd_upload_jobs(s);
     if (!ok) return SPLPAK_E_NOMEM;
@@ -2322,18 +2322,18 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     std::vector<int>().swap(t.bvar);
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (const char *e = std::getenv("SPLPAK_ND_DUMMY_STREAMS"))        // (experiment: how the streams fall onto the hardware queues)
+    if (const char *e = splpak::opt_get("SPLPAK_ND_DUMMY_STREAMS"))        // (experiment: how the streams fall onto the hardware queues)
         for (int i = 0; i < atoi(e); ++i) { hipStream_t q; (void)hipStreamCreateWithFlags(&q, hipStreamNonBlocking); }
     (void)hipStreamCreateWithPriority(&s->sP, hipStreamNonBlocking, hi);
     (void)hipStreamCreateWithFlags(&s->sU, hipStreamNonBlocking);
     for (hipEvent_t *e : {&s->ev0, &s->evJ, &s->evU, &s->evZlast, &s->evDone, &s->evPre, &s->evTail, &s->evR0}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
     // item queues of the update launches (two per step at most)
     s->nqueues = 8 * t.nblocks + 64;
-    if (const char *e = std::getenv("SPLPAK_ND_SMALL_GRID")) s->small_grid = atoi(e);
-    if (const char *e = std::getenv("SPLPAK_ND_WG4")) s->wg4 = atoi(e);
-    if (const char *e = std::getenv("SPLPAK_ND_PINNED_SPLIT")) s->pinned_split = atoi(e);
-    s->small_queue = std::getenv("SPLPAK_ND_SMALL_QUEUE") != nullptr;
-    if (const char *e = std::getenv("SPLPAK_ND_POTRF_WAVES")) s->potrf_waves = atoi(e);
+    if (const char *e = splpak::opt_get("SPLPAK_ND_SMALL_GRID")) s->small_grid = atoi(e);
+    if (const char *e = splpak::opt_get("SPLPAK_ND_WG4")) s->wg4 = atoi(e);
+    if (const char *e = splpak::opt_get("SPLPAK_ND_PINNED_SPLIT")) s->pinned_split = atoi(e);
+    s->small_queue = splpak::opt_get("SPLPAK_ND_SMALL_QUEUE") != nullptr;
+    if (const char *e = splpak::opt_get("SPLPAK_ND_POTRF_WAVES")) s->potrf_waves = atoi(e);
     if (!nd_alloc(s, &s->queues, (size_t)ND_QSTRIDE * s->nqueues) || !nd_alloc(s, &s->resmap, (size_t)128)) return SPLPAK_E_NOMEM;
     (void)hipMemset(s->resmap, 0, 128 * sizeof(unsigned));
     // A few CUs are left to the diagonal-block factorisations of the upper tree levels: v_mfma_f64 runs on the same
@@ -2341,8 +2341,8 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     // the update waves (rocprofv3, 64^3).  potrf is pinned to those CUs through a CU-masked stream; the update
     // waves are not masked, they step aside when they find themselves there (nd_syrk_kernel).  Only trees whose
     // upper levels are worth it (>= 8 block steps in the root) pay for the extra stream.
-    const int want_res = std::getenv("SPLPAK_ND_RES_CUS") ? atoi(std::getenv("SPLPAK_ND_RES_CUS")) : 8;
-    if (want_res > 0 && t.fr[(size_t)t.root].nsteps >= 8 && !std::getenv("SPLPAK_NO_PANEL_CU")) {
+    const int want_res = splpak::opt_get("SPLPAK_ND_RES_CUS") ? atoi(splpak::opt_get("SPLPAK_ND_RES_CUS")) : 8;
+    if (want_res > 0 && t.fr[(size_t)t.root].nsteps >= 8 && !splpak::opt_get("SPLPAK_NO_PANEL_CU")) {
         hipDeviceProp_t prop;
         (void)hipGetDeviceProperties(&prop, s->device);
         const int ncu = prop.multiProcessorCount;
@@ -2393,7 +2393,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     p->fn_code = s->mdist ? 5 : 4;
     if (factor_arena) *factor_arena = s->factor;
     if (factor_doubles) *factor_doubles = s->factor_doubles;
-    if (std::getenv("SPLPAK_DEBUG"))
+    if (splpak::opt_get("SPLPAK_DEBUG"))
         fprintf(stderr, "[splpak] nested dissection%s: %zu fronts, depth %d, factor %.2f GB, Schur arena %.2f GB (%s, %zu stages, cut %d), %.3e flop, %d reserved CUs\n",
                 s->mdist ? " (one rank of a multi-GPU fit)" : "", t.fr.size(), t.maxdepth, 8e-9 * (double)s->factor_doubles, 8e-9 * (double)s->sarena_doubles,
                 s->sc.packed ? "packed" : "square", s->sc.st.size(), s->sc.cut, t.flop, s->nres);

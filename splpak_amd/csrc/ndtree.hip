@@ -513,7 +513,7 @@ extern "C" int32_t splpak_debug_nd_tree(int32_t ndim, const int32_t *nodes, int3
         const std::string msg = nd_check(t);
         if (!msg.empty()) { set_error("nested dissection: " + msg); return SPLPAK_E_BADARG; }
     }
-    if (std::getenv("SPLPAK_DEBUG")) {
+    if (splpak::opt_get("SPLPAK_DEBUG")) {
         for (int d = 0; d <= t.maxdepth; ++d) {
             double sb = 0, fb = 0, fl = 0, flp = 0;
             int steps = 0, mw = 0, mh = 0;

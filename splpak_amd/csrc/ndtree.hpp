@@ -146,7 +146,7 @@ void nd_partition(const NdTree &t, int R, int chunk, NdPartition &pt);
 // 2.86 -> 2.46 ms per fit.
 inline int nd_default_split_min(int ndim = 3)
 {
-    if (const char *e = std::getenv("SPLPAK_ND_SPLIT")) return atoi(e);
+    if (const char *e = splpak::opt_get("SPLPAK_ND_SPLIT")) return atoi(e);
     return ndim <= 2 ? 16 : 8;
 }
 // split_min: a box whose largest extent is at least this is bisected (>= 5); returns false on inconsistency

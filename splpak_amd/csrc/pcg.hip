@@ -363,7 +363,7 @@ int pcg_attach(splpak_plan *p, PcgState **out)
     PcgState *s = new PcgState();
     (void)hipGetDevice(&s->device);
     s->g = g;
-    if (const char *e = std::getenv("SPLPAK_PCG_MAXIT")) s->maxit = std::max(1, atoi(e));
+    if (const char *e = splpak::opt_get("SPLPAK_PCG_MAXIT")) s->maxit = std::max(1, atoi(e));
     bool ok = true;
     long long ntab = 0;
     for (int k = 0; k < g.ndim; ++k) ntab += 4LL * g.nodes[k];
@@ -511,7 +511,7 @@ int pcg_solve(splpak_plan *p, PcgState *s, double *v, double tol, bool smooth, h
     const long long n = g.ncol;
     const dim3 gr((unsigned)((n + 255) / 256)), bl(256);
     const size_t nb = sizeof(double) * (size_t)n;
-    const bool debug = std::getenv("SPLPAK_DEBUG") != nullptr;
+    const bool debug = splpak::opt_get("SPLPAK_DEBUG") != nullptr;
     SortScratch rows = p->s;
     rows.ys = nullptr;                                   // the residual pass as operator: rho = -N x
     SPLPAK_HIP_TRY(hipMemcpyAsync(s->r, v, nb, hipMemcpyDeviceToDevice, st), SPLPAK_E_NODEVICE);

@@ -177,9 +177,11 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
 {
     if (!plan || !nodes || !xmin || !xmax) { set_error("null argument"); return SPLPAK_E_BADARG; }
     *plan = nullptr;
+    const Options snap = options_snapshot();        // the switches of this plan: process defaults over the environment, as of now
+    OptionsScope opt_scope(&snap);
     Grid g;
     long long ncol = 0;
-    const int v = build_grid(ndim, nodes, xmin, xmax, g, &ncol, std::getenv("SPLPAK_NO_REORDER") == nullptr);
+    const int v = build_grid(ndim, nodes, xmin, xmax, g, &ncol, splpak::opt_get("SPLPAK_NO_REORDER") == nullptr);
     if (v != 0) {
         if (v == SPLPAK_E_UNSUPPORTED) set_error("ndim > 4 or more than 2^30 nodes is not supported");
         return v;
@@ -193,6 +195,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     if (int r = device_ready()) return r;
 
     splpak_plan *p = new splpak_plan();
+    p->opt = snap;
     p->g = g;
     p->xtrap = xtrap;
     p->max_ndata = max_ndata;
@@ -238,19 +241,25 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     // the iteration of pcg.hip for the grids none fits (4-D from about 29^4 on one GPU) or by request -- SPLPAK_SOLVER =
     // direct | pcg | pcg+direct (the iteration first, the factorisation when it stagnates) | auto.
     int mode = 0;
-    if (const char *e = std::getenv("SPLPAK_SOLVER")) {
+    if (const char *e = splpak::opt_get("SPLPAK_SOLVER")) {
         if (!std::strcmp(e, "direct")) mode = 1;
         else if (!std::strcmp(e, "pcg")) mode = 2;
         else if (!std::strcmp(e, "pcg+direct")) mode = 3;
     }
     if (p->dm.R > 1) mode = 1;                      // (the one-process multi-GPU plans distribute a factorisation)
+    // Left to itself a LARGE 4-D grid (from 20^4 columns on: the factorisation takes seconds) tries the iteration first: where the
+    // constraint rows are dense (>= 2 per column: config 5's density of points) or absent it answers in a fraction of the
+    // factorisation's time (24^4: 0.5 s against 4.6 s, 28^4: ~1.4 s against 18 s); where it stagnates (1.2 .. 1.7 rows per column)
+    // the attempt costs 0.6 .. 1.4 s before the factorisation takes over (tools/pcg/density_sweep.py).
+    if (mode == 0 && g.ndim == 4 && g.ncol >= 160000) mode = 3;
+    const bool auto_mode = mode == 0 || (mode == 3 && !splpak::opt_get("SPLPAK_SOLVER"));
     bool direct = mode != 2;
     const bool use_nd = direct && allow_nd && (p->dm.R == 1 || ndgrp != nullptr) && nd_wanted(g, p->band);
     if (use_nd && ok) {
         double *arena = nullptr;
         long long arena_doubles = 0;
         const int rc = nd_attach(p, &arena, &arena_doubles, p->dm.R > 1 ? ndgrp : nullptr, r);
-        if (rc == SPLPAK_E_NOMEM && mode == 0 && p->dm.R == 1) {
+        if (rc == SPLPAK_E_NOMEM && auto_mode && p->dm.R == 1) {
             // no factorisation of this grid fits the device: the iteration instead
             if (p->fn_destroy) p->fn_destroy(p->fn_user);
             p->fn_user = nullptr; p->fn_destroy = nullptr; p->fn_bytes = nullptr; p->fn_name = nullptr; p->fn_code = 0;
@@ -266,7 +275,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
         }
     } else if (direct && ok) {
         const bool okb = dev_alloc(p, &p->band.ab, p->band.bytes / sizeof(double));
-        if (!okb && mode == 0 && p->dm.R == 1) direct = false;
+        if (!okb && auto_mode && p->dm.R == 1) direct = false;
         else ok = ok && okb;
     }
     if (!direct) { p->band.ab = nullptr; p->band.bytes = 0; }
@@ -275,7 +284,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
         // idle until the gather is done, holds it); otherwise slabs of what there is (launch_gram)
         const long long full = gram_scratch_doubles(g), least = gram_scratch_min_doubles(g);
         long long want = full;
-        const char *cap = std::getenv("SPLPAK_GRAM_SCRATCH_MB");
+        const char *cap = splpak::opt_get("SPLPAK_GRAM_SCRATCH_MB");
         const long long budget = cap ? atoll(cap) * (1LL << 17) : (1LL << 30);      // doubles (default 8 GB)
         if (want > budget) want = budget > least ? budget : least;
         const long long band_doubles = (long long)(p->band.bytes / sizeof(double));
@@ -330,7 +339,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     p->hist = p->scalG + SC_COUNT;
     p->scalH = p->hist + g.ncol;
     p->rho = p->scalH + SC_COUNT;
-    if (std::getenv("SPLPAK_NO_CONSTRAINT_TABLE")) p->ctab = nullptr;      // (A/B switch; the allocation stays with the plan's list)
+    if (splpak::opt_get("SPLPAK_NO_CONSTRAINT_TABLE")) p->ctab = nullptr;      // (A/B switch; the allocation stays with the plan's list)
     else if (!hip_ok(launch_constraint_table(g, p->ctab, nullptr), "constraint table") ||
              !hip_ok(hipStreamSynchronize(nullptr), "constraint table")) {
         splpak_plan_destroy(p);
@@ -424,6 +433,42 @@ void splpak_plan_stage_timing(const splpak_plan *p, double *out6)
     for (int i = 0; i < 6; ++i) out6[i] = p->stage_ms[i];
 }
 
+int32_t splpak_set_default_option(const char *name, const char *value)
+{
+    if (options_set_default(name, value) != 0) { set_error(std::string("unknown option: ") + (name ? name : "(null)")); return SPLPAK_E_BADARG; }
+    return 0;
+}
+
+int32_t splpak_plan_set_option(splpak_plan *p, const char *name, const char *value)
+{
+    if (!p) { set_error("null plan"); return SPLPAK_E_BADARG; }
+    std::string canon;
+    if (!option_canonical(name, canon)) { set_error(std::string("unknown option: ") + (name ? name : "(null)")); return SPLPAK_E_BADARG; }
+    // what shapes the plan's storage and job tables was consumed when the plan was created
+    static const char *const at_creation[] = {"SPLPAK_SOLVER", "SPLPAK_ND", "SPLPAK_ND_SPLIT", "SPLPAK_ND_CUT", "SPLPAK_ND_KB", "SPLPAK_ND_RES_CUS",
+                                              "SPLPAK_NO_REORDER", "SPLPAK_GRAM_SCRATCH_MB", "SPLPAK_PCG_MAXIT", "SPLPAK_MPLAN_RCCL", "SPLPAK_RCCL_LIB"};
+    for (const char *c : at_creation)
+        if (canon == c) {
+            set_error(canon + " shapes the plan and is read when it is created: set it with splpak_set_default_option (or the environment) before splpak_plan_create");
+            return SPLPAK_E_UNSUPPORTED;
+        }
+    if (value) p->opt.kv[canon] = value; else p->opt.kv.erase(canon);
+    return 0;
+}
+
+int32_t splpak_plan_get_option(const splpak_plan *p, const char *name, char *buf, int32_t buflen)
+{
+    if (!p) { set_error("null plan"); return SPLPAK_E_BADARG; }
+    std::string canon;
+    if (!option_canonical(name, canon)) { set_error(std::string("unknown option: ") + (name ? name : "(null)")); return SPLPAK_E_BADARG; }
+    const char *v = p->opt.get(canon.c_str());
+    if (buf && buflen > 0) {
+        std::strncpy(buf, v ? v : "", (size_t)buflen - 1);
+        buf[buflen - 1] = '\0';
+    }
+    return v ? 1 : 0;
+}
+
 void splpak_plan_pcg_stats(const splpak_plan *p, double *out6)
 {
     if (!out6) return;
@@ -458,7 +503,7 @@ int32_t splpak_plan_factorisation(const splpak_plan *p, char *buf, int32_t bufle
 // SPLPAK_DEBUG_SUMS: sum and absolute sum of a device buffer, printed with a label (diagnosing the sharded fit)
 static void debug_sum(const splpak_plan *p, const char *what, const double *buf, long long count, hipStream_t st)
 {
-    if (!std::getenv("SPLPAK_DEBUG_SUMS")) return;
+    if (!splpak::opt_get("SPLPAK_DEBUG_SUMS")) return;
     std::vector<double> h((size_t)count);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(h.data(), buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost);
@@ -495,6 +540,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
                             double *info)
 {
     if (!p || !coef_dev) { set_error("null argument"); return SPLPAK_E_BADARG; }
+    OptionsScope opt_scope(&p->opt);                                  // every switch a fit reads comes from the plan's snapshot
     if (ndata < 1 && p->world <= 1) return 105;                       // :759-764
     // A failure of ONE rank's arguments must not leave the others waiting in a collective: with more
     // than one rank it is carried through the first reduction as a flag and every rank returns.
@@ -615,7 +661,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
             SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
             ++steps;
             last_rel = (am[1] > 0.0) ? am[0] / am[1] : 0.0;
-            if (std::getenv("SPLPAK_DEBUG"))
+            if (splpak::opt_get("SPLPAK_DEBUG"))
                 fprintf(stderr, "[splpak] refinement step %d: |dx|/|x| = %.3e\n", steps, last_rel);
             if (!(last_rel == last_rel)) break;                   // NaN
             if (last_rel <= p->tol) { converged = true; break; }
@@ -635,7 +681,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
                 // (randomized sweep, tools/fuzz_parity.py big)
             }
             prev_rel = last_rel;
-            if (it + 1 >= p->max_refine && it + 1 < p->max_refine_hard && std::getenv("SPLPAK_DEBUG"))
+            if (it + 1 >= p->max_refine && it + 1 < p->max_refine_hard && splpak::opt_get("SPLPAK_DEBUG"))
                 fprintf(stderr, "[splpak] still contracting after %d steps: continuing\n", it + 1);
         }
         return 0;
@@ -646,8 +692,8 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     auto t2 = t1;
     if (p->pcg) {
         SPLPAK_HIP_TRY(pcg_prepare(p, p->pcg, hs[SC_COUNT + SC_SUMW2], smooth, st), SPLPAK_E_NODEVICE);
-        const double tol_first = std::getenv("SPLPAK_PCG_TOL1") ? atof(std::getenv("SPLPAK_PCG_TOL1")) : 1e-11;
-        const double tol_next = std::getenv("SPLPAK_PCG_TOL2") ? atof(std::getenv("SPLPAK_PCG_TOL2")) : 1e-3;
+        const double tol_first = splpak::opt_get("SPLPAK_PCG_TOL1") ? atof(splpak::opt_get("SPLPAK_PCG_TOL1")) : 1e-11;
+        const double tol_next = splpak::opt_get("SPLPAK_PCG_TOL2") ? atof(splpak::opt_get("SPLPAK_PCG_TOL2")) : 1e-3;
         const int r = solve_and_refine([&](double *v, bool first) -> int { return pcg_solve(p, p->pcg, v, first ? tol_first : tol_next, smooth, st); });
         if (r != 0 && r != 1) return r;
         double est = last_rel;
@@ -665,7 +711,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
             if (info) { info[2] = steps; info[3] = last_rel; }
             return 107;
         }
-        if (!solved && std::getenv("SPLPAK_DEBUG")) fprintf(stderr, "[splpak] the iteration gave up: factorisation instead\n");
+        if (!solved && splpak::opt_get("SPLPAK_DEBUG")) fprintf(stderr, "[splpak] the iteration gave up: factorisation instead\n");
     }
 
     // ---- factorisation --------------------------------------------------
@@ -789,7 +835,6 @@ struct HostFitCache {
     std::mutex mu;
     splpak_plan *plan = nullptr;
     int ndim = 0, nodes[MAXD] = {0, 0, 0, 0}, dev = -1;
-    int nd_env = -1;              // SPLPAK_ND as it was when the plan was created (it selects the factorisation)
     double xmin[MAXD] = {0, 0, 0, 0}, xmax[MAXD] = {0, 0, 0, 0}, xtrap = 0.0;
     double *dx = nullptr, *dy = nullptr, *dw = nullptr, *dc = nullptr;
     long long cap_x = 0, cap_y = 0, cap_w = 0, cap_c = 0;
@@ -847,12 +892,9 @@ static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const
     struct InFit { InFit() { t_in_fit_host = true; } ~InFit() { t_in_fit_host = false; } } in_fit;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    // switches that are read when a plan is created (they select or shape the factorisation): part of the cache key
-    int nd_env = std::getenv("SPLPAK_ND") ? atoi(std::getenv("SPLPAK_ND")) : -1;
-    for (const char *v : {"SPLPAK_ND_SPLIT", "SPLPAK_ND_KB", "SPLPAK_ND_RES_CUS", "SPLPAK_NO_PANEL_CU", "SPLPAK_ND_NO_ROOT_LOOKAHEAD", "SPLPAK_ND_NO_FUSE", "SPLPAK_ND_PIPES", "SPLPAK_ND_NO_OUTER", "SPLPAK_ND_SMALL_GRID", "SPLPAK_ND_WG4", "SPLPAK_ND_NO_EARLY_CLEAR", "SPLPAK_ND_PINNED_SPLIT", "SPLPAK_ND_SMALL_QUEUE", "SPLPAK_ND_POTRF_WAVES", "SPLPAK_ND_FULL_DIAG", "SPLPAK_ND_XCD"})
-        if (const char *e = std::getenv(v)) nd_env = nd_env * 31 + 7 * atoi(e) + (int)v[10];
-    if (const char *e = std::getenv("SPLPAK_SOLVER")) nd_env = nd_env * 31 + (int)std::strlen(e) * 131 + (int)e[0];
-    bool same = hc.plan && hc.dev == dev && hc.ndim == ndim && hc.xtrap == xtrap && hc.plan->max_ndata >= ndata && hc.nd_env == nd_env;
+    // the switches are part of the cache key as a whole (a plan keeps the snapshot it was created with)
+    const Options cur = options_snapshot();
+    bool same = hc.plan && hc.dev == dev && hc.ndim == ndim && hc.xtrap == xtrap && hc.plan->max_ndata >= ndata && hc.plan->opt == cur;
     for (int d = 0; same && d < ndim; ++d)
         same = hc.nodes[d] == nodes[d] && hc.xmin[d] == xmin[d] && hc.xmax[d] == xmax[d];
     if (!same) {
@@ -860,7 +902,6 @@ static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const
         int rc = splpak_plan_create(ndim, nodes, xmin, xmax, xtrap, ndata, nullptr, 0, &hc.plan);
         if (rc != 0) { hc.plan = nullptr; return rc; }
         hc.dev = dev;
-        hc.nd_env = nd_env;
         hc.ndim = ndim;
         hc.xtrap = xtrap;
         for (int d = 0; d < ndim; ++d) { hc.nodes[d] = nodes[d]; hc.xmin[d] = xmin[d]; hc.xmax[d] = xmax[d]; }
@@ -889,7 +930,7 @@ static int32_t fit_host(int32_t ndim, const double *xdata, int32_t l1xdat, const
             e = hipMemcpy(hist_out, p->hist, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost);
         if (!hip_ok(e, "hipMemcpy D2H")) rc = SPLPAK_E_NODEVICE;
     }
-    if (rc < 0 || std::getenv("SPLPAK_NO_PLAN_CACHE")) hc.release();
+    if (rc < 0 || splpak::opt_get("SPLPAK_NO_PLAN_CACHE")) hc.release();
     return rc;
 }
 
@@ -1170,7 +1211,7 @@ int32_t splpak_debug_spd_band_solve_f64(int32_t n, int32_t halfbw, const double 
 {
     if (n < 1 || halfbw < 0 || !a_lower || !bvec || !x) { set_error("bad argument"); return SPLPAK_E_BADARG; }
     if (int r = device_ready()) return r;
-    if (std::getenv("SPLPAK_DEBUG_TWOEND")) {          // the two-ended factorisation (twoend.hip) on the same input
+    if (splpak::opt_get("SPLPAK_DEBUG_TWOEND")) {          // the two-ended factorisation (twoend.hip) on the same input
         int hinfo = 0;
         const int rc = twoend_debug_solve(n, halfbw, a_lower, bvec, x, &hinfo);
         if (rc == 0) return hinfo != 0 ? 107 : 0;

@@ -102,6 +102,7 @@ struct splpak_plan {
     void (*fn_destroy)(void *user) = nullptr;      // releases fn_user with the plan (NULL: not the plan's to release)
     // iterative solve (pcg.hip): NULL = none.  solver_mode: 0 a factorisation only, 2 the iteration only (no factor storage: grids
     // no factorisation fits, or by request), 3 the iteration first and the factorisation when it stagnates
+    splpak::Options opt;                      // the switches as they were when the plan was created (+ splpak_plan_set_option)
     splpak::RowsOp *rowsop = nullptr;         // 4-D grids: the tiled residual pass (NULL: the cell-by-cell passes of assemble.hip)
     splpak::PcgState *pcg = nullptr;
     int solver_mode = 0;

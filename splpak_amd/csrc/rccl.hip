@@ -53,7 +53,7 @@ bool rccl_load()
     if (g_rccl.tried) return g_rccl.all_reduce != nullptr;
     g_rccl.tried = true;
     void *h = nullptr;
-    if (const char *e = std::getenv("SPLPAK_RCCL_LIB")) {
+    if (const char *e = splpak::opt_get("SPLPAK_RCCL_LIB")) {
         h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);          // an explicit library is the ONLY candidate: no silent second choice
     } else {
         // an RCCL the process already carries (PyTorch's) first: two RCCLs in one process would not share their state
@@ -145,7 +145,7 @@ int32_t splpak_plan_set_rccl(splpak_plan *plan, void *nccl_comm, int32_t rank, i
     std::free(plan->ar_owned);
     plan->ar_owned = h;
     // SPLPAK_RCCL_ONE_RANK_CALLS=1 (smoke tests on a one-GPU box): the reductions of a one-rank fit go through RCCL too
-    const int always = std::getenv("SPLPAK_RCCL_ONE_RANK_CALLS") ? SPLPAK_AR_ALWAYS : 0;
+    const int always = splpak::opt_get("SPLPAK_RCCL_ONE_RANK_CALLS") ? SPLPAK_AR_ALWAYS : 0;
     return splpak_plan_set_allreduce_ex(plan, rccl_allreduce, h, rank, world, SPLPAK_AR_ANY_POINTER | SPLPAK_AR_STREAM_ORDERED | always);
 }
 
@@ -185,11 +185,11 @@ static uint64_t job_tag_of(const char *job)
 {
     std::string key;
     if (job && *job) key = job;
-    else if (const char *e = std::getenv("SPLPAK_RCCL_JOB")) key = e;
+    else if (const char *e = splpak::opt_get("SPLPAK_RCCL_JOB")) key = e;
     else {
         // what launchers give every rank of ONE run: torchrun / torch.distributed, Slurm, Open MPI
         for (const char *name : {"TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID", "OMPI_MCA_ess_base_jobid"})
-            if (const char *e = std::getenv(name)) { key += name; key += '='; key += e; key += ';'; }
+            if (const char *e = splpak::opt_get(name)) { key += name; key += '='; key += e; key += ';'; }
     }
     uint64_t h = 1469598103934665603ull;              // FNV-1a
     for (unsigned char c : key) { h ^= c; h *= 1099511628211ull; }

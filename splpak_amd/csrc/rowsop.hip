@@ -301,7 +301,7 @@ size_t rowsop_bytes(const RowsOp *r) { return r ? r->bytes : 0; }
 int rowsop_create(const Grid &g, RowsOp **out)
 {
     *out = nullptr;
-    const char *sw = std::getenv("SPLPAK_ROWS_TILES");           // A/B switch: 0 = the cell-by-cell passes
+    const char *sw = splpak::opt_get("SPLPAK_ROWS_TILES");           // A/B switch: 0 = the cell-by-cell passes
     if (g.ndim != 4 || (sw && atoi(sw) == 0)) return 0;
     RowsOp *r = new RowsOp();
     r->ntiles = 1;

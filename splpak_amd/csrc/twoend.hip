@@ -285,7 +285,7 @@ hipError_t te_solve(splpak_plan *, double *x, double *tmp, hipStream_t st, void 
 // chain, bounds the factorisation and two chains would only share the matrix cores.
 void twoend_attach(splpak_plan *p)
 {
-    if (p->dm.R != 1 || p->factor_fn || std::getenv("SPLPAK_NO_TWOEND")) return;
+    if (p->dm.R != 1 || p->factor_fn || splpak::opt_get("SPLPAK_NO_TWOEND")) return;
     const int lim = narrow_band_limit();
     if (p->band.bw >= lim) return;
     TwoEnd *t = te_create(p->band);

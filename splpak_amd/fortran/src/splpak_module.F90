@@ -67,6 +67,7 @@ module splpak_module
         procedure,public :: evaluate_derivatives => splpak_derivs_many !! value + gradient (+ Hessian) of a batch (additive)
         procedure,public :: destroy       => destroy_splpak
         procedure,public :: last_fit_info => splpak_last_fit_info   !! reserr, row counts, ... of the last fit (additive)
+        procedure,public,nopass :: set_option => splpak_set_option    !! a named option of the HIP library for the following fits (additive)
         procedure,public :: set_gpus      => splpak_set_gpus        !! spread the following fits over n GPUs of this node (additive)
         procedure,public :: set_host      => splpak_set_host        !! run the following calls on the host solver (additive; explicit, never a fallback)
         procedure,private :: splcc
@@ -129,6 +130,10 @@ module splpak_module
 #endif
         subroutine c_shutdown() bind(C,name='splpak_shutdown')
         end subroutine c_shutdown
+        integer(c_int32_t) function c_set_default_option(name,val) bind(C,name='splpak_set_default_option')
+            import :: c_int32_t, c_char
+            character(kind=c_char) :: name(*), val(*)
+        end function c_set_default_option
         integer(c_int32_t) function c_last_error(buf,buflen) bind(C,name='splpak_last_error_message')
             import :: c_int32_t, c_char
             character(kind=c_char) :: buf(*)
@@ -169,6 +174,19 @@ module splpak_module
         me%host = flag
 #endif
     end subroutine splpak_set_host
+
+    !> `call solver%set_option('solver','pcg+direct',ierror)`: a named option of the HIP library (include/splpak_hip.h,
+    !! splpak_set_default_option; INTEGRATION.md lists them) for the fits that follow -- process wide, what SPLPAK_<NAME> in the
+    !! environment would set.  ierror = 0, or -3 for an unknown name (the library's message is printed).  No effect on the host solver.
+    subroutine splpak_set_option(name,value,ierror)
+        character(len=*),intent(in) :: name, value
+        integer,intent(out) :: ierror
+        ierror = 0
+#ifndef REAL128
+        ierror = int(c_set_default_option(trim(name)//c_null_char, trim(value)//c_null_char))
+        if (ierror < 0) call report_library_failure(ierror,'set_option')
+#endif
+    end subroutine splpak_set_option
 
     !> The following `initialize` calls of this object use `n` GPUs of the node: the points are sharded
     !! and the band of the normal equations is distributed over them (include/splpak_hip.h,

@@ -66,6 +66,16 @@ program test_api
     end do
     call solver%evaluate_derivatives(2,50,xs,2,1,coef,xmin,xmin,nodes,jet,6,ierror); call expect(ierror,103)
 
+    ! named options of the HIP library (round 6): an unknown name is refused, a known one is taken -- and the fit that follows,
+    ! with the iterative solve in front of the factorisation, returns the same plane
+    call solver%set_option('no_such_option','1',ierror); call expect(ierror,-3)
+    call solver%set_option('solver','pcg+direct',ierror); call expect(ierror,0)
+    coef = 0.0_wp
+    call solver%initialize(2,xdata,2,ydata,m,xmin,xmax,nodes,0.0_wp,coef,64,work,64*65,ierror); call expect(ierror,0)
+    f = solver%evaluate(2,x,coef,xmin,xmax,nodes,ierror)
+    if (abs(f - (1.0_wp + 2.0_wp*x(1) - 3.0_wp*x(2))) > 1.0e-10_wp) call fail('plane value with solver = pcg+direct')
+    call solver%set_option('solver','direct',ierror); call expect(ierror,0)
+
     if (nbad /= 0) error stop 'test_api FAILED'
     write(*,*) 'PASS test_api'
 contains
