@@ -578,15 +578,15 @@ def main():
     value = world * m * args.steps / elapsed
     fact_code, fact_name = plan.factorisation()
     # the roofline kernel with the chip to itself: one extra fit OUTSIDE the timed region with every launch of the
-    # factorisation on one stream (SPLPAK_NO_LOOKAHEAD, read at every call), so that no chain kernel shares the CUs with it
+    # factorisation on one stream (the plan's option no_lookahead), so that no chain kernel shares the CUs with it
     kt_alone = None
     if world == 1 and not args.no_kernel_timing:
-        os.environ["SPLPAK_NO_LOOKAHEAD"] = "1"
+        plan.set_option("no_lookahead", "1")                   # (a per-fit option of the plan: round 6, no getenv on the fit path)
         try:
             ierr_a, _ = plan.fit(x, y, w, coef, stream)
             kt_alone = plan.kernel_timing() if ierr_a == 0 else None
         finally:
-            os.environ.pop("SPLPAK_NO_LOOKAHEAD", None)
+            plan.set_option("no_lookahead", None)
         ierr, info = plan.fit(x, y, w, coef, stream)          # (the plan's streams and the reported diagnostics: back to the timed form)
 
     # strong scaling beside the weak headline (N > 1): config 3's 1e7 points IN ALL, sharded over the ranks
@@ -679,14 +679,17 @@ def main():
         line = {
             "metric": (f"fitted points/sec (splcw) + evals/sec (splfe), {nd}-D {m:.0e} pts {nod}^{nd} nodes"
                        .replace("e+0", "e").replace("e+", "e")),
-            "value": value,
+            # N > 1 (round-5 verdict): the headline is the STRONG-scaling number -- BASELINE's own workload, 1e7 points in all,
+            # sharded over the ranks; the factorisation (most of a fit) does not depend on the point count, so the weak number
+            # (1e7 points PER GPU, kept as `weak` below) rises ~N-fold by construction whatever the GPUs do
+            "value": strong["value"] if strong else value,
             "unit": "points/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": strong["ms_per_step"] if strong else 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -814,6 +817,11 @@ def main():
                                             "the band factorisation of round 2 needed 4.1e13 flop for this grid")
         if strong is not None:
             line["strong"] = strong
+            line["weak"] = {"workload": workload_label(world, nd, nod, m), "scaling": "weak", "value": value, "unit": "points/s",
+                            "ms_per_step": 1e3 * elapsed / args.steps, "points_per_gpu": m,
+                            "note": "the timed K steps of the contract ran on this workload too; the factorisation does not depend on the point count"}
+            line["config"]["workload"] = strong["workload"] + "; 3-D, 64^3 nodes, xtrap=1, real64 (BASELINE config 3's total)"
+            line["config"]["points_total"] = 10_000_000
         if world == 1 and not args.no_side_legs:
             plan.close()                      # the side legs have the GPU to themselves
             # every side leg is guarded: a failure becomes {"error": ...} inside the line, the headline survives
