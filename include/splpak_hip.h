@@ -188,7 +188,9 @@ int64_t splpak_plan_device_bytes(const splpak_plan *plan);
  * (src/splpak.F90:1516-1619): returns 0 band Cholesky (four-stream pipeline), 1 its narrow form, 2 two-ended band,
  * 3 band distributed over several GPUs, 4 nested-dissection multifrontal (2-D / 3-D grids of >= 4 096 columns, 4-D grids of
  * >= 20 000), 5 the same distributed over the GPUs of a one-process multi-GPU plan (subtrees per GPU, the fronts above them by
- * block columns), 6 NO factorisation: the iterative solve below (grids whose factor does not fit the device, or by request);
+ * block columns; the description names the elimination schedule's cut -- chosen from the free device memory unless the option
+ * nd_cut fixes it -- and run-to-run bit reproducibility of a large grid's coefficients is promised for the SAME cut: the order in
+ * which two siblings with different numbers of block steps add into their parent follows the schedule), 6 NO factorisation: the iterative solve below (grids whose factor does not fit the device, or by request);
  * a description is copied into buf. */
 int32_t splpak_plan_factorisation(const splpak_plan *plan, char *buf, int32_t buflen);
 /* Options (round 6).  Every switch of the library is a named option; a plan takes a snapshot of them when it is created --

@@ -437,7 +437,47 @@ int32_t splpak_mplan_create(int32_t ngpus, const int32_t *devices, int32_t chunk
     mp->bar.n = ngpus;
     // Grids that take the nested-dissection factorisation on one GPU take it here too, distributed: subtrees per GPU, the
     // fronts above them by block columns (round 4; SPLPAK_MPLAN_BAND=1 keeps the distributed band of round 2).
-    const bool want_nd = ngpus > 1 && !splpak::opt_get("SPLPAK_MPLAN_BAND") && nd_wanted_for(ndim, nodes, xmin, xmax);
+    bool want_nd = ngpus > 1 && !splpak::opt_get("SPLPAK_MPLAN_BAND") && nd_wanted_for(ndim, nodes, xmin, xmax);
+    if (want_nd) {
+        // The distributed nested dissection READS the other GPUs' memory from kernels and needs peer access between every pair of
+        // distinct devices; the distributed band only copies.  Probed BEFORE anything large is allocated (round-5 advice): without
+        // peer access the plan takes the band form where a rank's share of the band fits its device, and is refused otherwise.
+        bool peers = splpak::opt_get("SPLPAK_DEBUG_NO_PEER") == nullptr || virt;
+        int pa = -1, pb = -1;
+        for (int a = 0; a < ngpus && !virt; ++a)
+            for (int b2 = 0; b2 < ngpus; ++b2) {
+                const int da = devices ? devices[a] : a, db = devices ? devices[b2] : b2;
+                if (da == db || da < 0 || db < 0 || da >= ndev || db >= ndev) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can || splpak::opt_get("SPLPAK_DEBUG_NO_PEER")) { peers = false; pa = da; pb = db; }
+                (void)hipGetLastError();
+            }
+        if (!peers) {
+            Grid g0;
+            long long nc = 0;
+            Band b0{};
+            size_t fr = 0, tot = 0;
+            bool band_fits = false;
+            if (build_grid(ndim, nodes, xmin, xmax, g0, &nc, splpak::opt_get("SPLPAK_NO_REORDER") == nullptr) == 0 &&
+                hipMemGetInfo(&fr, &tot) == hipSuccess) {
+                band_bytes(g0.ncol, g0.halfbw, &b0);
+                band_fits = (double)b0.bytes / ngpus < 0.8 * (double)tot;
+            }
+            (void)hipGetLastError();
+            if (band_fits) {
+                want_nd = false;
+                if (splpak::opt_get("SPLPAK_DEBUG"))
+                    fprintf(stderr, "[splpak] multi-GPU plan: no peer access between devices %d and %d: the distributed band instead of the distributed nested dissection\n", pa, pb);
+            } else {
+                char buf[256];
+                snprintf(buf, sizeof buf, "multi-GPU plan: device %d cannot map device %d's memory (no peer access), which the distributed nested "
+                                          "dissection needs, and the distributed band does not fit the devices either", pa, pb);
+                set_error(buf);
+                delete mp;
+                return SPLPAK_E_UNSUPPORTED;
+            }
+        }
+    }
     if (want_nd) {
         const char *ck = splpak::opt_get("SPLPAK_ND_CHUNK");
         mp->ndgrp = nd_group_create(ngpus, ck ? atoi(ck) : 1, &mp->abort);

@@ -48,7 +48,7 @@ struct SortScratch {
     // stable partition (round 5; sp_* kernels of assemble.hip): per-block bin counts / bases, bin bases, intermediate records
     int *cntm;       // [ceil(cap / SP_Q)][SP_NB]
     int *binbase;    // [SP_NB + 1]
-    int *sppart;     // [chunks of 128 blocks][SP_NB]
+    int *sppart;     // [chunks of 16 blocks][SP_NB]
     double *rec;     // [cap][ndim + 3] records sorted by tile (grids of more cells than bins; else NULL)
 };
 constexpr int SP_Q = 8192;         // points per block of the stable partition

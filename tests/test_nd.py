@@ -352,6 +352,34 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
         assert e == 0 and np.array_equal(c, ref), env
 
 
+@pytest.mark.gpu
+def test_nd_schedule_variants_on_an_anisotropic_grid():
+    """Round-5 advice: the isotropic 32^3 grid of the variants test has no stage whose fronts differ in their number of block steps,
+    so neither the look-ahead inside the chain's groups nor the order of the extend-adds under different schedule cuts was ever
+    exercised with mixed fronts.  A 24 x 40 x 24 box has them.  Variants that only re-time the same operations must return the same
+    bits; a different schedule CUT may add two siblings into their parent in the other order -- the header promises run-to-run
+    reproducibility for the same cut only (include/splpak_hip.h) -- so across cuts the bar is rounding level, and the test says which
+    it was."""
+    from splpak_amd.synth import synth_points
+    nd, nodes, m = 3, [24, 40, 24], 150000
+    x, y, w = synth_points(nd, m)
+    inp = dict(ndim=nd, xdata=x, ydata=y, wdata=w, xmin=[0.0] * nd, xmax=[1.0] * nd, nodes=nodes, xtrap=1.0)
+    ref, e, _, info = _fit_env(inp, {"SPLPAK_ND": "1", "SPLPAK_ND_CUT": "0"})
+    assert e == 0 and info[9] < 1e-9
+    for env in ({"SPLPAK_ND_CHAIN_LA": "0"}, {"SPLPAK_ND_CHAIN_LA": "64"}, {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_KB": "2"}, {"SPLPAK_ND_NO_FUSE": "1"},
+                {"SPLPAK_NO_PANEL_CU": "1"}, {"SPLPAK_ND_PREP_EARLY": "1"}, {"SPLPAK_ND_PIN_FIRST": "1", "SPLPAK_ND_PIN_ROUNDS": "2"}):
+        c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1", SPLPAK_ND_CUT="0"))
+        assert e == 0 and np.array_equal(c, ref), env
+    again, e, _, _ = _fit_env(inp, {"SPLPAK_ND": "1", "SPLPAK_ND_CUT": "0", "SPLPAK_NO_PLAN_CACHE": "1"})
+    assert e == 0 and np.array_equal(again, ref)
+    for cut in ("1", "2", "4"):
+        c, e, _, _ = _fit_env(inp, {"SPLPAK_ND": "1", "SPLPAK_ND_CUT": cut})
+        assert e == 0
+        d = relmax(c, ref)
+        print(f"24 x 40 x 24, schedule cut {cut} against cut 0: {'same bits' if np.array_equal(c, ref) else f'{d:.1e} apart'}")
+        assert d < 1e-12
+
+
 def test_multi_gpu_partition_of_the_4d_32_grid_fits_eight_gpus():
     """BASELINE config 5's 4-D 32^4 grid does not fit one 288 GB GPU by any route (476 GB of panels); the
     one-process multi-GPU fit distributes the nested-dissection factorisation -- subtrees per GPU, the fronts above them by
