@@ -136,6 +136,65 @@ def test_sharded_fit_two_ranks_one_gpu(name):
     assert spec_rows == res[1][3][0]
 
 
+def _gpu_worker_pcg(rank, world, port, q):
+    """4-D 12^4 at config 5's density of points, the ITERATIVE solve alone (round 6), points sharded over the ranks."""
+    sys.path.insert(0, ROOT)
+    os.environ["SPLPAK_SOLVER"] = "pcg"
+    from splpak_amd import capi
+    from splpak_amd.dist import ShardedFit, shard_range
+    from splpak_amd.synth import synth_points
+    _init(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        nd, nod, m = 4, 12, 158122
+        xh, yh, wh = synth_points(nd, m)
+        first, cnt = shard_range(m, rank, world)
+        x = torch.tensor(xh[first:first + cnt], device=dev)
+        y = torch.tensor(yh[first:first + cnt], device=dev)
+        w = torch.tensor(wh[first:first + cnt], device=dev)
+        coef = torch.zeros(nod ** nd, dtype=torch.float64, device=dev)
+        sf = ShardedFit(nd, [nod] * nd, [0.0] * nd, [1.0] * nd, 1.0, cnt, dev, dist if world > 1 else None)
+        ierr, info = sf.fit(x, y, w, coef, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        q.put((rank, ierr, coef.cpu().numpy(), info, sf.plan.factorisation()[0], sf.plan.pcg_stats()))
+        sf.close()
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_iterative_solve_two_ranks_one_gpu():
+    """The iterative solve with the points sharded over two processes (one GPU here; route (a) of DESIGN section 5): every rank applies
+    the rows of ITS points, one all-reduce of the product per iteration, and the preconditioner's two moments travel with the
+    histogram's reduction so that every rank builds the same one -- the ranks end with identical coefficients, 1e-10 from the
+    single-process fit of all points (the sums over the points are ordered differently) and from the factorisation."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker_pcg, args=(r, 2, 29671, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    for rank, ierr, coef, info, code, ps in res:
+        assert ierr == 0 and code == 6 and ps["iterations"] > 0 and info[9] < 1e-9, (rank, ierr, code, ps)
+    assert np.array_equal(res[0][2], res[1][2])
+    assert res[0][5]["iterations"] == res[1][5]["iterations"]
+    from splpak_amd import capi
+    from splpak_amd.synth import synth_points
+    xh, yh, wh = synth_points(4, 158122)
+    os.environ["SPLPAK_SOLVER"] = "direct"
+    try:
+        c1, e1, _, _ = capi.fit(4, xh, yh, wh, [0.0] * 4, [1.0] * 4, [12] * 4, 1.0)
+    finally:
+        os.environ.pop("SPLPAK_SOLVER", None)
+    assert e1 == 0
+    print(f"two ranks, {res[0][5]['iterations']} iterations: {relmax(res[0][2], c1):.2e} from the single-GPU factorisation")
+    assert relmax(res[0][2], c1) < 1e-10
+
+
 def _gpu_worker_nd(rank, world, port, name, q):
     os.environ["SPLPAK_ND"] = "1"            # (the goldens' grids are below the size from which nested dissection is the default)
     os.environ.pop("SPLPAK_ND_DIST", None)
