@@ -2362,6 +2362,18 @@ hipError_t launch_constraint_rows(const Grid &g, const double *dcw, const unsign
     return hipGetLastError();
 }
 
+hipError_t launch_hist_total(const Grid &g, const double *hist, double *scal, hipStream_t st)
+{
+    hipLaunchKernelGGL(hist_total_kernel, dim3(1), dim3(1024), 0, st, hist, g.ncol, scal);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_sparse(const Grid &g, const unsigned char *spf, double *scal_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(count_sparse_kernel, dim3(1), dim3(1024), 0, st, spf, g.ncol, g.ndim * (g.ndim + 1) / 2, scal_out);
+    return hipGetLastError();
+}
+
 long long constraint_table_doubles(const Grid &g)
 {
     long long n = 0;

@@ -77,6 +77,10 @@ hipError_t launch_sparse_mark(const Grid &g, const double *hist, const double *s
 // constraint_table_doubles entries); NULL = evaluate them in place
 hipError_t launch_constraint_rows(const Grid &g, const double *dcw, const unsigned char *spf, const double *ctab, double *nst,
                                   double *scal_out, hipStream_t st);
+// the two single-workgroup reductions of the assembly on their own (the rows-only assembly of pcg-only plans, rowsop.hip):
+// scal[SC_TOTLWT] = sum of the histogram; scal_out[SC_NROWS_CONS] += rows of the data-sparse nodes
+hipError_t launch_hist_total(const Grid &g, const double *hist, double *scal, hipStream_t st);
+hipError_t launch_count_sparse(const Grid &g, const unsigned char *spf, double *scal_out, hipStream_t st);
 long long constraint_table_doubles(const Grid &g);
 hipError_t launch_constraint_table(const Grid &g, double *ctab, hipStream_t st);
 // refinement residual rho = A^T W (W y - W A x) [- C^T C x when `constraints`]; rcell: [ncell][nb] scratch,

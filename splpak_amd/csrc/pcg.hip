@@ -346,6 +346,8 @@ void pcg_destroy(PcgState *s)
 
 size_t pcg_bytes(const PcgState *s) { return s ? s->bytes : 0; }
 
+double *pcg_scratch(PcgState *s, int which) { return which == 0 ? s->t1 : s->t2; }
+
 void pcg_stats(const PcgState *s, double *out6)
 {
     if (!s || !out6) return;

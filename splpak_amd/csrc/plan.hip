@@ -279,10 +279,19 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
         else ok = ok && okb;
     }
     if (!direct) { p->band.ab = nullptr; p->band.bytes = 0; }
+    // Iteration-only plans of 4-D grids never assemble the normal equations (round 6): the iteration applies the ROWS, and the
+    // right-hand side, the histogram and the backward-error denominators come from the rows too (rowsop.hip) -- no half stencil
+    // (10 GB at 32^4, and its all-reduce in a sharded fit), no Gram scratch (8 GB), no Gram / gather / constraint-row kernels
+    // (0.30 of the 0.32 s of config 5's assembly).  pcg_assemble = 1 keeps the assembled form (A/B).
+    {
+        const char *rt = splpak::opt_get("SPLPAK_ROWS_TILES");
+        p->rows_only = !direct && g.ndim == 4 && !splpak::opt_get("SPLPAK_NO_CONSTRAINT_TABLE") && !(rt && atoi(rt) == 0) &&
+                       !splpak::opt_get("SPLPAK_PCG_ASSEMBLE");
+    }
     {
         // scratch of the per-cell Gram blocks: everything at once if <= 8 GB (or if the band storage, which is
         // idle until the gather is done, holds it); otherwise slabs of what there is (launch_gram)
-        const long long full = gram_scratch_doubles(g), least = gram_scratch_min_doubles(g);
+        const long long full = p->rows_only ? 8 : gram_scratch_doubles(g), least = p->rows_only ? 8 : gram_scratch_min_doubles(g);
         long long want = full;
         const char *cap = splpak::opt_get("SPLPAK_GRAM_SCRATCH_MB");
         const long long budget = cap ? atoll(cap) * (1LL << 17) : (1LL << 30);      // doubles (default 8 GB)
@@ -309,8 +318,8 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
             ok = hip_ok(hipMemcpy(p->own_blocks, p->own_blocks_host.data(), sizeof(int) * (size_t)p->nown, hipMemcpyHostToDevice),
                         "hipMemcpy of the block list");
     }
-    // communication buffer
-    p->comm_len = comm_len_of(g);
+    // communication buffer (rows-only plans: no half stencil in it -- right-hand side first)
+    p->comm_len = comm_len_of(g) - (p->rows_only ? (long long)g.ncol * g.hstencil : 0);
     if (comm_buf_dev) {
         if (comm_len < p->comm_len) {
             set_error("comm buffer too small");
@@ -330,11 +339,11 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
         splpak_plan_destroy(p);
         return SPLPAK_E_NOMEM;
     }
-    p->lenG = (long long)g.ncol * g.hstencil + g.ncol + SC_COUNT;
+    p->lenG = (p->rows_only ? 0 : (long long)g.ncol * g.hstencil) + g.ncol + SC_COUNT;
     p->lenH = (long long)g.ncol + SC_COUNT;
     p->lenR = p->band.npad + SC_COUNT;
-    p->nst = p->comm;
-    p->rhs = p->nst + (long long)g.ncol * g.hstencil;
+    p->nst = p->rows_only ? nullptr : p->comm;
+    p->rhs = p->comm + (p->rows_only ? 0 : (long long)g.ncol * g.hstencil);
     p->scalG = p->rhs + g.ncol;
     p->hist = p->scalG + SC_COUNT;
     p->scalH = p->hist + g.ncol;
@@ -582,7 +591,16 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     SPLPAK_HIP_TRY(launch_bin_points(g, ndata, x, l1xdat, y, w, p->s, p->scalH, st), SPLPAK_E_NODEVICE);
     if (p->pcg) SPLPAK_HIP_TRY(pcg_sum_w2(p, st), SPLPAK_E_NODEVICE);       // (rides the histogram's all-reduce)
     stamp(1);
-    SPLPAK_HIP_TRY(launch_gram(g, p->s, p->gscratch, p->gscratch_doubles, smooth, p->nst, p->rhs, p->hist, p->scalH, st), SPLPAK_E_NODEVICE);
+    if (p->rows_only) {
+        // the histogram from the rows (tile by tile); the right-hand side follows below, when the reduced histogram has gone
+        if (smooth) {
+            SPLPAK_HIP_TRY(rowsop_histogram(g, p->rowsop, p->s, p->hist, st), SPLPAK_E_NODEVICE);
+            SPLPAK_HIP_TRY(launch_hist_total(g, p->hist, p->scalH, st), SPLPAK_E_NODEVICE);
+        }
+        SPLPAK_HIP_TRY(hipMemsetAsync(p->xvec, 0, sizeof(double) * (size_t)b.npad, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(rowsop_apply(g, p->rowsop, p->s, p->xvec, p->dcw, p->spf, p->ctab, false, p->rhs, st), SPLPAK_E_NODEVICE);   // A^T W^2 y
+    } else
+        SPLPAK_HIP_TRY(launch_gram(g, p->s, p->gscratch, p->gscratch_doubles, smooth, p->nst, p->rhs, p->hist, p->scalH, st), SPLPAK_E_NODEVICE);
     stamp(2);
     double hs[2 * SC_COUNT];
     if (p->world > 1) {
@@ -601,10 +619,11 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     if (smooth && (p->rank == 0 || p->pcg))      // (every rank of an iterating fit: the preconditioner's second moment)
         SPLPAK_HIP_TRY(launch_sparse_mark(g, p->hist, p->scalH, p->xtrap, p->dcw, p->spf, st), SPLPAK_E_NODEVICE);
     if (smooth && p->rank == 0) {
-        SPLPAK_HIP_TRY(launch_constraint_rows(g, p->dcw, p->spf, p->ctab, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
+        if (p->rows_only) SPLPAK_HIP_TRY(launch_count_sparse(g, p->spf, p->scalG, st), SPLPAK_E_NODEVICE);      // (the rows are only counted)
+        else SPLPAK_HIP_TRY(launch_constraint_rows(g, p->dcw, p->spf, p->ctab, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
     }
     stamp(3);
-    if (int r = do_allreduce(p, p->nst, p->lenG, st)) return r;
+    if (int r = do_allreduce(p, p->rows_only ? p->rhs : p->nst, p->lenG, st)) return r;
 
     SPLPAK_HIP_TRY(hipMemcpyAsync(hs, p->scalG, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st), SPLPAK_E_NODEVICE);
     // scalG and scalH are not adjacent (hist sits between): fetch scalH separately
@@ -763,7 +782,14 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         // the backward error's denominators (|N| |x| + |rhs|: a pass over the half stencil) need the coefficients only; into the
         // solves' scratch vector.  (On a stream of their own beside the residual pass they gained nothing -- the two kernels
         // slowed each other down by what the overlap saved -- and one more stream per plan is not free: round 5)
-        SPLPAK_HIP_TRY(launch_backward_denominators(g, p->nst, p->xvec, p->rhs, p->tmp, st), SPLPAK_E_NODEVICE);
+        if (p->rows_only) {
+            // from the rows: |A|^T W^2 |A| |x| + |C|^T |C| |x| + |rhs| (this rank's points; the residual's all-reduce below does not
+            // carry it -- a sharded rows-only fit normalises by its own shard's terms + the constraint rows on rank 0, a lower bound
+            // of the sum, i.e. a pessimistic backward error)
+            SPLPAK_HIP_TRY(rowsop_backward_denominators(g, p->rowsop, p->s, p->xvec, p->rhs, p->dcw, p->spf, p->ctab, smooth && p->rank == 0,
+                                                        pcg_scratch(p->pcg, 0), pcg_scratch(p->pcg, 1), p->tmp, st), SPLPAK_E_NODEVICE);
+        } else
+            SPLPAK_HIP_TRY(launch_backward_denominators(g, p->nst, p->xvec, p->rhs, p->tmp, st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
         hipEvent_t r0 = stamps ? p->evStage[8] : nullptr, r1 = stamps ? p->evStage[9] : nullptr;   // (created with the other stage events)
         if (r0 && r1) (void)hipEventRecord(r0, st);

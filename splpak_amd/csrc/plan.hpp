@@ -106,6 +106,8 @@ struct splpak_plan {
     splpak::RowsOp *rowsop = nullptr;         // 4-D grids: the tiled residual pass (NULL: the cell-by-cell passes of assemble.hip)
     splpak::PcgState *pcg = nullptr;
     int solver_mode = 0;
+    bool rows_only = false;       // iteration-only 4-D plans: the normal equations are never assembled (right-hand side, histogram and
+                                  // backward-error denominators come from the rows: rowsop.hip); no half stencil, no Gram scratch
     const char *fn_name = nullptr;                 // what the hooks are (splpak_plan_factorisation); fn_code: 2 two-ended band, 4 nested dissection, 3 distributed band
     int fn_code = 0;
 };
@@ -151,6 +153,10 @@ void rowsop_destroy(RowsOp *r);
 size_t rowsop_bytes(const RowsOp *r);
 hipError_t rowsop_apply(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
                         const double *ctab, bool constraints, double *rho, hipStream_t st);
+hipError_t rowsop_histogram(const Grid &g, RowsOp *r, const SortScratch &rows, double *hist, hipStream_t st);
+hipError_t rowsop_backward_denominators(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *rhs, const double *dcw,
+                                        const unsigned char *spf, const double *ctab, bool constraints, double *absx, double *tmp, double *den,
+                                        hipStream_t st);
 // rho = A^T W (W y - W A x) [- C^T C x] of the plan's binned points (rows.ys == NULL: y = 0), by whichever pass the plan has
 inline hipError_t plan_rows_residual(splpak_plan *p, const SortScratch &rows, const double *xvec, bool constraints, double *rho, hipStream_t st)
 {
@@ -162,6 +168,7 @@ int pcg_attach(splpak_plan *p, PcgState **out);
 void pcg_destroy(PcgState *s);
 size_t pcg_bytes(const PcgState *s);
 void pcg_stats(const PcgState *s, double *out6);
+double *pcg_scratch(PcgState *s, int which);      // two vectors of ncol doubles, free between solves
 hipError_t pcg_sum_w2(splpak_plan *p, hipStream_t st);
 hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, hipStream_t st);
 int pcg_solve(splpak_plan *p, PcgState *s, double *v, double tol, bool smooth, hipStream_t st);

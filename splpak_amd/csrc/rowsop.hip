@@ -186,6 +186,7 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
 }
 
 // rho[i] = sum of the tile partials that hold node i (tile order, dimension 0 fastest) - cterm[i]
+template <bool REFADD>
 __global__ void __launch_bounds__(256)
 rows4_gather_kernel(Grid g, int nt0, int nt1, int nt2, int nt3, const double *__restrict__ partial, const double *__restrict__ cterm,
                     double *__restrict__ rho)
@@ -215,7 +216,109 @@ rows4_gather_kernel(Grid g, int nt0, int nt1, int nt2, int nt3, const double *__
                     const int li = (in[0] - TCELL * t0) + TB * ((in[1] - TCELL * t1) + TB * ((in[2] - TCELL * t2) + TB * (in[3] - TCELL * t3)));
                     acc += partial[tile * TB4 + li];
                 }
-    rho[node] = cterm ? acc - cterm[node] : acc;
+    if constexpr (REFADD) {                      // the histogram: kept in the caller's dimension order, on top of what is there
+        int refnode = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) refnode += in[d] * g.refstride[d];
+        rho[refnode] += acc;
+    } else {
+        rho[node] = cterm ? acc - cterm[node] : acc;
+    }
+}
+
+// The nearest-node histogram of the sparse-area test (:886-907), tile by tile like the rows: a wave takes every fourth cell of
+// the tile, lane = point computes the point's slot in its window (nearest_slot's arithmetic: the reference's per dimension), and
+// the weights are added into the wave's image of the tile in the points' order.  A point so far outside the grid that its
+// address is not a node of its window (the :899 quirk) is added to the histogram directly -- the one floating-point atomic of the
+// assembly, as in the Gram kernels.
+__global__ void __launch_bounds__(256)
+rows4_hist_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ offset, const double *__restrict__ xs,
+                  const double *__restrict__ ws, long long cap, double *__restrict__ partial, double *__restrict__ hist)
+{
+    __shared__ double acc[4][TB4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int t = blockIdx.x;
+    int cb[4];
+    cb[0] = (t % nt0) * TCELL; t /= nt0;
+    cb[1] = (t % nt1) * TCELL; t /= nt1;
+    cb[2] = (t % nt2) * TCELL; t /= nt2;
+    cb[3] = t * TCELL;
+    for (int idx = tid; idx < TB4; idx += 256)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc[w][idx] = 0.0;
+    __syncthreads();
+    double *__restrict__ myacc = acc[wave];
+    constexpr int NCT = TCELL * TCELL * TCELL * TCELL;
+    for (int lc = wave; lc < NCT; lc += 4) {
+        int r = lc, cell = 0, lbase = 0, mul = 1;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int a = r % TCELL;
+            r /= TCELL;
+            ok = ok && cb[d] + a < g.cells[d];
+            cell += (cb[d] + a) * g.cellstride[d];
+            lbase += a * mul;
+            mul *= TB;
+        }
+        if (!ok) continue;
+        const int beg = offset[cell], end = offset[cell + 1];
+        for (int p0 = beg; p0 < end; p0 += 64) {
+            const int np = end - p0 < 64 ? end - p0 : 64;
+            int li = -1;
+            double wv = 0.0;
+            if (lane < np) {
+                double xv[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) xv[d] = xs[(long long)d * cap + p0 + lane];
+                wv = ws[p0 + lane];
+                // nearest_slot (assemble.hip): the node's place in the cell's window, or outside it
+                bool inwin = true;
+                int loc = 0, m6 = 1;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+#pragma clang fp contract(off)
+                    const double tt = g.dxin[d] * (xv[d] - g.xmin[d]) + 0.5;
+                    const int inidim = (tt >= 2.0e9) ? 2000000000 : (tt <= -2.0e9 ? -2000000000 : (int)tt);
+                    int lo, hi;
+                    const int l = inidim - window_start(g, d, xv[d], lo, hi);
+                    inwin = inwin && inidim >= 0 && inidim <= g.nodes[d] - 1 && l >= 0 && l <= 3;
+                    loc += l * m6;
+                    m6 *= TB;
+                }
+                if (inwin) li = lbase + loc;
+                else {
+                    double xr[MAXD] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) xr[g.perm[d]] = xv[d];
+                    atomicAdd(&hist[nearest_node_address(g, xr)], wv);       // :905
+                }
+            }
+            for (int q = 0; q < np; ++q) {                 // in the points' order: one owner, fixed order
+                const int lq = __shfl(li, q, 64);
+                const double wq = __shfl(wv, q, 64);
+                if (lane == 0 && lq >= 0) myacc[lq] += wq;
+            }
+        }
+    }
+    __syncthreads();
+    double *__restrict__ out = partial + (long long)blockIdx.x * TB4;
+    for (int idx = tid; idx < TB4; idx += 256) out[idx] = ((acc[0][idx] + acc[1][idx]) + acc[2][idx]) + acc[3][idx];
+}
+
+__global__ void __launch_bounds__(256)
+abs_kernel(long long n, const double *__restrict__ x, double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = fabs(x[i]);
+}
+
+// den = |rhs| - nabs   (nabs = -(|A|^T W^2 |A| |x| + |C|^T |C| |x|): the residual pass's sign)
+__global__ void __launch_bounds__(256)
+den_kernel(long long n, const double *__restrict__ rhs, const double *__restrict__ nabs, double *__restrict__ den)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) den[i] = fabs(rhs[i]) - nabs[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -239,7 +342,7 @@ __device__ inline double node_factor(const Grid &g, const double *__restrict__ c
 }
 
 // forward: out_j[n] = w(n) sum_o F(n_k, o) in_src(j)[n + o e_k];  transposed: out_j[m] = sum_{sources} sum_o F(m_k + o, -o) in_s[m + o e_k]
-template <bool TRANSPOSED>
+template <bool TRANSPOSED, bool ABS>
 __global__ void __launch_bounds__(256)
 tri_pass_kernel(Grid g, int k, int ctbase, PassTable tabl, const double *__restrict__ ctab, const double *__restrict__ inpool,
                 double *__restrict__ outpool, const double *__restrict__ dcw, const unsigned char *__restrict__ spf)
@@ -258,7 +361,8 @@ tri_pass_kernel(Grid g, int k, int ctbase, PassTable tabl, const double *__restr
         for (int o = -1; o <= 1; ++o) {
             const int jk = ik + o;
             if (jk < 0 || jk > nk - 1) continue;
-            const double f = TRANSPOSED ? node_factor(g, ctab, ctbase, k, jk, -o, ord) : node_factor(g, ctab, ctbase, k, ik, o, ord);
+            double f = TRANSPOSED ? node_factor(g, ctab, ctbase, k, jk, -o, ord) : node_factor(g, ctab, ctbase, k, ik, o, ord);
+            if (ABS) f = fabs(f);
             acc = fma(f, in[node + o * stride], acc);
         }
     }
@@ -379,8 +483,8 @@ int rowsop_create(const Grid &g, RowsOp **out)
 }
 
 // rho = A^T W (W y - W A x) [- C^T C x]   (rows.ys == NULL: y = 0)
-hipError_t rowsop_apply(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
-                        const double *ctab, bool constraints, double *rho, hipStream_t st)
+static hipError_t rowsop_apply_t(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
+                                 const double *ctab, bool constraints, bool abs_factors, double *rho, hipStream_t st)
 {
     hipLaunchKernelGGL(rows4_tile_kernel, dim3((unsigned)r->ntiles), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], (const int *)rows.offset,
                        (const double *)rows.xs, (const double *)rows.ys, (const double *)rows.ws, rows.cap, xvec, r->partial);
@@ -393,19 +497,54 @@ hipError_t rowsop_apply(const Grid &g, RowsOp *r, const SortScratch &rows, const
         double *pools[2] = {r->poolA, r->poolB};
         int which = 0;
         for (int k = 0; k < D; ++k) {
-            hipLaunchKernelGGL(tri_pass_kernel<false>, dim3(gx, (unsigned)r->nfwd[k]), bl, 0, st, g, k, r->ctbase[k], r->fwd[k], ctab, in, pools[which], dcw, spf);
+            if (abs_factors) hipLaunchKernelGGL((tri_pass_kernel<false, true>), dim3(gx, (unsigned)r->nfwd[k]), bl, 0, st, g, k, r->ctbase[k], r->fwd[k], ctab, in, pools[which], dcw, spf);
+            else hipLaunchKernelGGL((tri_pass_kernel<false, false>), dim3(gx, (unsigned)r->nfwd[k]), bl, 0, st, g, k, r->ctbase[k], r->fwd[k], ctab, in, pools[which], dcw, spf);
             in = pools[which];
             which ^= 1;
         }
         for (int k = D - 1; k >= 0; --k) {
-            hipLaunchKernelGGL(tri_pass_kernel<true>, dim3(gx, (unsigned)r->nbwd[k]), bl, 0, st, g, k, r->ctbase[k], r->bwd[k], ctab, in, pools[which], dcw, spf);
+            if (abs_factors) hipLaunchKernelGGL((tri_pass_kernel<true, true>), dim3(gx, (unsigned)r->nbwd[k]), bl, 0, st, g, k, r->ctbase[k], r->bwd[k], ctab, in, pools[which], dcw, spf);
+            else hipLaunchKernelGGL((tri_pass_kernel<true, false>), dim3(gx, (unsigned)r->nbwd[k]), bl, 0, st, g, k, r->ctbase[k], r->bwd[k], ctab, in, pools[which], dcw, spf);
             in = pools[which];
             which ^= 1;
         }
         cterm = in;
     }
-    hipLaunchKernelGGL(rows4_gather_kernel, dim3((unsigned)((g.ncol + 255) / 256)), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], r->nt[3],
+    hipLaunchKernelGGL(rows4_gather_kernel<false>, dim3((unsigned)((g.ncol + 255) / 256)), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], r->nt[3],
                        (const double *)r->partial, cterm, rho);
+    return hipGetLastError();
+}
+
+hipError_t rowsop_apply(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
+                        const double *ctab, bool constraints, double *rho, hipStream_t st)
+{
+    return rowsop_apply_t(g, r, rows, xvec, dcw, spf, ctab, constraints, false, rho, st);
+}
+
+// hist (caller's dimension order; zero or holding other ranks' nothing yet) += the nearest-node histogram of the binned points
+hipError_t rowsop_histogram(const Grid &g, RowsOp *r, const SortScratch &rows, double *hist, hipStream_t st)
+{
+    hipLaunchKernelGGL(rows4_hist_kernel, dim3((unsigned)r->ntiles), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], (const int *)rows.offset,
+                       (const double *)rows.xs, (const double *)rows.ws, rows.cap, r->partial, hist);
+    hipLaunchKernelGGL(rows4_gather_kernel<true>, dim3((unsigned)((g.ncol + 255) / 256)), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], r->nt[3],
+                       (const double *)r->partial, (const double *)nullptr, hist);
+    return hipGetLastError();
+}
+
+// den[i] = (|A|^T W^2 |A| |x|)_i + (|C|^T |C| |x|)_i + |rhs_i|: the size of the terms whose sum the refinement residual is, from the
+// rows themselves (the basis functions are non-negative: |A| = A).  An upper bound of the half stencil's (|N| |x|)_i + |rhs_i| of
+// launch_backward_denominators (|sum c_i c_j| <= sum |c_i| |c_j|); absx, tmp: scratch of ncol doubles.
+hipError_t rowsop_backward_denominators(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *rhs, const double *dcw,
+                                        const unsigned char *spf, const double *ctab, bool constraints, double *absx, double *tmp, double *den,
+                                        hipStream_t st)
+{
+    const unsigned gx = (unsigned)((g.ncol + 255) / 256);
+    hipLaunchKernelGGL(abs_kernel, dim3(gx), dim3(256), 0, st, (long long)g.ncol, xvec, absx);
+    SortScratch op = rows;
+    op.ys = nullptr;
+    hipError_t e = rowsop_apply_t(g, r, op, absx, dcw, spf, ctab, constraints, true, tmp, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(den_kernel, dim3(gx), dim3(256), 0, st, (long long)g.ncol, rhs, (const double *)tmp, den);
     return hipGetLastError();
 }
 
