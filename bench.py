@@ -396,7 +396,7 @@ def bench_dist_band(capi, ngpus, nd, nod, m_total, virtual, steps):
 def c5_traffic():
     """Fabric bytes of the 4-D evaluation passes from the committed PMC profile (not measured in this run)."""
     try:
-        src = committed_profile("r05_eval_pmc.json", "r04_eval_pmc.json", "r03_eval_pmc.json")
+        src = committed_profile("r06_eval_pmc.json", "r05_eval_pmc.json", "r04_eval_pmc.json")
         pm = json.load(open(src))["4d_32"]
         kname, kv = next((k, v) for k, v in pm["kernels"].items() if k.startswith(("pr_eval_kernel<4", "eval_binned_kernel<4, true")))
         return {"kernel": kname, "bytes_per_launch": kv["hbm_bytes"],
@@ -644,7 +644,7 @@ def main():
     # fabric bytes of the evaluation passes: PMC passes of an earlier run of the same workload, kept under profiles/ --
     # NOT measured in this run
     eval_traffic = None
-    eval_pmc = committed_profile("r05_eval_pmc.json", "r04_eval_pmc.json", "r03_eval_pmc.json")
+    eval_pmc = committed_profile("r06_eval_pmc.json", "r05_eval_pmc.json", "r04_eval_pmc.json")
     try:
         pm = json.load(open(eval_pmc))["3d_64"]
         eval_traffic = {"kernel": "pr_eval_kernel<3,16,true,double> (evaluation pass of the persistent region path; all three passes in bytes_per_query_all_passes)", "bytes_per_launch": next(v for k, v in pm["kernels"].items() if k.startswith(("pr_eval_kernel<3", "eval_runs_kernel<3, true", "eval_binned_kernel<3, true")))["hbm_bytes"],
@@ -744,7 +744,7 @@ def main():
                 "gram blocks + stencil gather": hbm(m * bpp + 8.0 * ncol * hst, stages["gram_ms"]),
                 "constraint rows": {"ms": stages["constraints_ms"]},
                 "refinement residual pass": hbm(m * bpp, stages["residual_pass_ms"]),
-                "note": "the Gram stage moves 3.9 GB of per-cell blocks through HBM on top of its algorithmic bytes (PMC: profiles/r05_fit_pmc.json)"
+                "note": "the Gram stage moves 3.9 GB of per-cell blocks through HBM on top of its algorithmic bytes (PMC: profiles/r06_fit_pmc.json)"
                         if nd == 3 and nod == 64 else "",
             }
             if fact_code == 4:
@@ -764,7 +764,7 @@ def main():
             # fabric bytes per launch of the roofline kernel: PMC passes of an earlier run of the same workload, kept
             # under profiles/ -- NOT measured in this run (counters and kernel timing do not share a run)
             traffic = None
-            pmc = committed_profile("r05_fit_pmc.json", "r04_fit_pmc.json", "r03_fit_pmc.json") if nd_path else committed_profile("r02_fit_pmc.json")
+            pmc = committed_profile("r06_fit_pmc.json", "r05_fit_pmc.json", "r04_fit_pmc.json") if nd_path else committed_profile("r02_fit_pmc.json")
             if nd == 3 and nod == 64 and pmc:
                 try:
                     pj = json.load(open(pmc))

@@ -257,7 +257,7 @@ void    splpak_plan_stage_timing(const splpak_plan *plan, double *out6);
  *     every GPU stores and updates only its own block columns, the solved panel of every block step travels
  *     GPU-to-GPU, the triangular sweeps hand the active window from owner to owner (copies only: no peer mapping needed).
  * The sums over the ranks (histogram, normal equations, residuals) are reduce-scatter + all-gather over point-to-point
- * copies in rank order (bitwise reproducible), or -- SPLPAK_MPLAN_RCCL=1, round 5 -- grouped ncclAllReduce calls of a
+ * copies in rank order (bitwise reproducible), or -- option mplan_rccl, round 5 -- one ncclAllReduce per rank thread (no group call) of a
  * communicator the plan makes over its devices (ncclCommInitAll; distinct devices only).
  * Results are those of the single-GPU fit (same kernels per tile: with all points on rank 0 the coefficients are
  * bit-identical to it).

@@ -123,8 +123,14 @@ hipError_t reduce_all(MRank *me, double *buf, long long count)
         // Every rank thread enqueues its ncclAllReduce on its own stream (the calls of one collective come from R threads at
         // once, as RCCL requires of a multi-communicator process); the sum's order is RCCL's, not rank order: the result is
         // the same on every rank but not bitwise the peer-copy form's.
+        // Every thread enqueues first and the threads meet on the ENQUEUE status before anybody waits for the stream: a rank
+        // whose enqueue failed never joins the collective, and a thread that waited on its stream for a collective that cannot
+        // complete would hang instead of returning SPLPAK_E_COMM (round-5 advice).  On failure nobody synchronises.
         const int rc = rccl_allreduce_sum(me->nccl, buf, count, me->st);
-        hipError_t e = rc == 0 ? hipStreamSynchronize(me->st) : hipErrorUnknown;
+        if (rc != 0) mp->abort.store(1);
+        if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;
+        if (mp->abort.load()) return hipErrorUnknown;
+        hipError_t e = hipStreamSynchronize(me->st);
         if (e != hipSuccess) mp->abort.store(1);
         if (!mp->bar.wait(mp->abort)) return hipErrorUnknown;
         return mp->abort.load() ? (e != hipSuccess ? e : hipErrorUnknown) : hipSuccess;
