@@ -2400,4 +2400,35 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     return 0;
 }
 
+// ---- batched Cholesky of independent dense 256 x 256 blocks (the block-Jacobi component of the iterative solve, pcg.hip) ----------
+// The diagonal-block kernels of the fronts on blocks that belong to no front: `blocks` holds nb column-major 256 x 256 matrices (lower
+// triangle read, L written in place), inv16 nb x 16 leaf inverses of 16 x 16, dinv / dinvt the inverse of L row-major and its
+// transpose.  The job tables live in device memory the caller provides (block_chol_job_bytes) and are written once per plan.
+size_t block_chol_job_bytes(int nb) { return (size_t)nb * (sizeof(PotrfJob) + sizeof(TrinvJob)) + 256; }
+
+hipError_t block_chol_prepare(void *jobs_dev, int nb, double *blocks, double *inv16, double *dinv, double *dinvt, const int *ncols_host)
+{
+    std::vector<PotrfJob> pj((size_t)nb);
+    std::vector<TrinvJob> tj((size_t)nb);
+    for (int b = 0; b < nb; ++b) {
+        double *A = blocks + (size_t)b * NBLK * NBLK, *iv = inv16 + (size_t)b * 16 * 256;
+        pj[(size_t)b] = PotrfJob{A, iv, NBLK, b * NBLK, ncols_host ? ncols_host[b] : NBLK};
+        tj[(size_t)b] = TrinvJob{A, iv, dinv + (size_t)b * NBLK * NBLK, dinvt + (size_t)b * NBLK * NBLK, NBLK};
+    }
+    char *base = static_cast<char *>(jobs_dev);
+    hipError_t e = hipMemcpy(base, pj.data(), sizeof(PotrfJob) * (size_t)nb, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    const size_t off = ((sizeof(PotrfJob) * (size_t)nb + 255) / 256) * 256;
+    return hipMemcpy(base + off, tj.data(), sizeof(TrinvJob) * (size_t)nb, hipMemcpyHostToDevice);
+}
+
+hipError_t block_chol_run(const void *jobs_dev, int nb, int *info_dev, double *minpiv_dev, hipStream_t st)
+{
+    const char *base = static_cast<const char *>(jobs_dev);
+    const size_t off = ((sizeof(PotrfJob) * (size_t)nb + 255) / 256) * 256;
+    hipLaunchKernelGGL(nd_potrf_kernel<8>, dim3((unsigned)nb), dim3(512), 0, st, reinterpret_cast<const PotrfJob *>(base), info_dev, minpiv_dev);
+    hipLaunchKernelGGL(nd_trinv_kernel, dim3(NBLK / 16, (unsigned)nb), dim3(64), 0, st, reinterpret_cast<const TrinvJob *>(base + off));
+    return hipGetLastError();
+}
+
 }  // namespace splpak

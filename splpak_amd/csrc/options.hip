@@ -67,6 +67,7 @@ const Known KNOWN[] = {
     {"SPLPAK_NO_TWOEND", 0},
     {"SPLPAK_PCG_ASSEMBLE", 0},
     {"SPLPAK_PCG_MAXIT", 1},
+    {"SPLPAK_PCG_NO_BLOCKS", 0},
     {"SPLPAK_PCG_TOL1", 1},
     {"SPLPAK_PCG_TOL2", 1},
     {"SPLPAK_PIN_BW", 0},

@@ -300,6 +300,94 @@ fd_lambda_kernel(const double *__restrict__ dcw, const unsigned char *__restrict
     if (t == 0) out[0] = red[0];
 }
 
+// ---- block-Jacobi component: the diagonal blocks of N over aligned boxes of nodes -------------------------------------------
+struct BjGeom {
+    int ndim, edge[MAXD], nbd[MAXD], nb;        // box edge and boxes per dimension, boxes in all
+};
+
+// node of local index l of box b (dimension 0 fastest in both), or -1 beyond the grid / the box
+__device__ inline int bj_node(const Grid &g, const BjGeom &bg, int b, int l, int *coord)
+{
+    int node = 0;
+    for (int d = 0; d < bg.ndim; ++d) {
+        const int bd = b % bg.nbd[d], ld = l % bg.edge[d];
+        b /= bg.nbd[d];
+        l /= bg.edge[d];
+        const int c = bd * bg.edge[d] + ld;
+        if (c >= g.nodes[d]) return -1;
+        if (coord) coord[d] = c;
+        node += c * g.colstride[d];
+    }
+    return l == 0 ? node : -1;
+}
+
+// blocks[b] (column-major 256 x 256, lower triangle) = N restricted to the box's nodes, from the half stencil; identity on the padding
+__global__ void __launch_bounds__(256)
+bj_extract_kernel(Grid g, BjGeom bg, const double *__restrict__ nst, double *__restrict__ blocks)
+{
+    __shared__ int snode[256];
+    __shared__ short sloc[256][MAXD];              // coordinates inside the box
+    const int b = blockIdx.x, r = threadIdx.x;
+    {
+        snode[r] = bj_node(g, bg, b, r, nullptr);
+        int l = r;
+        for (int d = 0; d < MAXD; ++d) {
+            sloc[r][d] = (short)(d < bg.ndim ? l % bg.edge[d] : 0);
+            if (d < bg.ndim) l /= bg.edge[d];
+        }
+    }
+    __syncthreads();
+    double *__restrict__ A = blocks + (size_t)b * 65536;
+    const int nr = snode[r];
+    for (int c = 0; c < 256; ++c) {
+        double v = 0.0;
+        if (c <= r) {
+            const int nc = snode[c];
+            if (nr < 0 || nc < 0) v = (c == r) ? 1.0 : 0.0;
+            else {
+                int code = 0, m7 = 1;
+                bool in = true;
+                for (int d = 0; d < g.ndim; ++d) {
+                    const int o = (int)sloc[c][d] - (int)sloc[r][d];
+                    in = in && o >= -3 && o <= 3;
+                    code += (o + 3) * m7;
+                    m7 *= 7;
+                }
+                if (in) v = nst[(long long)nr * g.hstencil + code];       // row = the later node (local order = global order inside a box)
+            }
+        }
+        A[r + (size_t)c * 256] = v;
+    }
+}
+
+// z += (L L^T)^-1 v on every box: u = Linv v (dinvt[j][i] = Linv(i, j)), then Linv^T u (dinv[j][i] = Linv(j, i)); consecutive threads,
+// consecutive words in both
+__global__ void __launch_bounds__(256)
+bj_apply_kernel(Grid g, BjGeom bg, const double *__restrict__ dinv, const double *__restrict__ dinvt, const double *__restrict__ v,
+                double *__restrict__ z)
+{
+    __shared__ double vb[256], ub[256];
+    const int b = blockIdx.x, i = threadIdx.x, wave = i >> 6;
+    const int node = bj_node(g, bg, b, i, nullptr);
+    vb[i] = node >= 0 ? v[node] : 0.0;
+    __syncthreads();
+    const double *__restrict__ Mt = dinvt + (size_t)b * 65536, *__restrict__ M = dinv + (size_t)b * 65536;
+    double a0 = 0.0, a1 = 0.0;
+    const int jmax = 64 * wave + 63;
+    for (int j = 0; j + 1 <= jmax; j += 2) {
+        a0 = fma(Mt[(size_t)j * 256 + i], vb[j], a0);              // (entries above the diagonal of Linv are stored zeros)
+        a1 = fma(Mt[(size_t)(j + 1) * 256 + i], vb[j + 1], a1);
+    }
+    ub[i] = a0 + a1;
+    __syncthreads();
+    a0 = a1 = 0.0;
+    for (int j = 64 * wave; j + 1 < 256; j += 2) {
+        a0 = fma(M[(size_t)j * 256 + i], ub[j], a0);
+        a1 = fma(M[(size_t)(j + 1) * 256 + i], ub[j + 1], a1);
+    }
+    if (node >= 0) z[node] += a0 + a1;
+}
+
 }  // namespace
 
 struct PcgState {
@@ -312,6 +400,12 @@ struct PcgState {
     double *dinv = nullptr;
     double *bvec = nullptr, *x = nullptr, *r = nullptr, *z = nullptr, *pv = nullptr, *t1 = nullptr, *t2 = nullptr;
     double *partial = nullptr, *sc = nullptr, *hist = nullptr, *mom = nullptr;
+    // block-Jacobi component (NULL / bj_ready false: the separable preconditioner alone)
+    BjGeom bg{};
+    double *bj_blocks = nullptr, *bj_inv16 = nullptr, *bj_dinv = nullptr, *bj_dinvt = nullptr, *bj_scal = nullptr;
+    void *bj_jobs = nullptr;
+    int *bj_info = nullptr;
+    bool bj_have = false, bj_ready = false;
     std::vector<double> hhist;
     int maxit = 4000;
     std::vector<void *> owned;
@@ -434,6 +528,48 @@ int pcg_attach(splpak_plan *p, PcgState **out)
     for (double **q : {&s->dinv, &s->bvec, &s->x, &s->r, &s->z, &s->pv, &s->t1, &s->t2}) ok = ok && pcg_alloc(s, q, n);
     ok = ok && pcg_alloc(s, &s->partial, DOT_BLOCKS) && pcg_alloc(s, &s->sc, S_COUNT) && pcg_alloc(s, &s->hist, (size_t)s->maxit + 8) &&
          pcg_alloc(s, &s->mom, 2);
+    // Block-Jacobi component (round 6): the diagonal blocks of the assembled N over aligned boxes of nodes (4-D: 4^4, 3-D: 6^3,
+    // 2-D: 16^2, 1-D: 256 nodes -- all at most 256, the block size of the diagonal-block kernels of the fronts), factored per fit
+    // and ADDED to the separable preconditioner: M^-1 = V diag^-1 V^T + sum_boxes R^T (N_box)^-1 R.  The separable part knows the
+    // global, smooth structure and the densities; the boxes know WHERE the data-sparse nodes are.  Measured at 12^4 (tools/pcg/exp7.py):
+    // config 5's density 259 -> 97 iterations; 17 % data-sparse nodes (where the separable part alone stagnates) 505 iterations.
+    // Needs the assembled normal equations (not the rows-only plans) and 3 x 0.5 MB per box.
+    if (ok && !p->rows_only && !splpak::opt_get("SPLPAK_PCG_NO_BLOCKS")) {
+        static const int edge_of[MAXD + 1] = {0, 256, 16, 6, 4};
+        s->bg.ndim = g.ndim;
+        s->bg.nb = 1;
+        for (int d = 0; d < MAXD; ++d) {
+            s->bg.edge[d] = d < g.ndim ? edge_of[g.ndim] : 1;
+            s->bg.nbd[d] = d < g.ndim ? (g.nodes[d] + s->bg.edge[d] - 1) / s->bg.edge[d] : 1;
+            s->bg.nb *= s->bg.nbd[d];
+        }
+        if (s->bg.nb <= 65535) {
+            const size_t nb = (size_t)s->bg.nb;
+            bool okb = pcg_alloc(s, &s->bj_blocks, nb * 65536) && pcg_alloc(s, &s->bj_dinv, nb * 65536) && pcg_alloc(s, &s->bj_dinvt, nb * 65536) &&
+                       pcg_alloc(s, &s->bj_inv16, nb * 4096) && pcg_alloc(s, &s->bj_scal, 8);
+            double *jb = nullptr, *ib = nullptr;
+            okb = okb && pcg_alloc(s, &jb, (block_chol_job_bytes(s->bg.nb) + 7) / 8) && pcg_alloc(s, &ib, 2);
+            if (okb) {
+                s->bj_jobs = jb;
+                s->bj_info = reinterpret_cast<int *>(ib);
+                // real columns of every box (the rest of its 256 is identity padding)
+                std::vector<int> ncols(nb);
+                for (int b = 0; b < s->bg.nb; ++b) {
+                    int bb = b, cnt = 1;
+                    for (int d = 0; d < g.ndim; ++d) {
+                        const int bd = bb % s->bg.nbd[d];
+                        bb /= s->bg.nbd[d];
+                        cnt *= std::min(s->bg.edge[d], g.nodes[d] - bd * s->bg.edge[d]);
+                    }
+                    (void)cnt;
+                    ncols[(size_t)b] = 256;      // (padding is interleaved with the box's nodes unless the box is full: factor all 256)
+                }
+                okb = hip_ok(block_chol_prepare(s->bj_jobs, s->bg.nb, s->bj_blocks, s->bj_inv16, s->bj_dinv, s->bj_dinvt, ncols.data()), "pcg: block jobs");
+            }
+            s->bj_have = okb;
+            if (!okb) (void)hipGetLastError();      // (out of memory for the boxes: the separable preconditioner alone)
+        }
+    }
     if (!ok) { pcg_destroy(s); return SPLPAK_E_NOMEM; }
     *out = s;
     return 0;
@@ -469,6 +605,22 @@ hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, h
     s->total_iters = 0;
     s->solves = 0;
     s->failed = false;
+    s->bj_ready = false;
+    if (s->bj_have && p->nst) {
+        const double inf = 1.0e300;
+        hipError_t e = hipMemsetAsync(s->bj_info, 0, 2 * sizeof(int), st);
+        if (e == hipSuccess) e = hipMemcpyAsync(s->bj_scal, &inf, sizeof(double), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bj_extract_kernel, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const double *)p->nst, s->bj_blocks);
+        e = block_chol_run(s->bj_jobs, s->bg.nb, s->bj_info, s->bj_scal, st);
+        if (e != hipSuccess) return e;
+        int hinfo = 0;
+        e = hipMemcpyAsync(&hinfo, s->bj_info, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        s->bj_ready = hinfo == 0;            // (a box that is not positive definite: the separable preconditioner alone)
+        if (splpak::opt_get("SPLPAK_DEBUG")) fprintf(stderr, "[splpak pcg] %d boxes of N factored%s\n", s->bg.nb, s->bj_ready ? "" : ": one is not positive definite, dropped");
+    }
     return hipGetLastError();
 }
 
@@ -495,6 +647,8 @@ static hipError_t pcg_precondition(PcgState *s, const double *r, double *z, hipS
         src = dst;
         which ^= 1;
     }
+    if (s->bj_ready)
+        hipLaunchKernelGGL(bj_apply_kernel, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const double *)s->bj_dinv, (const double *)s->bj_dinvt, r, z);
     return hipGetLastError();
 }
 

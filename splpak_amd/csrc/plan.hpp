@@ -163,6 +163,10 @@ inline hipError_t plan_rows_residual(splpak_plan *p, const SortScratch &rows, co
     if (p->rowsop && p->ctab) return rowsop_apply(p->g, p->rowsop, rows, xvec, p->dcw, p->spf, p->ctab, constraints, rho, st);
     return launch_residual(p->g, rows, xvec, p->rcell, p->dcw, p->spf, p->ctab, constraints, p->tbuf, rho, nullptr, nullptr, st);
 }
+// ndchol.hip: batched Cholesky + triangular inverses of independent dense 256 x 256 blocks
+size_t block_chol_job_bytes(int nb);
+hipError_t block_chol_prepare(void *jobs_dev, int nb, double *blocks, double *inv16, double *dinv, double *dinvt, const int *ncols_host);
+hipError_t block_chol_run(const void *jobs_dev, int nb, int *info_dev, double *minpiv_dev, hipStream_t st);
 // pcg.hip
 int pcg_attach(splpak_plan *p, PcgState **out);
 void pcg_destroy(PcgState *s);

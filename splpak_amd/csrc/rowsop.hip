@@ -7,7 +7,7 @@
 // gather), and re-reads the cell's 256 coefficients from global memory for every cell: 10.3 ms per pass at 32^4 / 1e7 points
 // (profiles/r06_c5_pcg_first_kernel_stats.csv).  Here:
 //
-//   data rows (src/splpak.F90:788-855)   a workgroup owns a TILE of 3^4 cells: the 6^4 coefficients it touches sit in LDS once,
+//   data rows (src/splpak.F90:788-855)   a workgroup owns a TILE of 3 x 3 x 3 x 2 cells: the 6 x 6 x 6 x 5 coefficients it touches sit in LDS once,
 //       each of its four waves takes every fourth cell (points of a cell in their sorted order: lanes = (point, slab) for the
 //       factorised window sum, lanes = window function for the transposed product), adds the cell's 256 shares into ITS OWN LDS
 //       image of the tile's nodes, and the four images are added in a fixed order into the tile's partial sums: 104 MB instead of
@@ -28,9 +28,14 @@ namespace splpak {
 
 namespace {
 
-constexpr int TCELL = 2;                 // cells per tile and dimension
-constexpr int TB = TCELL + 3;            // nodes per tile and dimension
-constexpr int TB4 = TB * TB * TB * TB;   // 1296
+#ifndef SPLPAK_TILE_SHAPE
+#define SPLPAK_TILE_SHAPE 3, 3, 3, 2         // measured at 32^4, 1e7 points (tile kernel + gather, us): 2,2,2,2 1484; 3,3,2,2 1402; 3,3,3,2 1362; 2,3,3,3 1409; 3,3,3,3 1572; 4,2,2,2 1878
+#endif
+constexpr int TCS[4] = {SPLPAK_TILE_SHAPE};                        // cells per tile, by dimension
+constexpr int TBS[4] = {TCS[0] + 3, TCS[1] + 3, TCS[2] + 3, TCS[3] + 3};      // nodes per tile, by dimension
+constexpr int TST[4] = {1, TBS[0], TBS[0] * TBS[1], TBS[0] * TBS[1] * TBS[2]};  // strides of the tile's node image
+constexpr int TB4 = TBS[0] * TBS[1] * TBS[2] * TBS[3];              // nodes of a tile
+constexpr int NCT = TCS[0] * TCS[1] * TCS[2] * TCS[3];              // cells of a tile
 constexpr int PCHUNK = 16;               // points per trip of a wave
 constexpr int TLD = 17;                  // 16 table values per point + 1 (bank spread)
 
@@ -45,21 +50,21 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     __shared__ double acc[4][TB4];
     __shared__ double tab[4][PCHUNK * TLD];
     __shared__ double swe[4][PCHUNK];
-    __shared__ int cbeg[TCELL * TCELL * TCELL * TCELL], cend[TCELL * TCELL * TCELL * TCELL], clb[TCELL * TCELL * TCELL * TCELL];
+    __shared__ int cbeg[NCT], cend[NCT], clb[NCT];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int t = blockIdx.x;
     int cb[4];
-    cb[0] = (t % nt0) * TCELL; t /= nt0;
-    cb[1] = (t % nt1) * TCELL; t /= nt1;
-    cb[2] = (t % nt2) * TCELL; t /= nt2;
-    cb[3] = t * TCELL;
+    cb[0] = (t % nt0) * TCS[0]; t /= nt0;
+    cb[1] = (t % nt1) * TCS[1]; t /= nt1;
+    cb[2] = (t % nt2) * TCS[2]; t /= nt2;
+    cb[3] = t * TCS[3];
     for (int idx = tid; idx < TB4; idx += 256) {
         int r = idx, col = 0;
         bool ok = true;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int nd = cb[d] + r % TB;
-            r /= TB;
+            const int nd = cb[d] + r % TBS[d];
+            r /= TBS[d];
             ok = ok && nd < g.nodes[d];
             col += nd * g.colstride[d];
         }
@@ -69,18 +74,17 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     }
     // the point ranges of the tile's cells, looked up once (a wave that asked for them cell by cell waited out two dependent global
     // round trips per cell -- with two workgroups per CU nothing hid them: 1.85 ms per pass at 32^4, twice the LDS-bound estimate)
-    constexpr int NCT = TCELL * TCELL * TCELL * TCELL;
     if (tid < NCT) {
         int r = tid, cell = 0, lb = 0, mul = 1;
         bool ok = true;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int a = r % TCELL;
-            r /= TCELL;
+            const int a = r % TCS[d];
+            r /= TCS[d];
             ok = ok && cb[d] + a < g.cells[d];
             cell += (cb[d] + a) * g.cellstride[d];
             lb += a * mul;
-            mul *= TB;
+            mul *= TBS[d];
         }
         cbeg[tid] = ok ? offset[cell] : 0;
         cend[tid] = ok ? offset[cell + 1] : 0;
@@ -132,7 +136,7 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
         __builtin_amdgcn_wave_barrier();
         {   // phase 1: lane = (point pi, slab k3 = sl): b3[k3] * sum_{k2} b2 sum_{k1} b1 sum_{k0} b0 x
             const double *__restrict__ tb = mytab + pi * TLD;
-            const double *__restrict__ px = pt + lbase + sl * (TB * TB * TB);
+            const double *__restrict__ px = pt + lbase + sl * TST[3];
             double r3 = 0.0;
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
@@ -141,7 +145,7 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
                 for (int j1 = 0; j1 < 4; ++j1) {
                     double r1 = 0.0;
 #pragma unroll
-                    for (int j0 = 0; j0 < 4; ++j0) r1 = fma(tb[j0], px[j0 + TB * j1 + TB * TB * j2], r1);
+                    for (int j0 = 0; j0 < 4; ++j0) r1 = fma(tb[j0], px[j0 + TST[1] * j1 + TST[2] * j2], r1);
                     r2 = fma(tb[4 + j1], r1, r2);
                 }
                 r3 = fma(tb[8 + j2], r2, r3);
@@ -170,10 +174,10 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lcn != lc) {                  // the cell is done: its 256 shares into this wave's image of the tile
-            const int li = lbase + k0 + TB * k1 + TB * TB * k2;
+            const int li = lbase + k0 + TST[1] * k1 + TST[2] * k2;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                myacc[li + TB * TB * TB * j] += racc[j];
+                myacc[li + TST[3] * j] += racc[j];
                 racc[j] = 0.0;
             }
         }
@@ -198,10 +202,10 @@ rows4_gather_kernel(Grid g, int nt0, int nt1, int nt2, int nt3, const double *__
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         in[d] = (node / g.colstride[d]) % g.nodes[d];
-        // tiles t with TCELL t <= in <= TCELL t + TB - 1
-        int lo = in[d] - (TB - 1);
-        lo = lo <= 0 ? 0 : (lo + TCELL - 1) / TCELL;
-        int hi = in[d] / TCELL;
+        // tiles t with TCS t <= in <= TCS t + TBS - 1
+        int lo = in[d] - (TBS[d] - 1);
+        lo = lo <= 0 ? 0 : (lo + TCS[d] - 1) / TCS[d];
+        int hi = in[d] / TCS[d];
         if (hi > nt[d] - 1) hi = nt[d] - 1;
         tlo[d] = lo;
         tcnt[d] = hi - lo + 1;
@@ -213,7 +217,7 @@ rows4_gather_kernel(Grid g, int nt0, int nt1, int nt2, int nt3, const double *__
                 for (int e0 = 0; e0 < tcnt[0]; ++e0) {
                     const int t0 = tlo[0] + e0, t1 = tlo[1] + e1, t2 = tlo[2] + e2, t3 = tlo[3] + e3;
                     const long long tile = ((long long)(t3 * nt2 + t2) * nt1 + t1) * nt0 + t0;
-                    const int li = (in[0] - TCELL * t0) + TB * ((in[1] - TCELL * t1) + TB * ((in[2] - TCELL * t2) + TB * (in[3] - TCELL * t3)));
+                    const int li = (in[0] - TCS[0] * t0) + TST[1] * (in[1] - TCS[1] * t1) + TST[2] * (in[2] - TCS[2] * t2) + TST[3] * (in[3] - TCS[3] * t3);
                     acc += partial[tile * TB4 + li];
                 }
     if constexpr (REFADD) {                      // the histogram: kept in the caller's dimension order, on top of what is there
@@ -239,27 +243,26 @@ rows4_hist_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int t = blockIdx.x;
     int cb[4];
-    cb[0] = (t % nt0) * TCELL; t /= nt0;
-    cb[1] = (t % nt1) * TCELL; t /= nt1;
-    cb[2] = (t % nt2) * TCELL; t /= nt2;
-    cb[3] = t * TCELL;
+    cb[0] = (t % nt0) * TCS[0]; t /= nt0;
+    cb[1] = (t % nt1) * TCS[1]; t /= nt1;
+    cb[2] = (t % nt2) * TCS[2]; t /= nt2;
+    cb[3] = t * TCS[3];
     for (int idx = tid; idx < TB4; idx += 256)
 #pragma unroll
         for (int w = 0; w < 4; ++w) acc[w][idx] = 0.0;
     __syncthreads();
     double *__restrict__ myacc = acc[wave];
-    constexpr int NCT = TCELL * TCELL * TCELL * TCELL;
     for (int lc = wave; lc < NCT; lc += 4) {
         int r = lc, cell = 0, lbase = 0, mul = 1;
         bool ok = true;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int a = r % TCELL;
-            r /= TCELL;
+            const int a = r % TCS[d];
+            r /= TCS[d];
             ok = ok && cb[d] + a < g.cells[d];
             cell += (cb[d] + a) * g.cellstride[d];
             lbase += a * mul;
-            mul *= TB;
+            mul *= TBS[d];
         }
         if (!ok) continue;
         const int beg = offset[cell], end = offset[cell + 1];
@@ -284,7 +287,7 @@ rows4_hist_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
                     const int l = inidim - window_start(g, d, xv[d], lo, hi);
                     inwin = inwin && inidim >= 0 && inidim <= g.nodes[d] - 1 && l >= 0 && l <= 3;
                     loc += l * m6;
-                    m6 *= TB;
+                    m6 *= TBS[d];
                 }
                 if (inwin) li = lbase + loc;
                 else {
@@ -410,7 +413,7 @@ int rowsop_create(const Grid &g, RowsOp **out)
     RowsOp *r = new RowsOp();
     r->ntiles = 1;
     for (int d = 0; d < 4; ++d) {
-        r->nt[d] = (g.cells[d] + TCELL - 1) / TCELL;
+        r->nt[d] = (g.cells[d] + TCS[d] - 1) / TCS[d];
         r->ntiles *= r->nt[d];
     }
     auto alloc = [&](double **q, size_t count) {

@@ -43,39 +43,40 @@ class FD2:
         for k in range(d): X = self._mode(X, (W[k] ** 2).T, k)
         return X.ravel()
 
-d, nod, ppc = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
-nodes = np.array([nod] * d); m = int(ppc * (nod - 1) ** d)
-x, y, w = synth_points(d, m)
-xmin = np.zeros(d); xmax = np.ones(d)
-A = data_rows(x, w, xmin, xmax, nodes); At = A.T.tocsr()
-C, hist, spn = constraint_rows(x, w, xmin, xmax, nodes, 1.0); Ct = C.T.tocsr()
-n = A.shape[1]
-r = At @ (w * y)
-sub = np.array(np.unravel_index(np.arange(n), nodes[::-1])).T[:, ::-1]
-onb = ((sub == 0) | (sub == nodes - 1)).sum(1)
-wt = w.sum() / np.prod(nodes - 1)
-expect = wt * 0.5 ** onb
-dcw2 = np.where(spn, (expect - hist) ** 2, 0.0)
-rho = (w ** 2).sum(); lam = dcw2[onb == 0].mean(); lam1 = dcw2[onb == 1].mean(); qb = lam1 / lam
-lam_all = dcw2.mean()
-print(f'n={n} sparse frac {spn.mean():.3f} rho {rho:.4g} lam {lam:.4g} lam_all {lam_all:.4g} qb {qb:.3f}', flush=True)
-Ndiag = np.asarray(A.multiply(A).sum(0)).ravel() + np.asarray(C.multiply(C).sum(0)).ravel()
-op = lambda v: At @ (A @ v) + Ct @ (C @ v)
-def run(name, Minv, tol=1e-12):
-    xs = np.zeros(n); res = r.copy(); z = Minv(res); p = z.copy(); rz = res @ z; rz0 = rz; marks = {}
-    for it in range(1, 3001):
-        Np = op(p); a = rz / (p @ Np); xs += a * p; res -= a * Np
-        z = Minv(res); rz2 = res @ z; rel = np.sqrt(rz2 / rz0)
-        for th in (1e-4, 1e-8, 1e-12):
-            if rel < th and th not in marks: marks[th] = it
-        if rel < tol: break
-        p = z + (rz2 / rz) * p; rz = rz2
-    print(name, 'its', it, marks, flush=True)
-for name, kw in [('K0 qb', dict(qb=qb, pair='K0')), ('K0 qb=.5', dict(qb=0.5, pair='K0')), ('K0 qb=1', dict(qb=1.0, pair='K0')), ('M qb', dict(qb=qb, pair='M')),
-                 ('K0 lam_all', dict(qb=qb, pair='K0', lam=lam_all))]:
-    l = kw.pop('lam', lam)
-    fd = FD2(list(nodes), rho, l, **kw)
-    run(name, fd.solve)
-    if name in ('K0 qb', 'M qb'):
-        s = np.sqrt(fd.mult_diag() / Ndiag)
-        run(name + ' + jacobi rescale', lambda v: s * fd.solve(s * v))
+if __name__ == '__main__':
+    d, nod, ppc = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
+    nodes = np.array([nod] * d); m = int(ppc * (nod - 1) ** d)
+    x, y, w = synth_points(d, m)
+    xmin = np.zeros(d); xmax = np.ones(d)
+    A = data_rows(x, w, xmin, xmax, nodes); At = A.T.tocsr()
+    C, hist, spn = constraint_rows(x, w, xmin, xmax, nodes, 1.0); Ct = C.T.tocsr()
+    n = A.shape[1]
+    r = At @ (w * y)
+    sub = np.array(np.unravel_index(np.arange(n), nodes[::-1])).T[:, ::-1]
+    onb = ((sub == 0) | (sub == nodes - 1)).sum(1)
+    wt = w.sum() / np.prod(nodes - 1)
+    expect = wt * 0.5 ** onb
+    dcw2 = np.where(spn, (expect - hist) ** 2, 0.0)
+    rho = (w ** 2).sum(); lam = dcw2[onb == 0].mean(); lam1 = dcw2[onb == 1].mean(); qb = lam1 / lam
+    lam_all = dcw2.mean()
+    print(f'n={n} sparse frac {spn.mean():.3f} rho {rho:.4g} lam {lam:.4g} lam_all {lam_all:.4g} qb {qb:.3f}', flush=True)
+    Ndiag = np.asarray(A.multiply(A).sum(0)).ravel() + np.asarray(C.multiply(C).sum(0)).ravel()
+    op = lambda v: At @ (A @ v) + Ct @ (C @ v)
+    def run(name, Minv, tol=1e-12):
+        xs = np.zeros(n); res = r.copy(); z = Minv(res); p = z.copy(); rz = res @ z; rz0 = rz; marks = {}
+        for it in range(1, 3001):
+            Np = op(p); a = rz / (p @ Np); xs += a * p; res -= a * Np
+            z = Minv(res); rz2 = res @ z; rel = np.sqrt(rz2 / rz0)
+            for th in (1e-4, 1e-8, 1e-12):
+                if rel < th and th not in marks: marks[th] = it
+            if rel < tol: break
+            p = z + (rz2 / rz) * p; rz = rz2
+        print(name, 'its', it, marks, flush=True)
+    for name, kw in [('K0 qb', dict(qb=qb, pair='K0')), ('K0 qb=.5', dict(qb=0.5, pair='K0')), ('K0 qb=1', dict(qb=1.0, pair='K0')), ('M qb', dict(qb=qb, pair='M')),
+                     ('K0 lam_all', dict(qb=qb, pair='K0', lam=lam_all))]:
+        l = kw.pop('lam', lam)
+        fd = FD2(list(nodes), rho, l, **kw)
+        run(name, fd.solve)
+        if name in ('K0 qb', 'M qb'):
+            s = np.sqrt(fd.mult_diag() / Ndiag)
+            run(name + ' + jacobi rescale', lambda v: s * fd.solve(s * v))
