@@ -66,8 +66,10 @@ const Known KNOWN[] = {
     {"SPLPAK_NO_STOPEV", 0},
     {"SPLPAK_NO_TWOEND", 0},
     {"SPLPAK_PCG_ASSEMBLE", 0},
+    {"SPLPAK_PCG_BLOCKS_F64", 0},
     {"SPLPAK_PCG_MAXIT", 1},
     {"SPLPAK_PCG_NO_BLOCKS", 0},
+    {"SPLPAK_PCG_NO_PAIRS", 0},
     {"SPLPAK_PCG_TOL1", 1},
     {"SPLPAK_PCG_TOL2", 1},
     {"SPLPAK_PIN_BW", 0},

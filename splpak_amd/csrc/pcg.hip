@@ -162,6 +162,43 @@ mode_product_kernel(int nk, long long inner, long long total, const double *__re
     Y[e] = acc;
 }
 
+// Two adjacent modes k, k + 1 in ONE pass: the workgroup's tile [n_{k+1}][n_k][ci] (ci consecutive entries of the dimensions below k)
+// goes through LDS, mode k into a second image, mode k + 1 out of it to global memory (optionally scaled).  Halves the launches and
+// the passes over the vector of the separable preconditioner (8 launches of 34 us at 32^4 -> 4 of ~20).
+__global__ void __launch_bounds__(256)
+mode_pair_kernel(int na, int nb, long long inner, int ci, const double *__restrict__ MTa, const double *__restrict__ MTb,
+                 const double *__restrict__ X, double *__restrict__ Y, const double *__restrict__ scale)
+{
+    extern __shared__ double smem[];
+    const int tile = na * nb * ci;
+    double *__restrict__ T0 = smem, *__restrict__ T1 = smem + tile;
+    const long long nchunk = inner / ci;
+    const long long o = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
+    const long long base = o * ((long long)na * nb * inner) + ch * ci;
+    for (int e = threadIdx.x; e < tile; e += 256) {
+        const int c = e % ci, r = e / ci;            // r = ja + na * jb
+        T0[e] = X[base + c + inner * r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < tile; e += 256) {
+        const int c = e % ci, r = e / ci, ja = r % na, jb = r / na;
+        const double *__restrict__ t = T0 + c + (long long)ci * na * jb;
+        double acc = 0.0;
+        for (int ia = 0; ia < na; ++ia) acc = fma(MTa[ia * na + ja], t[ci * ia], acc);
+        T1[e] = acc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < tile; e += 256) {
+        const int c = e % ci, r = e / ci, ja = r % na, jb = r / na;
+        const double *__restrict__ t = T1 + c + ci * ja;
+        double acc = 0.0;
+        for (int ib = 0; ib < nb; ++ib) acc = fma(MTb[ib * nb + jb], t[(long long)ci * na * ib], acc);
+        const long long gi = base + c + inner * r;
+        if (scale) acc *= scale[gi];
+        Y[gi] = acc;
+    }
+}
+
 struct EvTabs {             // per-dimension diagonals in the eigenbasis (device arrays of nodes_k doubles each)
     const double *mu[MAXD], *k0[MAXD], *d1[MAXD], *l2[MAXD];
 };
@@ -362,8 +399,9 @@ bj_extract_kernel(Grid g, BjGeom bg, const double *__restrict__ nst, double *__r
 
 // z += (L L^T)^-1 v on every box: u = Linv v (dinvt[j][i] = Linv(i, j)), then Linv^T u (dinv[j][i] = Linv(j, i)); consecutive threads,
 // consecutive words in both
+template <typename T>
 __global__ void __launch_bounds__(256)
-bj_apply_kernel(Grid g, BjGeom bg, const double *__restrict__ dinv, const double *__restrict__ dinvt, const double *__restrict__ v,
+bj_apply_kernel(Grid g, BjGeom bg, const T *__restrict__ dinv, const T *__restrict__ dinvt, const double *__restrict__ v,
                 double *__restrict__ z)
 {
     __shared__ double vb[256], ub[256];
@@ -371,21 +409,49 @@ bj_apply_kernel(Grid g, BjGeom bg, const double *__restrict__ dinv, const double
     const int node = bj_node(g, bg, b, i, nullptr);
     vb[i] = node >= 0 ? v[node] : 0.0;
     __syncthreads();
-    const double *__restrict__ Mt = dinvt + (size_t)b * 65536, *__restrict__ M = dinv + (size_t)b * 65536;
+    const T *__restrict__ Mt = dinvt + (size_t)b * 65536, *__restrict__ M = dinv + (size_t)b * 65536;
     double a0 = 0.0, a1 = 0.0;
     const int jmax = 64 * wave + 63;
     for (int j = 0; j + 1 <= jmax; j += 2) {
-        a0 = fma(Mt[(size_t)j * 256 + i], vb[j], a0);              // (entries above the diagonal of Linv are stored zeros)
-        a1 = fma(Mt[(size_t)(j + 1) * 256 + i], vb[j + 1], a1);
+        a0 = fma((double)Mt[(size_t)j * 256 + i], vb[j], a0);      // (entries above the diagonal of Linv are stored zeros)
+        a1 = fma((double)Mt[(size_t)(j + 1) * 256 + i], vb[j + 1], a1);
     }
     ub[i] = a0 + a1;
     __syncthreads();
     a0 = a1 = 0.0;
     for (int j = 64 * wave; j + 1 < 256; j += 2) {
-        a0 = fma(M[(size_t)j * 256 + i], ub[j], a0);
-        a1 = fma(M[(size_t)(j + 1) * 256 + i], ub[j + 1], a1);
+        a0 = fma((double)M[(size_t)j * 256 + i], ub[j], a0);
+        a1 = fma((double)M[(size_t)(j + 1) * 256 + i], ub[j + 1], a1);
     }
     if (node >= 0) z[node] += a0 + a1;
+}
+
+// single-precision copies of the box inverses for the apply (a preconditioner: its rounding changes nothing the iteration converges
+// to; half the bytes of a pass that is bound by reading them -- 0.48 -> 0.25 ms per iteration at 32^4)
+__global__ void __launch_bounds__(256)
+to_f32_kernel(long long n, const double *__restrict__ a, const double *__restrict__ b, float *__restrict__ fa, float *__restrict__ fb)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { fa[i] = (float)a[i]; fb[i] = (float)b[i]; }
+}
+
+// out[0] = sum of squares of v[0 .. n) with n read from the device (n = offset[ncell]): partial sums by block, then one block adds them
+__global__ void __launch_bounds__(256)
+sumsq_partial_kernel(const double *__restrict__ v, const int *__restrict__ nptr, double *__restrict__ partial)
+{
+    __shared__ double red[256];
+    const long long n = nptr[0];
+    const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+    const long long beg = (long long)blockIdx.x * chunk, end = beg + chunk < n ? beg + chunk : n;
+    double s0 = 0.0;
+    for (long long i = beg + threadIdx.x; i < end; i += 256) s0 = fma(v[i], v[i], s0);
+    red[threadIdx.x] = s0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
 }  // namespace
@@ -403,9 +469,11 @@ struct PcgState {
     // block-Jacobi component (NULL / bj_ready false: the separable preconditioner alone)
     BjGeom bg{};
     double *bj_blocks = nullptr, *bj_inv16 = nullptr, *bj_dinv = nullptr, *bj_dinvt = nullptr, *bj_scal = nullptr;
+    float *bj_dinv32 = nullptr, *bj_dinvt32 = nullptr;     // single-precision copies for the apply (NULL: the f64 ones)
     void *bj_jobs = nullptr;
     int *bj_info = nullptr;
     bool bj_have = false, bj_ready = false;
+    bool no_pairs = false;                                 // A/B: the modes of the separable part one by one
     std::vector<double> hhist;
     int maxit = 4000;
     std::vector<void *> owned;
@@ -460,6 +528,7 @@ int pcg_attach(splpak_plan *p, PcgState **out)
     (void)hipGetDevice(&s->device);
     s->g = g;
     if (const char *e = splpak::opt_get("SPLPAK_PCG_MAXIT")) s->maxit = std::max(1, atoi(e));
+    s->no_pairs = splpak::opt_get("SPLPAK_PCG_NO_PAIRS") != nullptr;
     bool ok = true;
     long long ntab = 0;
     for (int k = 0; k < g.ndim; ++k) ntab += 4LL * g.nodes[k];
@@ -566,6 +635,13 @@ int pcg_attach(splpak_plan *p, PcgState **out)
                 }
                 okb = hip_ok(block_chol_prepare(s->bj_jobs, s->bg.nb, s->bj_blocks, s->bj_inv16, s->bj_dinv, s->bj_dinvt, ncols.data()), "pcg: block jobs");
             }
+            if (okb && !splpak::opt_get("SPLPAK_PCG_BLOCKS_F64")) {
+                double *f = nullptr;
+                if (pcg_alloc(s, &f, nb * 65536)) {            // two float arrays of nb * 65536 = one double array of that length
+                    s->bj_dinv32 = reinterpret_cast<float *>(f);
+                    s->bj_dinvt32 = s->bj_dinv32 + nb * 65536;
+                } else (void)hipGetLastError();
+            }
             s->bj_have = okb;
             if (!okb) (void)hipGetLastError();      // (out of memory for the boxes: the separable preconditioner alone)
         }
@@ -579,7 +655,10 @@ int pcg_attach(splpak_plan *p, PcgState **out)
 // all-reduce, so that every rank builds the same preconditioner).
 hipError_t pcg_sum_w2(splpak_plan *p, hipStream_t st)
 {
-    hipLaunchKernelGGL(fd_sumw2_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->s.ws, (const int *)p->s.offset, p->g.ncell, p->scalH + SC_SUMW2);
+    // (512 blocks, then one: the single-workgroup form took 2.4 ms for 1e7 weights)
+    PcgState *s = p->pcg;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st, (const double *)p->s.ws, (const int *)(p->s.offset + p->g.ncell), s->partial);
+    hipLaunchKernelGGL(dot_finish_kernel, dim3(1), dim3(DOT_BLOCKS), 0, st, (const double *)s->partial, 1.0, p->scalH, (int)SC_SUMW2, (double *)nullptr);
     return hipGetLastError();
 }
 
@@ -614,6 +693,11 @@ hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, h
         hipLaunchKernelGGL(bj_extract_kernel, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const double *)p->nst, s->bj_blocks);
         e = block_chol_run(s->bj_jobs, s->bg.nb, s->bj_info, s->bj_scal, st);
         if (e != hipSuccess) return e;
+        if (s->bj_dinv32) {
+            const long long nn = (long long)s->bg.nb * 65536;
+            hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, (const double *)s->bj_dinv, (const double *)s->bj_dinvt,
+                               s->bj_dinv32, s->bj_dinvt32);
+        }
         int hinfo = 0;
         e = hipMemcpyAsync(&hinfo, s->bj_info, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -633,22 +717,36 @@ static hipError_t pcg_precondition(PcgState *s, const double *r, double *z, hipS
     const double *src = r;
     double *bufs[2] = {s->t1, s->t2};
     int which = 0;
-    for (int k = 0; k < g.ndim; ++k) {                   // V_k^T along every dimension, the last one scaled by 1 / diag
-        double *dst = bufs[which];
-        hipLaunchKernelGGL(mode_product_kernel, gr, bl, 0, st, g.nodes[k], (long long)g.colstride[k], total, (const double *)s->V[k], src, dst,
-                           k == g.ndim - 1 ? (const double *)s->dinv : (const double *)nullptr);
-        src = dst;
-        which ^= 1;
-    }
-    for (int k = 0; k < g.ndim; ++k) {                   // V_k along every dimension
-        double *dst = (k == g.ndim - 1) ? z : bufs[which];
-        hipLaunchKernelGGL(mode_product_kernel, gr, bl, 0, st, g.nodes[k], (long long)g.colstride[k], total, (const double *)s->VT[k], src, dst,
-                           (const double *)nullptr);
-        src = dst;
-        which ^= 1;
-    }
-    if (s->bj_ready)
-        hipLaunchKernelGGL(bj_apply_kernel, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const double *)s->bj_dinv, (const double *)s->bj_dinvt, r, z);
+    // one direction of the transform: modes in pairs through LDS where the tile fits (both node counts <= 64), singly otherwise
+    auto sweep = [&](double *const *mats, const double *scale_last, double *final_dst) {
+        int k = 0;
+        while (k < g.ndim) {
+            const bool pair = !s->no_pairs && k + 1 < g.ndim && (long long)g.nodes[k] * g.nodes[k + 1] <= 4096;
+            const int kend = pair ? k + 1 : k;
+            double *dst = (kend == g.ndim - 1 && final_dst) ? final_dst : bufs[which];
+            const double *sc = kend == g.ndim - 1 ? scale_last : nullptr;
+            if (pair) {
+                const int na = g.nodes[k], nb = g.nodes[k + 1];
+                const long long inner = g.colstride[k];
+                int ci = 1;
+                for (int c = 8; c >= 1; --c)
+                    if (inner % c == 0 && (long long)na * nb * c <= 4096) { ci = c; break; }
+                const long long blocks = total / ((long long)na * nb * ci);
+                hipLaunchKernelGGL(mode_pair_kernel, dim3((unsigned)blocks), bl, sizeof(double) * 2 * (size_t)na * nb * ci, st, na, nb, inner, ci,
+                                   (const double *)mats[k], (const double *)mats[k + 1], src, dst, sc);
+            } else
+                hipLaunchKernelGGL(mode_product_kernel, gr, bl, 0, st, g.nodes[k], (long long)g.colstride[k], total, (const double *)mats[k], src, dst, sc);
+            src = dst;
+            which ^= 1;
+            k = kend + 1;
+        }
+    };
+    sweep(s->V, s->dinv, nullptr);           // V_k^T along every dimension, the last one scaled by 1 / diag
+    sweep(s->VT, nullptr, z);                // V_k along every dimension
+    if (s->bj_ready && s->bj_dinv32)
+        hipLaunchKernelGGL(bj_apply_kernel<float>, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const float *)s->bj_dinv32, (const float *)s->bj_dinvt32, r, z);
+    else if (s->bj_ready)
+        hipLaunchKernelGGL(bj_apply_kernel<double>, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const double *)s->bj_dinv, (const double *)s->bj_dinvt, r, z);
     return hipGetLastError();
 }
 
