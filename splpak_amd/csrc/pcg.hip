@@ -397,6 +397,141 @@ bj_extract_kernel(Grid g, BjGeom bg, const double *__restrict__ nst, double *__r
     }
 }
 
+// The boxes WITHOUT assembled normal equations (iteration-only 4-D plans): box = s M_box + P_box, with P_box the EXACT constraint
+// part (sum over the data-sparse nodes within one node of both entries, their rows in the reference's order, :921-1046) and the
+// data part replaced by the mass matrix's sub-block scaled to the box's own trace of A^T W^2 A (ddiag, from the rows).  Measured
+// (tools/pcg/exp8.py, 12^4): with constraint rows present the data part of a box does not matter -- exact, rho M, trace-scaled M
+// and even diag(D) give the same 97 / 246 iterations at 2.8 / 2.0 rows per column; without any (xtrap = 0) 184 against 97 exact.
+struct MassBands { const double *m[MAXD]; };      // per dimension [nodes][7]: M(i, i + o), o = -3 .. 3
+__global__ void __launch_bounds__(256)
+bj_build_kernel(Grid g, BjGeom bg, MassBands mb, const double *__restrict__ ctab, const double *__restrict__ dcw,      // (4-D grids only)
+                const unsigned char *__restrict__ spf, const double *__restrict__ ddiag, double *__restrict__ blocks)
+{
+    constexpr int HMAX = 1296;                     // nodes of a box and the nodes within one of it: (4 + 2)^4 (3-D: 8^3, 2-D: 18^2, 1-D: 258)
+    __shared__ int snode[256];
+    __shared__ short scrd[256][MAXD];              // grid coordinates of the box's nodes
+    __shared__ double red[2][256];
+    __shared__ double sw2[HMAX];                   // squared constraint weight of the halo's nodes (0: not data sparse / outside the grid)
+    __shared__ double sf[MAXD][18][3][3];          // sf[d][halo node][offset + 1][derivative]: the rows' factors (ctab) of the halo's nodes
+    const int b = blockIdx.x, r = threadIdx.x;
+    int h0[MAXD] = {0, 0, 0, 0}, hext[MAXD] = {1, 1, 1, 1};       // first halo coordinate and extent per dimension
+    {
+        int bb = b;
+        for (int d = 0; d < g.ndim; ++d) {
+            const int bd = bb % bg.nbd[d];
+            bb /= bg.nbd[d];
+            const int lo = bd * bg.edge[d] - 1, hi = bd * bg.edge[d] + bg.edge[d];
+            h0[d] = lo < 0 ? 0 : lo;
+            hext[d] = (hi > g.nodes[d] - 1 ? g.nodes[d] - 1 : hi) - h0[d] + 1;
+        }
+    }
+    int hs[MAXD] = {1, hext[0], hext[0] * hext[1], hext[0] * hext[1] * hext[2]};
+    const int htot = hs[3] * hext[3];
+    int cbase[MAXD] = {0, 0, 0, 0};
+    for (int d = 1; d < g.ndim; ++d) cbase[d] = cbase[d - 1] + 9 * g.nodes[d - 1];
+    {
+        int c[MAXD] = {0, 0, 0, 0};
+        snode[r] = bj_node(g, bg, b, r, c);
+        for (int d = 0; d < MAXD; ++d) scrd[r][d] = (short)c[d];
+    }
+    for (int e = r; e < htot; e += 256) {
+        int t = e, nn = 0;
+        for (int d = 0; d < g.ndim; ++d) { nn += (h0[d] + t % hext[d]) * g.colstride[d]; t /= hext[d]; }
+        double w2 = 0.0;
+        if (spf && spf[nn]) w2 = dcw[nn] * dcw[nn];
+        sw2[e] = w2;
+    }
+    for (int e = r; e < g.ndim * 18 * 9; e += 256) {
+        const int d = e / (18 * 9), hl = (e / 9) % 18, k = e % 9;
+        double v = 0.0;
+        if (hl < hext[d]) v = ctab[cbase[d] + (h0[d] + hl) * 9 + k];
+        sf[d][hl][k / 3][k % 3] = v;
+    }
+    __syncthreads();
+    const int nr = snode[r];
+    {   // s = (trace of the data rows' Gram matrix over the box) / (trace of the mass sub-block)
+        double td = 0.0, tm = 0.0;
+        if (nr >= 0) {
+            td = ddiag[nr];
+            tm = 1.0;
+            for (int d = 0; d < g.ndim; ++d) tm *= mb.m[d][scrd[r][d] * 7 + 3];
+        }
+        red[0][r] = td;
+        red[1][r] = tm;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (r < o) { red[0][r] += red[0][r + o]; red[1][r] += red[1][r + o]; }
+            __syncthreads();
+        }
+    }
+    const double sbox = red[1][0] > 0.0 ? red[0][0] / red[1][0] : 0.0;
+    double *__restrict__ A = blocks + (size_t)b * 65536;
+    for (int c = 0; c < 256; ++c) {
+        double v = 0.0;
+        if (c <= r) {
+            const int nc = snode[c];
+            if (nr < 0 || nc < 0) v = (c == r) ? 1.0 : 0.0;
+            else {
+                int lo[MAXD] = {0, 0, 0, 0}, hi[MAXD] = {0, 0, 0, 0};
+                bool near = true;
+                double mass = sbox;
+                for (int d = 0; d < g.ndim; ++d) {
+                    const int i = scrd[r][d], j = scrd[c][d];
+                    const int o = j - i;
+                    if (o < -3 || o > 3) { mass = 0.0; near = false; break; }
+                    mass *= mb.m[d][i * 7 + o + 3];
+                    lo[d] = (i > j ? i : j) - 1;
+                    hi[d] = (i < j ? i : j) + 1;
+                    if (lo[d] < 0) lo[d] = 0;
+                    if (hi[d] > g.nodes[d] - 1) hi[d] = g.nodes[d] - 1;
+                    near = near && lo[d] <= hi[d];
+                }
+                v = mass;
+                if (near && spf) {
+                    // the data-sparse nodes n within one node of both entries: lo <= n <= hi per dimension, dimension 0 fastest (fixed order).
+                    // Per node the ten rows' products in closed form: with G_d^a = f_d^a(i) f_d^a(j) the factor of dimension d at
+                    // derivative order a (order 2 -> 1 at a boundary node, :998),
+                    //   sum_rows = sum_i G_i^2 prod_{k != i} G_k^0 + 4 sum_{i<j} G_i^1 G_j^1 prod_{k != i,j} G_k^0     (weights dcw, 2 dcw: :983)
+                    double acc = 0.0;
+                    const int oi0 = scrd[r][0], oi1 = scrd[r][1], oi2 = scrd[r][2], oi3 = scrd[r][3];
+                    const int oj0 = scrd[c][0], oj1 = scrd[c][1], oj2 = scrd[c][2], oj3 = scrd[c][3];
+                    for (int n3 = lo[3]; n3 <= hi[3]; ++n3)
+                        for (int n2 = lo[2]; n2 <= hi[2]; ++n2)
+                            for (int n1 = lo[1]; n1 <= hi[1]; ++n1)
+                                for (int n0 = lo[0]; n0 <= hi[0]; ++n0) {
+                                    const int l0 = n0 - h0[0], l1 = n1 - h0[1], l2 = n2 - h0[2], l3 = n3 - h0[3];
+                                    const double w2 = sw2[l0 + hs[1] * l1 + hs[2] * l2 + hs[3] * l3];
+                                    if (w2 == 0.0) continue;
+                                    double G0[4], G1[4], G2[4];
+#define SPLPAK_G(d, nl, nn, oi, oj)                                                              \
+                                    {                                                            \
+                                        const double(*f)[3] = sf[d][nl];                         \
+                                        const int a = (oi) - (nn) + 1, bq = (oj) - (nn) + 1;     \
+                                        G0[d] = f[a][0] * f[bq][0];                              \
+                                        G1[d] = f[a][1] * f[bq][1];                              \
+                                        G2[d] = ((nn) == 0 || (nn) == g.nodes[d] - 1) ? G1[d] : f[a][2] * f[bq][2]; \
+                                    }
+                                    SPLPAK_G(0, l0, n0, oi0, oj0)
+                                    SPLPAK_G(1, l1, n1, oi1, oj1)
+                                    SPLPAK_G(2, l2, n2, oi2, oj2)
+                                    SPLPAK_G(3, l3, n3, oi3, oj3)
+#undef SPLPAK_G
+                                    const double p01 = G0[0] * G0[1], p23 = G0[2] * G0[3];
+                                    double sum = (G2[0] * G0[1] + G0[0] * G2[1]) * p23 + p01 * (G2[2] * G0[3] + G0[2] * G2[3]);
+                                    sum += 4.0 * (G1[0] * G1[1] * p23 + p01 * G1[2] * G1[3] +
+                                                  (G1[0] * G0[1] + G0[0] * G1[1]) * 0.0);
+                                    // mixed pairs across the two halves: (0,2), (0,3), (1,2), (1,3)
+                                    sum += 4.0 * ((G1[0] * G0[1]) * (G1[2] * G0[3] + G0[2] * G1[3]) + (G0[0] * G1[1]) * (G1[2] * G0[3] + G0[2] * G1[3]));
+                                    acc = fma(w2, sum, acc);
+                                }
+                    v += acc;
+                }
+            }
+        }
+        A[r + (size_t)c * 256] = v;
+    }
+}
+
 // z += (L L^T)^-1 v on every box: u = Linv v (dinvt[j][i] = Linv(i, j)), then Linv^T u (dinv[j][i] = Linv(j, i)); consecutive threads,
 // consecutive words in both
 template <typename T>
@@ -473,6 +608,9 @@ struct PcgState {
     void *bj_jobs = nullptr;
     int *bj_info = nullptr;
     bool bj_have = false, bj_ready = false;
+    double *mband = nullptr;                               // per dimension [nodes][7]: the 1-D mass matrix's bands (boxes without assembled N)
+    MassBands mbands{};
+    double *ddiag = nullptr;                               // diagonal of the data rows' Gram matrix (the same)
     bool no_pairs = false;                                 // A/B: the modes of the separable part one by one
     std::vector<double> hhist;
     int maxit = 4000;
@@ -535,6 +673,9 @@ int pcg_attach(splpak_plan *p, PcgState **out)
     ok = ok && pcg_alloc(s, &s->tabs, (size_t)ntab);
     std::vector<double> htabs((size_t)ntab);
     long long toff = 0;
+    long long mbtot = 0, mboff = 0, mboffs[MAXD] = {0, 0, 0, 0};
+    for (int k = 0; k < g.ndim; ++k) mbtot += 7LL * g.nodes[k];
+    std::vector<double> hmband((size_t)mbtot);
     const double qb = 0.5;          // boundary nodes: half the expected weight (:928) -> a quarter of dcw^2, about twice as often sparse
     for (int k = 0; k < g.ndim && ok; ++k) {
         const int n = g.nodes[k];
@@ -570,6 +711,11 @@ int pcg_attach(splpak_plan *p, PcgState **out)
                 }
         };
         gram(T0, K0); gram(T1, K1); gram(T2, K2);
+        for (int i = 0; i < n; ++i)
+            for (int o = -3; o <= 3; ++o)
+                hmband[(size_t)mboff + (size_t)i * 7 + (size_t)(o + 3)] = (i + o >= 0 && i + o < n) ? M[(size_t)i * n + (i + o)] : 0.0;
+        mboffs[k] = mboff;
+        mboff += 7LL * n;
         std::vector<double> w, V, mu, k0, d1, l2;
         if (!gen_eig(n, K2, K0, w, V)) { set_error("pcg: the nodal Gram matrix of a dimension is not positive definite"); ok = false; break; }
         congruence_diag(n, V, M, mu);
@@ -597,13 +743,16 @@ int pcg_attach(splpak_plan *p, PcgState **out)
     for (double **q : {&s->dinv, &s->bvec, &s->x, &s->r, &s->z, &s->pv, &s->t1, &s->t2}) ok = ok && pcg_alloc(s, q, n);
     ok = ok && pcg_alloc(s, &s->partial, DOT_BLOCKS) && pcg_alloc(s, &s->sc, S_COUNT) && pcg_alloc(s, &s->hist, (size_t)s->maxit + 8) &&
          pcg_alloc(s, &s->mom, 2);
+    ok = ok && pcg_alloc(s, &s->mband, (size_t)mbtot) && hip_ok(hipMemcpy(s->mband, hmband.data(), sizeof(double) * (size_t)mbtot, hipMemcpyHostToDevice), "pcg: upload");
+    for (int k = 0; k < MAXD; ++k) s->mbands.m[k] = s->mband + (k < g.ndim ? mboffs[k] : 0);
+    if (ok && p->rows_only) ok = pcg_alloc(s, &s->ddiag, n);
     // Block-Jacobi component (round 6): the diagonal blocks of the assembled N over aligned boxes of nodes (4-D: 4^4, 3-D: 6^3,
     // 2-D: 16^2, 1-D: 256 nodes -- all at most 256, the block size of the diagonal-block kernels of the fronts), factored per fit
     // and ADDED to the separable preconditioner: M^-1 = V diag^-1 V^T + sum_boxes R^T (N_box)^-1 R.  The separable part knows the
     // global, smooth structure and the densities; the boxes know WHERE the data-sparse nodes are.  Measured at 12^4 (tools/pcg/exp7.py):
     // config 5's density 259 -> 97 iterations; 17 % data-sparse nodes (where the separable part alone stagnates) 505 iterations.
     // Needs the assembled normal equations (not the rows-only plans) and 3 x 0.5 MB per box.
-    if (ok && !p->rows_only && !splpak::opt_get("SPLPAK_PCG_NO_BLOCKS")) {
+    if (ok && !splpak::opt_get("SPLPAK_PCG_NO_BLOCKS")) {
         static const int edge_of[MAXD + 1] = {0, 256, 16, 6, 4};
         s->bg.ndim = g.ndim;
         s->bg.nb = 1;
@@ -685,12 +834,30 @@ hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, h
     s->solves = 0;
     s->failed = false;
     s->bj_ready = false;
-    if (s->bj_have && p->nst) {
+    if (s->bj_have && (p->nst || (p->rows_only && s->ddiag))) {
         const double inf = 1.0e300;
         hipError_t e = hipMemsetAsync(s->bj_info, 0, 2 * sizeof(int), st);
         if (e == hipSuccess) e = hipMemcpyAsync(s->bj_scal, &inf, sizeof(double), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(bj_extract_kernel, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const double *)p->nst, s->bj_blocks);
+        if (p->nst)
+            hipLaunchKernelGGL(bj_extract_kernel, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const double *)p->nst, s->bj_blocks);
+        else {
+            // no assembled N: the diagonal of the data rows' Gram matrix from the rows (this rank's points; summed over the ranks through the
+            // residual window), then scaled mass + exact constraint part
+            e = rowsop_data_diagonal(g, p->rowsop, p->s, s->t1, s->ddiag, st);
+            if (e != hipSuccess) return e;
+            if (p->world > 1) {
+                e = hipMemcpyAsync(p->rho, s->ddiag, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return e;
+                e = hipMemsetAsync(p->rho + g.ncol, 0, sizeof(double) * (size_t)(p->lenR - g.ncol), st);
+                if (e != hipSuccess) return e;
+                if (plan_allreduce(p, p->rho, p->lenR, st) != 0) return hipErrorUnknown;
+                e = hipMemcpyAsync(s->ddiag, p->rho, sizeof(double) * (size_t)g.ncol, hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(bj_build_kernel, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, s->mbands, (const double *)p->ctab,
+                               (const double *)p->dcw, smooth ? (const unsigned char *)p->spf : (const unsigned char *)nullptr, (const double *)s->ddiag, s->bj_blocks);
+        }
         e = block_chol_run(s->bj_jobs, s->bg.nb, s->bj_info, s->bj_scal, st);
         if (e != hipSuccess) return e;
         if (s->bj_dinv32) {

@@ -286,7 +286,7 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
     {
         const char *rt = splpak::opt_get("SPLPAK_ROWS_TILES");
         p->rows_only = !direct && g.ndim == 4 && !splpak::opt_get("SPLPAK_NO_CONSTRAINT_TABLE") && !(rt && atoi(rt) == 0) &&
-                       splpak::opt_get("SPLPAK_PCG_NO_BLOCKS") && !splpak::opt_get("SPLPAK_PCG_ASSEMBLE");      // (the boxes need the assembled N)
+                       !splpak::opt_get("SPLPAK_PCG_ASSEMBLE");
     }
     {
         // scratch of the per-cell Gram blocks: everything at once if <= 8 GB (or if the band storage, which is

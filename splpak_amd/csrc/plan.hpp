@@ -154,6 +154,7 @@ size_t rowsop_bytes(const RowsOp *r);
 hipError_t rowsop_apply(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
                         const double *ctab, bool constraints, double *rho, hipStream_t st);
 hipError_t rowsop_histogram(const Grid &g, RowsOp *r, const SortScratch &rows, double *hist, hipStream_t st);
+hipError_t rowsop_data_diagonal(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, double *diag, hipStream_t st);
 hipError_t rowsop_backward_denominators(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *rhs, const double *dcw,
                                         const unsigned char *spf, const double *ctab, bool constraints, double *absx, double *tmp, double *den,
                                         hipStream_t st);

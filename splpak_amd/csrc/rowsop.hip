@@ -44,8 +44,9 @@ constexpr int TLD = 17;                  // 16 table values per point + 1 (bank 
 __global__ void __launch_bounds__(256)
 rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ offset, const double *__restrict__ xs,
                   const double *__restrict__ ys, const double *__restrict__ ws, long long cap, const double *__restrict__ xvec,
-                  double *__restrict__ partial)
-{
+                  double *__restrict__ partial, int squared)
+{   // squared != 0: the DIAGONAL of A^T W^2 A instead -- sum over the points of w^2 b_c^2: the tables hold the squares, every point's
+    // "residual" is w (the boxes of the iterative solve scale their data part by it, pcg.hip)
     __shared__ double pt[TB4];
     __shared__ double acc[4][TB4];
     __shared__ double tab[4][PCHUNK * TLD];
@@ -129,6 +130,10 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
             //  alone was 360 of the ~650 instructions of a trip, and the trip is issue bound; same values to rounding)
             int form;
             if (pi < np) window_table_selected(g, sl, xcur, b, form);
+            if (squared) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b[k] *= b[k];
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) mytab[pi * TLD + 4 * sl + k] = b[k];
         }
@@ -156,7 +161,7 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
             if (sl == 0) {
                 double we = 0.0;
                 if (pi < np) {
-                    const double e = wcur * ycur - wcur * tsum;      // row residual w y - (w b) . x  (y = 0: the rows as an operator)
+                    const double e = squared ? wcur : wcur * ycur - wcur * tsum;      // row residual w y - (w b) . x  (y = 0: the rows as an operator)
                     we = wcur * e;
                 }
                 mywe[pi] = we;
@@ -490,7 +495,7 @@ static hipError_t rowsop_apply_t(const Grid &g, RowsOp *r, const SortScratch &ro
                                  const double *ctab, bool constraints, bool abs_factors, double *rho, hipStream_t st)
 {
     hipLaunchKernelGGL(rows4_tile_kernel, dim3((unsigned)r->ntiles), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], (const int *)rows.offset,
-                       (const double *)rows.xs, (const double *)rows.ys, (const double *)rows.ws, rows.cap, xvec, r->partial);
+                       (const double *)rows.xs, (const double *)rows.ys, (const double *)rows.ws, rows.cap, xvec, r->partial, 0);
     const double *cterm = nullptr;
     if (constraints) {
         const int D = g.ndim;
@@ -522,6 +527,16 @@ hipError_t rowsop_apply(const Grid &g, RowsOp *r, const SortScratch &rows, const
                         const double *ctab, bool constraints, double *rho, hipStream_t st)
 {
     return rowsop_apply_t(g, r, rows, xvec, dcw, spf, ctab, constraints, false, rho, st);
+}
+
+// diag[i] = sum over the points of w^2 b_i(x)^2: the diagonal of the data rows' Gram matrix (xvec: any vector of ncol doubles, unused)
+hipError_t rowsop_data_diagonal(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, double *diag, hipStream_t st)
+{
+    hipLaunchKernelGGL(rows4_tile_kernel, dim3((unsigned)r->ntiles), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], (const int *)rows.offset,
+                       (const double *)rows.xs, (const double *)nullptr, (const double *)rows.ws, rows.cap, xvec, r->partial, 1);
+    hipLaunchKernelGGL(rows4_gather_kernel<false>, dim3((unsigned)((g.ncol + 255) / 256)), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], r->nt[3],
+                       (const double *)r->partial, (const double *)nullptr, diag);
+    return hipGetLastError();
 }
 
 // hist (caller's dimension order; zero or holding other ranks' nothing yet) += the nearest-node histogram of the binned points
