@@ -665,6 +665,7 @@ int pcg_attach(splpak_plan *p, PcgState **out)
     PcgState *s = new PcgState();
     (void)hipGetDevice(&s->device);
     s->g = g;
+    if (!p->band.ab && !p->fn_user) s->maxit = 12000;        // (nothing but the iteration: see the stagnation rule)
     if (const char *e = splpak::opt_get("SPLPAK_PCG_MAXIT")) s->maxit = std::max(1, atoi(e));
     s->no_pairs = splpak::opt_get("SPLPAK_PCG_NO_PAIRS") != nullptr;
     bool ok = true;
@@ -981,8 +982,10 @@ int pcg_solve(splpak_plan *p, PcgState *s, double *v, double tol, bool smooth, h
         if (debug) fprintf(stderr, "[splpak pcg] iteration %d: preconditioned residual %.3e (best %.3e at %d)\n", it, rel, best, best_it);
         if (bad) { status = 1; break; }
         if (rel <= tol) { status = 0; break; }
-        // stagnation: no factor of ten gained in 400 iterations (a converging 4-D fit gains one in 40 .. 60)
-        if (it - last_gain_it > 400) { status = 1; break; }
+        // stagnation: no factor of ten gained in 400 iterations (a converging 4-D fit gains one in 10 .. 60) where a factorisation
+        // stands behind the iteration; a plan that has nothing else is patient: 1 500 iterations per factor of ten (between 1.2 and
+        // 1.5 constraint rows per column the iteration crawls at ~200 .. 600 per factor of ten, but it arrives)
+        if (it - last_gain_it > (p->solver_mode == 2 ? 1500 : 400)) { status = 1; break; }
     }
     s->last_iters = it;
     s->last_rel = rel;
