@@ -143,6 +143,45 @@ def test_iteration_agrees_with_nested_dissection_at_4d_24(port):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nodes,m,xtrap", [([12] * 4, 158122, 1.0), ([13, 12, 14, 11], 200000, 1.0), ([12] * 4, 366025, 1.0), ([12] * 4, 158122, 0.0)])
+def test_forms_of_the_preconditioner_agree_with_the_factorisation(nodes, m, xtrap):
+    """The iteration-only plan of a 4-D grid in its three forms -- nothing assembled, boxes = scaled mass + exact constraint part (the
+    default); normal equations assembled, boxes extracted from them (pcg_assemble); separable part alone (pcg_no_blocks) -- against
+    the nested-dissection factorisation: every form that converges agrees at 1e-10 with the same row counts; the default and the
+    assembled form take the same number of iterations where constraint rows are present (the data part of a box does not matter
+    there: DESIGN section 4c); a grid whose node counts are not multiples of the box edge has partial boxes."""
+    import torch
+    nd = 4
+    lo, hi = [0.0] * nd, [1.0] * nd
+    x, y, w, st = _device_points(nd, m)
+    ref, e0, i0, _, _, _ = _plan_fit(nd, nodes, lo, hi, xtrap, x, y, w, st, "direct")
+    assert e0 == 0
+    its = {}
+    for form, env in (("rows", {}), ("assembled", {"SPLPAK_PCG_ASSEMBLE": "1"}), ("separable", {"SPLPAK_PCG_NO_BLOCKS": "1"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            c, e, info, fac, ps, dt = _plan_fit(nd, nodes, lo, hi, xtrap, x, y, w, st, "pcg")
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert fac[0] == 6 and e in (0, 107), (form, e)
+        its[form] = (e, ps["iterations"])
+        if e == 0:
+            assert relmax(c, ref) < COEF_TOL and info[9] < 1e-9, form
+            assert info[0] == i0[0] and info[1] == i0[1], form
+            assert abs(info[8] - i0[8]) <= 1e-9 * i0[8], form
+    print(f"{nodes}, {m} points, xtrap {xtrap}: iterations rows-only {its['rows']}, assembled {its['assembled']}, separable alone {its['separable']}")
+    assert its["rows"][0] == 0 and its["assembled"][0] == 0
+    if xtrap != 0.0:
+        assert abs(its["rows"][1] - its["assembled"][1]) <= 10
+        assert its["rows"][1] < its["separable"][1] or its["separable"][0] == 107
+
+
+@pytest.mark.gpu
 def test_config5_fit_4d_32_on_one_gpu(port):
     """BASELINE config 5's fit half at its own size: 4-D, 32^4 = 1 048 576 columns, 1e7 weighted scattered points, xtrap = 1, ONE
     GPU.  No factorisation fits (476 GB of nested-dissection panels, band 851 GB: SPLPAK_SOLVER=direct is refused with the
