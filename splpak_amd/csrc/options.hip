@@ -71,6 +71,7 @@ const Known KNOWN[] = {
     {"SPLPAK_PCG_NO_BLOCKS", 0},
     {"SPLPAK_PCG_NO_PAIRS", 0},
     {"SPLPAK_PCG_TOL1", 1},
+    {"SPLPAK_PCG_TRI_PAIRS", 0},
     {"SPLPAK_PCG_TOL2", 1},
     {"SPLPAK_PIN_BW", 0},
     {"SPLPAK_PR_C0", 0},

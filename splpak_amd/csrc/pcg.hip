@@ -466,9 +466,15 @@ bj_build_kernel(Grid g, BjGeom bg, MassBands mb, const double *__restrict__ ctab
     }
     const double sbox = red[1][0] > 0.0 ? red[0][0] / red[1][0] : 0.0;
     double *__restrict__ A = blocks + (size_t)b * 65536;
-    for (int c = 0; c < 256; ++c) {
+    // the lower triangle, balanced: a thread takes the rows q and 255 - q (257 entries together) and of those the columns of its parity
+    const int tq = threadIdx.x & 127, th = threadIdx.x >> 7;
+    for (int pass = 0; pass < 2; ++pass)
+    for (int c = th; c < 256; c += 2) {
+        const int r = pass == 0 ? tq : 255 - tq;
+        const int nr = snode[r];
         double v = 0.0;
-        if (c <= r) {
+        if (c > r) { A[r + (size_t)c * 256] = 0.0; continue; }
+        {
             const int nc = snode[c];
             if (nr < 0 || nc < 0) v = (c == r) ? 1.0 : 0.0;
             else {
