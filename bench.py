@@ -269,6 +269,20 @@ def bench_c5_fit(capi, dev, stream):
            "iterations": ps["iterations"], "solves": ps["solves"],
            "ms_per_iteration": 1e3 * float(info[7]) / max(ps["iterations"], 1),
            "refine_steps": int(info[2]), "optimality_residual": float(info[9]), "constraint_rows": int(info[1])}
+    # roofline of an iteration: algorithmic bytes = one pass over the sorted points (4 coordinates + weight) + the vector in and out,
+    # against the HBM peak; the counters' traffic of the same workload from the committed PMC passes (not measured in this run)
+    alg = m * 8.0 * (nd + 1) + 2 * 8.0 * nod ** nd
+    traffic = None
+    try:
+        pm = json.load(open(committed_profile("r06_c5_pcg_pmc.json")))
+        traffic = {"hbm_bytes_per_iteration": pm["hbm_bytes_per_iteration_all_kernels"], "source": "profiles/r06_c5_pcg_pmc.json (rocprofv3 --pmc "
+                   "FETCH_SIZE / WRITE_SIZE passes of the same workload; not measured in this run)"}
+    except Exception:
+        pass
+    ms_it = out["ms_per_iteration"]
+    out["roofline"] = {"bound": "hbm", "kernel": "one iteration of the solve (rows4_tile_kernel = 58 % of it: VALU-issue bound, not HBM bound)",
+                       "achieved": alg / (ms_it * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "algorithmic_bytes_per_iteration": alg, "traffic": traffic}
     torch.cuda.empty_cache()
     out["largest_grid_with_a_factorisation"] = guarded(bench_c5_fit_nd28, capi, dev, stream)
     return out
