@@ -494,7 +494,10 @@ void rowsop_destroy(RowsOp *r)
 
 size_t rowsop_bytes(const RowsOp *r) { return r ? r->bytes : 0; }
 
-// 4-D grids only (the 1-D .. 3-D passes of assemble.hip take 1.7 ms at 64^3 / 1e7 points); NULL for the others
+// 4-D grids only; NULL for the others.  (A 3-D form of the tile kernel -- 64 window functions, a lane each in the transposed product --
+// was built and measured in round 6: 22.4 ms of solves + refinement per fit at config 3 against 22.5 ms with the wave-per-cell pass of
+// assemble.hip, and 59.6 against 47.9 ms at 1e8 points (440 points per cell: the wave-per-cell pass takes 64 points per trip, the
+// tile kernel 16).  Removed again.)
 int rowsop_create(const Grid &g, RowsOp **out)
 {
     *out = nullptr;
