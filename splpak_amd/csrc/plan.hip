@@ -709,7 +709,17 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     // ---- the iteration (pcg.hip), where the plan has it --------------------
     bool solved = false;
     auto t2 = t1;
-    if (p->pcg) {
+    // Where a factorisation stands behind the iteration, the attempt is skipped in the regime in which it is known to stagnate or
+    // crawl (between 0 and ~1.6 constraint rows per column; it works with none and from ~1.7 on)
+    bool try_iteration = p->pcg != nullptr;
+    if (try_iteration && p->solver_mode == 3 && !splpak::opt_get("SPLPAK_PCG_ALWAYS")) {
+        const double rpc = rows_cons / (double)g.ncol;
+        if (rows_cons > 0.0 && rpc < 1.6) {
+            try_iteration = false;
+            if (splpak::opt_get("SPLPAK_DEBUG")) fprintf(stderr, "[splpak] %.2f constraint rows per column: the factorisation without an attempt of the iteration\n", rpc);
+        }
+    }
+    if (try_iteration) {
         SPLPAK_HIP_TRY(pcg_prepare(p, p->pcg, hs[SC_COUNT + SC_SUMW2], smooth, st), SPLPAK_E_NODEVICE);
         const double tol_first = splpak::opt_get("SPLPAK_PCG_TOL1") ? atof(splpak::opt_get("SPLPAK_PCG_TOL1")) : 1e-11;
         const double tol_next = splpak::opt_get("SPLPAK_PCG_TOL2") ? atof(splpak::opt_get("SPLPAK_PCG_TOL2")) : 1e-3;

@@ -48,7 +48,9 @@ def _iteration_answered(info):
 def test_every_golden_with_the_iteration_in_front_of_the_factorisation(name):
     gold = load_golden(name)
     inp = make_inputs(CASES[name])
-    c, rc, _, info = _fit_env(inp, {"SPLPAK_SOLVER": "pcg+direct"})
+    # (pcg_always: also in the regime -- between 0 and 1.6 constraint rows per column -- in which a plan with a factorisation behind the
+    #  iteration would not even try it: the hand-over after a stagnating attempt is what is tested here)
+    c, rc, _, info = _fit_env(inp, {"SPLPAK_SOLVER": "pcg+direct", "SPLPAK_PCG_ALWAYS": "1"})
     c0, rc0, _, info0 = _fit_env(inp, {"SPLPAK_SOLVER": "direct"})
     assert rc == 0 and rc0 == 0
     err = relmax(c, gold["coef"])
@@ -80,6 +82,19 @@ def test_iteration_alone_is_right_or_107(name):
         print(f"{name}: 107: {msg}")
         assert "iterative solve did not converge" in msg
         assert np.all(c == 0.0)
+
+
+@pytest.mark.gpu
+def test_known_bad_regime_goes_straight_to_the_factorisation():
+    """A plan with a factorisation behind the iteration does not spend an attempt where the iteration is known to stagnate (0 < constraint
+    rows per column < 1.6: DESIGN section 4c): 2d32 (0.2 rows per column) is answered by the factorisation with no iteration at all, 4d6
+    (2.6) by the iteration."""
+    for name, expect_iteration in (("2d32", False), ("4d6", True)):
+        inp = make_inputs(CASES[name])
+        gold = load_golden(name)
+        c, rc, _, info = _fit_env(inp, {"SPLPAK_SOLVER": "pcg+direct"})
+        assert rc == 0 and relmax(c, gold["coef"]) < COEF_TOL
+        assert _iteration_answered(info) == expect_iteration, (name, info[1] / np.prod(inp["nodes"]))
 
 
 def _device_points(nd, m):
