@@ -65,7 +65,7 @@ const Known KNOWN[] = {
     {"SPLPAK_NO_REORDER", 1},
     {"SPLPAK_NO_STOPEV", 0},
     {"SPLPAK_NO_TWOEND", 0},
-    {"SPLPAK_PCG_ALWAYS", 1},
+    {"SPLPAK_PCG_ALWAYS", 0},
     {"SPLPAK_PCG_ASSEMBLE", 0},
     {"SPLPAK_PCG_BLOCKS_F64", 0},
     {"SPLPAK_PCG_MAXIT", 1},
