@@ -2049,7 +2049,9 @@ bool nd_make_schedule(NdState *s, int cut, size_t other_bytes)
             cut = best_cut;         // (nothing fits: the smallest arena -- the allocation then fails with the byte counts in the message)
         }
     }
-    nd_schedule(t, cut, packed, &s->mine, &s->needs, dlow, s->sc);
+    // (the half-stages: single-GPU plans in the level-by-level order)
+    const int halves = (cut == 0 && !s->mdist && !s->dist && splpak::opt_get("SPLPAK_ND_HALVES")) ? atoi(splpak::opt_get("SPLPAK_ND_HALVES")) : 0;
+    nd_schedule(t, cut, packed, &s->mine, &s->needs, dlow, s->sc, halves);
     const int ns = (int)s->sc.st.size();
     s->starts.assign((size_t)std::max(ns, 1), {});
     s->root_stage = -1;

@@ -180,7 +180,7 @@ bool nd_build(const Grid &g, NdTree &t, int split_min)
     return true;
 }
 
-void nd_schedule(const NdTree &t, int cut, bool packed, const std::vector<char> *mine, const std::vector<char> *needs, int dlow, NdSchedule &sc)
+void nd_schedule(const NdTree &t, int cut, bool packed, const std::vector<char> *mine, const std::vector<char> *needs, int dlow, NdSchedule &sc, int halves)
 {
     sc = NdSchedule();
     sc.cut = cut < 0 ? 0 : cut;
@@ -209,6 +209,29 @@ void nd_schedule(const NdTree &t, int cut, bool packed, const std::vector<char> 
             const NdFront &f = t.fr[(size_t)id];
             if (is_mine(id)) lev[(size_t)f.depth].push_back(id);
             for (int c : f.child) if (c >= 0) stack.push_back(c);
+        }
+        // `halves` (level-by-level order of the whole tree only): the depths 1 .. halves are split by the root's two subtrees and
+        // the halves interleaved -- left d, right d, left d - 1, right d - 1, ... -- so that the chain of a half-stage, which waits
+        // for the last Schur passes of ITS children only, starts beside the passes of the other half of the depth below instead of
+        // behind them (a whole stage ends in one batched last pass, and the chip then waited for the first block steps of the
+        // next stage's chain: 25 of 226 ms at 64^3).  A front's two children stay in one half, in their order: same bits.
+        if (halves > 0 && r == t.root && sc.cut == 0 && t.fr[(size_t)r].child[0] >= 0 && t.fr[(size_t)r].child[1] >= 0) {
+            std::vector<char> right(t.fr.size(), 0);
+            std::vector<int> st2{t.fr[(size_t)r].child[1]};
+            while (!st2.empty()) {
+                const int id = st2.back();
+                st2.pop_back();
+                right[(size_t)id] = 1;
+                for (int c : t.fr[(size_t)id].child) if (c >= 0) st2.push_back(c);
+            }
+            for (int d = t.maxdepth; d >= 0; --d) {
+                if (d < 1 || d > halves) { add_stage(lev[(size_t)d], d); continue; }
+                std::vector<int> a, b;
+                for (int id : lev[(size_t)d]) (right[(size_t)id] ? b : a).push_back(id);
+                add_stage(a, d);
+                add_stage(b, d);
+            }
+            return;
         }
         for (int d = t.maxdepth; d >= 0; --d) add_stage(lev[(size_t)d], d);
     };

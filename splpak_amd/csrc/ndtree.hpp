@@ -112,7 +112,8 @@ inline long long nd_schur_doubles(const NdFront &f, bool packed)
 inline long long nd_schur_ld(const NdFront &f, bool packed) { return packed ? -(long long)(f.hp + 16) : f.lds; }
 // mine: fronts this schedule eliminates (NULL: all); needs: fronts whose buffer is materialised (NULL: every front with a
 // border); dlow: fronts above this depth are left out (multi-GPU: the top phase has them), and those AT dlow > 0 are kept
-void nd_schedule(const NdTree &t, int cut, bool packed, const std::vector<char> *mine, const std::vector<char> *needs, int dlow, NdSchedule &sc);
+// halves > 0 (cut = 0 only): the depths 1 .. halves as two half-stages each, by the root's subtrees, interleaved (see nd_schedule)
+void nd_schedule(const NdTree &t, int cut, bool packed, const std::vector<char> *mine, const std::vector<char> *needs, int dlow, NdSchedule &sc, int halves = 0);
 
 // Distribution of the tree over the R GPUs of a one-process multi-GPU fit (round 4; ndchol.hip "top phase"):
 //   * the subtrees below tree depth dcut = ceil(log2 R) are dealt to the ranks (subtree i of the depth-dcut fronts -> rank

@@ -37,6 +37,7 @@ const Known KNOWN[] = {
     {"SPLPAK_ND_DIST", 0},
     {"SPLPAK_ND_DUMMY_STREAMS", 0},
     {"SPLPAK_ND_FULL_DIAG", 0},
+    {"SPLPAK_ND_HALVES", 0},
     {"SPLPAK_ND_JOIN_SQUARE", 0},
     {"SPLPAK_ND_KB", 1},
     {"SPLPAK_ND_NO_EARLY_CLEAR", 0},

@@ -454,7 +454,7 @@ int32_t splpak_plan_set_option(splpak_plan *p, const char *name, const char *val
     std::string canon;
     if (!option_canonical(name, canon)) { set_error(std::string("unknown option: ") + (name ? name : "(null)")); return SPLPAK_E_BADARG; }
     // what shapes the plan's storage and job tables was consumed when the plan was created
-    static const char *const at_creation[] = {"SPLPAK_SOLVER", "SPLPAK_ND", "SPLPAK_ND_SPLIT", "SPLPAK_ND_CUT", "SPLPAK_ND_KB", "SPLPAK_ND_RES_CUS",
+    static const char *const at_creation[] = {"SPLPAK_SOLVER", "SPLPAK_ND", "SPLPAK_ND_SPLIT", "SPLPAK_ND_CUT", "SPLPAK_ND_HALVES", "SPLPAK_ND_KB", "SPLPAK_ND_RES_CUS",
                                               "SPLPAK_NO_REORDER", "SPLPAK_GRAM_SCRATCH_MB", "SPLPAK_PCG_MAXIT", "SPLPAK_MPLAN_RCCL", "SPLPAK_RCCL_LIB"};
     for (const char *c : at_creation)
         if (canon == c) {

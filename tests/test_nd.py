@@ -347,7 +347,10 @@ def test_nd_pinned_queue_lookahead_variants_are_bitwise_equal():
                 {"SPLPAK_ND_STAGED_INIT": "0"}, {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_CLEAR_WGS": "0"}, {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_NO_EARLY_CLEAR": "1"},
                 {"SPLPAK_ND_STAGED_INIT": "0", "SPLPAK_ND_CUT": "2"},
                 # the root's look-ahead over the next diagonal block only (round 4)
-                {"SPLPAK_ND_ROOT_LA": "1"}):
+                {"SPLPAK_ND_ROOT_LA": "1"},
+                # round 6: the upper depths as two interleaved half-stages (the root's two subtrees); off
+                {"SPLPAK_ND_HALVES": "0"}, {"SPLPAK_ND_HALVES": "1"}, {"SPLPAK_ND_HALVES": "9"}, {"SPLPAK_ND_HALVES": "2", "SPLPAK_NO_LOOKAHEAD": "1"},
+                {"SPLPAK_ND_HALVES": "3", "SPLPAK_ND_NO_FUSE": "1"}, {"SPLPAK_ND_HALVES": "9", "SPLPAK_ND_SQUARE": "1"}):
         c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1"))
         assert e == 0 and np.array_equal(c, ref), env
 
@@ -367,7 +370,8 @@ def test_nd_schedule_variants_on_an_anisotropic_grid():
     ref, e, _, info = _fit_env(inp, {"SPLPAK_ND": "1", "SPLPAK_ND_CUT": "0"})
     assert e == 0 and info[9] < 1e-9
     for env in ({"SPLPAK_ND_CHAIN_LA": "0"}, {"SPLPAK_ND_CHAIN_LA": "64"}, {"SPLPAK_NO_LOOKAHEAD": "1"}, {"SPLPAK_ND_KB": "2"}, {"SPLPAK_ND_NO_FUSE": "1"},
-                {"SPLPAK_NO_PANEL_CU": "1"}, {"SPLPAK_ND_PREP_EARLY": "1"}, {"SPLPAK_ND_PIN_FIRST": "1", "SPLPAK_ND_PIN_ROUNDS": "2"}):
+                {"SPLPAK_NO_PANEL_CU": "1"}, {"SPLPAK_ND_PREP_EARLY": "1"}, {"SPLPAK_ND_PIN_FIRST": "1", "SPLPAK_ND_PIN_ROUNDS": "2"},
+                {"SPLPAK_ND_HALVES": "0"}, {"SPLPAK_ND_HALVES": "2"}, {"SPLPAK_ND_HALVES": "9"}):
         c, e, _, _ = _fit_env(inp, dict(env, SPLPAK_ND="1", SPLPAK_ND_CUT="0"))
         assert e == 0 and np.array_equal(c, ref), env
     again, e, _, _ = _fit_env(inp, {"SPLPAK_ND": "1", "SPLPAK_ND_CUT": "0", "SPLPAK_NO_PLAN_CACHE": "1"})
