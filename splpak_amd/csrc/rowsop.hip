@@ -38,6 +38,7 @@ constexpr int TB4 = TBS[0] * TBS[1] * TBS[2] * TBS[3];              // nodes of 
 constexpr int NCT = TCS[0] * TCS[1] * TCS[2] * TCS[3];              // cells of a tile
 constexpr int PCHUNK = 16;               // points per trip of a wave
 constexpr int TLD = 17;                  // 16 table values per point + 1 (bank spread)
+typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // data rows
@@ -95,8 +96,8 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     double *__restrict__ mytab = tab[wave];
     double *__restrict__ mywe = swe[wave];
     double *__restrict__ myacc = acc[wave];
-    const int k0 = lane & 3, k1 = (lane >> 2) & 3, k2 = lane >> 4;        // phase 2: the lane's window functions (k0, k1, k2, *)
-    const int pi = lane & 15, sl = lane >> 4;                              // staging: (point, dimension); phase 1: (point, slab k3)
+    const int pi = lane & 15, sl = lane >> 4;                              // staging: (point, dimension)
+    const int l15 = lane & 15, g4 = lane >> 4;                             // the matrix products' lane coordinates
     auto next_cell = [&](int lc) { while (lc < NCT && cbeg[lc] == cend[lc]) lc += 4; return lc; };
     // the chunk after the current one is loaded while the current one is worked on
     double xpre = 0.0, wpre = 0.0, ypre = 0.0;
@@ -113,7 +114,9 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     int lc = next_cell(wave);
     int p0 = lc < NCT ? cbeg[lc] : 0;
     issue(lc, p0);
-    double racc[4] = {0.0, 0.0, 0.0, 0.0};
+    d4_t racc = {0.0, 0.0, 0.0, 0.0};
+    double cw[4] = {0.0, 0.0, 0.0, 0.0};
+    bool cell_new = true;
     while (lc < NCT) {
         const int end = cend[lc], lbase = clb[lc];
         const int np = end - p0 < PCHUNK ? end - p0 : PCHUNK;
@@ -139,47 +142,56 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        {   // phase 1: lane = (point pi, slab k3 = sl): b3[k3] * sum_{k2} b2 sum_{k1} b1 sum_{k0} b0 x
-            const double *__restrict__ tb = mytab + pi * TLD;
-            const double *__restrict__ px = pt + lbase + sl * TST[3];
-            double r3 = 0.0;
+        // Both products of a trip are small matrix products over the cell's 16 x 16 window of coefficients, W[m][n] with
+        // m = k2 + 4 k3 and n = k0 + 4 k1 -- a point's row is v (x) u with u[n] = b0[k0] b1[k1], v[m] = b2[k2] b3[k3] -- and run on the
+        // matrix pipe (v_mfma_f64_16x16x4_f64: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15], result rows
+        // (lane >> 4) + 4 r in register r).  The pipe has the vector unit's f64 rate on this chip; what it saves is the issue slots
+        // around the multiply-adds: the vector form read two LDS operands and spent twelve further instructions per point on the
+        // transposed product alone (650 wave instructions per trip of 16 points, the kernel was issue bound).
+        if (cell_new) {                   // the window's entries this lane feeds the forward product with: W[m = l15][n = 4 s + g4]
+            const double *__restrict__ px = pt + lbase + g4 + TST[2] * (l15 & 3) + TST[3] * (l15 >> 2);
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                double r2 = 0.0;
+            for (int s4 = 0; s4 < 4; ++s4) cw[s4] = px[TST[1] * s4];
+        }
+        {   // forward: T = W U, U[n][q] = u_q[n] (K = n: four steps), then s_q = sum_m v_q[m] T[m][q]
+            const double *__restrict__ tb = mytab + l15 * TLD;
+            const double ub = tb[g4];
+            d4_t T = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int j1 = 0; j1 < 4; ++j1) {
-                    double r1 = 0.0;
-#pragma unroll
-                    for (int j0 = 0; j0 < 4; ++j0) r1 = fma(tb[j0], px[j0 + TST[1] * j1 + TST[2] * j2], r1);
-                    r2 = fma(tb[4 + j1], r1, r2);
-                }
-                r3 = fma(tb[8 + j2], r2, r3);
-            }
-            const double part = tb[12 + sl] * r3;
-            const double q0 = __shfl(part, pi, 64), q1 = __shfl(part, pi + 16, 64), q2 = __shfl(part, pi + 32, 64), q3 = __shfl(part, pi + 48, 64);
+            for (int s4 = 0; s4 < 4; ++s4) T = __builtin_amdgcn_mfma_f64_16x16x4f64(cw[s4], ub * tb[4 + s4], T, 0, 0, 0);
+            // this lane: rows m = g4 + 4 r of point l15, i.e. k2 = g4, k3 = r
+            double r3 = T[0] * tb[12];
+            r3 = fma(T[1], tb[13], r3);
+            r3 = fma(T[2], tb[14], r3);
+            r3 = fma(T[3], tb[15], r3);
+            const double part = tb[8 + g4] * r3;
+            const double q0 = __shfl(part, l15, 64), q1 = __shfl(part, l15 + 16, 64), q2 = __shfl(part, l15 + 32, 64), q3 = __shfl(part, l15 + 48, 64);
             const double tsum = ((q0 + q1) + q2) + q3;
-            if (sl == 0) {
+            if (g4 == 0) {
                 double we = 0.0;
-                if (pi < np) {
+                if (l15 < np) {
                     const double e = squared ? wcur : wcur * ycur - wcur * tsum;      // row residual w y - (w b) . x  (y = 0: the rows as an operator)
                     we = wcur * e;
                 }
-                mywe[pi] = we;
+                mywe[l15] = we;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // phase 2: lane = window functions (k0, k1, k2, 0..3): racc += (w b)_c e over the points (their order)
-        for (int q = 0; q < np; ++q) {
-            const double *__restrict__ tb = mytab + q * TLD;
-            const double c = ((mywe[q] * tb[k0]) * tb[4 + k1]) * tb[8 + k2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) racc[j] = fma(c, tb[12 + j], racc[j]);
+        {   // transposed: G[m][n] += sum_q (we_q v_q[m]) u_q[n]  (K = the points, four per step, in their order)
+            const int nsteps = (np + 3) >> 2;
+            for (int s4 = 0; s4 < nsteps; ++s4) {
+                const double *__restrict__ tq = mytab + (4 * s4 + g4) * TLD;
+                const double a = (mywe[4 * s4 + g4] * tq[8 + (l15 & 3)]) * tq[12 + (l15 >> 2)];
+                const double b = tq[l15 & 3] * tq[4 + (l15 >> 2)];
+                racc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, racc, 0, 0, 0);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lcn != lc) {                  // the cell is done: its 256 shares into this wave's image of the tile
-            const int li = lbase + k0 + TST[1] * k1 + TST[2] * k2;
+        cell_new = lcn != lc;
+        if (cell_new) {                   // the cell is done: its 256 shares (k0 = l15 & 3, k1 = l15 >> 2, k2 = g4, k3 = register) into this wave's image of the tile
+            const int li = lbase + (l15 & 3) + TST[1] * (l15 >> 2) + TST[2] * g4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 myacc[li + TST[3] * j] += racc[j];
