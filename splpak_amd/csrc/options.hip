@@ -72,6 +72,7 @@ const Known KNOWN[] = {
     {"SPLPAK_PCG_MAXIT", 1},
     {"SPLPAK_PCG_NO_BLOCKS", 0},
     {"SPLPAK_PCG_NO_PAIRS", 0},
+    {"SPLPAK_PCG_PAIRS_VALU", 0},
     {"SPLPAK_PCG_TOL1", 1},
     {"SPLPAK_PCG_TRI_PAIRS", 0},
     {"SPLPAK_PCG_TOL2", 1},

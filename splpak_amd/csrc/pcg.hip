@@ -199,6 +199,91 @@ mode_pair_kernel(int na, int nb, long long inner, int ci, const double *__restri
     }
 }
 
+// The same pass on the matrix pipe.  Each mode product of a tile is a small matrix product -- mode a: out[ja][(c, jb)] = sum_ia
+// MTa[ia][ja] T0[ia][(c, jb)], mode b: out[jb][(c, ja)] = sum_ib MTb[ib][jb] T1[ib][(c, ja)] -- in 16 x 16 output tiles dealt to the
+// four waves, K in steps of four (v_mfma_f64_16x16x4_f64; operand and result lane maps as in rowsop.hip).  The vector form above
+// issues one LDS read and one cached global read per multiply-add (43 us per launch at 32^4, 3 TFLOP/s); this one reads two LDS
+// operands per 1 024 of them.  LDS: T0 [nb][kpa][ci] and T1 [kpb][na][ci] with zero rows up to the next multiple of four (no
+// guards in the K loop), the two matrices zero-padded to [kp][mp].
+typedef double pcg_d4_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+mode_pair_mfma_kernel(int na, int nb, long long inner, int ci, const double *__restrict__ MTa, const double *__restrict__ MTb,
+                      const double *__restrict__ X, double *__restrict__ Y, const double *__restrict__ scale)
+{
+    extern __shared__ double smem[];
+    const int kpa = (na + 3) & ~3, mpa = (na + 15) & ~15, kpb = (nb + 3) & ~3, mpb = (nb + 15) & ~15;
+    double *__restrict__ T0 = smem;
+    double *__restrict__ T1 = T0 + nb * kpa * ci;
+    double *__restrict__ SA = T1 + kpb * na * ci;
+    double *__restrict__ SB = SA + kpa * mpa;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const long long nchunk = inner / ci;
+    const long long o = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
+    const long long base = o * ((long long)na * nb * inner) + ch * ci;
+    for (int e = tid; e < nb * kpa * ci; e += 256) {
+        const int c = e % ci, r = e / ci, ia = r % kpa, jb = r / kpa;
+        T0[e] = ia < na ? X[base + c + inner * (ia + (long long)na * jb)] : 0.0;
+    }
+    for (int e = tid; e < kpa * mpa; e += 256) {
+        const int ja = e % mpa, ia = e / mpa;
+        SA[e] = (ia < na && ja < na) ? MTa[ia * na + ja] : 0.0;
+    }
+    for (int e = tid; e < kpb * mpb; e += 256) {
+        const int jb = e % mpb, ib = e / mpb;
+        SB[e] = (ib < nb && jb < nb) ? MTb[ib * nb + jb] : 0.0;
+    }
+    for (int e = tid; e < (kpb - nb) * na * ci; e += 256) T1[nb * na * ci + e] = 0.0;
+    __syncthreads();
+    {   // mode a
+        const int ncol = ci * nb, nct = (ncol + 15) >> 4, nmt = mpa >> 4;
+        for (int t = wave; t < nmt * nct; t += 4) {
+            const int mt = t % nmt, ct = t / nmt;
+            const int col = 16 * ct + l15;
+            const bool okc = col < ncol;
+            const int cc = okc ? col : 0, c = cc % ci, jb = cc / ci;
+            const double *__restrict__ bp = T0 + c + ci * (kpa * jb + g4);
+            const double *__restrict__ ap = SA + g4 * mpa + 16 * mt + l15;
+            pcg_d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            for (int s4 = 0; s4 < kpa; s4 += 4) {
+                const double bv = bp[ci * s4];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[mpa * s4], okc ? bv : 0.0, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ja = 16 * mt + g4 + 4 * r;
+                if (okc && ja < na) T1[c + ci * (ja + na * jb)] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    {   // mode b
+        const int ncol = ci * na, nct = (ncol + 15) >> 4, nmt = mpb >> 4;
+        for (int t = wave; t < nmt * nct; t += 4) {
+            const int mt = t % nmt, ct = t / nmt;
+            const int col = 16 * ct + l15;
+            const bool okc = col < ncol;
+            const int cc = okc ? col : 0, c = cc % ci, ja = cc / ci;
+            const double *__restrict__ bp = T1 + cc + ci * na * g4;
+            const double *__restrict__ ap = SB + g4 * mpb + 16 * mt + l15;
+            pcg_d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            for (int s4 = 0; s4 < kpb; s4 += 4) {
+                const double bv = bp[ci * na * s4];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[mpb * s4], okc ? bv : 0.0, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jb = 16 * mt + g4 + 4 * r;
+                if (okc && jb < nb) {
+                    const long long gi = base + c + inner * (ja + (long long)na * jb);
+                    double v = acc[r];
+                    if (scale) v *= scale[gi];
+                    Y[gi] = v;
+                }
+            }
+        }
+    }
+}
+
 struct EvTabs {             // per-dimension diagonals in the eigenbasis (device arrays of nodes_k doubles each)
     const double *mu[MAXD], *k0[MAXD], *d1[MAXD], *l2[MAXD];
 };
@@ -618,6 +703,7 @@ struct PcgState {
     MassBands mbands{};
     double *ddiag = nullptr;                               // diagonal of the data rows' Gram matrix (the same)
     bool no_pairs = false;                                 // A/B: the modes of the separable part one by one
+    bool pairs_valu = false;                               // A/B: the pairs on the vector unit (round 6's first form)
     std::vector<double> hhist;
     int maxit = 4000;
     std::vector<void *> owned;
@@ -674,6 +760,7 @@ int pcg_attach(splpak_plan *p, PcgState **out)
     if (!p->band.ab && !p->fn_user) s->maxit = 12000;        // (nothing but the iteration: see the stagnation rule)
     if (const char *e = splpak::opt_get("SPLPAK_PCG_MAXIT")) s->maxit = std::max(1, atoi(e));
     s->no_pairs = splpak::opt_get("SPLPAK_PCG_NO_PAIRS") != nullptr;
+    s->pairs_valu = splpak::opt_get("SPLPAK_PCG_PAIRS_VALU") != nullptr;
     bool ok = true;
     long long ntab = 0;
     for (int k = 0; k < g.ndim; ++k) ntab += 4LL * g.nodes[k];
@@ -903,11 +990,22 @@ static hipError_t pcg_precondition(PcgState *s, const double *r, double *z, hipS
                 const int na = g.nodes[k], nb = g.nodes[k + 1];
                 const long long inner = g.colstride[k];
                 int ci = 1;
-                for (int c = 8; c >= 1; --c)
-                    if (inner % c == 0 && (long long)na * nb * c <= 4096) { ci = c; break; }
-                const long long blocks = total / ((long long)na * nb * ci);
-                hipLaunchKernelGGL(mode_pair_kernel, dim3((unsigned)blocks), bl, sizeof(double) * 2 * (size_t)na * nb * ci, st, na, nb, inner, ci,
-                                   (const double *)mats[k], (const double *)mats[k + 1], src, dst, sc);
+                const int kpa = (na + 3) & ~3, mpa = (na + 15) & ~15, kpb = (nb + 3) & ~3, mpb = (nb + 15) & ~15;
+                auto lds_doubles = [&](int c) { return (long long)nb * kpa * c + (long long)kpb * na * c + (long long)kpa * mpa + (long long)kpb * mpb; };
+                if (s->pairs_valu || lds_doubles(1) > 8192) {           // (the matrix-pipe form's images do not fit 64 KB: node counts near 64)
+                    for (int c = 8; c >= 1; --c)
+                        if (inner % c == 0 && (long long)na * nb * c <= 4096) { ci = c; break; }
+                    const long long blocks = total / ((long long)na * nb * ci);
+                    hipLaunchKernelGGL(mode_pair_kernel, dim3((unsigned)blocks), bl, sizeof(double) * 2 * (size_t)na * nb * ci, st, na, nb, inner, ci,
+                                       (const double *)mats[k], (const double *)mats[k + 1], src, dst, sc);
+                } else {
+                    // (64 KB of LDS: the two images of the tile with their zero rows + the two padded matrices)
+                    for (int c = 8; c >= 1; --c)
+                        if (inner % c == 0 && lds_doubles(c) <= 8192) { ci = c; break; }
+                    const long long blocks = total / ((long long)na * nb * ci);
+                    hipLaunchKernelGGL(mode_pair_mfma_kernel, dim3((unsigned)blocks), bl, sizeof(double) * (size_t)lds_doubles(ci), st, na, nb, inner, ci,
+                                       (const double *)mats[k], (const double *)mats[k + 1], src, dst, sc);
+                }
             } else
                 hipLaunchKernelGGL(mode_product_kernel, gr, bl, 0, st, g.nodes[k], (long long)g.colstride[k], total, (const double *)mats[k], src, dst, sc);
             src = dst;

@@ -180,11 +180,17 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
         __builtin_amdgcn_wave_barrier();
         {   // transposed: G[m][n] += sum_q (we_q v_q[m]) u_q[n]  (K = the points, four per step, in their order)
             const int nsteps = (np + 3) >> 2;
-            for (int s4 = 0; s4 < nsteps; ++s4) {
-                const double *__restrict__ tq = mytab + (4 * s4 + g4) * TLD;
-                const double a = (mywe[4 * s4 + g4] * tq[8 + (l15 & 3)]) * tq[12 + (l15 >> 2)];
-                const double b = tq[l15 & 3] * tq[4 + (l15 >> 2)];
-                racc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, racc, 0, 0, 0);
+            const double *__restrict__ tq0 = mytab + g4 * TLD;
+            const double *__restrict__ we0 = mywe + g4;
+            const int ia = 8 + (l15 & 3), ja = 12 + (l15 >> 2), ib = l15 & 3, jb = 4 + (l15 >> 2);
+#pragma unroll
+            for (int s4 = 0; s4 < PCHUNK / 4; ++s4) {      // (unrolled: the steps' LDS addresses differ by constants)
+                if (s4 < nsteps) {
+                    const double *__restrict__ tq = tq0 + 4 * s4 * TLD;
+                    const double a = (we0[4 * s4] * tq[ia]) * tq[ja];
+                    const double b = tq[ib] * tq[jb];
+                    racc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, racc, 0, 0, 0);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -173,7 +173,9 @@ def test_forms_of_the_preconditioner_agree_with_the_factorisation(nodes, m, xtra
     ref, e0, i0, _, _, _ = _plan_fit(nd, nodes, lo, hi, xtrap, x, y, w, st, "direct")
     assert e0 == 0
     its = {}
-    for form, env in (("rows", {}), ("assembled", {"SPLPAK_PCG_ASSEMBLE": "1"}), ("separable", {"SPLPAK_PCG_NO_BLOCKS": "1"})):
+    # (the separable part's mode products: pairs on the matrix pipe (default), pairs on the vector unit, one mode per launch)
+    for form, env in (("rows", {}), ("assembled", {"SPLPAK_PCG_ASSEMBLE": "1"}), ("separable", {"SPLPAK_PCG_NO_BLOCKS": "1"}),
+                      ("pairs_valu", {"SPLPAK_PCG_PAIRS_VALU": "1"}), ("no_pairs", {"SPLPAK_PCG_NO_PAIRS": "1"})):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -192,6 +194,9 @@ def test_forms_of_the_preconditioner_agree_with_the_factorisation(nodes, m, xtra
             assert abs(info[8] - i0[8]) <= 1e-9 * i0[8], form
     print(f"{nodes}, {m} points, xtrap {xtrap}: iterations rows-only {its['rows']}, assembled {its['assembled']}, separable alone {its['separable']}")
     assert its["rows"][0] == 0 and its["assembled"][0] == 0
+    # the same transform computed three ways: the iteration counts differ by rounding at most
+    assert its["pairs_valu"][0] == 0 and its["no_pairs"][0] == 0
+    assert abs(its["rows"][1] - its["pairs_valu"][1]) <= 5 and abs(its["rows"][1] - its["no_pairs"][1]) <= 5, its
     if xtrap != 0.0:
         assert abs(its["rows"][1] - its["assembled"][1]) <= 10
         assert its["rows"][1] < its["separable"][1] or its["separable"][0] == 107
