@@ -652,6 +652,75 @@ bj_apply_kernel(Grid g, BjGeom bg, const T *__restrict__ dinv, const T *__restri
     if (node >= 0) z[node] += a0 + a1;
 }
 
+// The apply from ONE single-precision copy of L^-1 (round 6, second form): the ten 64 x 64 blocks of its lower triangle, packed block
+// row by block row.  Block row I (its I + 1 blocks) goes through LDS once and serves both products -- u_I = sum_J B_IJ v_J, complete
+// after the row, then z_J += B_IJ^T u_I for the same blocks: 164 KB per box instead of the 328 KB the two triangular matrix-vector
+// products read from the straight and the transposed copy (the pass is bound by these bytes).  Sums in a fixed order.
+constexpr int BJ_LD = 65;          // floats per LDS row of a block (odd: the row-wise reads of the first product spread over the banks)
+__global__ void __launch_bounds__(256)
+bj_pack_kernel(long long nblk, const double *__restrict__ dinv, float *__restrict__ pk)
+{   // pk[box][blk(I, J) = I (I + 1) / 2 + J][i][j] = Linv[64 I + i][64 J + j]   (dinv: row-major Linv)
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nblk * 40960) return;
+    const long long b = e / 40960;
+    const int r = (int)(e % 40960), blk = r >> 12, i = (r >> 6) & 63, j = r & 63;
+    const int I = blk < 1 ? 0 : (blk < 3 ? 1 : (blk < 6 ? 2 : 3)), J = blk - I * (I + 1) / 2;
+    pk[e] = (float)dinv[b * 65536 + (long long)(64 * I + i) * 256 + 64 * J + j];
+}
+
+__global__ void __launch_bounds__(256)
+bj_apply_packed_kernel(Grid g, BjGeom bg, const float *__restrict__ pk, const double *__restrict__ v, double *__restrict__ z)
+{
+    __shared__ float sblk[4 * 64 * BJ_LD];
+    __shared__ double vb[256], ub[64], red[256];
+    const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63, part = tid >> 6;
+    const int node = bj_node(g, bg, b, tid, nullptr);
+    vb[tid] = node >= 0 ? v[node] : 0.0;
+    const float *__restrict__ src = pk + (size_t)b * 40960;
+    double zacc[4] = {0.0, 0.0, 0.0, 0.0};           // this thread's share (rows 16 part .. 16 part + 15 of every block) of z[64 J + l]
+    for (int I = 0; I < 4; ++I) {
+        const int nbk = I + 1;
+        const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src + (size_t)(I * (I + 1) / 2) * 4096);
+        __syncthreads();                             // (the previous row's blocks are used up; first trip: vb is written)
+        for (int e = tid; e < nbk * 1024; e += 256) {
+            const float4 q = s4[e];
+            const int J = e >> 10, i = (e >> 4) & 63, j = (e & 15) * 4;
+            float *__restrict__ d = sblk + (J * 64 + i) * BJ_LD + j;
+            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+        }
+        __syncthreads();
+        {   // u_I[l]: thread (l, part) sums the columns 16 part .. 16 part + 15 of every block of the row
+            double a = 0.0;
+            for (int J = 0; J < nbk; ++J) {
+                const float *__restrict__ row = sblk + (J * 64 + l) * BJ_LD + 16 * part;
+                const double *__restrict__ vv = vb + 64 * J + 16 * part;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a = fma((double)row[j], vv[j], a);
+            }
+            red[tid] = a;
+        }
+        __syncthreads();
+        if (tid < 64) ub[tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+        __syncthreads();
+        for (int J = 0; J < nbk; ++J) {              // z_J[l] += sum_i B_IJ[i][l] u_I[i], i in this thread's sixteen rows
+            const float *__restrict__ col = sblk + (J * 64 + 16 * part) * BJ_LD + l;
+            double a = zacc[J];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a = fma((double)col[i * BJ_LD], ub[16 * part + i], a);
+            zacc[J] = a;
+        }
+    }
+    __syncthreads();
+    double *__restrict__ zs = vb;                    // (vb is used up) z[64 J + l] = the four parts in order
+    for (int J = 0; J < 4; ++J) {
+        red[tid] = zacc[J];
+        __syncthreads();
+        if (tid < 64) zs[64 * J + tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+        __syncthreads();
+    }
+    if (node >= 0) z[node] += zs[tid];
+}
+
 // single-precision copies of the box inverses for the apply (a preconditioner: its rounding changes nothing the iteration converges
 // to; half the bytes of a pass that is bound by reading them -- 0.48 -> 0.25 ms per iteration at 32^4)
 __global__ void __launch_bounds__(256)
@@ -696,6 +765,7 @@ struct PcgState {
     BjGeom bg{};
     double *bj_blocks = nullptr, *bj_inv16 = nullptr, *bj_dinv = nullptr, *bj_dinvt = nullptr, *bj_scal = nullptr;
     float *bj_dinv32 = nullptr, *bj_dinvt32 = nullptr;     // single-precision copies for the apply (NULL: the f64 ones)
+    float *bj_pk32 = nullptr;                              // the packed single-precision lower triangle of L^-1 (the default apply)
     void *bj_jobs = nullptr;
     int *bj_info = nullptr;
     bool bj_have = false, bj_ready = false;
@@ -878,7 +948,12 @@ int pcg_attach(splpak_plan *p, PcgState **out)
                 }
                 okb = hip_ok(block_chol_prepare(s->bj_jobs, s->bg.nb, s->bj_blocks, s->bj_inv16, s->bj_dinv, s->bj_dinvt, ncols.data()), "pcg: block jobs");
             }
-            if (okb && !splpak::opt_get("SPLPAK_PCG_BLOCKS_F64")) {
+            if (okb && !splpak::opt_get("SPLPAK_PCG_BLOCKS_F64") && !splpak::opt_get("SPLPAK_PCG_BLOCKS_UNPACKED")) {
+                double *f = nullptr;
+                if (pcg_alloc(s, &f, nb * 20480)) s->bj_pk32 = reinterpret_cast<float *>(f);         // nb * 40 960 floats
+                else (void)hipGetLastError();
+            }
+            if (okb && !s->bj_pk32 && !splpak::opt_get("SPLPAK_PCG_BLOCKS_F64")) {
                 double *f = nullptr;
                 if (pcg_alloc(s, &f, nb * 65536)) {            // two float arrays of nb * 65536 = one double array of that length
                     s->bj_dinv32 = reinterpret_cast<float *>(f);
@@ -954,6 +1029,10 @@ hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, h
         }
         e = block_chol_run(s->bj_jobs, s->bg.nb, s->bj_info, s->bj_scal, st);
         if (e != hipSuccess) return e;
+        if (s->bj_pk32) {
+            const long long nn = (long long)s->bg.nb * 40960;
+            hipLaunchKernelGGL(bj_pack_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, (long long)s->bg.nb, (const double *)s->bj_dinv, s->bj_pk32);
+        }
         if (s->bj_dinv32) {
             const long long nn = (long long)s->bg.nb * 65536;
             hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, (const double *)s->bj_dinv, (const double *)s->bj_dinvt,
@@ -1015,7 +1094,9 @@ static hipError_t pcg_precondition(PcgState *s, const double *r, double *z, hipS
     };
     sweep(s->V, s->dinv, nullptr);           // V_k^T along every dimension, the last one scaled by 1 / diag
     sweep(s->VT, nullptr, z);                // V_k along every dimension
-    if (s->bj_ready && s->bj_dinv32)
+    if (s->bj_ready && s->bj_pk32)
+        hipLaunchKernelGGL(bj_apply_packed_kernel, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const float *)s->bj_pk32, r, z);
+    else if (s->bj_ready && s->bj_dinv32)
         hipLaunchKernelGGL(bj_apply_kernel<float>, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const float *)s->bj_dinv32, (const float *)s->bj_dinvt32, r, z);
     else if (s->bj_ready)
         hipLaunchKernelGGL(bj_apply_kernel<double>, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const double *)s->bj_dinv, (const double *)s->bj_dinvt, r, z);
