@@ -53,7 +53,8 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     __shared__ double tab[4][PCHUNK * TLD];
     __shared__ double swe[4][PCHUNK];
     __shared__ int cbeg[NCT], cend[NCT], clb[NCT];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (known to be uniform: the walk over the cells below stays in scalar registers)
     int t = blockIdx.x;
     int cb[4];
     cb[0] = (t % nt0) * TCS[0]; t /= nt0;
@@ -98,12 +99,17 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     double *__restrict__ myacc = acc[wave];
     const int pi = lane & 15, sl = lane >> 4;                              // staging: (point, dimension)
     const int l15 = lane & 15, g4 = lane >> 4;                             // the matrix products' lane coordinates
-    auto next_cell = [&](int lc) { while (lc < NCT && cbeg[lc] == cend[lc]) lc += 4; return lc; };
+    // (the cells' ranges come out of LDS at uniform addresses: into scalar registers, so that the walk needs no lane masks)
+    auto sld = [&](const int *q) { return __builtin_amdgcn_readfirstlane(*q); };
+    auto next_cell = [&](int lc) { while (lc < NCT && sld(&cbeg[lc]) == sld(&cend[lc])) lc += 4; return lc; };
+    // this lane's dimension of the grid, as dimension 0 of a copy: the table code below then reads registers, not the argument block
+    Grid gl = g;
+    gl.nodes[0] = g.nodes[sl]; gl.xmin[0] = g.xmin[sl]; gl.dx[0] = g.dx[sl]; gl.dxin[0] = g.dxin[sl];
     // the chunk after the current one is loaded while the current one is worked on
     double xpre = 0.0, wpre = 0.0, ypre = 0.0;
     auto issue = [&](int lc, int p0) {
         if (lc >= NCT) return;
-        if (p0 + pi < cend[lc]) {
+        if (p0 + pi < sld(&cend[lc])) {
             xpre = xs[(long long)sl * cap + p0 + pi];
             if (sl == 0) {
                 wpre = ws[p0 + pi];
@@ -112,19 +118,19 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
         }
     };
     int lc = next_cell(wave);
-    int p0 = lc < NCT ? cbeg[lc] : 0;
+    int p0 = lc < NCT ? sld(&cbeg[lc]) : 0;
     issue(lc, p0);
     d4_t racc = {0.0, 0.0, 0.0, 0.0};
     double cw[4] = {0.0, 0.0, 0.0, 0.0};
     bool cell_new = true;
     while (lc < NCT) {
-        const int end = cend[lc], lbase = clb[lc];
+        const int end = sld(&cend[lc]), lbase = sld(&clb[lc]);
         const int np = end - p0 < PCHUNK ? end - p0 : PCHUNK;
         const double xcur = xpre, wcur = wpre, ycur = ypre;
         int lcn = lc, p0n = p0 + PCHUNK;
         if (p0n >= end) {
             lcn = next_cell(lc + 4);
-            p0n = lcn < NCT ? cbeg[lcn] : 0;
+            p0n = lcn < NCT ? sld(&cbeg[lcn]) : 0;
         }
         issue(lcn, p0n);
         {   // window tables: lane = (point pi, dimension sl)
@@ -132,7 +138,7 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
             // (the closed forms of the evaluation kernels -- interior window / next to an end / general, basis.hpp -- : the general form
             //  alone was 360 of the ~650 instructions of a trip, and the trip is issue bound; same values to rounding)
             int form;
-            if (pi < np) window_table_selected(g, sl, xcur, b, form);
+            if (pi < np) window_table_selected(gl, 0, xcur, b, form);
             if (squared) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) b[k] *= b[k];
