@@ -235,8 +235,8 @@ def bench_small(capi, dev, stream, steps, nd, nod, m, weighted, label):
 def bench_c5_fit(capi, dev, stream):
     """BASELINE config 5, fit half, AT ITS OWN SIZE on one GPU (round 6): 4-D, 32^4 = 1 048 576 columns, 1e7 weighted scattered
     points, xtrap = 1.  No factorisation of that grid fits the device (476 GB of nested-dissection panels, band 851 GB), so the
-    plan takes the iterative solve by itself (csrc/pcg.hip: conjugate gradients on the rows, separable preconditioner, inside the
-    same refinement against the rows).  The largest grid that still has a factorisation, 28^4, is timed beside it."""
+    plan takes the iterative solve by itself (csrc/pcg.hip: conjugate gradients on the rows, separable + block-Jacobi preconditioner,
+    inside the same refinement against the rows).  The largest grid that still has a factorisation, 28^4, is timed beside it."""
     import torch
     nd, nod, m = 4, 32, 10_000_000
     nodes = [nod] * nd
@@ -280,7 +280,7 @@ def bench_c5_fit(capi, dev, stream):
     except Exception:
         pass
     ms_it = out["ms_per_iteration"]
-    out["roofline"] = {"bound": "hbm", "kernel": "one iteration of the solve (rows4_tile_kernel = 58 % of it: VALU-issue bound, not HBM bound)",
+    out["roofline"] = {"bound": "hbm", "kernel": "one iteration of the solve (rows4_tile_kernel = half of it: issue bound -- window tables + f64 matrix-pipe products --, not HBM bound)",
                        "achieved": alg / (ms_it * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "algorithmic_bytes_per_iteration": alg, "traffic": traffic}
     torch.cuda.empty_cache()
@@ -424,7 +424,7 @@ def c5_traffic():
 def bench_c5_eval(capi, dev, stream):
     """BASELINE config 5, evaluation half at full size: 4-D 32^4 coefficients (8 MB), 1e8 queries of the
     seeded stream, splfe and two splde derivative patterns; real64 resident data.  (The fit half of
-    config 5: bench_c5_fit -- 28^4 on one GPU; 32^4 itself is the 8-GPU route's.)"""
+    config 5: bench_c5_fit -- 32^4 on one GPU by the iterative solve, 28^4 by nested dissection beside it.)"""
     import torch
     nd, nod, nq = 4, 32, 100_000_000
     nodes, lo, hi = [nod] * nd, [0.0] * nd, [1.0] * nd
