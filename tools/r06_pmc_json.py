@@ -79,6 +79,13 @@ try:
     pcg = kernels([os.path.join(src, f) for f in ("c5_pcg_fetch.counters.csv", "c5_pcg_write.counters.csv")])
     tile = next(v for k, v in pcg.items() if k.startswith("rows4_tile_kernel"))
     per_iter = sum(v.get("hbm_bytes", 0.0) * v["launches"] for v in pcg.values()) / max(tile["launches"], 1)
+    try:        # issue counters of the tile kernel (own pass): vector instructions per point, the matrix pipe's share of the SIMD cycles
+        vv = kernels([os.path.join(src, "c5_pcg_valu.counters.csv")])
+        tv = next(v for k, v in vv.items() if k.startswith("rows4_tile_kernel"))
+        tile["valu_wave_instructions_per_point"] = tv["SQ_INSTS_VALU"] / 1e7
+        tile.update({c: tv[c] for c in ("SQ_INSTS_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_LDS") if c in tv})
+    except Exception as exc:
+        print("no issue counters of the tile kernel:", exc)
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; tools/r06_profiles.sh) of ONE fit of BASELINE config 5 at its own size "
                          "(tools/c2_profile.py 4 32 10000000: 4-D, 32^4 nodes, 1e7 weighted points, iterative solve); means per launch",
                "correction": corr,

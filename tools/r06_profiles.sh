@@ -26,7 +26,8 @@ ls gpurun_out/r06
 # config 5's fit at its own size by the iterative solve (round 6): kernel stats and the traffic of its kernels (one fit each)
 export C2_WARM=0 C2_REPS=1
 bash tools/prof.sh r06/c5_pcg_stats python3 /root/repo/tools/c2_profile.py 4 32 10000000 > /dev/null
-bash tools/pmc.sh r06/c5_pcg_fetch "FETCH_SIZE" "rows4|tri_pass|mode_product|dot_|update_" python3 /root/repo/tools/c2_profile.py 4 32 10000000 > /dev/null
-bash tools/pmc.sh r06/c5_pcg_write "WRITE_SIZE" "rows4|tri_pass|mode_product|dot_|update_" python3 /root/repo/tools/c2_profile.py 4 32 10000000 > /dev/null
+bash tools/pmc.sh r06/c5_pcg_fetch "FETCH_SIZE" "rows4|tri_pass|mode_p|bj_apply|dot_|update_" python3 /root/repo/tools/c2_profile.py 4 32 10000000 > /dev/null
+bash tools/pmc.sh r06/c5_pcg_write "WRITE_SIZE" "rows4|tri_pass|mode_p|bj_apply|dot_|update_" python3 /root/repo/tools/c2_profile.py 4 32 10000000 > /dev/null
+bash tools/pmc.sh r06/c5_pcg_valu "SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS" "rows4_tile" python3 /root/repo/tools/c2_profile.py 4 32 10000000 > /dev/null
 echo "c5 pcg done"
 ls gpurun_out/r06
