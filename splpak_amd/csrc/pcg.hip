@@ -769,6 +769,7 @@ struct PcgState {
     void *bj_jobs = nullptr;
     int *bj_info = nullptr;
     bool bj_have = false, bj_ready = false;
+    bool singular = false;                                 // this fit: a box of the assembled N failed the factorisations' pivot test
     double *mband = nullptr;                               // per dimension [nodes][7]: the 1-D mass matrix's bands (boxes without assembled N)
     MassBands mbands{};
     double *ddiag = nullptr;                               // diagonal of the data rows' Gram matrix (the same)
@@ -809,6 +810,7 @@ void pcg_destroy(PcgState *s)
 size_t pcg_bytes(const PcgState *s) { return s ? s->bytes : 0; }
 
 double *pcg_scratch(PcgState *s, int which) { return which == 0 ? s->t1 : s->t2; }
+bool pcg_singular(const PcgState *s) { return s->singular; }
 
 void pcg_stats(const PcgState *s, double *out6)
 {
@@ -1003,6 +1005,7 @@ hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, h
     s->solves = 0;
     s->failed = false;
     s->bj_ready = false;
+    s->singular = false;
     if (s->bj_have && (p->nst || (p->rows_only && s->ddiag))) {
         const double inf = 1.0e300;
         hipError_t e = hipMemsetAsync(s->bj_info, 0, 2 * sizeof(int), st);
@@ -1043,6 +1046,7 @@ hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, h
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return e;
         s->bj_ready = hinfo == 0;            // (a box that is not positive definite: the separable preconditioner alone)
+        s->singular = hinfo != 0 && p->nst != nullptr;      // (an exact principal submatrix of N: N is not positive definite either)
         if (splpak::opt_get("SPLPAK_DEBUG")) fprintf(stderr, "[splpak pcg] %d boxes of N factored%s\n", s->bg.nb, s->bj_ready ? "" : ": one is not positive definite, dropped");
     }
     return hipGetLastError();

@@ -721,6 +721,22 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     }
     if (try_iteration) {
         SPLPAK_HIP_TRY(pcg_prepare(p, p->pcg, hs[SC_COUNT + SC_SUMW2], smooth, st), SPLPAK_E_NODEVICE);
+        if (pcg_singular(p->pcg)) {
+            // A box taken out of the ASSEMBLED normal equations -- a principal submatrix of N -- is not positive definite by the pivot
+            // test of the factorisations: neither is N (a column without data and, with xtrap = 0, without a constraint row; the
+            // reference's "system is singular", suprls 34 -> 107).  The iteration would still run to a minimiser with arbitrary
+            // values on what the rows do not see: the factorisation gets to say 107, or the plan that has none says it here
+            // (randomised sweep tools/pcg/fuzz_pcg.py: 1-D, 150 nodes, 361 points, xtrap = 0)
+            if (p->solver_mode == 2) {
+                SPLPAK_HIP_TRY(hipMemsetAsync(coef_dev, 0, sizeof(double) * (size_t)g.ncol, st), SPLPAK_E_NODEVICE);
+                SPLPAK_HIP_TRY(hipStreamSynchronize(st), SPLPAK_E_NODEVICE);
+                set_error("normal equations not positive definite (suprls 34): a block of them failed the pivot test");
+                return 107;
+            }
+            try_iteration = false;
+        }
+    }
+    if (try_iteration) {
         const double tol_first = splpak::opt_get("SPLPAK_PCG_TOL1") ? atof(splpak::opt_get("SPLPAK_PCG_TOL1")) : 1e-11;
         const double tol_next = splpak::opt_get("SPLPAK_PCG_TOL2") ? atof(splpak::opt_get("SPLPAK_PCG_TOL2")) : 1e-3;
         const int r = solve_and_refine([&](double *v, bool first) -> int { return pcg_solve(p, p->pcg, v, first ? tol_first : tol_next, smooth, st); });

@@ -174,6 +174,7 @@ void pcg_destroy(PcgState *s);
 size_t pcg_bytes(const PcgState *s);
 void pcg_stats(const PcgState *s, double *out6);
 double *pcg_scratch(PcgState *s, int which);      // two vectors of ncol doubles, free between solves
+bool pcg_singular(const PcgState *s);             // after pcg_prepare: a box of the ASSEMBLED normal equations is not positive definite
 hipError_t pcg_sum_w2(splpak_plan *p, hipStream_t st);
 hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, hipStream_t st);
 int pcg_solve(splpak_plan *p, PcgState *s, double *v, double tol, bool smooth, hipStream_t st);

@@ -97,6 +97,32 @@ def test_known_bad_regime_goes_straight_to_the_factorisation():
         assert _iteration_answered(info) == expect_iteration, (name, info[1] / np.prod(inp["nodes"]))
 
 
+@pytest.mark.gpu
+def test_singular_normal_equations_are_107_from_the_iteration_too():
+    """xtrap = 0 and nodes without any data: the normal equations have zero columns, the reference's "system is singular" (suprls 34 ->
+    107, src/splpak.F90:1662-1667) and the factorisations' failed pivot test.  The iteration would run on to a minimiser that is
+    arbitrary where the rows see nothing; since a box of the assembled normal equations fails the same pivot test, it says 107 as
+    well -- alone and in front of the factorisation (found by tools/pcg/fuzz_pcg.py, seed 9 trial 99)."""
+    rng = np.random.default_rng(3)
+    nodes, m = [150], 361
+    x = np.concatenate([0.45 * rng.random(m // 2), 0.55 + 0.45 * rng.random(m - m // 2)])[:, None]      # nothing in [0.45, 0.55]
+    y = np.sin(3.0 * x[:, 0])
+    w = 0.5 + rng.random(m)
+    inp = dict(ndim=1, xdata=x, ydata=y, wdata=w, xmin=[0.0], xmax=[1.0], nodes=nodes, xtrap=0.0)
+    for solver in ("direct", "pcg", "pcg+direct"):
+        c, rc, _, info = _fit_env(inp, {"SPLPAK_SOLVER": solver, "SPLPAK_PCG_ALWAYS": "1"})
+        assert rc == 107, solver
+        assert "suprls 34" in capi.last_error(), (solver, capi.last_error())
+    # with constraint rows the same data are a regular problem for all three
+    inp["xtrap"] = 1.0
+    ref = None
+    for solver in ("direct", "pcg+direct"):
+        c, rc, _, info = _fit_env(inp, {"SPLPAK_SOLVER": solver, "SPLPAK_PCG_ALWAYS": "1"})
+        assert rc == 0 and info[9] < 1e-9, solver
+        ref = c if ref is None else ref
+        assert relmax(c, ref) < COEF_TOL
+
+
 def _device_points(nd, m):
     import torch
     dev = torch.device("cuda", 0)
