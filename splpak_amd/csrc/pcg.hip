@@ -1052,7 +1052,8 @@ hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, h
     return hipGetLastError();
 }
 
-// z = M^-1 r
+// z = M^-1 r.  (The boxes' term on a stream of its own beside the separable part's mode products was tried -- the way the constraint passes
+// run beside the rows' tile kernel, rowsop.hip -- and bought nothing: 0.281 s per fit at 32^4 either way; both parts live on the memory system.)
 static hipError_t pcg_precondition(PcgState *s, const double *r, double *z, hipStream_t st)
 {
     const Grid &g = s->g;

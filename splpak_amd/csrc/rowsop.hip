@@ -506,12 +506,20 @@ struct RowsOp {
     int nfwd[MAXD] = {0, 0, 0, 0}, nbwd[MAXD] = {0, 0, 0, 0};
     size_t bytes = 0;
     bool no_pairs = false;            // A/B: the passes of the constraint rows one dimension at a time
+    // the constraint rows' passes run BESIDE the data rows' tile kernel, on a stream of their own: the tile kernel is bound by the
+    // issue of vector / matrix instructions and leaves wave slots and the memory system to them (0.26 of an iteration's 1.29 ms at
+    // 32^4 were these passes behind it).  NULL: one stream (SPLPAK_ROWS_ONE_STREAM, or the stream could not be had)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::vector<void *> owned;
 };
 
 void rowsop_destroy(RowsOp *r)
 {
     if (!r) return;
+    if (r->side) { (void)hipStreamSynchronize(r->side); (void)hipStreamDestroy(r->side); }
+    if (r->ev_in) (void)hipEventDestroy(r->ev_in);
+    if (r->ev_out) (void)hipEventDestroy(r->ev_out);
     for (void *q : r->owned) (void)hipFree(q);
     delete r;
 }
@@ -548,6 +556,14 @@ int rowsop_create(const Grid &g, RowsOp **out)
         rowsop_destroy(r);
         set_error("rows operator: device allocation failed");
         return SPLPAK_E_NOMEM;
+    }
+    if (!splpak::opt_get("SPLPAK_ROWS_ONE_STREAM")) {
+        if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&r->ev_out, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (r->side) (void)hipStreamDestroy(r->side);
+            r->side = nullptr;
+        }
     }
     int base = 0;
     for (int d = 0; d < g.ndim; ++d) { r->ctbase[d] = base; base += 9 * g.nodes[d]; }
@@ -609,9 +625,15 @@ int rowsop_create(const Grid &g, RowsOp **out)
 static hipError_t rowsop_apply_t(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
                                  const double *ctab, bool constraints, bool abs_factors, double *rho, hipStream_t st)
 {
-    hipLaunchKernelGGL(rows4_tile_kernel, dim3((unsigned)r->ntiles), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], (const int *)rows.offset,
+    hipStream_t st_rows = st;
+    if (constraints && r->side) {             // (the vector is ready on `st`; the passes' arrays were last read by the previous gather, on `st` too)
+        (void)hipEventRecord(r->ev_in, st_rows);
+        (void)hipStreamWaitEvent(r->side, r->ev_in, 0);
+    }
+    hipLaunchKernelGGL(rows4_tile_kernel, dim3((unsigned)r->ntiles), dim3(256), 0, st_rows, g, r->nt[0], r->nt[1], r->nt[2], (const int *)rows.offset,
                        (const double *)rows.xs, (const double *)rows.ys, (const double *)rows.ws, rows.cap, xvec, r->partial, 0);
     const double *cterm = nullptr;
+    if (constraints && r->side) st = r->side;
     if (constraints) {
         const int D = g.ndim;
         const dim3 bl(256);
@@ -647,6 +669,11 @@ static hipError_t rowsop_apply_t(const Grid &g, RowsOp *r, const SortScratch &ro
             which ^= 1;
         }
         cterm = in;
+    }
+    if (st != st_rows) {
+        (void)hipEventRecord(r->ev_out, st);
+        st = st_rows;
+        (void)hipStreamWaitEvent(st, r->ev_out, 0);
     }
     hipLaunchKernelGGL(rows4_gather_kernel<false>, dim3((unsigned)((g.ncol + 255) / 256)), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], r->nt[3],
                        (const double *)r->partial, cterm, rho);
