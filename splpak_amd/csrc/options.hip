@@ -70,6 +70,7 @@ const Known KNOWN[] = {
     {"SPLPAK_PCG_ASSEMBLE", 0},
     {"SPLPAK_PCG_BLOCKS_F64", 0},
     {"SPLPAK_PCG_BLOCKS_UNPACKED", 0},
+    {"SPLPAK_PCG_EAGER", 0},
     {"SPLPAK_PCG_MAXIT", 1},
     {"SPLPAK_PCG_NO_BLOCKS", 0},
     {"SPLPAK_PCG_NO_PAIRS", 0},

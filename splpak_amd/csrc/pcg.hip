@@ -811,6 +811,7 @@ size_t pcg_bytes(const PcgState *s) { return s ? s->bytes : 0; }
 
 double *pcg_scratch(PcgState *s, int which) { return which == 0 ? s->t1 : s->t2; }
 bool pcg_singular(const PcgState *s) { return s->singular; }
+bool pcg_boxes_from_rows(const PcgState *s) { return s->bj_have && s->ddiag != nullptr; }
 
 void pcg_stats(const PcgState *s, double *out6)
 {
@@ -911,7 +912,11 @@ int pcg_attach(splpak_plan *p, PcgState **out)
          pcg_alloc(s, &s->mom, 2);
     ok = ok && pcg_alloc(s, &s->mband, (size_t)mbtot) && hip_ok(hipMemcpy(s->mband, hmband.data(), sizeof(double) * (size_t)mbtot, hipMemcpyHostToDevice), "pcg: upload");
     for (int k = 0; k < MAXD; ++k) s->mbands.m[k] = s->mband + (k < g.ndim ? mboffs[k] : 0);
-    if (ok && p->rows_only) ok = pcg_alloc(s, &s->ddiag, n);
+    // (also for the plans that have a factorisation behind the iteration: their fits assemble nothing until it is needed, plan.hip "lazy")
+    if (ok && g.ndim == 4 && p->rowsop && p->ctab && (p->rows_only || p->solver_mode == 3)) {
+        if (p->rows_only) ok = pcg_alloc(s, &s->ddiag, n);
+        else if (!pcg_alloc(s, &s->ddiag, n)) { (void)hipGetLastError(); s->ddiag = nullptr; }
+    }
     // Block-Jacobi component (round 6): the diagonal blocks of the assembled N over aligned boxes of nodes (4-D: 4^4, 3-D: 6^3,
     // 2-D: 16^2, 1-D: 256 nodes -- all at most 256, the block size of the diagonal-block kernels of the fronts), factored per fit
     // and ADDED to the separable preconditioner: M^-1 = V diag^-1 V^T + sum_boxes R^T (N_box)^-1 R.  The separable part knows the
@@ -984,8 +989,8 @@ hipError_t pcg_sum_w2(splpak_plan *p, hipStream_t st)
 
 // Per fit, after the assembly: the two moments of the preconditioner (density of w^2: sumw2 as reduced over the ranks; mean squared
 // constraint weight: from dcw / spf, which every rank of a fit that iterates computes) and its diagonal.
-hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, hipStream_t st)
-{
+hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, bool from_rows, hipStream_t st)
+{   // from_rows: the normal equations of this fit are not assembled (boxes = scaled mass + exact constraint part, bj_build_kernel)
     const Grid &g = p->g;
     double lam = 0.0;
     if (smooth) {
@@ -1006,12 +1011,12 @@ hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, h
     s->failed = false;
     s->bj_ready = false;
     s->singular = false;
-    if (s->bj_have && (p->nst || (p->rows_only && s->ddiag))) {
+    if (s->bj_have && ((p->nst && !from_rows) || (from_rows && s->ddiag))) {
         const double inf = 1.0e300;
         hipError_t e = hipMemsetAsync(s->bj_info, 0, 2 * sizeof(int), st);
         if (e == hipSuccess) e = hipMemcpyAsync(s->bj_scal, &inf, sizeof(double), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return e;
-        if (p->nst)
+        if (!from_rows)
             hipLaunchKernelGGL(bj_extract_kernel, dim3((unsigned)s->bg.nb), dim3(256), 0, st, g, s->bg, (const double *)p->nst, s->bj_blocks);
         else {
             // no assembled N: the diagonal of the data rows' Gram matrix from the rows (this rank's points; summed over the ranks through the
@@ -1046,7 +1051,7 @@ hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, h
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return e;
         s->bj_ready = hinfo == 0;            // (a box that is not positive definite: the separable preconditioner alone)
-        s->singular = hinfo != 0 && p->nst != nullptr;      // (an exact principal submatrix of N: N is not positive definite either)
+        s->singular = hinfo != 0 && !from_rows;      // (an exact principal submatrix of N: N is not positive definite either)
         if (splpak::opt_get("SPLPAK_DEBUG")) fprintf(stderr, "[splpak pcg] %d boxes of N factored%s\n", s->bg.nb, s->bj_ready ? "" : ": one is not positive definite, dropped");
     }
     return hipGetLastError();

@@ -355,13 +355,14 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
         return SPLPAK_E_NODEVICE;
     }
     if (p->ctab) {
-        const int rc = rowsop_create(g, &p->rowsop);
+        const int rc = rowsop_create(g, !direct, &p->rowsop);
         if (rc != 0) {
             splpak_plan_destroy(p);
             return rc;
         }
     }
     if (direct) twoend_attach(p);
+    p->solver_mode = !direct ? 2 : (mode == 3 ? 3 : 0);
     if (!direct || mode == 3) {
         const int rc = pcg_attach(p, &p->pcg);
         if (rc != 0) {
@@ -369,7 +370,6 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
             return rc;
         }
     }
-    p->solver_mode = !direct ? 2 : (mode == 3 ? 3 : 0);
     *plan = p;
     return 0;
 }
@@ -583,7 +583,16 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         for (hipEvent_t &e : p->evStage)
             if (!e) SPLPAK_HIP_TRY(hipEventCreate(&e), SPLPAK_E_NODEVICE);
     auto stamp = [&](int i) { if (stamps) (void)hipEventRecord(p->evStage[i], st); };
-    SPLPAK_HIP_TRY(hipMemsetAsync(p->comm, 0, sizeof(double) * (size_t)(p->lenG + p->lenH), st), SPLPAK_E_NODEVICE);
+    // A 4-D plan that has the iteration IN FRONT of a factorisation assembles the normal equations only when the factorisation is
+    // going to need them (round 6): the iteration applies the rows, its boxes are built from the rows (bj_build_kernel), and whether
+    // it is tried at all is known from the histogram -- so the fit starts as an iteration-only plan's does (3 ms) and falls back to
+    // the assembly (62 ms at 24^4: 40 % of such a fit) where the iteration is not tried or gives up.  One rank, no reduction hook.
+    const bool lazy = !p->rows_only && p->pcg && p->solver_mode == 3 && p->rowsop && p->ctab && smooth && p->world <= 1 && !p->ar &&
+                      pcg_boxes_from_rows(p->pcg) && !splpak::opt_get("SPLPAK_PCG_EAGER");
+    {   // (lazy: the half stencil is cleared when -- if -- it is assembled)
+        const long long skip = lazy ? (long long)(p->rhs - p->comm) : 0;
+        SPLPAK_HIP_TRY(hipMemsetAsync(p->comm + skip, 0, sizeof(double) * (size_t)(p->lenG + p->lenH - skip), st), SPLPAK_E_NODEVICE);
+    }
     // (after the memset: the early clear of the factor arena that prefit starts on another stream is ordered behind this point of
     //  `st`, and the two used to share the memory system -- 0.07 ms of clearing took 0.7 ms beside it)
     if (p->prefit_fn) SPLPAK_HIP_TRY(p->prefit_fn(p, st, p->fn_user), SPLPAK_E_NODEVICE);
@@ -591,7 +600,17 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     SPLPAK_HIP_TRY(launch_bin_points(g, ndata, x, l1xdat, y, w, p->s, p->scalH, st), SPLPAK_E_NODEVICE);
     if (p->pcg) SPLPAK_HIP_TRY(pcg_sum_w2(p, st), SPLPAK_E_NODEVICE);       // (rides the histogram's all-reduce)
     stamp(1);
-    if (p->rows_only) {
+    bool rows_fit = p->rows_only || lazy;              // the normal equations are not assembled (yet)
+    auto assemble_now = [&]() -> int {                 // (lazy fits: everything the eager order would have written; same kernels, same bits)
+        SPLPAK_HIP_TRY(hipMemsetAsync(p->comm, 0, sizeof(double) * (size_t)(p->lenG + p->lenH), st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_gram(g, p->s, p->gscratch, p->gscratch_doubles, smooth, p->nst, p->rhs, p->hist, p->scalH, st), SPLPAK_E_NODEVICE);
+        // (the weights of the constraint rows again, from THIS histogram: the rows' one differs from it in the last bits)
+        SPLPAK_HIP_TRY(launch_sparse_mark(g, p->hist, p->scalH, p->xtrap, p->dcw, p->spf, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(launch_constraint_rows(g, p->dcw, p->spf, p->ctab, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
+        rows_fit = false;
+        return 0;
+    };
+    if (rows_fit) {
         // the histogram from the rows (tile by tile); the right-hand side follows below, when the reduced histogram has gone
         if (smooth) {
             SPLPAK_HIP_TRY(rowsop_histogram(g, p->rowsop, p->s, p->hist, st), SPLPAK_E_NODEVICE);
@@ -619,7 +638,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     if (smooth && (p->rank == 0 || p->pcg))      // (every rank of an iterating fit: the preconditioner's second moment)
         SPLPAK_HIP_TRY(launch_sparse_mark(g, p->hist, p->scalH, p->xtrap, p->dcw, p->spf, st), SPLPAK_E_NODEVICE);
     if (smooth && p->rank == 0) {
-        if (p->rows_only) SPLPAK_HIP_TRY(launch_count_sparse(g, p->spf, p->scalG, st), SPLPAK_E_NODEVICE);      // (the rows are only counted)
+        if (rows_fit) SPLPAK_HIP_TRY(launch_count_sparse(g, p->spf, p->scalG, st), SPLPAK_E_NODEVICE);      // (the rows are only counted)
         else SPLPAK_HIP_TRY(launch_constraint_rows(g, p->dcw, p->spf, p->ctab, p->nst, p->scalG, st), SPLPAK_E_NODEVICE);
     }
     stamp(3);
@@ -719,8 +738,10 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
             if (splpak::opt_get("SPLPAK_DEBUG")) fprintf(stderr, "[splpak] %.2f constraint rows per column: the factorisation without an attempt of the iteration\n", rpc);
         }
     }
+    if (lazy && !try_iteration)
+        if (int r = assemble_now()) return r;
     if (try_iteration) {
-        SPLPAK_HIP_TRY(pcg_prepare(p, p->pcg, hs[SC_COUNT + SC_SUMW2], smooth, st), SPLPAK_E_NODEVICE);
+        SPLPAK_HIP_TRY(pcg_prepare(p, p->pcg, hs[SC_COUNT + SC_SUMW2], smooth, rows_fit, st), SPLPAK_E_NODEVICE);
         if (pcg_singular(p->pcg)) {
             // A box taken out of the ASSEMBLED normal equations -- a principal submatrix of N -- is not positive definite by the pivot
             // test of the factorisations: neither is N (a column without data and, with xtrap = 0, without a constraint row; the
@@ -760,6 +781,8 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     }
 
     // ---- factorisation --------------------------------------------------
+    if (!solved && rows_fit && lazy)
+        if (int r = assemble_now()) return r;
     if (!solved) {
         SPLPAK_HIP_TRY(hipMemsetAsync(p->info, 0, 2 * sizeof(int), st), SPLPAK_E_NODEVICE);
         SPLPAK_HIP_TRY(hipMemcpyAsync(p->small + 2, &inf, sizeof(double), hipMemcpyHostToDevice, st), SPLPAK_E_NODEVICE);
@@ -808,7 +831,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         // the backward error's denominators (|N| |x| + |rhs|: a pass over the half stencil) need the coefficients only; into the
         // solves' scratch vector.  (On a stream of their own beside the residual pass they gained nothing -- the two kernels
         // slowed each other down by what the overlap saved -- and one more stream per plan is not free: round 5)
-        if (p->rows_only) {
+        if (rows_fit) {
             // from the rows: |A|^T W^2 |A| |x| + |C|^T |C| |x| + |rhs| (this rank's points; the residual's all-reduce below does not
             // carry it -- a sharded rows-only fit normalises by its own shard's terms + the constraint rows on rank 0, a lower bound
             // of the sum, i.e. a pessimistic backward error)

@@ -148,7 +148,7 @@ int plan_allreduce(splpak_plan *p, double *buf, long long count, hipStream_t st)
 void twoend_attach(splpak_plan *p);
 void twoend_detach(splpak_plan *p);
 // rowsop.hip
-int rowsop_create(const Grid &g, RowsOp **out);
+int rowsop_create(const Grid &g, bool side_stream, RowsOp **out);
 void rowsop_destroy(RowsOp *r);
 size_t rowsop_bytes(const RowsOp *r);
 hipError_t rowsop_apply(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
@@ -176,7 +176,8 @@ void pcg_stats(const PcgState *s, double *out6);
 double *pcg_scratch(PcgState *s, int which);      // two vectors of ncol doubles, free between solves
 bool pcg_singular(const PcgState *s);             // after pcg_prepare: a box of the ASSEMBLED normal equations is not positive definite
 hipError_t pcg_sum_w2(splpak_plan *p, hipStream_t st);
-hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, hipStream_t st);
+hipError_t pcg_prepare(splpak_plan *p, PcgState *s, double sumw2, bool smooth, bool from_rows, hipStream_t st);
+bool pcg_boxes_from_rows(const PcgState *s);      // the state can build its boxes from the rows (4-D: the fit may leave the normal equations unassembled)
 int pcg_solve(splpak_plan *p, PcgState *s, double *v, double tol, bool smooth, hipStream_t st);
 int twoend_debug_solve(int n, int halfbw, const double *a_lower, const double *bvec, double *x_out, int *hinfo_out);
 }  // namespace splpak

@@ -530,8 +530,10 @@ size_t rowsop_bytes(const RowsOp *r) { return r ? r->bytes : 0; }
 // was built and measured in round 6: 22.4 ms of solves + refinement per fit at config 3 against 22.5 ms with the wave-per-cell pass of
 // assemble.hip, and 59.6 against 47.9 ms at 1e8 points (440 points per cell: the wave-per-cell pass takes 64 points per trip, the
 // tile kernel 16).  Removed again.)
-int rowsop_create(const Grid &g, RowsOp **out)
-{
+int rowsop_create(const Grid &g, bool side_stream, RowsOp **out)
+{   // side_stream: the plan has no factorisation.  (Beside a nested-dissection plan's streams -- one of them bound to eight reserved CUs --
+    //  the operator's own stream made the iteration SLOWER: 181 against 112 ms per fit at 24^4; the runtime maps streams onto a few
+    //  hardware queues, and a queue carries its CU mask.)
     *out = nullptr;
     const char *sw = splpak::opt_get("SPLPAK_ROWS_TILES");           // A/B switch: 0 = the cell-by-cell passes
     if (g.ndim != 4 || (sw && atoi(sw) == 0)) return 0;
@@ -557,7 +559,7 @@ int rowsop_create(const Grid &g, RowsOp **out)
         set_error("rows operator: device allocation failed");
         return SPLPAK_E_NOMEM;
     }
-    if (!splpak::opt_get("SPLPAK_ROWS_ONE_STREAM")) {
+    if (side_stream && !splpak::opt_get("SPLPAK_ROWS_ONE_STREAM")) {
         if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&r->ev_out, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();

@@ -123,6 +123,49 @@ def test_singular_normal_equations_are_107_from_the_iteration_too():
         assert relmax(c, ref) < COEF_TOL
 
 
+@pytest.mark.gpu
+def test_plans_with_both_solvers_assemble_the_normal_equations_only_for_the_factorisation():
+    """A 4-D plan with the iteration in front of a factorisation starts its fit as an iteration-only plan does -- histogram, right-hand
+    side and boxes from the rows -- and assembles the half stencil only where the factorisation is going to run: the iteration is
+    not tried (the known bad regime) or gave up.  Then the factorisation sees exactly what the eager order (pcg_eager) gives it:
+    same bits as solver = direct.  Where the iteration answers, the two orders agree to rounding (their boxes differ: built from the
+    rows / cut out of the assembled equations)."""
+    nd, nodes = 4, [12] * 4
+    lo, hi = [0.0] * nd, [1.0] * nd
+    # (a) the iteration answers: 2.5 constraint rows per column
+    x, y, w, st = _device_points(nd, 158122)
+    ref, e0, i0, _, _, _ = _plan_fit(nd, nodes, lo, hi, 1.0, x, y, w, st, "direct")
+    assert e0 == 0
+    got = {}
+    for name, env in (("lazy", {}), ("eager", {"SPLPAK_PCG_EAGER": "1"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            c, e, info, fac, ps, dt = _plan_fit(nd, nodes, lo, hi, 1.0, x, y, w, st, "pcg+direct")
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        assert e == 0 and ps["iterations"] > 0 and relmax(c, ref) < COEF_TOL and info[9] < 1e-9, name
+        assert info[0] == i0[0] and info[1] == i0[1] and abs(info[8] - i0[8]) <= 1e-9 * i0[8], name
+        got[name] = (c, info[5], ps["iterations"])
+    print(f"12^4: assembly {1e3 * got['lazy'][1]:.2f} ms (nothing assembled) against {1e3 * got['eager'][1]:.2f} ms; iterations {got['lazy'][2]} / {got['eager'][2]}")
+    assert relmax(got["lazy"][0], got["eager"][0]) < 1e-12
+    assert got["lazy"][1] < got["eager"][1]
+    # (b) the bad regime (1.0 constraint rows per column): no attempt, the assembly follows, the factorisation answers -- the bits of solver = direct
+    x, y, w, st = _device_points(nd, 366025 * 2)
+    ref, e0, i0, _, _, _ = _plan_fit(nd, nodes, lo, hi, 1.0, x, y, w, st, "direct")
+    c, e, info, fac, ps, dt = _plan_fit(nd, nodes, lo, hi, 1.0, x, y, w, st, "pcg+direct")
+    assert e0 == 0 and e == 0 and 0.0 < info[1] / 12 ** 4 < 1.6, info[1] / 12 ** 4
+    assert ps["iterations"] == 0 and np.array_equal(c, ref)
+    # (c) the iteration is tried there all the same (pcg_always), gives up or not: the answer stays within the bar
+    os.environ["SPLPAK_PCG_ALWAYS"] = "1"
+    try:
+        c, e, info, fac, ps, dt = _plan_fit(nd, nodes, lo, hi, 1.0, x, y, w, st, "pcg+direct")
+    finally:
+        os.environ.pop("SPLPAK_PCG_ALWAYS", None)
+    assert e == 0 and ps["iterations"] > 0 and relmax(c, ref) < COEF_TOL
+
+
 def _device_points(nd, m):
     import torch
     dev = torch.device("cuda", 0)
