@@ -8,14 +8,16 @@
 // (profiles/r06_c5_pcg_first_kernel_stats.csv).  Here:
 //
 //   data rows (src/splpak.F90:788-855)   a workgroup owns a TILE of 3 x 3 x 3 x 2 cells: the 6 x 6 x 6 x 5 coefficients it touches sit in LDS once,
-//       each of its four waves takes every fourth cell (points of a cell in their sorted order: lanes = (point, slab) for the
-//       factorised window sum, lanes = window function for the transposed product), adds the cell's 256 shares into ITS OWN LDS
+//       each of its four waves takes every fourth cell (points of a cell in their sorted order, sixteen per trip: lanes = (point,
+//       dimension) for the window tables, then both products of the trip -- the window of coefficients times the points' factor
+//       tables and its transpose -- as small matrix products on the f64 matrix pipe), adds the cell's 256 shares into ITS OWN LDS
 //       image of the tile's nodes, and the four images are added in a fixed order into the tile's partial sums: 104 MB instead of
 //       1.45 GB, coalesced, no atomics -- the bits do not depend on the schedule.
 //   constraint rows (:921-1046)   every row is a tensor product of tridiagonal node matrices (values / first / second derivative of
 //       the three basis functions around a node; boundary nodes take the first derivative, :998) times a node weight: C x and
 //       C^T (C x) are d + d passes of tridiagonal mode products over arrays that share their prefixes (3, 6, 10, 10 arrays
 //       forward, 10, 6, 3, 1 back in 4-D) -- 0.5 GB of cache traffic instead of 81 entries x 10 rows x 4 table look-ups per node.
+//       In a plan without a factorisation these passes run beside the tile kernel, on a stream of the operator's own.
 //   gather   node i adds the <= 16 tile partials that hold it (tile order) and subtracts the constraint term.
 #include "plan.hpp"
 #include "basis.hpp"
