@@ -2447,6 +2447,12 @@ hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xv
     return hipGetLastError();
 }
 
+hipError_t launch_sum_fixed(const double *v, long long n, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(sum_fixed_kernel, dim3(1), dim3(1024), 0, st, v, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_backward_denominators(const Grid &g, const double *nst, const double *xvec, const double *rhs, double *den, hipStream_t st)
 {
     dim3 gr((unsigned)((g.ncol + 255) / 256)), bl(256);           // (256 rows per workgroup: the kernel's tile)

@@ -86,6 +86,7 @@ hipError_t launch_constraint_table(const Grid &g, double *ctab, hipStream_t st);
 // refinement residual rho = A^T W (W y - W A x) [- C^T C x when `constraints`]; rcell: [ncell][nb] scratch,
 // tbuf: [ncol][ndim(ndim+1)/2] scratch; ssq != NULL: also the sum of squared row residuals, from the per-cell / per-node
 // shares in e2buf ([ncell + ncol] scratch) added in a fixed order
+hipError_t launch_sum_fixed(const double *v, long long n, double *out, hipStream_t st);      // out[0] = sum of v[0 .. n) in a fixed order
 hipError_t launch_residual(const Grid &g, const SortScratch &s, const double *xvec, double *rcell,
                            const double *dcw, const unsigned char *spf, const double *ctab, bool constraints,
                            double *tbuf, double *rho, double *ssq, double *e2buf, hipStream_t st);

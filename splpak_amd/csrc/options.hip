@@ -85,6 +85,7 @@ const Known KNOWN[] = {
     {"SPLPAK_RCCL_JOB", 0},
     {"SPLPAK_RCCL_LIB", 1},
     {"SPLPAK_RCCL_ONE_RANK_CALLS", 0},
+    {"SPLPAK_RESIDUAL_CELLS", 0},
     {"SPLPAK_RESIDUAL_STAGED", 0},
     {"SPLPAK_ROWS_ONE_STREAM", 0},
     {"SPLPAK_ROWS_TILES", 0},

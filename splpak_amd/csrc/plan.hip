@@ -842,8 +842,12 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
         hipEvent_t r0 = stamps ? p->evStage[8] : nullptr, r1 = stamps ? p->evStage[9] : nullptr;   // (created with the other stage events)
         if (r0 && r1) (void)hipEventRecord(r0, st);
-        SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, p->ctab, smooth && p->rank == 0,
-                                       p->tbuf, p->rho, scalR, p->e2buf, st), SPLPAK_E_NODEVICE);
+        if (p->rowsop && p->ctab && !splpak::opt_get("SPLPAK_RESIDUAL_CELLS"))      // (4-D: tile by tile, as the refinement's passes; 8.3 -> 1 ms at 32^4)
+            SPLPAK_HIP_TRY(rowsop_residual(g, p->rowsop, p->s, p->xvec, p->dcw, p->spf, p->ctab, smooth && p->rank == 0, p->rho, scalR, p->e2buf, st),
+                           SPLPAK_E_NODEVICE);
+        else
+            SPLPAK_HIP_TRY(launch_residual(g, p->s, p->xvec, p->rcell, p->dcw, p->spf, p->ctab, smooth && p->rank == 0,
+                                           p->tbuf, p->rho, scalR, p->e2buf, st), SPLPAK_E_NODEVICE);
         if (r0 && r1) {
             (void)hipEventRecord(r1, st);
             (void)hipEventSynchronize(r1);

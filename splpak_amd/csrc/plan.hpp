@@ -159,6 +159,8 @@ hipError_t rowsop_backward_denominators(const Grid &g, RowsOp *r, const SortScra
                                         const unsigned char *spf, const double *ctab, bool constraints, double *absx, double *tmp, double *den,
                                         hipStream_t st);
 // rho = A^T W (W y - W A x) [- C^T C x] of the plan's binned points (rows.ys == NULL: y = 0), by whichever pass the plan has
+hipError_t rowsop_residual(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
+                           const double *ctab, bool constraints, double *rho, double *ssq, double *e2buf, hipStream_t st);
 inline hipError_t plan_rows_residual(splpak_plan *p, const SortScratch &rows, const double *xvec, bool constraints, double *rho, hipStream_t st)
 {
     if (p->rowsop && p->ctab) return rowsop_apply(p->g, p->rowsop, rows, xvec, p->dcw, p->spf, p->ctab, constraints, rho, st);

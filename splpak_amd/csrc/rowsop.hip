@@ -47,8 +47,9 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ offset, const double *__restrict__ xs,
                   const double *__restrict__ ys, const double *__restrict__ ws, long long cap, const double *__restrict__ xvec,
-                  double *__restrict__ partial, int squared)
-{   // squared != 0: the DIAGONAL of A^T W^2 A instead -- sum over the points of w^2 b_c^2: the tables hold the squares, every point's
+                  double *__restrict__ partial, int squared, double *__restrict__ esq)
+{   // esq != NULL: also esq[tile] = the sum of the squared row residuals of the tile's points (the fit's `reserr`), in a fixed order
+    // squared != 0: the DIAGONAL of A^T W^2 A instead -- sum over the points of w^2 b_c^2: the tables hold the squares, every point's
     // "residual" is w (the boxes of the iterative solve scale their data part by it, pcg.hip)
     __shared__ double pt[TB4];
     __shared__ double acc[4][TB4];
@@ -123,6 +124,7 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     int p0 = lc < NCT ? sld(&cbeg[lc]) : 0;
     issue(lc, p0);
     d4_t racc = {0.0, 0.0, 0.0, 0.0};
+    double esum = 0.0;
     double cw[4] = {0.0, 0.0, 0.0, 0.0};
     bool cell_new = true;
     while (lc < NCT) {
@@ -180,6 +182,7 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
                 if (l15 < np) {
                     const double e = squared ? wcur : wcur * ycur - wcur * tsum;      // row residual w y - (w b) . x  (y = 0: the rows as an operator)
                     we = wcur * e;
+                    esum = fma(e, e, esum);
                 }
                 mywe[l15] = we;
             }
@@ -215,7 +218,13 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
         lc = lcn;
         p0 = p0n;
     }
+    if (esq) {                            // lanes 0 .. 15 of every wave hold shares: a fixed tree over them, then the waves in order
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) esum += __shfl_down(esum, o, 64);
+        if (lane == 0) swe[wave][0] = esum;
+    }
     __syncthreads();
+    if (esq && tid == 0) esq[blockIdx.x] = ((swe[0][0] + swe[1][0]) + swe[2][0]) + swe[3][0];
     double *__restrict__ out = partial + (long long)blockIdx.x * TB4;
     for (int idx = tid; idx < TB4; idx += 256) out[idx] = ((acc[0][idx] + acc[1][idx]) + acc[2][idx]) + acc[3][idx];
 }
@@ -497,6 +506,27 @@ tri_bwd2_kernel(Grid g, int k, int ctb0, int ctb1, PassTable t0, PassTable t1, c
 
 }  // namespace
 
+// share[node] = sum over the node's constraint rows of (row weight x row . x)^2 from the last forward pass's arrays, which hold
+// (row weight)^2 (row . x): the constraint rows' part of the sum of squared residuals (`reserr`), node by node for a fixed-order sum
+struct WeightSel { int w[MAXJOBS]; };
+__global__ void __launch_bounds__(256)
+cons_sq_kernel(long long ncol, int narr, WeightSel ws, const double *__restrict__ pool, const double *__restrict__ dcw,
+               const unsigned char *__restrict__ spf, double *__restrict__ share)
+{
+    const long long node = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (node >= ncol) return;
+    double acc = 0.0;
+    if (spf[node]) {
+        const double dc = dcw[node];
+        for (int j = 0; j < narr; ++j) {
+            const double rw = ws.w[j] == 1 ? dc : 2.0 * dc;
+            const double v = rw != 0.0 ? pool[(long long)j * ncol + node] / rw : 0.0;
+            acc = fma(v, v, acc);
+        }
+    }
+    share[node] = acc;
+}
+
 struct RowsOp {
     int nt[4] = {1, 1, 1, 1};
     long long ntiles = 0;
@@ -627,15 +657,16 @@ int rowsop_create(const Grid &g, bool side_stream, RowsOp **out)
 
 // rho = A^T W (W y - W A x) [- C^T C x]   (rows.ys == NULL: y = 0)
 static hipError_t rowsop_apply_t(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
-                                 const double *ctab, bool constraints, bool abs_factors, double *rho, hipStream_t st)
-{
+                                 const double *ctab, bool constraints, bool abs_factors, double *rho, hipStream_t st,
+                                 double *e2tiles = nullptr, double *e2nodes = nullptr)
+{   // e2tiles [ntiles], e2nodes [ncol] (both or none): the shares of the sum of squared row residuals, data rows by tile, constraint rows by node
     hipStream_t st_rows = st;
     if (constraints && r->side) {             // (the vector is ready on `st`; the passes' arrays were last read by the previous gather, on `st` too)
         (void)hipEventRecord(r->ev_in, st_rows);
         (void)hipStreamWaitEvent(r->side, r->ev_in, 0);
     }
     hipLaunchKernelGGL(rows4_tile_kernel, dim3((unsigned)r->ntiles), dim3(256), 0, st_rows, g, r->nt[0], r->nt[1], r->nt[2], (const int *)rows.offset,
-                       (const double *)rows.xs, (const double *)rows.ys, (const double *)rows.ws, rows.cap, xvec, r->partial, 0);
+                       (const double *)rows.xs, (const double *)rows.ys, (const double *)rows.ws, rows.cap, xvec, r->partial, 0, e2tiles);
     const double *cterm = nullptr;
     if (constraints && r->side) st = r->side;
     if (constraints) {
@@ -667,6 +698,11 @@ static hipError_t rowsop_apply_t(const Grid &g, RowsOp *r, const SortScratch &ro
             which ^= 1;
         }
         for (int k = D - 1; k >= 0 && !pairs; --k) {
+            if (k == D - 1 && e2nodes) {             // (between the forward and the transposed passes: `in` = the weighted row products)
+                WeightSel ws{};
+                for (int j = 0; j < r->nfwd[D - 1]; ++j) ws.w[j] = r->fwd[D - 1].job[j].wsel;
+                hipLaunchKernelGGL(cons_sq_kernel, dim3(gx), bl, 0, st, (long long)g.ncol, r->nfwd[D - 1], ws, in, dcw, spf, e2nodes);
+            }
             if (abs_factors) hipLaunchKernelGGL((tri_pass_kernel<true, true>), dim3(gx, (unsigned)r->nbwd[k]), bl, 0, st, g, k, r->ctbase[k], r->bwd[k], ctab, in, pools[which], dcw, spf);
             else hipLaunchKernelGGL((tri_pass_kernel<true, false>), dim3(gx, (unsigned)r->nbwd[k]), bl, 0, st, g, k, r->ctbase[k], r->bwd[k], ctab, in, pools[which], dcw, spf);
             in = pools[which];
@@ -690,11 +726,27 @@ hipError_t rowsop_apply(const Grid &g, RowsOp *r, const SortScratch &rows, const
     return rowsop_apply_t(g, r, rows, xvec, dcw, spf, ctab, constraints, false, rho, st);
 }
 
+// The same pass with the sum of the squared row residuals (data and constraint rows: the reference's `reserr`^2, suprls :1693) into
+// ssq[0]: e2buf [ncell + ncol] takes the shares -- tiles first, nodes from ncell on -- and one workgroup adds them in a fixed order.
+// (Tiled pairs of passes, the A/B form, leave no array of row products: they take the single passes here.)
+hipError_t rowsop_residual(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, const double *dcw, const unsigned char *spf,
+                           const double *ctab, bool constraints, double *rho, double *ssq, double *e2buf, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(e2buf, 0, sizeof(double) * ((size_t)g.ncell + (size_t)g.ncol), st);
+    if (e != hipSuccess) return e;
+    const bool keep = r->no_pairs;
+    r->no_pairs = true;
+    e = rowsop_apply_t(g, r, rows, xvec, dcw, spf, ctab, constraints, false, rho, st, e2buf, constraints ? e2buf + g.ncell : nullptr);
+    r->no_pairs = keep;
+    if (e != hipSuccess) return e;
+    return launch_sum_fixed(e2buf, (long long)g.ncell + g.ncol, ssq, st);
+}
+
 // diag[i] = sum over the points of w^2 b_i(x)^2: the diagonal of the data rows' Gram matrix (xvec: any vector of ncol doubles, unused)
 hipError_t rowsop_data_diagonal(const Grid &g, RowsOp *r, const SortScratch &rows, const double *xvec, double *diag, hipStream_t st)
 {
     hipLaunchKernelGGL(rows4_tile_kernel, dim3((unsigned)r->ntiles), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], (const int *)rows.offset,
-                       (const double *)rows.xs, (const double *)nullptr, (const double *)rows.ws, rows.cap, xvec, r->partial, 1);
+                       (const double *)rows.xs, (const double *)nullptr, (const double *)rows.ws, rows.cap, xvec, r->partial, 1, (double *)nullptr);
     hipLaunchKernelGGL(rows4_gather_kernel<false>, dim3((unsigned)((g.ncol + 255) / 256)), dim3(256), 0, st, g, r->nt[0], r->nt[1], r->nt[2], r->nt[3],
                        (const double *)r->partial, (const double *)nullptr, diag);
     return hipGetLastError();
