@@ -219,7 +219,12 @@ int splpak::plan_create_dist(int ndim, const int *nodes, const double *xmin, con
         const long long rd = bin_record_doubles(g, max_ndata);
         if (rd > 0) ok = ok && dev_alloc(p, &p->s.rec, (size_t)rd);
     }
-    ok = ok && dev_alloc(p, &p->rcell, (size_t)g.ncell * g.nb);
+    {   // per-cell shares of the residual passes of assemble.hip: 1-D .. 3-D grids; a 4-D grid's passes go tile by tile (rowsop.hip)
+        // and leave this scratch out (1.45 GB at 32^4) unless the A/B switches ask for the cell-by-cell forms
+        const char *rt = splpak::opt_get("SPLPAK_ROWS_TILES");
+        const bool tiled = g.ndim == 4 && !splpak::opt_get("SPLPAK_NO_CONSTRAINT_TABLE") && !(rt && atoi(rt) == 0) && !splpak::opt_get("SPLPAK_RESIDUAL_CELLS");
+        if (!tiled) ok = ok && dev_alloc(p, &p->rcell, (size_t)g.ncell * g.nb);
+    }
     ok = ok && dev_alloc(p, &p->tbuf, (size_t)g.ncol * (g.ndim * (g.ndim + 1) / 2));
     ok = ok && dev_alloc(p, &p->dcw, (size_t)g.ncol);
     ok = ok && dev_alloc(p, &p->ctab, (size_t)constraint_table_doubles(g));
@@ -842,7 +847,7 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
         SPLPAK_HIP_TRY(hipMemsetAsync(p->rho, 0, sizeof(double) * (size_t)(b.npad + SC_COUNT), st), SPLPAK_E_NODEVICE);
         hipEvent_t r0 = stamps ? p->evStage[8] : nullptr, r1 = stamps ? p->evStage[9] : nullptr;   // (created with the other stage events)
         if (r0 && r1) (void)hipEventRecord(r0, st);
-        if (p->rowsop && p->ctab && !splpak::opt_get("SPLPAK_RESIDUAL_CELLS"))      // (4-D: tile by tile, as the refinement's passes; 8.3 -> 1 ms at 32^4)
+        if (p->rowsop && p->ctab && (!p->rcell || !splpak::opt_get("SPLPAK_RESIDUAL_CELLS")))      // (4-D: tile by tile, as the refinement's passes; 8.3 -> 1 ms at 32^4)
             SPLPAK_HIP_TRY(rowsop_residual(g, p->rowsop, p->s, p->xvec, p->dcw, p->spf, p->ctab, smooth && p->rank == 0, p->rho, scalR, p->e2buf, st),
                            SPLPAK_E_NODEVICE);
         else
