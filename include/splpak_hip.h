@@ -52,7 +52,9 @@ extern "C" {
  * work(1:ncol) (:879-907).  `info` (optional, 10 doubles) receives diagnostics:
  *   [0] data rows used, [1] constraint rows, [2] refinement steps taken,
  *   [3] |last correction|_inf / |coef|_inf, [4] min Cholesky pivot (0 when no factorisation ran: the iterative solve answered),
- *   [5] seconds in assembly, [6] seconds in factorisation, [7] seconds in solve+refine,
+ *   [5] seconds in assembly, [6] seconds in factorisation, [7] seconds in solve+refine (a 4-D plan with the iterative solve in
+ *       front of a factorisation assembles the normal equations only when the factorisation is going to run: that assembly,
+ *       and an attempt of the iteration that gave up, are then counted in [6]),
  *   [8] residual norm ||rows*coef - rhs||_2 over data and constraint rows -- the `reserr` that the
  *       reference computes (suprls :1693) and drops (splcw :690, :1052),
  *   [9] measured optimality residual of the returned coefficients: the gradient

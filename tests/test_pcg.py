@@ -241,12 +241,14 @@ def test_forms_of_the_preconditioner_agree_with_the_factorisation(nodes, m, xtra
     x, y, w, st = _device_points(nd, m)
     ref, e0, i0, _, _, _ = _plan_fit(nd, nodes, lo, hi, xtrap, x, y, w, st, "direct")
     assert e0 == 0
-    its, coefs = {}, {}
+    its, coefs, diag = {}, {}, {}
     # (the separable part's mode products: pairs on the matrix pipe (default), pairs on the vector unit, one mode per launch)
     for form, env in (("rows", {}), ("assembled", {"SPLPAK_PCG_ASSEMBLE": "1"}), ("separable", {"SPLPAK_PCG_NO_BLOCKS": "1"}),
                       ("pairs_valu", {"SPLPAK_PCG_PAIRS_VALU": "1"}), ("no_pairs", {"SPLPAK_PCG_NO_PAIRS": "1"}),
                       # the constraint rows' passes behind the data rows' tile kernel instead of beside it (a stream of their own)
-                      ("one_stream", {"SPLPAK_ROWS_ONE_STREAM": "1"})):
+                      ("one_stream", {"SPLPAK_ROWS_ONE_STREAM": "1"}),
+                      # the final residual pass and reserr cell by cell (assemble.hip) instead of tile by tile
+                      ("cells", {"SPLPAK_RESIDUAL_CELLS": "1"})):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -260,12 +262,16 @@ def test_forms_of_the_preconditioner_agree_with_the_factorisation(nodes, m, xtra
         assert fac[0] == 6 and e in (0, 107), (form, e)
         its[form] = (e, ps["iterations"])
         coefs[form] = c
+        diag[form] = (info[8], info[9])
         if e == 0:
             assert relmax(c, ref) < COEF_TOL and info[9] < 1e-9, form
             assert info[0] == i0[0] and info[1] == i0[1], form
             assert abs(info[8] - i0[8]) <= 1e-9 * i0[8], form
     print(f"{nodes}, {m} points, xtrap {xtrap}: iterations rows-only {its['rows']}, assembled {its['assembled']}, separable alone {its['separable']}")
     assert its["rows"][0] == 0 and its["assembled"][0] == 0
+    # the two forms of the final pass see the same coefficients: the same residual norm and backward error to rounding
+    assert np.array_equal(coefs["cells"], coefs["rows"])
+    assert abs(diag["cells"][0] - diag["rows"][0]) <= 1e-12 * diag["rows"][0] and max(diag["cells"][1], diag["rows"][1]) < 1e-13, diag
     # the side stream only re-times the same operations: identical bits
     assert its["one_stream"] == its["rows"] and np.array_equal(coefs["one_stream"], coefs["rows"])
     # the same transform computed three ways: the iteration counts differ by rounding at most
