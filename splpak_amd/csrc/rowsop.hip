@@ -105,6 +105,9 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     // (the cells' ranges come out of LDS at uniform addresses: into scalar registers, so that the walk needs no lane masks)
     auto sld = [&](const int *q) { return __builtin_amdgcn_readfirstlane(*q); };
     auto next_cell = [&](int lc) { while (lc < NCT && sld(&cbeg[lc]) == sld(&cend[lc])) lc += 4; return lc; };
+    // (Tried: the points' window tables kept from one pass to the next -- they depend on the points alone, 128 B per point read instead
+    //  of ~half of the kernel's vector instructions -- : 0.274 -> 0.268 s per fit at 32^4 for 1.3 GB; not kept.  The kernel waits on the
+    //  dependent matrix-pipe and LDS steps of a trip with three waves per SIMD, not on the issue of the tables alone.)
     // this lane's dimension of the grid, as dimension 0 of a copy: the table code below then reads registers, not the argument block
     Grid gl = g;
     gl.nodes[0] = g.nodes[sl]; gl.xmin[0] = g.xmin[sl]; gl.dx[0] = g.dx[sl]; gl.dxin[0] = g.dxin[sl];
