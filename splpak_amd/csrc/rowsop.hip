@@ -111,7 +111,8 @@ rows4_tile_kernel(Grid g, int nt0, int nt1, int nt2, const int *__restrict__ off
     // this lane's dimension of the grid, as dimension 0 of a copy: the table code below then reads registers, not the argument block
     Grid gl = g;
     gl.nodes[0] = g.nodes[sl]; gl.xmin[0] = g.xmin[sl]; gl.dx[0] = g.dx[sl]; gl.dxin[0] = g.dxin[sl];
-    // the chunk after the current one is loaded while the current one is worked on
+    // the chunk after the current one is loaded while the current one is worked on  (two trips ahead, with the shorter trips of the
+    // matrix-pipe form: measured again, no gain -- 0.276 against 0.272 s per fit)
     double xpre = 0.0, wpre = 0.0, ypre = 0.0;
     auto issue = [&](int lc, int p0) {
         if (lc >= NCT) return;
