@@ -59,7 +59,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     sc = max(np.max(np.abs(c0[:ncol])), 1e-300)
     illposed = np.max(np.abs(c0[:ncol])) > 100.0 * np.max(np.abs(y))
     r2 = np.max(np.abs(c2[:ncol] - c0[:ncol])) / sc if e2 == 0 else np.inf
-    hbad = h1 is not None and np.max(np.abs(h1[:ncol] - h0[:ncol])) > 1e-12 * max(np.max(np.abs(h0[:ncol])), 1)
+    htol = (2e-6 if r32 else 1e-12) * max(np.max(np.abs(h0[:ncol])), 1)
+    hbad = (h1 is not None and np.max(np.abs(h1[:ncol] - h0[:ncol])) > htol) or (e2 == 0 and h2 is not None and np.max(np.abs(h2[:ncol] - h0[:ncol])) > htol)
     if e1 == 107:
         gaveup += 1
         r1 = 0.0
