@@ -2393,6 +2393,7 @@ int nd_attach(splpak_plan *p, double **factor_arena, long long *factor_doubles, 
     }
     p->fn_name = s->desc.c_str();
     p->fn_code = s->mdist ? 5 : 4;
+    p->factor_flop = t.flop;                 // (what the iteration in front of this factorisation may spend is weighed against it, plan.hip)
     if (factor_arena) *factor_arena = s->factor;
     if (factor_doubles) *factor_doubles = s->factor_doubles;
     if (splpak::opt_get("SPLPAK_DEBUG"))

@@ -1180,7 +1180,9 @@ int pcg_solve(splpak_plan *p, PcgState *s, double *v, double tol, bool smooth, h
         // stagnation: no factor of ten gained in 400 iterations (a converging 4-D fit gains one in 10 .. 60) where a factorisation
         // stands behind the iteration; a plan that has nothing else is patient: 1 500 iterations per factor of ten (between 1.2 and
         // 1.5 constraint rows per column the iteration crawls at ~200 .. 600 per factor of ten, but it arrives)
-        if (it - last_gain_it > (p->solver_mode == 2 ? 1500 : 400)) { status = 1; break; }
+        // (patience: 400 iterations without a factor of ten where a cheap factorisation stands behind the iteration, 1 500 where none
+        //  does or it would take seconds)
+        if (it - last_gain_it > ((p->solver_mode == 2 || p->factor_flop / 45.0e12 >= 1.0) ? 1500 : 400)) { status = 1; break; }
     }
     s->last_iters = it;
     s->last_rel = rel;

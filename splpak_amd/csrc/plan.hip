@@ -738,7 +738,11 @@ int32_t splpak_plan_fit_dev(splpak_plan *p, const double *x, int32_t l1xdat, con
     bool try_iteration = p->pcg != nullptr;
     if (try_iteration && p->solver_mode == 3 && !splpak::opt_get("SPLPAK_PCG_ALWAYS")) {
         const double rpc = rows_cons / (double)g.ncol;
-        if (rows_cons > 0.0 && rpc < 1.6) {
+        // (a factorisation of seconds -- 24^4: 4.5 s, 28^4: 18 s -- is worth a patient attempt where the iteration only crawls: 24^4 at
+        //  1.5 / 1.4 / 1.33 rows per column 1.0 / 2.1 / 3.1 s; at 1.27 it gives up after 2.8 s.  45 TFLOP/s: what the factorisation sustains)
+        const double fac_s = p->factor_flop / 45.0e12;
+        const double lo = fac_s >= 10.0 ? 1.3 : (fac_s >= 1.0 ? 1.35 : 1.6);
+        if (rows_cons > 0.0 && rpc < lo) {
             try_iteration = false;
             if (splpak::opt_get("SPLPAK_DEBUG")) fprintf(stderr, "[splpak] %.2f constraint rows per column: the factorisation without an attempt of the iteration\n", rpc);
         }

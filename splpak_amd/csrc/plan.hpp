@@ -106,6 +106,7 @@ struct splpak_plan {
     splpak::RowsOp *rowsop = nullptr;         // 4-D grids: the tiled residual pass (NULL: the cell-by-cell passes of assemble.hip)
     splpak::PcgState *pcg = nullptr;
     int solver_mode = 0;
+    double factor_flop = 0.0;     // flop of the plan's factorisation where known (nested dissection), else 0
     bool rows_only = false;       // iteration-only 4-D plans: the normal equations are never assembled (right-hand side, histogram and
                                   // backward-error denominators come from the rows: rowsop.hip); no half stencil, no Gram scratch
     const char *fn_name = nullptr;                 // what the hooks are (splpak_plan_factorisation); fn_code: 2 two-ended band, 4 nested dissection, 3 distributed band
